@@ -1,0 +1,130 @@
+"""ctypes binding of libadfp.so (include/adfp.h).
+
+The product path has no CPU fallback: if the HIP library is missing, ``lib()`` raises and
+every compute entry point of this package fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libadfp.so')
+
+STAGE = {'low': 0, 'high': 1, 'color': 2}
+DEC_KIND = {'low': 0, 'high': 1, 'color': 2}
+PTS_RAYS, PTS_F64, PTS_F32 = 0, 1, 2
+
+ERRORS = {-1: 'ADFP_E_ARG (null pointer / bad size)',
+          -2: 'ADFP_E_UNSUPPORTED',
+          -3: 'ADFP_E_WORKSPACE (workspace too small)'}
+
+
+class AdfpGrid(C.Structure):
+    _fields_ = [('data', C.c_void_p), ('Z', C.c_int), ('Y', C.c_int), ('X', C.c_int)]
+
+
+class AdfpTsdf(C.Structure):
+    _fields_ = [('data', C.c_void_p), ('Z', C.c_int), ('Y', C.c_int), ('X', C.c_int),
+                ('sZ', C.c_longlong), ('sY', C.c_longlong), ('sX', C.c_longlong)]
+
+
+class AdfpScene(C.Structure):
+    _fields_ = [('bound', (C.c_double * 2) * 3), ('tsdf_bnds', (C.c_double * 2) * 3),
+                ('low', AdfpGrid), ('high', AdfpGrid), ('color', AdfpGrid), ('tsdf', AdfpTsdf),
+                ('w_low', C.c_void_p), ('w_high', C.c_void_p), ('w_color', C.c_void_p), ('w_att', C.c_void_p)]
+
+
+class AdfpPoints(C.Structure):
+    _fields_ = [('mode', C.c_int), ('n_points', C.c_longlong), ('pts', C.c_void_p),
+                ('rays_o', C.c_void_p), ('rays_d', C.c_void_p), ('z_vals', C.c_void_p), ('S', C.c_int)]
+
+
+class AdfpRenderArgs(C.Structure):
+    _fields_ = [('stage', C.c_int), ('n_rays', C.c_int), ('n_samples', C.c_int), ('n_surface', C.c_int),
+                ('lindisp', C.c_int), ('perturb', C.c_float),
+                ('rays_o', C.c_void_p), ('rays_d', C.c_void_p), ('gt_depth', C.c_void_p),
+                ('t_rand', C.c_void_p), ('depth_max', C.c_void_p),
+                ('depth', C.c_void_p), ('uncertainty', C.c_void_p), ('color', C.c_void_p),
+                ('weight', C.c_void_p), ('z_vals', C.c_void_p), ('raw', C.c_void_p),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+
+
+Bound = (C.c_double * 2) * 3
+
+# every symbol include/adfp.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ('adfp_version', C.c_int, []),
+    ('adfp_decoder_flat_floats', C.c_longlong, [C.c_int]),
+    ('adfp_decoder_packed_floats', C.c_longlong, [C.c_int]),
+    ('adfp_attention_flat_floats', C.c_longlong, []),
+    ('adfp_attention_packed_floats', C.c_longlong, []),
+    ('adfp_workspace_bytes', C.c_size_t, [C.c_longlong]),
+    ('adfp_relayout_grid', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ('adfp_relayout_grid_back', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ('adfp_pack_decoder', C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_pack_attention', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_get_rays', C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_sample_rays', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Bound),
+                                   C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_eval_points', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ('adfp_sample_tsdf', C.c_int, [C.POINTER(AdfpTsdf), C.POINTER(Bound), C.POINTER(AdfpPoints),
+                                   C.c_void_p, C.c_void_p]),
+    ('adfp_composite', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_render_forward', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpRenderArgs), C.c_void_p]),
+    ('adfp_tsdf_stage', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load libadfp.so once.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: build the HIP extension first '
+                '(python -c "import __graft_entry__ as g; g.build()" or attentive_dfprior_amd/csrc/build.sh). '
+                'attentive_dfprior_amd has no CPU fallback.')
+        handle = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise RuntimeError(f'{what}: {ERRORS.get(rc, rc)}')
+    raise RuntimeError(f'{what}: hipError_t {rc}')
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def current_stream(device):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def fill_bound(dst, values):
+    """values: nested [[lo,hi]]*3 python floats."""
+    for k in range(3):
+        dst[k][0] = float(values[k][0])
+        dst[k][1] = float(values[k][1])
+
+
+def require_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f'{name} is on {t.device}: attentive_dfprior_amd runs only on an MI355X through libadfp.so; '
+            'there is no CPU fallback.')

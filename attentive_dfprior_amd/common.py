@@ -1,0 +1,123 @@
+"""
+Drop-in for the hot-path functions of the reference's ``src/common.py`` (rays, compositing,
+coordinate normalisation).  Signatures and argument meaning follow the reference so that
+``src/Mapper.py`` / ``src/Tracker.py`` / ``src/utils/Visualizer.py`` call them unchanged.
+
+Ray generation on a GPU device and compositing run in libadfp.so.  Pixel selection keeps
+``torch.randint`` as its RNG so the index stream is the reference's (src/common.py:101).
+Pose utilities (quad2rotation ... src/common.py:139-203) are tracker-only and out of scope.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, ptr, check
+
+
+def _pixel_dirs(i, j, fx, fy, cx, cy):
+    # camera-frame direction of pixel (i, j): x right, y up, looking along -z (unnormalised)
+    return torch.stack([(i - cx) / fx, -(j - cy) / fy, -torch.ones_like(i)], -1)
+
+
+def get_rays(H, W, fx, fy, cx, cy, c2w, device):
+    """Rays of a whole image -> (rays_o, rays_d) [H,W,3] (reference src/common.py:254-272)."""
+    if isinstance(c2w, np.ndarray):
+        c2w = torch.from_numpy(c2w)
+    dev = torch.device(device)
+    if dev.type == 'cuda':
+        m = c2w.detach().to(dev, torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            ro = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+            rd = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+            check(lib().adfp_get_rays(H, W, fx, fy, cx, cy, ptr(m), ptr(ro), ptr(rd), _lib.current_stream(dev)),
+                  'adfp_get_rays')
+        return ro, rd
+    # host tensors (dataset / keyframe bookkeeping on the CPU): plain indexing arithmetic
+    jj, ii = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32),
+                            indexing='ij')
+    dirs = _pixel_dirs(ii, jj, fx, fy, cx, cy).to(device)
+    rot = c2w[:3, :3].to(device)
+    rays_d = (dirs[..., None, :] * rot).sum(-1)
+    rays_o = c2w[:3, -1].to(device).expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def get_rays_from_uv(i, j, c2w, H, W, fx, fy, cx, cy, device):
+    """Rays through the given pixel coordinates (reference src/common.py:76-91)."""
+    if isinstance(c2w, np.ndarray):
+        c2w = torch.from_numpy(c2w).to(device)
+    dirs = _pixel_dirs(i, j, fx, fy, cx, cy).to(device).reshape(-1, 1, 3)
+    rays_d = (dirs * c2w[:3, :3]).sum(-1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def select_uv(i, j, n, depth, color, device='cuda:0'):
+    """n uniformly random pixels out of the dense (i, j) lattice (reference src/common.py:94-109)."""
+    i = i.reshape(-1)
+    j = j.reshape(-1)
+    pick = torch.randint(i.shape[0], (n,), device=device).clamp(0, i.shape[0])
+    return i[pick], j[pick], depth.reshape(-1)[pick], color.reshape(-1, 3)[pick]
+
+
+def get_sample_uv(H0, H1, W0, W1, n, depth, color, device='cuda:0'):
+    """Sample n pixels from the window [H0,H1) x [W0,W1) (reference src/common.py:112-124)."""
+    depth = depth[H0:H1, W0:W1]
+    color = color[H0:H1, W0:W1]
+    jj, ii = torch.meshgrid(torch.linspace(H0, H1 - 1, H1 - H0).to(device),
+                            torch.linspace(W0, W1 - 1, W1 - W0).to(device), indexing='ij')
+    return select_uv(ii, jj, n, depth, color, device=device)
+
+
+def get_samples(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, c2w, depth, color, device):
+    """n random rays of one frame with their depth / colour (reference src/common.py:127-136)."""
+    i, j, sample_depth, sample_color = get_sample_uv(H0, H1, W0, W1, n, depth, color, device=device)
+    rays_o, rays_d = get_rays_from_uv(i, j, c2w, H, W, fx, fy, cx, cy, device)
+    return rays_o, rays_d, sample_depth, sample_color
+
+
+def random_select(l, k):
+    """k distinct indices out of range(l) (reference src/common.py:68-73)."""
+    return list(np.random.permutation(np.arange(l))[:min(l, k)])
+
+
+def normalize_3d_coordinate(p, bound):
+    """Map world coordinates into [-1, 1] of ``bound`` IN PLACE, like the reference
+    (src/common.py:275-290); the kernels do this internally, the function is kept for callers."""
+    p = p.reshape(-1, 3)
+    for k in range(3):
+        p[:, k] = ((p[:, k] - bound[k, 0]) / (bound[k, 1] - bound[k, 0])) * 2 - 1.0
+    return p
+
+
+def raw2outputs_nerf_color(raw, z_vals, rays_d, occupancy=False, device='cuda:0'):
+    """Alpha compositing (reference src/common.py:206-251, ``occupancy=True`` branch) on the GPU.
+
+    raw [N,S,4] (rgb, occ), z_vals [N,S] -> depth [N], depth_var [N], rgb [N,3], weights [N,S].
+    depth / variance are float64 like the reference's when z_vals is float64.
+    """
+    if not occupancy:
+        raise NotImplementedError('libadfp implements the occupancy=True branch (configs/df_prior.yaml:4)')
+    _lib.require_cuda(raw, 'raw')
+    dev = raw.device
+    N, S = raw.shape[0], raw.shape[1]
+    with torch.cuda.device(dev):
+        r = raw.detach().float().contiguous()
+        z = z_vals.detach().to(torch.float64).contiguous()
+        depth = torch.empty((N,), dtype=torch.float64, device=dev)
+        var = torch.empty((N,), dtype=torch.float64, device=dev)
+        rgb = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        wts = torch.empty((N, S), dtype=torch.float32, device=dev)
+        check(lib().adfp_composite(ptr(r), ptr(z), N, S, ptr(depth), ptr(var), ptr(rgb), ptr(wts),
+                                   _lib.current_stream(dev)), 'adfp_composite')
+    if z_vals.dtype != torch.float64:
+        depth, var = depth.to(z_vals.dtype), var.to(z_vals.dtype)
+    return depth, var, rgb, wts
+
+
+def sample_pdf(*args, **kwargs):
+    """Hierarchical resampling is dead code in the reference (``N_importance: 0``,
+    configs/df_prior.yaml:96; its enabled branch re-evaluates stale points, Renderer.py:246)."""
+    raise NotImplementedError('N_importance > 0 is not supported (dead in the reference)')

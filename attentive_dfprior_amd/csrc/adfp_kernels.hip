@@ -1,0 +1,894 @@
+// adfp_kernels.hip -- gfx950 kernels + the C ABI of libadfp.so (see include/adfp.h).
+//
+// Forward pipeline of Renderer.render_batch_ray (reference src/utils/Renderer.py:110-255):
+//
+//   k_depth_max   batch-global max(gt_depth)                      Renderer.py:159, :195
+//   k_sample      z_vals[N,S] f64: uniform + surface, rank-merged  Renderer.py:163-221
+//   k_tsdf        TSDF trilerp, band mask, compaction of in-band   decoder.py:295-303, :329
+//                 points (the HBM-streaming stage)
+//   k_decode<LOW>   low decoder on every point (MFMA f32)           decoder.py:177-203
+//   k_decode<COLOR> colour decoder on every point (stage color)
+//   k_decode<HIGH>  high decoder on the in-band list only -- its output is dead
+//                   everywhere else (decoder.py:333: unmasked points keep `low`)
+//   k_attention   mlp_tsdf on the in-band list (MFMA f32)          decoder.py:240-258
+//   k_composite   sigmoid(10 occ), transmittance scan, sums         common.py:234-251
+//
+// Each MFMA kernel keeps ONE network's weights resident in LDS (64-134 KB) in MFMA operand
+// order and chains layers accumulator -> next B operand without leaving registers.
+#include "adfp_device.h"
+#include <math.h>
+#include <string.h>
+
+#define ADFP_CHECK_LAUNCH()                         \
+    do {                                            \
+        hipError_t e_ = hipGetLastError();          \
+        if (e_ != hipSuccess) return (int)e_;       \
+    } while (0)
+
+// =====================================================================================
+// layout conversion
+// =====================================================================================
+// [C=32][V] -> [V][32], through a padded LDS tile so both sides are coalesced.
+__global__ __launch_bounds__(256) void k_relayout_cm_to_cl(const float* __restrict__ src, float* __restrict__ dst, long long V) {
+    __shared__ float tile[32][65];
+    const long long v0 = (long long)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+#pragma unroll
+    for (int c = ty; c < 32; c += 4) {
+        const long long v = v0 + tx;
+        tile[c][tx] = v < V ? src[(long long)c * V + v] : 0.f;
+    }
+    __syncthreads();
+    const int cx = threadIdx.x & 31, vy = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int j = vy; j < 64; j += 8) {
+        const long long v = v0 + j;
+        if (v < V) dst[v * 32 + cx] = tile[cx][j];
+    }
+}
+__global__ __launch_bounds__(256) void k_relayout_cl_to_cm(const float* __restrict__ src, float* __restrict__ dst, long long V) {
+    __shared__ float tile[32][65];
+    const long long v0 = (long long)blockIdx.x * 64;
+    const int cx = threadIdx.x & 31, vy = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = vy; j < 64; j += 8) {
+        const long long v = v0 + j;
+        tile[cx][j] = v < V ? src[v * 32 + cx] : 0.f;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = ty; c < 32; c += 4) {
+        const long long v = v0 + tx;
+        if (v < V) dst[(long long)c * V + v] = tile[c][tx];
+    }
+}
+
+// =====================================================================================
+// weight packing: flat state_dict order -> MFMA operand order
+// =====================================================================================
+template <int CDIM, int NOUT>
+__device__ int dec_src_index(int t) {
+    using L = DecLayout<CDIM, NOUT>;
+    if (t < 384) {
+        const int j = t >> 2, c = t & 3;
+        return (j < 93 && c < 3) ? L::F_EB + c * 93 + j : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        if (t < L::P_BP(i)) {                       // pts_linears.i weight chain
+            const int u = t - L::P_WP(i);
+            const int s = (u >> 8) * 4 + (u & 3), h = (u >> 7) & 1, row = (u >> 2) & 31;
+            int col;
+            if (i == 0) { col = 2 * s + h; if (col >= 93) col = -1; }
+            else if (i == 3) {
+                if (s < L::KSE) { col = 2 * s + h; if (col >= 93) col = -1; }
+                else col = 93 + kmapH(s - L::KSE, h);
+            } else col = kmapH(s, h);
+            return col < 0 ? -1 : L::F_PL(i) + row * L::in_dim(i) + col;
+        }
+        if (t < L::P_WC(i)) return L::F_PL(i) + 32 * L::in_dim(i) + (t - L::P_BP(i));
+        if (t < L::P_BC(i)) {                       // fc_c.i weight chain
+            const int u = t - L::P_WC(i);
+            const int s = (u >> 8) * 4 + (u & 3), h = (u >> 7) & 1, row = (u >> 2) & 31;
+            return L::F_FC(i) + row * CDIM + L::cmap(s, h);
+        }
+        if (t < L::P_BC(i) + 32) return L::F_FC(i) + 32 * CDIM + (t - L::P_BC(i));
+    }
+    if (t < L::P_BO) {
+        const int u = t - L::P_WO;
+        const int h = u / (NOUT * 16), o = (u >> 4) % NOUT, r = u & 15;
+        return L::F_OW + o * 32 + kmapH(r, h);
+    }
+    const int o = t - L::P_BO;
+    return o < NOUT ? L::F_OB + o : -1;
+}
+
+template <int CDIM, int NOUT>
+__global__ void k_pack_decoder(const float* __restrict__ flat, float* __restrict__ packed) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= DecLayout<CDIM, NOUT>::P_TOTAL) return;
+    const int s = dec_src_index<CDIM, NOUT>(t);
+    packed[t] = s < 0 ? 0.f : flat[s];
+}
+
+__device__ int att_src_index(int t) {
+    using A = AttLayout;
+    if (t < A::P_W1) {
+        const int k = t >> 2, c = t & 3;
+        return c < 2 ? A::F_W0 + k * 2 + c : (c == 2 ? A::F_B0 + k : -1);
+    }
+    if (t < A::P_B1) {                              // 64 -> 128, input k = 2s + h
+        const int u = t - A::P_W1, blk = u / 2048, v = u % 2048;
+        const int s = (v >> 8) * 4 + (v & 3), h = (v >> 7) & 1, row = (v >> 2) & 31;
+        return A::F_W1 + (blk * 32 + row) * 64 + (2 * s + h);
+    }
+    if (t < A::P_W2) return A::F_B1 + (t - A::P_B1);
+    if (t < A::P_B2) {                              // 128 -> 128, input k = 32*(s>>4) + kmapH(s&15,h)
+        const int u = t - A::P_W2, blk = u / 4096, v = u % 4096;
+        const int s = (v >> 8) * 4 + (v & 3), h = (v >> 7) & 1, row = (v >> 2) & 31;
+        return A::F_W2 + (blk * 32 + row) * 128 + 32 * (s >> 4) + kmapH(s & 15, h);
+    }
+    if (t < A::P_W3) return A::F_B2 + (t - A::P_B2);
+    if (t < A::P_B3) {
+        const int u = t - A::P_W3, blk = u / 4096, v = u % 4096;
+        const int s = (v >> 8) * 4 + (v & 3), h = (v >> 7) & 1, row = (v >> 2) & 31;
+        return A::F_W3 + (blk * 32 + row) * 128 + 32 * (s >> 4) + kmapH(s & 15, h);
+    }
+    if (t < A::P_WO) return A::F_B3 + (t - A::P_B3);
+    if (t < A::P_BO) {                              // [h][o][32]: hidden 32*(j>>4) + kmapH(j&15,h)
+        const int u = t - A::P_WO, h = u >> 6, o = (u >> 5) & 1, j = u & 31;
+        return A::F_WO + o * 64 + 32 * (j >> 4) + kmapH(j & 15, h);
+    }
+    const int o = t - A::P_BO;
+    return o < 2 ? A::F_BO + o : -1;
+}
+__global__ void k_pack_attention(const float* __restrict__ flat, float* __restrict__ packed) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= AttLayout::P_TOTAL) return;
+    const int s = att_src_index(t);
+    packed[t] = s < 0 ? 0.f : flat[s];
+}
+
+// =====================================================================================
+// a1: get_rays (common.py:254-272)
+// =====================================================================================
+__global__ void k_get_rays(int H, int W, float fx, float fy, float cx, float cy, const float* __restrict__ c2w,
+                           float* __restrict__ ro, float* __restrict__ rd) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const int j = idx / W, i = idx - j * W;
+    // torch.linspace(0, W-1, W) is exactly the integers; dirs = ((i-cx)/fx, -(j-cy)/fy, -1)
+    const float dx = ((float)i - cx) / fx, dy = -((float)j - cy) / fy, dz = -1.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // torch.sum(dirs * c2w[:3,:3], -1): products then left-to-right adds
+        const float s = __fadd_rn(__fadd_rn(__fmul_rn(dx, c2w[4 * k + 0]), __fmul_rn(dy, c2w[4 * k + 1])),
+                                  __fmul_rn(dz, c2w[4 * k + 2]));
+        rd[3 * idx + k] = s;
+        ro[3 * idx + k] = c2w[4 * k + 3];
+    }
+}
+
+// =====================================================================================
+// a4: sampler
+// =====================================================================================
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__global__ __launch_bounds__(256) void k_depth_max(const float* __restrict__ d, int n, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned v = f2ord(d[i]);
+        m = v > m ? v : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned v = __shfl_xor(m, o);
+        m = v > m ? v : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+struct SampleArgs {
+    const float* ro; const float* rd; const float* depth; const float* t_rand;
+    const float* dmax_f;        // device float (caller-provided) or NULL
+    const unsigned* dmax_ord;   // ordered-uint reduction result or NULL
+    double b[6];                // bound lo/hi per axis
+    int n_rays, n_samples, n_surface, lindisp;
+    float perturb;
+    double* z;
+};
+
+// torch.linspace(0, 1, n) for float32 (ATen RangeFactories: symmetric fill)
+ADFP_DEV float linspace01(int i, int n) {
+    if (n == 1) return 0.f;
+    const float step = 1.0f / (float)(n - 1);
+    return (i < n / 2) ? __fmul_rn(step, (float)i) : __fsub_rn(1.0f, __fmul_rn(step, (float)(n - i - 1)));
+}
+
+struct RaySampler {
+    float nearf; double neard; double far; float dep; double dmax; int ns, nf; bool has_depth, lindisp, perturb;
+    const float* trand;
+    // uniform sample k before perturbation (Renderer.py:203-208)
+    ADFP_DEV double zu_raw(int k) const {
+        const float t = linspace01(k, ns);
+        if (!lindisp) {
+            if (has_depth) return __dadd_rn((double)__fmul_rn(nearf, __fsub_rn(1.f, t)), __dmul_rn(far, (double)t));
+            return __dadd_rn((double)__fmul_rn(0.01f, __fsub_rn(1.f, t)), __dmul_rn(far, (double)t));
+        }
+        if (has_depth) {
+            const double a = (double)__fmul_rn(__fdiv_rn(1.f, nearf), __fsub_rn(1.f, t));
+            return 1.0 / __dadd_rn(a, __dmul_rn(1.0 / far, (double)t));
+        }
+        return 1.0 / __dadd_rn((double)__fmul_rn(100.f, __fsub_rn(1.f, t)), __dmul_rn(1.0 / far, (double)t));
+    }
+    // with stratified jitter (Renderer.py:210-217)
+    ADFP_DEV double zu(int k) const {
+        const double z = zu_raw(k);
+        if (!perturb) return z;
+        const double lo = k == 0 ? z : .5 * (z + zu_raw(k - 1));
+        const double up = k == ns - 1 ? z : .5 * (zu_raw(k + 1) + z);
+        return lo + (up - lo) * (double)trand[k];
+    }
+    // surface sample j (Renderer.py:179-201)
+    ADFP_DEV double zs(int j) const {
+        const double t = (double)linspace01(j, nf);
+        if (dep > 0.f) return __dadd_rn(__dmul_rn((double)__fmul_rn(0.95f, dep), 1.0 - t),
+                                        __dmul_rn((double)__fmul_rn(1.05f, dep), t));
+        return __dadd_rn(__dmul_rn(0.001, 1.0 - t), __dmul_rn(dmax, t));
+    }
+};
+
+// One wave per ray.  Lane e computes merged-list element e (uniform e < ns, surface otherwise),
+// stages it in LDS, and finds its rank in the sorted union by counting (only the values
+// matter: torch.sort, Renderer.py:220).
+__global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
+    __shared__ double sv[4][ADFP_MAX_SAMPLES];
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool active = ray < a.n_rays;
+    double* v = sv[threadIdx.x >> 6];
+    RaySampler rs;
+    rs.ns = a.n_samples; rs.lindisp = a.lindisp != 0; rs.perturb = a.perturb > 0.f;
+    rs.has_depth = a.depth != nullptr;
+    rs.nf = rs.has_depth ? a.n_surface : 0;
+    const int S = rs.ns + rs.nf;
+    if (active) {
+        rs.trand = a.t_rand ? a.t_rand + (long long)ray * a.n_samples : nullptr;
+        float dmaxf = 0.f;
+        if (rs.has_depth) dmaxf = a.dmax_f ? *a.dmax_f : ord2f(*a.dmax_ord);
+        rs.dmax = (double)dmaxf;
+        rs.dep = rs.has_depth ? a.depth[ray] : 0.f;
+        rs.nearf = __fmul_rn(rs.dep, 0.01f);
+        // far_bb = min_axis max_side (bound - o)/d + 0.01   (Renderer.py:151-156), f64
+        double far_bb = INFINITY;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double o = (double)a.ro[3 * ray + k], d = (double)a.rd[3 * ray + k];
+            const double t0 = (a.b[2 * k] - o) / d, t1 = (a.b[2 * k + 1] - o) / d;
+            const double tm = t0 > t1 ? t0 : t1;          // torch.max propagates NaN; not reproduced
+            far_bb = tm < far_bb ? tm : far_bb;
+        }
+        far_bb += 0.01;
+        if (rs.has_depth) {
+            const double hi = (double)__fmul_rn(dmaxf, 1.2f);
+            double f = far_bb < 0.0 ? 0.0 : far_bb;       // clamp(far_bb, 0, max(gt_depth*1.2))
+            rs.far = f > hi ? hi : f;
+        } else rs.far = far_bb;
+        for (int e = lane; e < S; e += 64) v[e] = e < rs.ns ? rs.zu(e) : rs.zs(e - rs.ns);
+    }
+    __syncthreads();
+    if (!active) return;
+    double* zrow = a.z + (long long)ray * S;
+    if (rs.nf == 0) {                                  // no sort in the reference either
+        for (int e = lane; e < S; e += 64) zrow[e] = v[e];
+        return;
+    }
+    for (int e = lane; e < S; e += 64) {
+        const double val = v[e];
+        int rank = 0;
+        for (int k = 0; k < S; ++k) { const double o = v[k]; rank += (o < val) || (o == val && k < e); }
+        zrow[rank] = val;
+    }
+}
+
+// =====================================================================================
+// TSDF stage (a10): trilerp + band mask + compaction.  One block = 2048 consecutive points;
+// in-band points are staged in LDS and appended to the global list with ONE atomic per block.
+// =====================================================================================
+struct TsdfArgs {
+    PtsDev P; NormDev nt; TsdfDev t; double b[6];
+    unsigned char* flags; int* list; float* att_u; float* w; int* counter; float* tsdf_out;
+};
+#define TSDF_CHUNK 2048
+__global__ __launch_bounds__(256) void k_tsdf(TsdfArgs a) {
+    __shared__ int s_q[TSDF_CHUNK];
+    __shared__ float s_u[TSDF_CHUNK];
+    __shared__ int s_cnt, s_base;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int q0 = blockIdx.x * TSDF_CHUNK;
+#pragma unroll 2
+    for (int it = 0; it < TSDF_CHUNK / 256; ++it) {
+        const int q = q0 + it * 256 + threadIdx.x;
+        bool band = false; float u = 0.f;
+        if (q < a.P.n) {
+            double p[3]; float pn[3];
+            load_point(a.P, q, p);
+            normalize3(a.nt, p, pn);
+            const float t = trilerp_scalar(a.t, pn);
+            if (a.tsdf_out) a.tsdf_out[q] = t;
+            band = (t > (float)(-1.0 + 1e-4)) & (t < (float)(1.0 - 1e-4));
+            if (a.flags) a.flags[q] = (unsigned char)((in_bound(p, a.b) ? ADFP_F_INBOUND : 0u) | (band ? ADFP_F_BAND : 0u));
+            if (a.w) a.w[q] = 1.f;
+            if (band) u = inv_tsdf(t);
+        }
+        if (a.list) {
+            const unsigned long long m = __ballot(band);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_cnt, __popcll(m));
+                base = __shfl(base, 0);
+                if (band) {
+                    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                    s_q[pos] = q; s_u[pos] = u;
+                }
+            }
+        }
+    }
+    if (!a.list) return;
+    __syncthreads();
+    const int n = s_cnt;
+    if (n == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(a.counter, n);
+    __syncthreads();
+    const int base = s_base;
+    for (int i = threadIdx.x; i < n; i += 256) { a.list[base + i] = s_q[i]; a.att_u[base + i] = s_u[i]; }
+}
+
+// =====================================================================================
+// decoder kernels (a7-a9): gather -> Fourier -> 5 layers on MFMA -> output layer on VALU
+// =====================================================================================
+#define ROLE_LOW 0
+#define ROLE_HIGH 1
+#define ROLE_COLOR 2
+
+struct DecodeArgs {
+    PtsDev P; NormDev nb; double b[6];
+    GridDev g0;                // own grid
+    GridDev g1;                // low grid (HIGH only: concat_feature, decoder.py:182-187)
+    const float* packed;
+    const int* list;           // HIGH: in-band point ids
+    const int* count_ptr;      // HIGH: device-side list length
+    const unsigned char* flags;
+    float* raw;                // [P,4]
+    float* w;                  // [P] (LOW writes 1 when there is no TSDF stage)
+    float* att_occ;            // HIGH: high+low per list entry
+    int write_w;
+    int apply_bound;           // Renderer.eval_points' ret[~mask,3] = 100 (Renderer.py:64)
+};
+
+template <int CDIM, int NOUT, int ROLE, int NT>
+__global__ __launch_bounds__(NT, 2) void k_decode(DecodeArgs a) {
+    using L = DecLayout<CDIM, NOUT>;
+    __shared__ __attribute__((aligned(16))) float lds[L::P_TOTAL];
+    for (int i = threadIdx.x; i < L::P_TOTAL / 4; i += NT) ((f32x4*)lds)[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+    const int lane_off4 = (h * 32 + p) * 4;
+    const int wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (NT / 64);
+    const int count = (ROLE == ROLE_HIGH) ? *a.count_ptr : a.P.n;
+    const int ntiles = (count + 31) >> 5;
+
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int idx = tile * 32 + p;
+        const bool valid = idx < count;
+        int q = valid ? idx : 0;
+        if (ROLE == ROLE_HIGH) q = a.list[q];
+
+        double pt[3]; float pn[3], pf[3];
+        load_point(a.P, q, pt);
+        normalize3(a.nb, pt, pn);
+        pf[0] = (float)pt[0]; pf[1] = (float)pt[1]; pf[2] = (float)pt[2];   // p.float() decoder.py:189
+
+        float c[L::KSC];
+        gather16(a.g0, pn, h, c);
+        if (CDIM == 64) gather16(a.g1, pn, h, c + 16);
+
+        // Fourier features sin(p @ B), feature j = 2s + h (decoder.py:26-30)
+        float e[L::KSE];
+#pragma unroll
+        for (int s = 0; s < L::KSE; ++s) {
+            const f32x4 bm = *(const f32x4*)(lds + L::P_BM + (2 * s + h) * 4);
+            const float arg = fmaf(pf[2], bm.z, fmaf(pf[1], bm.y, pf[0] * bm.x));
+            e[s] = adfp_sinf(arg);
+        }
+
+        // h = relu(W_i h + b_i) + (Wc_i c + bc_i); skip-concat [emb, h] feeds layer 3 (decoder.py:192-199)
+        f32x16 hcur, acc;
+        bias_init(acc, lds + L::P_BP(0), h);
+        mfma_chain<L::KSE>(acc, lds + L::P_WP(0), lane_off4, e);
+        relu_bias(acc, lds + L::P_BC(0), h);
+        mfma_chain<L::KSC>(acc, lds + L::P_WC(0), lane_off4, c);
+        hcur = acc;
+#pragma unroll
+        for (int i = 1; i < 5; ++i) {
+            bias_init(acc, lds + L::P_BP(i), h);
+            if (i == 3) {
+                mfma_chain<L::KSE>(acc, lds + L::P_WP(i), lane_off4, e);
+                mfma_chain<16>(acc, lds + L::P_WP(i) + L::KSE * 64, lane_off4, hcur);
+            } else {
+                mfma_chain<16>(acc, lds + L::P_WP(i), lane_off4, hcur);
+            }
+            relu_bias(acc, lds + L::P_BC(i), h);
+            mfma_chain<L::KSC>(acc, lds + L::P_WC(i), lane_off4, c);
+            hcur = acc;
+        }
+
+        // output_linear on the VALU: each half holds 16 of the 32 hidden units
+        float out[NOUT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const float* wo = lds + L::P_WO + (h * NOUT + o) * 16;
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s = fmaf(hcur[r], wo[r], s);
+            s += __shfl_xor(s, 32);
+            out[o] = s + lds[L::P_BO + o];
+        }
+
+        if (valid && h == 0) {
+            if (ROLE == ROLE_LOW) {
+                const bool inb = in_bound(pt, a.b);
+                const unsigned f = a.flags ? a.flags[q] : 0u;
+                // in-band points keep the true value for the HIGH pass; the attention pass
+                // overwrites them (and applies the bound rule) afterwards.
+                a.raw[4ll * q + 3] = ((f & ADFP_F_BAND) || inb || !a.apply_bound) ? out[0] : 100.f;   // Renderer.py:64
+                if (a.write_w) a.w[q] = 1.f;
+            } else if (ROLE == ROLE_COLOR) {
+                a.raw[4ll * q + 0] = out[0]; a.raw[4ll * q + 1] = out[1]; a.raw[4ll * q + 2] = out[2];
+            } else {
+                a.att_occ[idx] = out[0] + a.raw[4ll * q + 3];                        // high + low, decoder.py:342
+            }
+        }
+    }
+}
+
+// =====================================================================================
+// attention fusion mlp_tsdf (a11) on the in-band list
+// =====================================================================================
+struct AttArgs {
+    const float* packed; const int* list; const int* count_ptr;
+    const float* att_occ; const float* att_u; const unsigned char* flags;
+    float* raw; float* w; int apply_bound;
+};
+
+__global__ __launch_bounds__(512, 2) void k_attention(AttArgs a) {
+    using A = AttLayout;
+    __shared__ __attribute__((aligned(16))) float lds[A::P_TOTAL];
+    for (int i = threadIdx.x; i < A::P_TOTAL / 4; i += 512) ((f32x4*)lds)[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+    const int lane_off4 = (h * 32 + p) * 4;
+    const int wave = blockIdx.x * 8 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 8;
+    const int count = *a.count_ptr;
+    const int ntiles = (count + 31) >> 5;
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int idx = tile * 32 + p;
+        const bool valid = idx < count;
+        const int ii = valid ? idx : 0;
+        const float occ = a.att_occ[ii], u = a.att_u[ii];
+        // layer 0 (2 -> 64) on the VALU; unit k = 2s + h
+        float h0[32];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const f32x4 t = *(const f32x4*)(lds + A::P_A0 + (2 * s + h) * 4);
+            h0[s] = fmaxf(fmaf(u, t.y, fmaf(occ, t.x, t.z)), 0.f);
+        }
+        // layer 1: 64 -> 128
+        float h1[64];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            f32x16 acc;
+            bias_init(acc, lds + A::P_B1 + 32 * ob, h);
+            mfma_chain<32>(acc, lds + A::P_W1 + ob * 2048, lane_off4, h0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h1[16 * ob + r] = fmaxf(acc[r], 0.f);
+        }
+        // layer 2: 128 -> 128
+        float h2[64];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            f32x16 acc;
+            bias_init(acc, lds + A::P_B2 + 32 * ob, h);
+            mfma_chain<64>(acc, lds + A::P_W2 + ob * 4096, lane_off4, h1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h2[16 * ob + r] = fmaxf(acc[r], 0.f);
+        }
+        // layer 3: 128 -> 64, output 64 -> 2 on the VALU
+        float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+            f32x16 acc;
+            bias_init(acc, lds + A::P_B3 + 32 * ob, h);
+            mfma_chain<64>(acc, lds + A::P_W3 + ob * 4096, lane_off4, h2);
+            const float* w0 = lds + A::P_WO + (h * 2 + 0) * 32 + 16 * ob;
+            const float* w1 = lds + A::P_WO + (h * 2 + 1) * 32 + 16 * ob;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = fmaxf(acc[r], 0.f);
+                l0 = fmaf(v, w0[r], l0);
+                l1 = fmaf(v, w1[r], l1);
+            }
+        }
+        l0 += __shfl_xor(l0, 32); l1 += __shfl_xor(l1, 32);
+        l0 += lds[A::P_BO]; l1 += lds[A::P_BO + 1];
+        // softmax over 2, convex blend (decoder.py:255-258)
+        const float m = fmaxf(l0, l1);
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+        const float den = e0 + e1;
+        const float a0 = e0 / den, a1 = e1 / den;
+        const float fused = a0 * occ + a1 * u;
+        if (valid && h == 0) {
+            const int q = a.list[ii];
+            const bool inb = (a.flags[q] & ADFP_F_INBOUND) != 0;
+            a.raw[4ll * q + 3] = (inb || !a.apply_bound) ? fused : 100.f;   // Renderer.py:64
+            a.w[q] = a1;
+        }
+    }
+}
+
+// =====================================================================================
+// a13: compositing.  One wave per ray, lane = sample (chunks of 64), wave scan for T.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw, const double* __restrict__ z, int n_rays, int S,
+                                                   double* __restrict__ depth, double* __restrict__ var,
+                                                   float* __restrict__ color, float* __restrict__ weights) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    float carry = 1.f;                 // running prod of (1 - alpha + 1e-10) over previous chunks
+    float cr = 0.f, cg = 0.f, cb = 0.f;
+    double sw = 0.0, swz = 0.0, swzz = 0.0;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + lane;
+        const bool ok = s < S;
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        double zz = 0.0;
+        if (ok) { r = *(const f32x4*)(raw + ((long long)ray * S + s) * 4); zz = z[(long long)ray * S + s]; }
+        const float alpha = ok ? sigmoidf_(10.f * r.w) : 0.f;                   // common.py:236
+        float f = ok ? (1.f - alpha + 1e-10f) : 1.f;
+        // inclusive product scan across the wave
+        float incl = f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float v = __shfl_up(incl, o);
+            if (lane >= o) incl *= v;
+        }
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.f;
+        const float T = carry * excl;
+        const float w = alpha * T;                                                // common.py:244
+        carry *= __shfl(incl, 63);
+        if (ok && weights) weights[(long long)ray * S + s] = w;
+        cr = fmaf(w, r.x, cr); cg = fmaf(w, r.y, cg); cb = fmaf(w, r.z, cb);
+        const double wd = (double)w;
+        sw += wd; swz += wd * zz; swzz += wd * zz * zz;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cr += __shfl_xor(cr, o); cg += __shfl_xor(cg, o); cb += __shfl_xor(cb, o);
+        sw += __shfl_xor(sw, o); swz += __shfl_xor(swz, o); swzz += __shfl_xor(swzz, o);
+    }
+    if (lane == 0) {
+        depth[ray] = swz;
+        // sum w (z - d)^2 = sum w z^2 - 2 d sum w z + d^2 sum w        (common.py:248-250)
+        var[ray] = swzz - 2.0 * swz * swz + swz * swz * sw;
+        color[3 * ray + 0] = cr; color[3 * ray + 1] = cg; color[3 * ray + 2] = cb;
+    }
+}
+
+// =====================================================================================
+// host side: C ABI
+// =====================================================================================
+static int g_num_cu = 0;
+static int num_cu() {
+    if (g_num_cu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_num_cu = prop.multiProcessorCount;
+        if (g_num_cu <= 0) g_num_cu = 256;
+    }
+    return g_num_cu;
+}
+
+static NormDev make_norm(const double b[3][2]) {
+    NormDev n;
+    for (int k = 0; k < 3; ++k) { n.lo[k] = b[k][0]; n.inv[k] = 1.0 / (b[k][1] - b[k][0]); }
+    return n;
+}
+static void fill_bound(double out[6], const double b[3][2]) {
+    for (int k = 0; k < 3; ++k) { out[2 * k] = b[k][0]; out[2 * k + 1] = b[k][1]; }
+}
+static GridDev make_grid(const adfp_grid& g) { GridDev d; d.data = g.data; d.Z = g.Z; d.Y = g.Y; d.X = g.X; return d; }
+static TsdfDev make_tsdf(const adfp_tsdf& t) {
+    TsdfDev d; d.data = t.data; d.Z = t.Z; d.Y = t.Y; d.X = t.X; d.sZ = t.sZ; d.sY = t.sY; d.sX = t.sX; return d;
+}
+static int make_pts(const adfp_points* p, PtsDev* d) {
+    if (!p || p->n_points < 0) return ADFP_E_ARG;
+    if (p->n_points > 0x7fffffffll) return ADFP_E_UNSUPPORTED;
+    d->mode = p->mode; d->S = p->S > 0 ? p->S : 1; d->n = (int)p->n_points;
+    d->pts = p->pts; d->ro = p->rays_o; d->rd = p->rays_d; d->z = p->z_vals;
+    if (p->mode == ADFP_PTS_RAYS) { if (!p->rays_o || !p->rays_d || !p->z_vals || p->S <= 0) return ADFP_E_ARG; }
+    else if (p->mode == ADFP_PTS_F64 || p->mode == ADFP_PTS_F32) { if (!p->pts && p->n_points) return ADFP_E_ARG; }
+    else return ADFP_E_ARG;
+    return 0;
+}
+
+// workspace carve-up (all offsets 256-B aligned)
+struct Workspace {
+    double* z; float* raw; unsigned char* flags; int* list; float* att_occ; float* att_u; int* counter;
+    size_t bytes;
+};
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static Workspace carve(void* base, long long P) {
+    Workspace w; size_t o = 0; char* b = (char*)base;
+    w.counter = (int*)(b + o); o += 256;
+    w.z = (double*)(b + o); o += align256((size_t)P * 8);
+    w.raw = (float*)(b + o); o += align256((size_t)P * 16);
+    w.list = (int*)(b + o); o += align256((size_t)P * 4);
+    w.att_occ = (float*)(b + o); o += align256((size_t)P * 4);
+    w.att_u = (float*)(b + o); o += align256((size_t)P * 4);
+    w.flags = (unsigned char*)(b + o); o += align256((size_t)P);
+    w.bytes = o;
+    return w;
+}
+
+extern "C" {
+
+int adfp_version(void) { return ADFP_VERSION; }
+
+long long adfp_decoder_flat_floats(int kind) {
+    switch (kind) {
+        case ADFP_DEC_LOW: return DecLayout<32, 1>::F_TOTAL;
+        case ADFP_DEC_HIGH: return DecLayout<64, 1>::F_TOTAL;
+        case ADFP_DEC_COLOR: return DecLayout<32, 4>::F_TOTAL;
+    }
+    return ADFP_E_ARG;
+}
+long long adfp_decoder_packed_floats(int kind) {
+    switch (kind) {
+        case ADFP_DEC_LOW: return DecLayout<32, 1>::P_TOTAL;
+        case ADFP_DEC_HIGH: return DecLayout<64, 1>::P_TOTAL;
+        case ADFP_DEC_COLOR: return DecLayout<32, 4>::P_TOTAL;
+    }
+    return ADFP_E_ARG;
+}
+long long adfp_attention_flat_floats(void) { return AttLayout::F_TOTAL; }
+long long adfp_attention_packed_floats(void) { return AttLayout::P_TOTAL; }
+
+size_t adfp_workspace_bytes(long long n_points) {
+    if (n_points < 0) return 0;
+    return carve(nullptr, n_points).bytes;
+}
+
+int adfp_relayout_grid(const float* src, float* dst, int C, int Z, int Y, int X, void* stream) {
+    if (!src || !dst || Z <= 0 || Y <= 0 || X <= 0) return ADFP_E_ARG;
+    if (C != 32) return ADFP_E_UNSUPPORTED;
+    const long long V = (long long)Z * Y * X;
+    hipLaunchKernelGGL(k_relayout_cm_to_cl, dim3((unsigned)((V + 63) / 64)), dim3(256), 0, (hipStream_t)stream, src, dst, V);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+int adfp_relayout_grid_back(const float* src, float* dst, int C, int Z, int Y, int X, void* stream) {
+    if (!src || !dst || Z <= 0 || Y <= 0 || X <= 0) return ADFP_E_ARG;
+    if (C != 32) return ADFP_E_UNSUPPORTED;
+    const long long V = (long long)Z * Y * X;
+    hipLaunchKernelGGL(k_relayout_cl_to_cm, dim3((unsigned)((V + 63) / 64)), dim3(256), 0, (hipStream_t)stream, src, dst, V);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
+int adfp_pack_decoder(int kind, const float* flat, float* packed, void* stream) {
+    if (!flat || !packed) return ADFP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (kind) {
+        case ADFP_DEC_LOW:
+            hipLaunchKernelGGL((k_pack_decoder<32, 1>), dim3((DecLayout<32, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, packed);
+            break;
+        case ADFP_DEC_HIGH:
+            hipLaunchKernelGGL((k_pack_decoder<64, 1>), dim3((DecLayout<64, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, packed);
+            break;
+        case ADFP_DEC_COLOR:
+            hipLaunchKernelGGL((k_pack_decoder<32, 4>), dim3((DecLayout<32, 4>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, packed);
+            break;
+        default: return ADFP_E_ARG;
+    }
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+int adfp_pack_attention(const float* flat, float* packed, void* stream) {
+    if (!flat || !packed) return ADFP_E_ARG;
+    hipLaunchKernelGGL(k_pack_attention, dim3((AttLayout::P_TOTAL + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat, packed);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
+int adfp_get_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w, float* rays_o, float* rays_d, void* stream) {
+    if (!c2w || !rays_o || !rays_d || H <= 0 || W <= 0) return ADFP_E_ARG;
+    hipLaunchKernelGGL(k_get_rays, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, H, W, fx, fy, cx, cy, c2w, rays_o, rays_d);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
+int adfp_sample_rays(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double bound[3][2],
+                     int n_samples, int n_surface, int lindisp, float perturb, const float* t_rand, const float* depth_max,
+                     double* z_vals, void* scratch, void* stream) {
+    if (!rays_o || !rays_d || !z_vals || !bound || n_rays < 0 || n_samples <= 0 || n_surface < 0) return ADFP_E_ARG;
+    if (perturb > 0.f && !t_rand) return ADFP_E_ARG;
+    if (n_samples + n_surface > ADFP_MAX_SAMPLES) return ADFP_E_UNSUPPORTED;
+    if (n_rays == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    SampleArgs a;
+    a.ro = rays_o; a.rd = rays_d; a.depth = gt_depth; a.t_rand = perturb > 0.f ? t_rand : nullptr;
+    a.dmax_f = depth_max; a.dmax_ord = nullptr;
+    fill_bound(a.b, bound);
+    a.n_rays = n_rays; a.n_samples = n_samples; a.n_surface = n_surface; a.lindisp = lindisp; a.perturb = perturb; a.z = z_vals;
+    if (gt_depth && !depth_max) {
+        if (!scratch) return ADFP_E_ARG;
+        hipError_t e = hipMemsetAsync(scratch, 0, 16, st);
+        if (e != hipSuccess) return (int)e;
+        int blocks = (n_rays + 255) / 256; if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(k_depth_max, dim3(blocks), dim3(256), 0, st, gt_depth, n_rays, (unsigned*)scratch);
+        ADFP_CHECK_LAUNCH();
+        a.dmax_ord = (const unsigned*)scratch;
+    }
+    hipLaunchKernelGGL(k_sample, dim3((n_rays + 3) / 4), dim3(256), 0, st, a);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
+static int launch_tsdf(const adfp_scene* sc, const PtsDev& P, unsigned char* flags, int* list, float* att_u, float* w,
+                       int* counter, float* tsdf_out, hipStream_t st) {
+    TsdfArgs a;
+    a.P = P; a.nt = make_norm(sc->tsdf_bnds); a.t = make_tsdf(sc->tsdf); fill_bound(a.b, sc->bound);
+    a.flags = flags; a.list = list; a.att_u = att_u; a.w = w; a.counter = counter; a.tsdf_out = tsdf_out;
+    if (P.n == 0) return 0;
+    hipLaunchKernelGGL(k_tsdf, dim3((P.n + TSDF_CHUNK - 1) / TSDF_CHUNK), dim3(256), 0, st, a);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
+int adfp_tsdf_stage(const adfp_scene* scene, const adfp_points* pts, unsigned char* flags, int* list, float* att_u, float* w,
+                    int* counter, void* stream) {
+    if (!scene || !pts || !scene->tsdf.data) return ADFP_E_ARG;
+    if (list && (!att_u || !counter)) return ADFP_E_ARG;
+    PtsDev P; int rc = make_pts(pts, &P); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (counter) { hipError_t e = hipMemsetAsync(counter, 0, 4, st); if (e != hipSuccess) return (int)e; }
+    return launch_tsdf(scene, P, flags, list, att_u, w, counter, nullptr, st);
+}
+
+int adfp_sample_tsdf(const adfp_tsdf* tsdf, const double tsdf_bnds[3][2], const adfp_points* pts, float* out, void* stream) {
+    if (!tsdf || !tsdf->data || !tsdf_bnds || !pts || !out) return ADFP_E_ARG;
+    PtsDev P; int rc = make_pts(pts, &P); if (rc) return rc;
+    adfp_scene sc; memset(&sc, 0, sizeof(sc));
+    sc.tsdf = *tsdf;
+    for (int k = 0; k < 3; ++k) { sc.tsdf_bnds[k][0] = tsdf_bnds[k][0]; sc.tsdf_bnds[k][1] = tsdf_bnds[k][1]; sc.bound[k][0] = 0; sc.bound[k][1] = 1; }
+    return launch_tsdf(&sc, P, nullptr, nullptr, nullptr, nullptr, nullptr, out, (hipStream_t)stream);
+}
+
+static int decode_grid(int ntiles, int waves_per_wg, int wg_per_cu) {
+    int g = (ntiles + waves_per_wg - 1) / waves_per_wg;
+    const int cap = num_cu() * wg_per_cu;
+    if (g > cap) g = cap;
+    return g < 1 ? 1 : g;
+}
+
+static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, int apply_bound, float* raw, float* w, Workspace& ws, hipStream_t st) {
+    if (P.n == 0) return 0;
+    hipError_t e;
+    const bool fuse = stage != ADFP_STAGE_LOW;
+    if (stage != ADFP_STAGE_COLOR) {           // rgb = 0 in stages low/high (decoder.py:317, :323)
+        e = hipMemsetAsync(raw, 0, (size_t)P.n * 16, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (fuse) {
+        e = hipMemsetAsync(ws.counter, 0, 4, st);
+        if (e != hipSuccess) return (int)e;
+        int rc = launch_tsdf(sc, P, ws.flags, ws.list, ws.att_u, w, ws.counter, nullptr, st);
+        if (rc) return rc;
+    }
+    DecodeArgs a;
+    a.P = P; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
+    a.list = nullptr; a.count_ptr = nullptr; a.flags = fuse ? ws.flags : nullptr;
+    a.raw = raw; a.w = w; a.att_occ = nullptr; a.write_w = fuse ? 0 : 1; a.apply_bound = apply_bound;
+    const int ntiles = (P.n + 31) / 32;
+    // LOW on every point
+    a.g0 = make_grid(sc->low); a.g1 = a.g0; a.packed = sc->w_low;
+    hipLaunchKernelGGL((k_decode<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+    ADFP_CHECK_LAUNCH();
+    if (stage == ADFP_STAGE_COLOR) {
+        a.g0 = make_grid(sc->color); a.g1 = a.g0; a.packed = sc->w_color;
+        hipLaunchKernelGGL((k_decode<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+        ADFP_CHECK_LAUNCH();
+    }
+    if (fuse) {
+        a.g0 = make_grid(sc->high); a.g1 = make_grid(sc->low); a.packed = sc->w_high;
+        a.list = ws.list; a.count_ptr = ws.counter; a.att_occ = ws.att_occ;
+        hipLaunchKernelGGL((k_decode<64, 1, ROLE_HIGH, 512>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
+        ADFP_CHECK_LAUNCH();
+        AttArgs t;
+        t.packed = sc->w_att; t.list = ws.list; t.count_ptr = ws.counter; t.att_occ = ws.att_occ; t.att_u = ws.att_u;
+        t.flags = ws.flags; t.raw = raw; t.w = w; t.apply_bound = apply_bound;
+        hipLaunchKernelGGL(k_attention, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
+        ADFP_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+static int check_scene(const adfp_scene* sc, int stage) {
+    if (!sc) return ADFP_E_ARG;
+    if (stage < ADFP_STAGE_LOW || stage > ADFP_STAGE_COLOR) return ADFP_E_ARG;
+    if (!sc->low.data || !sc->w_low) return ADFP_E_ARG;
+    if (stage >= ADFP_STAGE_HIGH && (!sc->high.data || !sc->w_high || !sc->w_att || !sc->tsdf.data)) return ADFP_E_ARG;
+    if (stage == ADFP_STAGE_COLOR && (!sc->color.data || !sc->w_color)) return ADFP_E_ARG;
+    return 0;
+}
+
+int adfp_eval_points(const adfp_scene* scene, const adfp_points* pts, int stage, int flags, float* raw, float* w,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_scene(scene, stage); if (rc) return rc;
+    if (!raw || !w || !workspace) return ADFP_E_ARG;
+    PtsDev P; rc = make_pts(pts, &P); if (rc) return rc;
+    Workspace ws = carve(workspace, P.n);
+    if (workspace_bytes < ws.bytes) return ADFP_E_WORKSPACE;
+    return eval_points_impl(scene, P, stage, (flags & ADFP_EVAL_APPLY_BOUND) ? 1 : 0, raw, w, ws, (hipStream_t)stream);
+}
+
+int adfp_composite(const float* raw, const double* z_vals, int n_rays, int S, double* depth, double* uncertainty, float* color,
+                   float* weights, void* stream) {
+    if (!raw || !z_vals || !depth || !uncertainty || !color || n_rays < 0 || S <= 0) return ADFP_E_ARG;
+    if (n_rays == 0) return 0;
+    hipLaunchKernelGGL(k_composite, dim3((n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, raw, z_vals, n_rays, S, depth,
+                       uncertainty, color, weights);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
+int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void* stream) {
+    if (!r) return ADFP_E_ARG;
+    int rc = check_scene(scene, r->stage); if (rc) return rc;
+    if (!r->rays_o || !r->rays_d || !r->depth || !r->uncertainty || !r->color || !r->weight || !r->workspace) return ADFP_E_ARG;
+    if (r->n_rays < 0 || r->n_samples <= 0 || r->n_surface < 0) return ADFP_E_ARG;
+    const int S = r->n_samples + (r->gt_depth ? r->n_surface : 0);
+    if (S > ADFP_MAX_SAMPLES) return ADFP_E_UNSUPPORTED;
+    const long long Pn = (long long)r->n_rays * S;
+    if (Pn > 0x7fffffffll) return ADFP_E_UNSUPPORTED;
+    Workspace ws = carve(r->workspace, Pn);
+    if (r->workspace_bytes < ws.bytes) return ADFP_E_WORKSPACE;
+    if (r->n_rays == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    double* z = r->z_vals ? r->z_vals : ws.z;
+    float* raw = r->raw ? r->raw : ws.raw;
+    rc = adfp_sample_rays(r->rays_o, r->rays_d, r->gt_depth, r->n_rays, scene->bound, r->n_samples, r->n_surface, r->lindisp,
+                          r->perturb, r->t_rand, r->depth_max, z, (char*)ws.counter + 64, stream);
+    if (rc) return rc;
+    PtsDev P;
+    P.mode = ADFP_PTS_RAYS; P.S = S; P.n = (int)Pn; P.pts = nullptr; P.ro = r->rays_o; P.rd = r->rays_d; P.z = z;
+    rc = eval_points_impl(scene, P, r->stage, 1, raw, r->weight, ws, st);
+    if (rc) return rc;
+    return adfp_composite(raw, z, r->n_rays, S, r->depth, r->uncertainty, r->color, nullptr, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,199 @@
+"""
+Drop-in for the reference's ``src/conv_onet/models/decoder.py``: the same nn.Module tree
+(``DF`` -> ``low_decoder`` / ``high_decoder`` / ``color_decoder`` : ``MLP``, ``mlp`` : ``mlp_tsdf``)
+with the same parameter names (``fc_c.{i}``, ``embedder._B``, ``pts_linears.{i}``,
+``output_linear``), so ``state_dict`` / ``load_state_dict`` / ``deepcopy`` / ``share_memory`` /
+``.parameters()`` behave as src/DF_Prior.py:191-218, src/Mapper.py:364-371, src/Tracker.py:144
+and src/utils/Logger.py:26 expect -- but ``DF.forward`` runs on the MI355X through libadfp.so.
+
+The modules only OWN parameters; all arithmetic happens in the HIP kernels.  There is no
+PyTorch fallback: calling ``DF`` on CPU tensors raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import lib
+
+
+class GaussianFourierFeatureTransform(nn.Module):
+    """Owner of the [3, 93] Gaussian projection ``_B`` (reference decoder.py:7-30)."""
+
+    def __init__(self, num_input_channels, mapping_size=93, scale=25, learnable=True):
+        super().__init__()
+        b = torch.randn((num_input_channels, mapping_size)) * scale
+        if learnable:
+            self._B = nn.Parameter(b)
+        else:
+            self._B = b
+
+
+class DenseLayer(nn.Linear):
+    """nn.Linear with xavier-uniform(gain(activation)) weights and zero bias (decoder.py:68-77)."""
+
+    def __init__(self, in_dim, out_dim, activation='relu', *args, **kwargs):
+        self.activation = activation
+        super().__init__(in_dim, out_dim, *args, **kwargs)
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.weight, gain=nn.init.calculate_gain(self.activation))
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+
+class MLP(nn.Module):
+    """Parameter container of one conv_onet decoder (reference decoder.py:91-166).
+
+    Fourier-93 -> 5 x 32 ReLU layers with per-layer feature injection ``fc_c`` and a skip
+    concat after layer 2.  Only ``pos_embedding_method='fourier'`` (configs/df_prior.yaml:103)
+    is implemented by the kernels.
+    """
+
+    def __init__(self, name='', dim=3, c_dim=128, hidden_size=256, n_blocks=5, leaky=False,
+                 sample_mode='bilinear', color=False, skips=[2], grid_len=0.16,
+                 pos_embedding_method='fourier', concat_feature=False):
+        super().__init__()
+        if pos_embedding_method != 'fourier':
+            raise NotImplementedError("libadfp implements pos_embedding_method='fourier' only")
+        if hidden_size != 32 or n_blocks != 5 or list(skips) != [2] or dim != 3:
+            raise NotImplementedError('libadfp implements the hidden=32, 5-block, skips=[2] decoder only')
+        self.name = name
+        self.color = color
+        self.no_grad_feature = False
+        self.c_dim = c_dim
+        self.grid_len = grid_len
+        self.concat_feature = concat_feature
+        self.n_blocks = n_blocks
+        self.skips = skips
+        self.sample_mode = sample_mode
+        self.fc_c = nn.ModuleList([nn.Linear(c_dim, hidden_size) for _ in range(n_blocks)])
+        emb = 93
+        self.embedder = GaussianFourierFeatureTransform(dim, mapping_size=emb, scale=25)
+        layers = [DenseLayer(emb, hidden_size, activation='relu')]
+        for i in range(n_blocks - 1):
+            fan_in = hidden_size + emb if i in skips else hidden_size
+            layers.append(DenseLayer(fan_in, hidden_size, activation='relu'))
+        self.pts_linears = nn.ModuleList(layers)
+        self.output_linear = DenseLayer(hidden_size, 4 if color else 1, activation='linear')
+
+    def forward(self, p, c_grid=None):
+        raise NotImplementedError('the decoders are evaluated fused inside DF.forward (libadfp.so); '
+                                  'call the DF module')
+
+
+class mlp_tsdf(nn.Module):
+    """Parameter container of the attention fusion MLP 2->64->128->128->64->2 (decoder.py:206-228)."""
+
+    def __init__(self):
+        super().__init__()
+        self.no_grad_feature = False
+        self.sample_mode = 'bilinear'
+        self.pts_linears = nn.ModuleList([DenseLayer(2, 64, activation='relu'),
+                                          DenseLayer(64, 128, activation='relu'),
+                                          DenseLayer(128, 128, activation='relu'),
+                                          DenseLayer(128, 64, activation='relu')])
+        self.output_linear = DenseLayer(64, 2, activation='linear')
+        self.softmax = nn.Softmax(dim=1)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, *a, **k):
+        raise NotImplementedError('mlp_tsdf is evaluated fused inside DF.forward (libadfp.so)')
+
+
+def _flat_params(module):
+    return torch.cat([p.detach().reshape(-1).float() for p in module.parameters()])
+
+
+def _version_key(module):
+    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+
+
+class DF(nn.Module):
+    """Drop-in for the reference's ``DF`` (decoder.py:262-353).
+
+    ``decoders(p[1,P,3], c_grid=dict, tsdf_volume=, tsdf_bnds=, stage=)`` -> ``(raw[P,4], w[P])``
+    exactly as src/utils/Renderer.py:57 and src/utils/Mesher.py:315 call it.  NOTE: like the
+    reference's DF.forward this returns the decoder output WITHOUT the out-of-bound rule
+    (``ret[~mask,3] = 100`` is applied by the callers, Renderer.py:64 / Mesher.py:322).
+    """
+
+    def __init__(self, dim=3, c_dim=32, low_grid_len=0.16, high_grid_len=0.16, color_grid_len=0.16,
+                 hidden_size=32, pos_embedding_method='fourier'):
+        super().__init__()
+        if c_dim != 32:
+            raise NotImplementedError('libadfp implements c_dim=32 only (configs/df_prior.yaml:102)')
+        self.low_decoder = MLP(name='low', dim=dim, c_dim=c_dim, color=False, skips=[2], n_blocks=5,
+                               hidden_size=hidden_size, grid_len=low_grid_len,
+                               pos_embedding_method=pos_embedding_method)
+        self.high_decoder = MLP(name='high', dim=dim, c_dim=c_dim * 2, color=False, skips=[2], n_blocks=5,
+                                hidden_size=hidden_size, grid_len=high_grid_len, concat_feature=True,
+                                pos_embedding_method=pos_embedding_method)
+        self.color_decoder = MLP(name='color', dim=dim, c_dim=c_dim, color=True, skips=[2], n_blocks=5,
+                                 hidden_size=hidden_size, grid_len=color_grid_len,
+                                 pos_embedding_method=pos_embedding_method)
+        self.mlp = mlp_tsdf()
+        self._packed = {}       # name -> (version key, packed tensor)
+        self._engine = None
+
+    # ---- weight images for the kernels -------------------------------------------------
+    def packed_weights(self, name):
+        """Packed (MFMA operand order) image of one sub-network, rebuilt only when a parameter
+        changed (optimizer step bumps Parameter._version)."""
+        module = {'low': self.low_decoder, 'high': self.high_decoder, 'color': self.color_decoder,
+                  'att': self.mlp}[name]
+        key = _version_key(module)
+        hit = self._packed.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        flat = _flat_params(module)
+        _lib.require_cuda(flat, f'{name} decoder parameters')
+        L = lib()
+        dev = flat.device
+        with torch.cuda.device(dev):
+            stream = _lib.current_stream(dev)
+            if name == 'att':
+                assert flat.numel() == L.adfp_attention_flat_floats()
+                packed = torch.empty(L.adfp_attention_packed_floats(), dtype=torch.float32, device=dev)
+                _lib.check(L.adfp_pack_attention(_lib.ptr(flat), _lib.ptr(packed), stream), 'adfp_pack_attention')
+            else:
+                kind = _lib.DEC_KIND[name]
+                assert flat.numel() == L.adfp_decoder_flat_floats(kind)
+                packed = torch.empty(L.adfp_decoder_packed_floats(kind), dtype=torch.float32, device=dev)
+                _lib.check(L.adfp_pack_decoder(kind, _lib.ptr(flat), _lib.ptr(packed), stream), 'adfp_pack_decoder')
+        self._packed[name] = (key, packed)
+        return packed
+
+    def __deepcopy__(self, memo):
+        # src/Tracker.py:144 deep-copies the shared decoders; caches must not be shared
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k in ('_packed', '_engine'):
+                continue
+            setattr(new, k, copy.deepcopy(v, memo))
+        new._packed = {}
+        new._engine = None
+        return new
+
+    def __getstate__(self):
+        # torch.multiprocessing spawn pickles the module (src/DF_Prior.py:302-311)
+        d = self.__dict__.copy()
+        d['_packed'] = {}
+        d['_engine'] = None
+        return d
+
+    def forward(self, p, c_grid, tsdf_volume, tsdf_bnds, stage='low', **kwargs):
+        from .engine import Engine
+        if self._engine is None:
+            self._engine = Engine()
+        bound = getattr(self, 'bound', None)
+        if bound is None:
+            raise RuntimeError('DF.bound is not set (src/DF_Prior.py:191 assigns it in load_bound)')
+        pts = p.reshape(-1, 3)
+        raw, w = self._engine.eval_points(self, pts, c_grid, tsdf_volume, tsdf_bnds, bound, stage,
+                                          apply_bound_rule=False)
+        return raw, w

@@ -1,0 +1,91 @@
+"""
+Ray sharding over the GPUs of one node (new functionality: the reference has no distributed
+code at all).  One process per GPU, torch.distributed with backend "nccl"
+(= RCCL over xGMI on ROCm); the same code runs under "gloo" for the CPU tests.
+
+Rays are independent units of the path, so the data path needs NO collective.  The only
+batch-global quantity is max(gt_depth) in the far clamp and in the zero-depth surface range
+(reference src/utils/Renderer.py:159, :195): it is all-reduced (MAX, one float) BEFORE sharding and
+handed to the kernels (adfp_render_args.depth_max) so that a sharded render reproduces the
+single-GPU result bit for bit.  Outputs are all-gathered (20 B/ray).  Training adds one
+flat-bucket all-reduce (SUM) of the loss gradients per iteration; because the Mapper losses are
+plain sums (src/Mapper.py:457-469) the summed shard gradients equal the single-GPU gradient
+(up to fp32 summation order) with no rescaling.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, rank, world):
+    """Contiguous slice [lo, hi) of n units owned by `rank` (sizes differ by at most one)."""
+    lo = (n * rank) // world
+    hi = (n * (rank + 1)) // world
+    return lo, hi
+
+
+def global_depth_max(gt_depth, group=None):
+    """max(gt_depth) over every rank's rays, as a 1-element float32 tensor on gt_depth's device."""
+    m = gt_depth.detach().reshape(-1).float().max().reshape(1) if gt_depth.numel() else \
+        torch.full((1,), float('-inf'), device=gt_depth.device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+    return m
+
+
+def _all_gather_rows(x, sizes, group):
+    """all-gather tensors whose first dim differs per rank (sizes[r] rows on rank r)."""
+    world = len(sizes)
+    pad = max(sizes)
+    buf = torch.zeros((pad,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    buf[:x.shape[0]] = x
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
+
+
+def render_rays_sharded(render_fn, rays_o, rays_d, gt_depth, group=None, gather=True):
+    """Every rank holds the full ray batch; rank r renders rays shard_range(N, r, world) with the
+    full-batch depth max and (optionally) all-gathers the outputs.
+
+    render_fn(rays_o, rays_d, gt_depth, depth_max) -> tuple of tensors with leading dim = #rays
+    (e.g. lambda o, d, z, m: renderer.render_batch_ray(c, dec, d, o, dev, tsdf, bnds, stage, z, depth_max=m)).
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = rays_o.shape[0]
+    lo, hi = shard_range(n, rank, world)
+    dmax = None
+    if gt_depth is not None:
+        # every rank already holds the full depth vector, so the max needs no communication;
+        # global_depth_max() is for callers that hold only their own shard
+        dmax = gt_depth.detach().reshape(-1).float().max().reshape(1)
+    outs = render_fn(rays_o[lo:hi], rays_d[lo:hi], None if gt_depth is None else gt_depth.reshape(-1)[lo:hi], dmax)
+    if not gather or world == 1:
+        return outs
+    sizes = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+    return tuple(_all_gather_rows(o.contiguous(), sizes, group) for o in outs)
+
+
+def allreduce_grads(tensors, group=None):
+    """One flat-bucket all-reduce (SUM, fp32) of the gradients of `tensors` (parameters or grids).
+    Tensors without a gradient contribute zeros so that every rank issues the same collective."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    tensors = [t for t in tensors if t.requires_grad]
+    if not tensors:
+        return
+    flats = []
+    for t in tensors:
+        g = t.grad if t.grad is not None else torch.zeros_like(t)
+        flats.append(g.reshape(-1).float())
+    bucket = torch.cat(flats)
+    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        g = bucket[off:off + n].reshape(t.shape).to(t.dtype)
+        if t.grad is None:
+            t.grad = g.clone()
+        else:
+            t.grad.copy_(g)
+        off += n

@@ -1,0 +1,222 @@
+"""
+Host-side plumbing between the reference-shaped Python objects (Renderer / DF) and the C ABI of
+libadfp.so: builds the ``adfp_scene`` descriptor from PyTorch tensors, owns the scratch
+workspace, and caches the two per-call conversions the kernels need
+
+  * feature grids  [1,32,Z,Y,X] (src/DF_Prior.py:243-264)  ->  channels-last [Z,Y,X,32]
+  * decoder parameters -> packed MFMA images (decoder.DF.packed_weights)
+
+keyed on ``(data_ptr, _version, shape)`` because the Mapper re-materialises the grids every
+iteration (src/Mapper.py:382-388) and the Tracker reads them from another process.
+
+PyTorch here is device memory + streams only; no arithmetic of the hot path runs in torch.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import lib, ptr, check
+
+
+def _host_bound(t):
+    """[3,2] tensor (any device) -> nested python floats (one device sync if on GPU)."""
+    return [[float(v) for v in row] for row in t.detach().to('cpu', torch.float64).tolist()]
+
+
+class Engine(object):
+    def __init__(self):
+        self._ws = None
+        self._grid_cache = {}    # key name -> (key, channels-last tensor)
+        self._bound_cache = {}   # id -> (key, host list)
+
+    # ---- caches --------------------------------------------------------------------------
+    def workspace(self, n_points, device):
+        need = lib().adfp_workspace_bytes(int(n_points))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(int(need * 1.25) + 1024, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def host_bound(self, t, slot):
+        key = (t.data_ptr(), t._version, str(t.device))
+        hit = self._bound_cache.get(slot)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        val = _host_bound(t)
+        self._bound_cache[slot] = (key, val)
+        return val
+
+    def grid_cl(self, name, g):
+        """channels-last copy of a [1,32,Z,Y,X] grid, converted by adfp_relayout_grid."""
+        _lib.require_cuda(g, name)
+        if g.dim() != 5 or g.shape[0] != 1 or g.shape[1] != 32:
+            raise RuntimeError(f'{name}: expected [1,32,Z,Y,X], got {tuple(g.shape)}')
+        key = (g.data_ptr(), g._version, tuple(g.shape), tuple(g.stride()))
+        hit = self._grid_cache.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        src = g.detach()
+        if src.dtype != torch.float32:
+            src = src.float()
+        src = src.contiguous()
+        Z, Y, X = src.shape[2:]
+        if hit is not None and hit[1].shape == (Z, Y, X, 32) and hit[1].device == src.device:
+            dst = hit[1]
+        else:
+            dst = torch.empty((Z, Y, X, 32), dtype=torch.float32, device=src.device)
+        check(lib().adfp_relayout_grid(ptr(src), ptr(dst), 32, Z, Y, X, _lib.current_stream(src.device)),
+              'adfp_relayout_grid')
+        self._grid_cache[name] = (key, dst)
+        return dst
+
+    # ---- descriptor ----------------------------------------------------------------------
+    def scene(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage):
+        """Returns (AdfpScene, keepalive list)."""
+        sc = _lib.AdfpScene()
+        keep = []
+        _lib.fill_bound(sc.bound, self.host_bound(bound, 'bound'))
+        grids = [('low', 'grid_low')]
+        if stage != 'low':
+            grids.append(('high', 'grid_high'))
+        if stage == 'color':
+            grids.append(('color', 'grid_color'))
+        for field, key in grids:
+            g = self.grid_cl(key, c[key])
+            keep.append(g)
+            gd = getattr(sc, field)
+            gd.data = g.data_ptr()
+            gd.Z, gd.Y, gd.X = g.shape[0], g.shape[1], g.shape[2]
+        sc.w_low = decoders.packed_weights('low').data_ptr()
+        if stage != 'low':
+            sc.w_high = decoders.packed_weights('high').data_ptr()
+            sc.w_att = decoders.packed_weights('att').data_ptr()
+            _lib.fill_bound(sc.tsdf_bnds, self.host_bound(tsdf_bnds, 'tsdf_bnds'))
+            self.fill_tsdf(sc.tsdf, tsdf_volume, keep)
+        if stage == 'color':
+            sc.w_color = decoders.packed_weights('color').data_ptr()
+        return sc, keep
+
+    @staticmethod
+    def fill_tsdf(td, tsdf_volume, keep):
+        _lib.require_cuda(tsdf_volume, 'tsdf_volume')
+        t = tsdf_volume
+        if t.dtype != torch.float32:
+            t = t.float()
+            keep.append(t)
+        if t.dim() != 5 or t.shape[0] != 1 or t.shape[1] != 1:
+            raise RuntimeError(f'tsdf_volume: expected [1,1,Z,Y,X], got {tuple(t.shape)}')
+        td.data = t.data_ptr()
+        td.Z, td.Y, td.X = t.shape[2], t.shape[3], t.shape[4]
+        td.sZ, td.sY, td.sX = t.stride(2), t.stride(3), t.stride(4)
+
+    # ---- a5..a12 ---------------------------------------------------------------------------
+    def eval_points(self, decoders, pts, c, tsdf_volume, tsdf_bnds, bound, stage, apply_bound_rule=True):
+        """pts [P,3] f64/f32 on the GPU -> raw [P,4] f32, w [P] f32."""
+        _lib.require_cuda(pts, 'points')
+        if torch.is_grad_enabled() and (pts.requires_grad or any(v.requires_grad for v in c.values())
+                                         or any(p.requires_grad for p in decoders.parameters())):
+            # point-wise queries are inference-only in the reference too (Mesher under no_grad,
+            # src/utils/Mesher.py:437-447); training goes through Renderer.render_batch_ray
+            pass
+        dev = pts.device
+        with torch.cuda.device(dev):
+            if pts.dtype == torch.float64:
+                mode = _lib.PTS_F64
+            else:
+                mode = _lib.PTS_F32
+                if pts.dtype != torch.float32:
+                    pts = pts.float()
+            pts = pts.detach().contiguous()
+            P = pts.shape[0]
+            raw = torch.empty((P, 4), dtype=torch.float32, device=dev)
+            w = torch.empty((P,), dtype=torch.float32, device=dev)
+            if P == 0:
+                return raw, w
+            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage)
+            ap = _lib.AdfpPoints()
+            ap.mode = mode
+            ap.n_points = P
+            ap.pts = pts.data_ptr()
+            ws = self.workspace(P, dev)
+            check(lib().adfp_eval_points(C.byref(sc), C.byref(ap), _lib.STAGE[stage], 1 if apply_bound_rule else 0,
+                                         ptr(raw), ptr(w), ptr(ws), ws.numel(), _lib.current_stream(dev)),
+                  'adfp_eval_points')
+        return raw, w
+
+    def sample_tsdf(self, pts, tsdf_volume, tsdf_bnds):
+        _lib.require_cuda(pts, 'points')
+        dev = pts.device
+        with torch.cuda.device(dev):
+            mode = _lib.PTS_F64 if pts.dtype == torch.float64 else _lib.PTS_F32
+            if mode == _lib.PTS_F32 and pts.dtype != torch.float32:
+                pts = pts.float()
+            pts = pts.detach().reshape(-1, 3).contiguous()
+            P = pts.shape[0]
+            out = torch.empty((P,), dtype=torch.float32, device=dev)
+            if P == 0:
+                return out
+            td = _lib.AdfpTsdf()
+            keep = []
+            self.fill_tsdf(td, tsdf_volume, keep)
+            b = _lib.Bound()
+            _lib.fill_bound(b, self.host_bound(tsdf_bnds, 'tsdf_bnds'))
+            ap = _lib.AdfpPoints()
+            ap.mode = mode
+            ap.n_points = P
+            ap.pts = pts.data_ptr()
+            check(lib().adfp_sample_tsdf(C.byref(td), C.byref(b), C.byref(ap), ptr(out), _lib.current_stream(dev)),
+                  'adfp_sample_tsdf')
+        return out
+
+    # ---- a4..a13 ---------------------------------------------------------------------------
+    def render_forward(self, decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage,
+                       n_samples, n_surface, lindisp=False, perturb=0.0, t_rand=None, depth_max=None,
+                       want_aux=False):
+        _lib.require_cuda(rays_o, 'rays_o')
+        dev = rays_o.device
+        with torch.cuda.device(dev):
+            ro = rays_o.detach().float().contiguous()
+            rd = rays_d.detach().float().contiguous()
+            N = ro.shape[0]
+            gd = None
+            if gt_depth is not None:
+                gd = gt_depth.detach().reshape(-1).float().contiguous()
+            S = n_samples + (n_surface if gd is not None else 0)
+            depth = torch.empty((N,), dtype=torch.float64, device=dev)
+            unc = torch.empty((N,), dtype=torch.float64, device=dev)
+            color = torch.empty((N, 3), dtype=torch.float32, device=dev)
+            weight = torch.empty((N, S, 1), dtype=torch.float32, device=dev)
+            aux = None
+            if N == 0:
+                return depth, unc, color, weight, aux
+            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage)
+            a = _lib.AdfpRenderArgs()
+            a.stage = _lib.STAGE[stage]
+            a.n_rays = N
+            a.n_samples = n_samples
+            a.n_surface = n_surface
+            a.lindisp = 1 if lindisp else 0
+            a.perturb = float(perturb)
+            a.rays_o = ro.data_ptr()
+            a.rays_d = rd.data_ptr()
+            a.gt_depth = gd.data_ptr() if gd is not None else None
+            if perturb > 0:
+                t_rand = t_rand.to(dev, torch.float32).contiguous()
+                a.t_rand = t_rand.data_ptr()
+            if depth_max is not None:
+                depth_max = depth_max.to(dev, torch.float32).reshape(1).contiguous()
+                a.depth_max = depth_max.data_ptr()
+            a.depth = depth.data_ptr()
+            a.uncertainty = unc.data_ptr()
+            a.color = color.data_ptr()
+            a.weight = weight.data_ptr()
+            if want_aux:
+                aux = {'z_vals': torch.empty((N, S), dtype=torch.float64, device=dev),
+                       'raw': torch.empty((N, S, 4), dtype=torch.float32, device=dev)}
+                a.z_vals = aux['z_vals'].data_ptr()
+                a.raw = aux['raw'].data_ptr()
+            ws = self.workspace(N * S, dev)
+            a.workspace = ws.data_ptr()
+            a.workspace_bytes = ws.numel()
+            check(lib().adfp_render_forward(C.byref(sc), C.byref(a), _lib.current_stream(dev)), 'adfp_render_forward')
+        return depth, unc, color, weight, aux

@@ -1,0 +1,108 @@
+"""
+Drop-in for the reference's ``src/utils/Renderer.py``: same constructor, same methods, same
+argument order (note ``render_batch_ray(c, decoders, rays_d, rays_o, ...)`` takes d BEFORE o),
+same return dtypes -- implemented on the MI355X by libadfp.so.
+
+  Renderer(cfg, args, slam, points_batch_size=500000, ray_batch_size=100000)   Renderer.py:7-25
+  eval_points(p, decoders, tsdf_volume, tsdf_bnds, c, stage, device)            Renderer.py:27-71
+  sample_grid_tsdf / eval_points_tsdf                                          Renderer.py:73-107
+  render_batch_ray(c, decoders, rays_d, rays_o, device, tsdf_volume, tsdf_bnds,
+                   stage, gt_depth) -> (depth f64, uncertainty f64, color, weight[N,S,1])
+                                                                                Renderer.py:110-255
+  render_img(c, decoders, c2w, device, tsdf_volume, tsdf_bnds, stage, gt_depth)  Renderer.py:258-327
+"""
+import torch
+
+from . import _lib
+from .common import get_rays
+from .engine import Engine
+
+
+class Renderer(object):
+    def __init__(self, cfg, args, slam, points_batch_size=500000, ray_batch_size=100000):
+        self.ray_batch_size = ray_batch_size
+        self.points_batch_size = points_batch_size      # kept for API parity; the kernels do not chunk
+        r = cfg['rendering']
+        self.lindisp = r['lindisp']
+        self.perturb = r['perturb']
+        self.N_samples = r['N_samples']
+        self.N_surface = r['N_surface']
+        self.N_importance = r['N_importance']
+        self.scale = cfg['scale']
+        self.occupancy = cfg['occupancy']
+        self.bound = slam.bound
+        self.sample_mode = 'bilinear'
+        self.tsdf_bnds = slam.vol_bnds
+        self.H, self.W, self.fx, self.fy, self.cx, self.cy = slam.H, slam.W, slam.fx, slam.fy, slam.cx, slam.cy
+        self.resolution = cfg['meshing']['resolution']
+        if self.N_importance > 0:
+            raise NotImplementedError('N_importance > 0 is dead (and broken) in the reference '
+                                      '(configs/df_prior.yaml:96, Renderer.py:235-252); not supported')
+        if not self.occupancy:
+            raise NotImplementedError('occupancy=False (density compositing) is not used by the reference '
+                                      'configs (configs/df_prior.yaml:4); not supported')
+        self._engine = Engine()
+
+    # ---- point queries --------------------------------------------------------------------
+    def eval_points(self, p, decoders, tsdf_volume, tsdf_bnds, c=None, stage='color', device='cuda:0'):
+        """raw [P,4] (rgb, occ; occ = 100 outside ``self.bound``) and attention weight [P]."""
+        return self._engine.eval_points(decoders, p, c, tsdf_volume, tsdf_bnds, self.bound, stage,
+                                        apply_bound_rule=True)
+
+    def sample_grid_tsdf(self, p, tsdf_volume, device='cuda:0'):
+        """Trilinear TSDF lookup of p [..., P, 3] -> [1, P] (Renderer.py:73-81)."""
+        return self._engine.sample_tsdf(p, tsdf_volume, self.tsdf_bnds).reshape(1, -1)
+
+    def eval_points_tsdf(self, p, tsdf_volume, device='cuda:0'):
+        """TSDF value of every point of p [P,3] -> [1, P] (Renderer.py:84-107)."""
+        return self.sample_grid_tsdf(p, tsdf_volume, device)
+
+    # ---- rays -----------------------------------------------------------------------------
+    def render_batch_ray(self, c, decoders, rays_d, rays_o, device, tsdf_volume, tsdf_bnds, stage, gt_depth=None,
+                         depth_max=None):
+        """Render depth / uncertainty / colour / attention weight of a batch of rays.
+
+        ``depth_max`` (not in the reference) lets a ray shard use the max sensor depth of the full
+        batch so that sharded renders reproduce the unsharded far clamp (Renderer.py:159, :195)."""
+        _lib.require_cuda(rays_o, 'rays_o')
+        N = rays_o.shape[0]
+        t_rand = None
+        if self.perturb > 0.:
+            t_rand = torch.rand(N, self.N_samples)                        # CPU generator, as Renderer.py:216
+        needs_grad = torch.is_grad_enabled() and (
+            any(v.requires_grad for v in c.values()) or any(p.requires_grad for p in decoders.parameters())
+            or rays_o.requires_grad or rays_d.requires_grad)
+        if needs_grad:
+            from .autograd import render_with_grad
+            return render_with_grad(self._engine, decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds,
+                                    self.bound, stage, self.N_samples, self.N_surface, self.lindisp, self.perturb,
+                                    t_rand, depth_max)
+        depth, unc, color, weight, _ = self._engine.render_forward(
+            decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, self.bound, stage,
+            self.N_samples, self.N_surface, self.lindisp, self.perturb, t_rand, depth_max)
+        return depth, unc, color, weight
+
+    def render_img(self, c, decoders, c2w, device, tsdf_volume, tsdf_bnds, stage, gt_depth=None):
+        """Full-frame render under no_grad in ``ray_batch_size`` batches -> depth [H,W] f64,
+        uncertainty [H,W] f64, color [H,W,3] f32.  Each batch clamps ``far`` with ITS OWN max
+        depth, exactly like the reference's loop (Renderer.py:294-313)."""
+        with torch.no_grad():
+            H, W = self.H, self.W
+            rays_o, rays_d = get_rays(H, W, self.fx, self.fy, self.cx, self.cy, c2w, device)
+            rays_o = rays_o.reshape(-1, 3)
+            rays_d = rays_d.reshape(-1, 3)
+            if gt_depth is not None:
+                gt_depth = gt_depth.reshape(-1)
+            ds, us, cs = [], [], []
+            for i in range(0, rays_d.shape[0], self.ray_batch_size):
+                sl = slice(i, i + self.ray_batch_size)
+                d, u, col, _ = self.render_batch_ray(c, decoders, rays_d[sl], rays_o[sl], device, tsdf_volume,
+                                                     tsdf_bnds, stage,
+                                                     gt_depth=None if gt_depth is None else gt_depth[sl])
+                ds.append(d.double())
+                us.append(u.double())
+                cs.append(col)
+            depth = torch.cat(ds, dim=0).reshape(H, W)
+            uncertainty = torch.cat(us, dim=0).reshape(H, W)
+            color = torch.cat(cs, dim=0).reshape(H, W, 3)
+            return depth, uncertainty, color

@@ -1,0 +1,177 @@
+/*
+ * adfp.h -- C ABI of libadfp.so: the MI355X (gfx950) implementation of the per-ray
+ * volume-rendering hot path of MachinePerceptionLab/Attentive_DFPrior.
+ *
+ * The reference offers no C ABI, plugin or operator registry for this path; its boundary
+ * is two Python objects (src/DF_Prior.py:50-51 `shared_decoders`, :111 `renderer`).  The
+ * entry points below are what a ctypes binding under those two objects calls; each cites the
+ * reference function it replaces.  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer owned by the caller (PyTorch) unless it says "host".
+ *    The library never allocates, frees or retains device memory.
+ *  - All work is enqueued asynchronously on `stream` (a hipStream_t passed as void*).
+ *  - Return value: 0 = ok; <0 = argument error detected on the host (ADFP_E_*);
+ *    >0 = hipError_t of a failed launch.  No exception crosses the ABI.
+ *  - Feature grids are consumed channels-last ([Z][Y][X][32] fp32; one voxel = one 128-B
+ *    line); adfp_relayout_grid converts from the reference's [1,32,Z,Y,X] layout
+ *    (src/DF_Prior.py:243-264).  The TSDF is consumed in place through element strides, so the
+ *    permuted view of get_tsdf.py:95-97 needs no copy.
+ *  - Decoder weights are consumed as "packed images" (MFMA operand order)
+ *    produced by adfp_pack_decoder / adfp_pack_attention from a flat fp32 buffer that is the
+ *    concatenation of the module's parameters in state_dict order (decoder.py:110-166,
+ *    :212-228).
+ */
+#ifndef ADFP_H
+#define ADFP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADFP_VERSION 100
+
+/* error codes (host-detected) */
+#define ADFP_E_ARG        (-1)   /* null pointer / negative size */
+#define ADFP_E_UNSUPPORTED (-2)  /* N_importance>0, occupancy=False, S too large ... */
+#define ADFP_E_WORKSPACE  (-3)   /* workspace too small */
+
+/* stage enum: DF.forward(stage=...) decoder.py:307 */
+#define ADFP_STAGE_LOW   0
+#define ADFP_STAGE_HIGH  1
+#define ADFP_STAGE_COLOR 2
+
+/* decoder kinds for packing */
+#define ADFP_DEC_LOW   0   /* MLP(name='low',  c_dim=32, color=False) decoder.py:276 */
+#define ADFP_DEC_HIGH  1   /* MLP(name='high', c_dim=64, concat_feature) decoder.py:279 */
+#define ADFP_DEC_COLOR 2   /* MLP(name='color',c_dim=32, color=True) decoder.py:282 */
+
+/* point source modes for adfp_eval_points */
+#define ADFP_PTS_RAYS 0    /* p = rays_o[r] + rays_d[r] * z_vals[r][s]  (Renderer.py:223) */
+#define ADFP_PTS_F64  1    /* explicit [P,3] float64 */
+#define ADFP_PTS_F32  2    /* explicit [P,3] float32 */
+
+#define ADFP_MAX_SAMPLES 256
+
+typedef struct adfp_grid {
+    const float* data;      /* channels-last [Z][Y][X][32] */
+    int Z, Y, X;
+} adfp_grid;
+
+typedef struct adfp_tsdf {
+    const float* data;      /* element (z,y,x) at data[z*sZ + y*sY + x*sX] */
+    int Z, Y, X;
+    long long sZ, sY, sX;   /* element strides (the reference's view has sZ=1) */
+} adfp_tsdf;
+
+/* Everything DF.forward reads besides the points: decoder.py:307-353. */
+typedef struct adfp_scene {
+    double bound[3][2];       /* Renderer.bound / MLP.bound   (src/DF_Prior.py:177-194), f64 */
+    double tsdf_bnds[3][2];   /* tsdf_bnds                    (src/DF_Prior.py:86-91),   f64 */
+    adfp_grid low, high, color;
+    adfp_tsdf tsdf;
+    const float* w_low;       /* packed images (adfp_pack_decoder / adfp_pack_attention) */
+    const float* w_high;
+    const float* w_color;
+    const float* w_att;
+} adfp_scene;
+
+typedef struct adfp_points {
+    int mode;                 /* ADFP_PTS_* */
+    long long n_points;       /* P (= n_rays * S in ray mode) */
+    const void* pts;          /* [P,3] f64 or f32 (explicit modes) */
+    const float* rays_o;      /* [N,3] (ray mode) */
+    const float* rays_d;      /* [N,3] */
+    const double* z_vals;     /* [N,S] */
+    int S;
+} adfp_points;
+
+/* ---- info ------------------------------------------------------------------------- */
+int adfp_version(void);
+/* number of floats of the flat parameter buffer / of the packed image for a decoder kind */
+long long adfp_decoder_flat_floats(int kind);
+long long adfp_decoder_packed_floats(int kind);
+long long adfp_attention_flat_floats(void);
+long long adfp_attention_packed_floats(void);
+/* bytes of scratch adfp_render_forward / adfp_eval_points need for P points */
+size_t adfp_workspace_bytes(long long n_points);
+
+/* ---- layout conversion -------------------------------------------------------------- */
+/* [1,32,Z,Y,X] -> [Z,Y,X,32]  (and back, for gradients).  C must be 32. */
+int adfp_relayout_grid(const float* src_cm, float* dst_cl, int C, int Z, int Y, int X, void* stream);
+int adfp_relayout_grid_back(const float* src_cl, float* dst_cm, int C, int Z, int Y, int X, void* stream);
+/* flat state_dict-order parameters -> packed MFMA image (MLP: decoder.py:91-203) */
+int adfp_pack_decoder(int kind, const float* flat, float* packed, void* stream);
+/* mlp_tsdf parameters (decoder.py:206-258) */
+int adfp_pack_attention(const float* flat, float* packed, void* stream);
+
+/* ---- a1: get_rays (src/common.py:254-272) ------------------------------------------- */
+/* c2w: [4,4] row-major fp32 on device (only the top 3 rows are read). */
+int adfp_get_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w,
+                  float* rays_o /*[H*W,3]*/, float* rays_d /*[H*W,3]*/, void* stream);
+
+/* ---- a4: sampler (src/utils/Renderer.py:134-221) ------------------------------------ */
+/* gt_depth may be NULL (then n_surface is ignored, near = 0.01).  t_rand [N,n_samples] is
+ * the caller's torch.rand draw when perturb > 0 (Renderer.py:216), else NULL.
+ * depth_max: optional device float holding max(gt_depth) over the FULL batch (used by the
+ * multi-GPU path so that shards reproduce the single-GPU far clamp, Renderer.py:159/:195);
+ * NULL = reduce it here.  scratch: >= 16 bytes of device memory. */
+int adfp_sample_rays(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays,
+                     const double bound[3][2], int n_samples, int n_surface, int lindisp,
+                     float perturb, const float* t_rand, const float* depth_max,
+                     double* z_vals /*[N, S]*/, void* scratch, void* stream);
+
+/* ---- a5..a12: Renderer.eval_points + DF.forward (Renderer.py:27-71, decoder.py:307-353) */
+/* raw [P,4] fp32 (rgb, occ), w [P] fp32 (attention weight).
+ * flags & ADFP_EVAL_APPLY_BOUND: occ forced to 100 outside scene->bound (Renderer.py:51-64);
+ * without it the call is DF.forward alone (what src/utils/Mesher.py:315 calls before applying
+ * its own mask). */
+#define ADFP_EVAL_APPLY_BOUND 1
+int adfp_eval_points(const adfp_scene* scene /*host*/, const adfp_points* pts /*host*/, int stage, int flags,
+                     float* raw, float* w, void* workspace, size_t workspace_bytes, void* stream);
+
+/* a10 alone: Renderer.sample_grid_tsdf / eval_points_tsdf (Renderer.py:73-107) */
+int adfp_sample_tsdf(const adfp_tsdf* tsdf /*host*/, const double tsdf_bnds[3][2],
+                     const adfp_points* pts /*host*/, float* out /*[P]*/, void* stream);
+
+/* ---- a13: raw2outputs_nerf_color, occupancy branch (src/common.py:206-251) ------------ */
+/* weights may be NULL.  depth/uncertainty are float64 like the reference's. */
+int adfp_composite(const float* raw /*[N,S,4]*/, const double* z_vals /*[N,S]*/, int n_rays, int S,
+                   double* depth, double* uncertainty, float* color /*[N,3]*/,
+                   float* weights /*[N,S] or NULL*/, void* stream);
+
+/* ---- a4..a13 in one call: Renderer.render_batch_ray (Renderer.py:110-255) ------------- */
+typedef struct adfp_render_args {
+    int stage;
+    int n_rays;
+    int n_samples, n_surface;   /* cfg['rendering'] (configs/df_prior.yaml:93-98) */
+    int lindisp;
+    float perturb;
+    const float* rays_o;        /* [N,3] */
+    const float* rays_d;        /* [N,3] */
+    const float* gt_depth;      /* [N] or NULL */
+    const float* t_rand;        /* [N,n_samples] or NULL */
+    const float* depth_max;     /* device float or NULL */
+    double* depth;              /* [N]   out */
+    double* uncertainty;        /* [N]   out */
+    float* color;               /* [N,3] out */
+    float* weight;              /* [N,S] out: attention weight (decoder.py:333) */
+    double* z_vals;             /* [N,S] out, optional (NULL = keep in workspace) */
+    float* raw;                 /* [N,S,4] out, optional */
+    void* workspace;
+    size_t workspace_bytes;
+} adfp_render_args;
+
+int adfp_render_forward(const adfp_scene* scene /*host*/, const adfp_render_args* args /*host*/, void* stream);
+
+/* Per-stage timing hook for bench.py: runs ONLY the TSDF trilerp + band-mask kernel (a10). */
+int adfp_tsdf_stage(const adfp_scene* scene, const adfp_points* pts, unsigned char* flags,
+                    int* list, float* att_u, float* w, int* counter, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADFP_H */

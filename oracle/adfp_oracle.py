@@ -1,0 +1,381 @@
+"""
+ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product.
+
+CPU restatement (plain PyTorch ops on CPU tensors) of the per-ray volume-rendering
+hot path of MachinePerceptionLab/Attentive_DFPrior.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module, and only as the checker / the timed CPU baseline.  The product package
+``attentive_dfprior_amd`` never imports it and has no CPU fallback.
+
+Parity pinning: the reference holds no tests or golden vectors for this path
+(SURVEY.md section 4), so this restatement is pinned against the reference itself,
+imported read-only in the build container by ``oracle/validate_against_reference.py``
+(0.0 max-abs difference on forward) and against the committed
+fixtures under ``tests/golden/`` that ``tests/golden/make_golden.py`` generated from
+the reference's own modules.
+
+Every function cites the reference file:line it follows (paths relative to the
+reference checkout).  Decoder weights are passed as a flat ``dict`` keyed exactly like
+``DF.state_dict()`` in the reference (``low_decoder.fc_c.0.weight`` ...), so the
+oracle does not depend on any nn.Module of the product.
+
+dtype conventions follow the reference exactly: rays f32, ``bound``/``tsdf_bnds`` f64,
+z_vals/pts f64, normalised coords cast to f32 before ``grid_sample``, decoders f32,
+depth/uncertainty f64, colour/weight f32.
+"""
+import torch
+import torch.nn.functional as F
+
+STAGES = ('low', 'high', 'color')
+DECODERS = ('low', 'high', 'color')
+
+
+# ----------------------------------------------------------------------------------
+# a1/a2: rays  (src/common.py:254-272, :76-91)
+# ----------------------------------------------------------------------------------
+def get_rays(H, W, fx, fy, cx, cy, c2w):
+    """src/common.py:254-272.  Directions are NOT normalised."""
+    i, j = torch.meshgrid(torch.linspace(0, W - 1, W), torch.linspace(0, H - 1, H), indexing='ij')
+    i = i.t()
+    j = j.t()
+    dirs = torch.stack([(i - cx) / fx, -(j - cy) / fy, -torch.ones_like(i)], -1)
+    dirs = dirs.reshape(H, W, 1, 3)
+    rays_d = torch.sum(dirs * c2w[:3, :3], -1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def get_rays_from_uv(i, j, c2w, fx, fy, cx, cy):
+    """src/common.py:76-91."""
+    dirs = torch.stack([(i - cx) / fx, -(j - cy) / fy, -torch.ones_like(i)], -1)
+    dirs = dirs.reshape(-1, 1, 3)
+    rays_d = torch.sum(dirs * c2w[:3, :3], -1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def select_uv(H0, H1, W0, W1, indices, depth, color):
+    """src/common.py:94-124 with the random ``indices`` supplied by the caller
+    (the reference draws them with torch.randint, common.py:101)."""
+    depth = depth[H0:H1, W0:W1]
+    color = color[H0:H1, W0:W1]
+    i, j = torch.meshgrid(torch.linspace(W0, W1 - 1, W1 - W0), torch.linspace(H0, H1 - 1, H1 - H0),
+                          indexing='ij')
+    i = i.t().reshape(-1)
+    j = j.t().reshape(-1)
+    return i[indices], j[indices], depth.reshape(-1)[indices], color.reshape(-1, 3)[indices]
+
+
+# ----------------------------------------------------------------------------------
+# a4: sampler  (src/utils/Renderer.py:134-225)
+# ----------------------------------------------------------------------------------
+def sample_z(rays_o, rays_d, gt_depth, bound, N_samples, N_surface, lindisp=False, perturb=0.0,
+             t_rand=None):
+    """z_vals [N, S] (f64 when bound is f64) -- src/utils/Renderer.py:134-221.
+    ``t_rand`` replaces the reference's torch.rand draw (Renderer.py:216) when perturb > 0."""
+    if gt_depth is None:
+        N_surface = 0
+        near = 0.01
+    else:
+        gt_depth = gt_depth.reshape(-1, 1)
+        near = gt_depth.repeat(1, N_samples) * 0.01
+    det_rays_o = rays_o.detach().unsqueeze(-1)
+    det_rays_d = rays_d.detach().unsqueeze(-1)
+    t = (bound.unsqueeze(0) - det_rays_o) / det_rays_d                     # Renderer.py:151
+    far_bb, _ = torch.min(torch.max(t, dim=2)[0], dim=1)
+    far_bb = far_bb.unsqueeze(-1)
+    far_bb = far_bb + 0.01
+    if gt_depth is not None:
+        far = torch.clamp(far_bb, 0, torch.max(gt_depth * 1.2))            # Renderer.py:159
+    else:
+        far = far_bb
+    if N_surface > 0:
+        nz = gt_depth > 0                                                  # Renderer.py:179
+        gt_nz = gt_depth[nz].unsqueeze(-1).repeat(1, N_surface)
+        ts = torch.linspace(0., 1., steps=N_surface).double()
+        z_nz = 0.95 * gt_nz * (1. - ts) + 1.05 * gt_nz * ts                # Renderer.py:186
+        z_surf = torch.zeros(gt_depth.shape[0], N_surface).double()
+        nz = nz.squeeze(-1)
+        z_surf[nz, :] = z_nz
+        far_surface = torch.max(gt_depth)
+        z_zero = 0.001 * (1. - ts) + far_surface * ts                      # Renderer.py:196
+        z_surf[~nz, :] = z_zero
+    t_vals = torch.linspace(0., 1., steps=N_samples)
+    if not lindisp:
+        z_vals = near * (1. - t_vals) + far * t_vals                       # Renderer.py:206
+    else:
+        z_vals = 1. / (1. / near * (1. - t_vals) + 1. / far * t_vals)
+    if perturb > 0.:
+        mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])                   # Renderer.py:212
+        upper = torch.cat([mids, z_vals[..., -1:]], -1)
+        lower = torch.cat([z_vals[..., :1], mids], -1)
+        z_vals = lower + (upper - lower) * t_rand
+    if N_surface > 0:
+        z_vals, _ = torch.sort(torch.cat([z_vals, z_surf.double()], -1), -1)  # Renderer.py:220
+    return z_vals
+
+
+# ----------------------------------------------------------------------------------
+# a6/a7/a10: normalisation and trilinear lookup  (src/common.py:275-290, decoder.py:168-175)
+# ----------------------------------------------------------------------------------
+def normalize_3d_coordinate(p, bound):
+    """src/common.py:275-290 (out of place)."""
+    p = p.reshape(-1, 3)
+    x = ((p[:, 0] - bound[0, 0]) / (bound[0, 1] - bound[0, 0])) * 2 - 1.0
+    y = ((p[:, 1] - bound[1, 0]) / (bound[1, 1] - bound[1, 0])) * 2 - 1.0
+    z = ((p[:, 2] - bound[2, 0]) / (bound[2, 1] - bound[2, 0])) * 2 - 1.0
+    return torch.stack([x, y, z], -1)
+
+
+def trilerp(vol, p, bound):
+    """F.grid_sample 5-D, bilinear, border, align_corners=True -- decoder.py:168-175, :295-303.
+    vol [1,C,Z,Y,X] (any strides), p [P,3] world coords -> [C,P]."""
+    p_nor = normalize_3d_coordinate(p, bound).unsqueeze(0)
+    vgrid = p_nor[:, :, None, None].float()
+    out = F.grid_sample(vol, vgrid, padding_mode='border', align_corners=True, mode='bilinear')
+    return out.squeeze(-1).squeeze(-1).squeeze(0)
+
+
+def trilerp_explicit(vol, p, bound):
+    """The same lookup written out corner by corner (ATen grid_sampler_3d semantics:
+    unnormalise ((x+1)/2)*(size-1), clip to [0,size-1], floor, 8 weighted corners with
+    out-of-range corners contributing zero).  Used by tests to pin the arithmetic the HIP
+    kernels implement."""
+    _, C, D, Hh, Ww = vol.shape
+    pn = normalize_3d_coordinate(p, bound).float()
+
+    def unnorm(c, size):
+        c = ((c + 1.0) / 2.0) * (size - 1)
+        return torch.clamp(c, 0.0, float(size - 1))
+    ix, iy, iz = unnorm(pn[:, 0], Ww), unnorm(pn[:, 1], Hh), unnorm(pn[:, 2], D)
+    x0, y0, z0 = torch.floor(ix), torch.floor(iy), torch.floor(iz)
+    tx, ty, tz = ix - x0, iy - y0, iz - z0
+    x0, y0, z0 = x0.long(), y0.long(), z0.long()
+    out = torch.zeros(C, p.shape[0])
+    v = vol[0]
+    for dz in (0, 1):
+        for dy in (0, 1):
+            for dx in (0, 1):
+                w = (tx if dx else 1 - tx) * (ty if dy else 1 - ty) * (tz if dz else 1 - tz)
+                xi, yi, zi = x0 + dx, y0 + dy, z0 + dz
+                ok = (xi < Ww) & (yi < Hh) & (zi < D)
+                val = v[:, zi.clamp(max=D - 1), yi.clamp(max=Hh - 1), xi.clamp(max=Ww - 1)]
+                out = out + torch.where(ok, w, torch.zeros_like(w)) * val
+    return out
+
+
+# ----------------------------------------------------------------------------------
+# a8/a9: decoder MLP  (decoder.py:26-30, :177-203)
+# ----------------------------------------------------------------------------------
+def mlp_forward(sd, name, p, c_grid, bound):
+    """MLP.forward, decoder.py:177-203.  sd: state dict, name in DECODERS, p [P,3] f64/f32."""
+    pre = f'{name}_decoder.'
+    c = trilerp(c_grid['grid_' + name], p, bound).t()                       # decoder.py:179-180
+    if name == 'high':                                                      # concat_feature, :182-187
+        with torch.no_grad():
+            c_low = trilerp(c_grid['grid_low'], p, bound).t()
+        c = torch.cat([c, c_low], dim=1)
+    pf = p.float()
+    emb = torch.sin(pf @ sd[pre + 'embedder._B'])                           # decoder.py:29-30
+    h = emb
+    for i in range(5):
+        h = F.linear(h, sd[pre + f'pts_linears.{i}.weight'], sd[pre + f'pts_linears.{i}.bias'])
+        h = F.relu(h)
+        h = h + F.linear(c, sd[pre + f'fc_c.{i}.weight'], sd[pre + f'fc_c.{i}.bias'])
+        if i == 2:
+            h = torch.cat([emb, h], -1)
+    out = F.linear(h, sd[pre + 'output_linear.weight'], sd[pre + 'output_linear.bias'])
+    if name != 'color':
+        out = out.squeeze(-1)
+    return out
+
+
+def inv_tsdf(tsdf_val):
+    """decoder.py:244-248."""
+    s = 1. - (tsdf_val + 1.) / 2.
+    s = torch.clamp(s, 0.0, 1.0)
+    u = -0.1 * torch.log((1 / (s + 1e-8)) - 1 + 1e-7)
+    return torch.clamp(u, -100.0, 100.0)
+
+
+def mlp_tsdf_forward(sd, occ, tsdf_val):
+    """mlp_tsdf.forward, decoder.py:240-258, given the TSDF value at the points."""
+    u = inv_tsdf(tsdf_val)
+    inp = torch.stack([occ, u], dim=1)
+    h = inp
+    for i in range(4):
+        h = F.relu(F.linear(h, sd[f'mlp.pts_linears.{i}.weight'], sd[f'mlp.pts_linears.{i}.bias']))
+    a = torch.softmax(F.linear(h, sd['mlp.output_linear.weight'], sd['mlp.output_linear.bias']), dim=1)
+    out = (a * inp).sum(dim=1)
+    return out, a[:, 1]
+
+
+# ----------------------------------------------------------------------------------
+# a12: DF.forward  (decoder.py:307-353)
+# ----------------------------------------------------------------------------------
+def df_forward(sd, p, c_grid, tsdf_volume, tsdf_bnds, bound, stage, return_aux=False):
+    """p [P,3] -> raw [P,4], w [P]."""
+    P = p.shape[0]
+    low = mlp_forward(sd, 'low', p, c_grid, bound)
+    aux = {}
+    if stage == 'low':
+        raw = torch.zeros(P, 4)
+        raw = torch.cat([raw[:, :3], low.unsqueeze(-1)], -1)
+        w = torch.ones(P)
+        return (raw, w, aux) if return_aux else (raw, w)
+    high = mlp_forward(sd, 'high', p, c_grid, bound)
+    if stage == 'color':
+        rgb = mlp_forward(sd, 'color', p, c_grid, bound)[:, :3]
+    else:
+        rgb = torch.zeros(P, 3)
+    f_add = high + low                                                       # decoder.py:325/:342
+    t = trilerp(tsdf_volume, p, tsdf_bnds).reshape(-1)
+    mask = (t > -1.0 + 1e-4) & (t < 1.0 - 1e-4)                              # decoder.py:329/:346
+    fused, a1 = mlp_tsdf_forward(sd, f_add[mask], t[mask])
+    occ = low.clone()
+    occ[mask] = fused                                                        # unmasked keep LOW only
+    w = torch.ones(P)
+    w[mask] = a1
+    raw = torch.cat([rgb, occ.unsqueeze(-1)], -1)
+    if return_aux:
+        aux = {'tsdf': t, 'band': mask}
+        return raw, w, aux
+    return raw, w
+
+
+def eval_points(sd, p, c_grid, tsdf_volume, tsdf_bnds, bound, stage, return_aux=False):
+    """Renderer.eval_points, src/utils/Renderer.py:27-71 (chunking is value-neutral)."""
+    mask = ((p[:, 0] < bound[0][1]) & (p[:, 0] > bound[0][0]) &
+            (p[:, 1] < bound[1][1]) & (p[:, 1] > bound[1][0]) &
+            (p[:, 2] < bound[2][1]) & (p[:, 2] > bound[2][0]))
+    res = df_forward(sd, p, c_grid, tsdf_volume, tsdf_bnds, bound, stage, return_aux)
+    raw, w = res[0], res[1]
+    occ = torch.where(mask, raw[:, 3], torch.full_like(raw[:, 3], 100.0))  # Renderer.py:64
+    raw = torch.cat([raw[:, :3], occ.unsqueeze(-1)], -1)
+    if return_aux:
+        aux = res[2]
+        aux['inbound'] = mask
+        return raw, w, aux
+    return raw, w
+
+
+# ----------------------------------------------------------------------------------
+# a13: compositing  (src/common.py:206-251, occupancy=True branch)
+# ----------------------------------------------------------------------------------
+def raw2outputs(raw, z_vals):
+    rgb = raw[..., :3]
+    alpha = torch.sigmoid(10 * raw[..., 3])                                  # common.py:236
+    ones = torch.ones((alpha.shape[0], 1))
+    weights = alpha.float() * torch.cumprod(
+        torch.cat([ones, (1. - alpha + 1e-10).float()], -1).float(), -1)[:, :-1]
+    rgb_map = torch.sum(weights[..., None] * rgb, -2)
+    depth_map = torch.sum(weights * z_vals, -1)
+    tmp = z_vals - depth_map.unsqueeze(-1)
+    depth_var = torch.sum(weights * tmp * tmp, dim=1)
+    return depth_map, depth_var, rgb_map, weights
+
+
+# ----------------------------------------------------------------------------------
+# a4..a13: render_batch_ray  (src/utils/Renderer.py:110-255) and a14 render_img (:258-327)
+# ----------------------------------------------------------------------------------
+def render_batch_ray(sd, c_grid, rays_d, rays_o, tsdf_volume, tsdf_bnds, bound, stage, gt_depth,
+                     N_samples, N_surface, lindisp=False, perturb=0.0, t_rand=None, return_aux=False):
+    """Returns (depth f64 [N], uncertainty f64 [N], color f32 [N,3], weight f32 [N,S,1])."""
+    N = rays_o.shape[0]
+    z_vals = sample_z(rays_o, rays_d, gt_depth, bound, N_samples, N_surface, lindisp, perturb, t_rand)
+    S = z_vals.shape[1]
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]   # Renderer.py:223
+    res = eval_points(sd, pts.reshape(-1, 3), c_grid, tsdf_volume, tsdf_bnds, bound, stage, return_aux)
+    raw = res[0].reshape(N, S, 4)
+    weight = res[1].reshape(N, S, 1)
+    depth, var, color, cw = raw2outputs(raw, z_vals)
+    if return_aux:
+        aux = res[2]
+        aux.update({'z_vals': z_vals, 'raw': raw, 'composite_weights': cw})
+        return depth, var, color, weight, aux
+    return depth, var, color, weight
+
+
+def render_img(sd, c_grid, c2w, H, W, fx, fy, cx, cy, tsdf_volume, tsdf_bnds, bound, stage, gt_depth,
+               N_samples, N_surface, ray_batch_size=100000):
+    """src/utils/Renderer.py:258-327.  The far clamp uses the per-batch max depth (:159)."""
+    with torch.no_grad():
+        rays_o, rays_d = get_rays(H, W, fx, fy, cx, cy, c2w)
+        rays_o = rays_o.reshape(-1, 3)
+        rays_d = rays_d.reshape(-1, 3)
+        gt_depth = gt_depth.reshape(-1)
+        ds, us, cs = [], [], []
+        for i in range(0, rays_d.shape[0], ray_batch_size):
+            d, u, c, _ = render_batch_ray(sd, c_grid, rays_d[i:i + ray_batch_size], rays_o[i:i + ray_batch_size],
+                                          tsdf_volume, tsdf_bnds, bound, stage, gt_depth[i:i + ray_batch_size],
+                                          N_samples, N_surface)
+            ds.append(d.double())
+            us.append(u.double())
+            cs.append(c)
+        return (torch.cat(ds).reshape(H, W), torch.cat(us).reshape(H, W), torch.cat(cs).reshape(H, W, 3))
+
+
+# ----------------------------------------------------------------------------------
+# a15: Mapper loss  (src/Mapper.py:457-469)
+# ----------------------------------------------------------------------------------
+def mapper_loss(depth, color, weight, gt_depth, gt_color, stage, warmup=False, w_color_loss=0.2):
+    depth_mask = gt_depth > 0
+    loss = torch.abs(gt_depth[depth_mask] - depth[depth_mask]).sum()
+    if warmup:
+        loss = loss + torch.abs(weight - torch.ones(weight.shape)).sum()
+    if stage == 'color':
+        loss = loss + w_color_loss * torch.abs(gt_color - color).sum()
+    return loss
+
+
+# ----------------------------------------------------------------------------------
+# helpers shared by tests / bench (synthetic scene of SURVEY.md section 8d)
+# ----------------------------------------------------------------------------------
+def decoder_param_shapes(c_dim=32, hidden=32, emb=93):
+    """Parameter names/shapes of DF.state_dict() (decoder.py:110-166, :212-228, :276-292),
+    in registration order."""
+    shapes = []
+    for name, cd, nout in (('low', c_dim, 1), ('high', 2 * c_dim, 1), ('color', c_dim, 4)):
+        pre = f'{name}_decoder.'
+        for i in range(5):
+            shapes += [(pre + f'fc_c.{i}.weight', (hidden, cd)), (pre + f'fc_c.{i}.bias', (hidden,))]
+        shapes += [(pre + 'embedder._B', (3, emb))]
+        ins = [emb, hidden, hidden, hidden + emb, hidden]
+        for i in range(5):
+            shapes += [(pre + f'pts_linears.{i}.weight', (hidden, ins[i])),
+                       (pre + f'pts_linears.{i}.bias', (hidden,))]
+        shapes += [(pre + 'output_linear.weight', (nout, hidden)), (pre + 'output_linear.bias', (nout,))]
+    dims = [2, 64, 128, 128, 64]
+    for i in range(4):
+        shapes += [(f'mlp.pts_linears.{i}.weight', (dims[i + 1], dims[i])),
+                   (f'mlp.pts_linears.{i}.bias', (dims[i + 1],))]
+    shapes += [('mlp.output_linear.weight', (2, 64)), ('mlp.output_linear.bias', (2,))]
+    return shapes
+
+
+def random_state_dict(seed=0, bias_scale=0.05, occ_bias=-0.5, out_scale=0.15):
+    """Seeded weights with the reference's init distributions (xavier-uniform weights,
+    N(0,25^2) Fourier matrix, nn.Linear default for fc_c) but non-zero biases so that
+    bias handling is exercised.  The occupancy heads are damped (out_scale) and biased
+    negative (occ_bias) so that free space is mostly transparent and compositing weights
+    spread over many samples, as with the pretrained decoders the snapshot lacks."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, shp in decoder_param_shapes():
+        if k.endswith('_B'):
+            sd[k] = torch.randn(shp, generator=g) * 25
+        elif k.endswith('weight'):
+            fan_out, fan_in = shp
+            gain = 1.0 if 'output_linear' in k else 2 ** 0.5
+            if 'fc_c' in k:
+                a = (1.0 / fan_in) ** 0.5
+            else:
+                a = gain * (6.0 / (fan_in + fan_out)) ** 0.5
+            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * a
+        else:
+            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * bias_scale
+    for name in ('low', 'high'):
+        sd[f'{name}_decoder.output_linear.weight'] *= out_scale
+    sd['low_decoder.output_linear.bias'] += occ_bias
+    sd['color_decoder.output_linear.weight'][3] *= out_scale
+    return sd

@@ -1,0 +1,90 @@
+"""
+ORACLE VALIDATION -- BUILD CONTAINER ONLY (needs /root/reference).
+
+Runs the reference's own Renderer / DF (imported read-only, oracle/ref_import.py) and the
+restatement in oracle/adfp_oracle.py on identical seeded inputs, for all three stages, forward
+and Mapper-loss gradients, and prints the max abs differences.  This is how the oracle is
+pinned (the reference holds no tests or golden vectors for this path).
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/validate_against_reference.py
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import adfp_oracle as O          # noqa: E402
+from oracle import ref_import                # noqa: E402
+from attentive_dfprior_amd import synthetic  # noqa: E402
+
+
+def run(stage, n_samples=32, n_surface=16, n_rays=200, warmup=False, with_depth=True, lindisp=False, perturb=0.0):
+    torch.manual_seed(0)
+    scene = synthetic.mini_scene()
+    sd = O.random_state_dict(seed=3)
+    rays_o, rays_d, depth, color = synthetic.make_ray_batch(scene, n_rays, seed=5)
+    df, rend, rcommon = ref_import.make_reference_objects(scene, sd, n_samples, n_surface, lindisp, perturb)
+
+    # reference, autograd on grids + every decoder parameter
+    c_ref = {k: v.clone().requires_grad_(True) for k, v in scene.c.items()}
+    for p in df.parameters():
+        p.requires_grad_(True)
+    torch.manual_seed(11)
+    d, u, col, w = rend.render_batch_ray(c_ref, df, rays_d, rays_o, 'cpu', scene.tsdf_volume, scene.tsdf_bnds,
+                                         stage, gt_depth=depth if with_depth else None)
+    gt_d = depth
+    mask = gt_d > 0
+    loss = torch.abs(gt_d[mask] - d[mask]).sum()
+    if warmup:
+        loss = loss + torch.abs(w - torch.ones(w.shape)).sum()
+    if stage == 'color':
+        loss = loss + 0.2 * torch.abs(color - col).sum()
+    loss.backward()
+
+    # oracle
+    c_or = {k: v.clone().requires_grad_(True) for k, v in scene.c.items()}
+    sd_or = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    t_rand = None
+    if perturb > 0:
+        torch.manual_seed(11)
+        t_rand = torch.rand(n_rays, n_samples)
+    d2, u2, col2, w2 = O.render_batch_ray(sd_or, c_or, rays_d, rays_o, scene.tsdf_volume, scene.tsdf_bnds,
+                                          scene.bound, stage, depth if with_depth else None, n_samples, n_surface,
+                                          lindisp, perturb, t_rand)
+    loss2 = O.mapper_loss(d2, col2, w2, gt_d, color, stage, warmup)
+    loss2.backward()
+
+    out = {'depth': (d - d2).abs().max().item(), 'unc': (u - u2).abs().max().item(),
+           'color': (col - col2).abs().max().item(), 'weight': (w - w2).abs().max().item(),
+           'loss': abs(loss.item() - loss2.item())}
+    assert d.dtype == d2.dtype and u.dtype == u2.dtype and col.dtype == col2.dtype and w.dtype == w2.dtype
+    assert w.shape == w2.shape
+    for k in c_ref:
+        g1 = c_ref[k].grad
+        g2 = c_or[k].grad
+        if g1 is None and g2 is None:
+            continue
+        g1 = torch.zeros_like(c_ref[k]) if g1 is None else g1
+        g2 = torch.zeros_like(c_or[k]) if g2 is None else g2
+        out['g_' + k] = (g1 - g2).abs().max().item()
+    gmax = 0.0
+    for name, p in df.named_parameters():
+        g1 = p.grad if p.grad is not None else torch.zeros_like(p)
+        g2 = sd_or[name].grad if sd_or[name].grad is not None else torch.zeros_like(p)
+        gmax = max(gmax, (g1 - g2).abs().max().item())
+    out['g_params'] = gmax
+    return out
+
+
+if __name__ == '__main__':
+    worst = 0.0
+    for stage in O.STAGES:
+        for kw in ({}, {'warmup': True}, {'with_depth': False}, {'n_samples': 48, 'n_surface': 16},
+                   {'lindisp': True}, {'perturb': 1.0}):
+            if kw.get('warmup') and stage == 'low':
+                pass
+            r = run(stage, **kw)
+            worst = max(worst, max(r.values()))
+            print(stage, kw, {k: f'{v:.2e}' for k, v in r.items()})
+    print('WORST max-abs difference oracle vs reference:', worst)

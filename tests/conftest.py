@@ -1,0 +1,83 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+class Mini(object):
+    """The committed mini scene (tests/golden/mini_inputs.npz) as CPU tensors."""
+
+    def __init__(self):
+        z = np.load(os.path.join(GOLDEN, 'mini_inputs.npz'))
+        self.bound = torch.from_numpy(z['bound'])
+        self.tsdf_bnds = torch.from_numpy(z['tsdf_bnds'])
+        phys = torch.from_numpy(z['tsdf_xyz'])                              # [X,Y,Z] contiguous
+        X, Y, Z = phys.shape
+        # the reference's permuted, non-contiguous view (get_tsdf.py:95-97)
+        self.tsdf_volume = phys.reshape(1, 1, X, Y, Z).permute(0, 1, 4, 3, 2)
+        self.c = {k: torch.from_numpy(z[k]) for k in ('grid_low', 'grid_high', 'grid_color')}
+        self.sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('sd.')}
+        self.rays_o = torch.from_numpy(z['rays_o'])
+        self.rays_d = torch.from_numpy(z['rays_d'])
+        self.gt_depth = torch.from_numpy(z['gt_depth'])
+        self.gt_color = torch.from_numpy(z['gt_color'])
+        self.query_points = torch.from_numpy(z['query_points'])
+        self.c2w = torch.from_numpy(z['c2w'])
+        self.depth_img = torch.from_numpy(z['depth_img'])
+        H, W, fx, fy, cx, cy = z['intrinsics'].tolist()
+        self.H, self.W, self.fx, self.fy, self.cx, self.cy = int(H), int(W), fx, fy, cx, cy
+        self.n_samples = int(z['n_samples'])
+        self.n_surface = int(z['n_surface'])
+        self.vol_bnds = self.tsdf_bnds
+
+    def golden(self, name):
+        z = np.load(os.path.join(GOLDEN, f'mini_{name}.npz'))
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope='session')
+def mini():
+    return Mini()
+
+
+def make_cfg(n_samples=32, n_surface=16, lindisp=False, perturb=0.0):
+    return {'rendering': {'lindisp': lindisp, 'perturb': perturb, 'N_samples': n_samples,
+                          'N_surface': n_surface, 'N_importance': 0},
+            'scale': 1, 'occupancy': True, 'meshing': {'resolution': 256}}
+
+
+def to_dev(x, dev):
+    if isinstance(x, dict):
+        return {k: to_dev(v, dev) for k, v in x.items()}
+    return x.to(dev)
+
+
+def rel_err(a, b):
+    """max |a-b| / max|b|  (global relative error)."""
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def assert_close(a, b, tol, what):
+    """The parity bar of BASELINE.json's north_star: <= 1e-4 relative (fp32).  Elementwise
+    |a-b| <= tol * (|b| + max|b|/10): relative to the element with a floor of a tenth of the
+    tensor's scale so that values crossing zero do not blow the ratio up."""
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    assert a.shape == b.shape, f'{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}'
+    scale = b.abs().max().clamp_min(1e-30)
+    bad = (a - b).abs() > tol * (b.abs() + 0.1 * scale)
+    assert not bad.any(), (f'{what}: {int(bad.sum())}/{bad.numel()} elements beyond tol={tol}; '
+                           f'max abs diff {(a - b).abs().max().item():.3e}, scale {scale.item():.3e}')

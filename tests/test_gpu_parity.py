@@ -1,0 +1,319 @@
+"""GPU (MI355X): the HIP path, called through the C ABI of libadfp.so by the reference-shaped
+Python objects, against (1) the golden vectors generated from the reference and (2) the oracle
+on seeded inputs.  Tolerance: BASELINE.json north_star -- <= 1e-4 relative, fp32."""
+import numpy as np
+import pytest
+import torch
+
+import attentive_dfprior_amd as A
+from attentive_dfprior_amd import common, synthetic
+from oracle import adfp_oracle as O
+from conftest import make_cfg, to_dev, assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = 'cuda:0'
+
+
+def build(mini_like, sd, n_samples=32, n_surface=16, **kw):
+    dec = A.DF()
+    dec.load_state_dict(sd)
+    dec.bound = mini_like.bound
+    dec = dec.to(DEV)
+    rend = A.Renderer(make_cfg(n_samples, n_surface, **kw), None, mini_like)
+    return dec, rend
+
+
+@pytest.fixture(scope='module')
+def gm(mini):
+    """mini scene on the GPU (the TSDF stays the permuted, non-contiguous view)."""
+    class G(object):
+        pass
+    g = G()
+    g.c = to_dev(mini.c, DEV)
+    g.tsdf = mini.tsdf_volume.to(DEV)
+    assert not g.tsdf.is_contiguous() and g.tsdf.stride() == mini.tsdf_volume.stride()
+    g.tsdf_bnds = mini.tsdf_bnds.to(DEV)
+    g.rays_o, g.rays_d = mini.rays_o.to(DEV), mini.rays_d.to(DEV)
+    g.gt_depth, g.gt_color = mini.gt_depth.to(DEV), mini.gt_color.to(DEV)
+    g.dec, g.rend = build(mini, mini.sd, mini.n_samples, mini.n_surface)
+    return g
+
+
+def test_native_library_is_loaded(gm):
+    from attentive_dfprior_amd import _lib
+    assert _lib.lib().adfp_version() == 100
+    assert 'libadfp.so' in open('/proc/self/maps').read()
+
+
+# --------------------------------------------------------------------------- golden vectors
+@pytest.mark.parametrize('stage', O.STAGES)
+def test_render_batch_ray_vs_reference_golden(mini, gm, stage):
+    g = mini.golden(stage)
+    with torch.no_grad():
+        d, u, c, w = gm.rend.render_batch_ray(gm.c, gm.dec, gm.rays_d, gm.rays_o, DEV, gm.tsdf, gm.tsdf_bnds, stage,
+                                              gt_depth=gm.gt_depth)
+    assert d.dtype == torch.float64 and u.dtype == torch.float64           # Renderer.py:183-190
+    assert c.dtype == torch.float32 and w.dtype == torch.float32
+    assert tuple(w.shape) == g['weight'].shape
+    assert_close(d, g['depth'], TOL, f'{stage} depth')
+    assert_close(c, g['color'], TOL, f'{stage} color') if stage == 'color' else None
+    assert_close(w, g['weight'], TOL, f'{stage} weight')
+    assert_close(u, g['uncertainty'], 5 * TOL, f'{stage} uncertainty')
+
+
+@pytest.mark.parametrize('stage', O.STAGES)
+def test_intermediates_vs_golden(mini, gm, stage):
+    """z_vals bit-exact; raw within tolerance; report band-mask flips (discontinuity)."""
+    g = mini.golden(stage)
+    with torch.no_grad():
+        d, u, c, w, aux = gm.rend._engine.render_forward(
+            gm.dec, gm.c, gm.rays_o, gm.rays_d, gm.gt_depth, gm.tsdf, gm.tsdf_bnds, mini.bound, stage,
+            mini.n_samples, mini.n_surface, want_aux=True)
+    z = aux['z_vals'].cpu().numpy()
+    assert np.abs(z - g['z_vals']).max() <= 4e-16 * np.abs(g['z_vals']).max()
+    assert (np.diff(z, axis=1) >= 0).all()
+    raw = aux['raw'].cpu()
+    ref = torch.from_numpy(g['raw'])
+    assert torch.equal(raw[..., 3] == 100, ref[..., 3] == 100), 'out-of-bound sample sets differ'
+    flips = int(((w.cpu().reshape(-1) == 1) != (torch.from_numpy(g['weight']).reshape(-1) == 1)).sum())
+    assert flips == 0, f'{flips} samples flipped across the TSDF band mask'
+    assert_close(raw[..., 3], ref[..., 3], TOL, f'{stage} occ')
+    if stage == 'color':
+        assert_close(raw[..., :3], ref[..., :3], TOL, 'rgb')
+
+
+@pytest.mark.parametrize('stage', O.STAGES)
+def test_render_without_sensor_depth_vs_golden(mini, gm, stage):
+    g = mini.golden(stage)
+    with torch.no_grad():
+        d, u, c, w = gm.rend.render_batch_ray(gm.c, gm.dec, gm.rays_d, gm.rays_o, DEV, gm.tsdf, gm.tsdf_bnds, stage)
+    assert tuple(w.shape) == g['nd_weight'].shape
+    assert_close(d, g['nd_depth'], TOL, 'nd depth')
+    assert_close(c, g['nd_color'], TOL, 'nd color')
+    assert_close(w, g['nd_weight'], TOL, 'nd weight')
+
+
+@pytest.mark.parametrize('stage', O.STAGES)
+def test_eval_points_and_df_forward_vs_golden(mini, gm, stage):
+    g = mini.golden(stage)
+    qp = mini.query_points.to(DEV)
+    with torch.no_grad():
+        raw, w = gm.rend.eval_points(qp, gm.dec, gm.tsdf, gm.tsdf_bnds, gm.c, stage, DEV)
+        raw2, w2 = gm.dec(qp.unsqueeze(0), c_grid=gm.c, tsdf_volume=gm.tsdf, tsdf_bnds=gm.tsdf_bnds, stage=stage)
+        raw3, _ = gm.rend.eval_points(qp.float(), gm.dec, gm.tsdf, gm.tsdf_bnds, gm.c, stage, DEV)
+    assert torch.equal(raw[:, 3].cpu() == 100, torch.from_numpy(g['q_raw'])[:, 3] == 100)
+    assert_close(raw, g['q_raw'], TOL, 'eval_points raw')
+    assert_close(w, g['q_w'], TOL, 'eval_points w')
+    assert_close(raw2, g['df_raw'], TOL, 'DF.forward raw (no bound rule)')
+    assert_close(w2, g['df_w'], TOL, 'DF.forward w')
+    assert raw3.shape == raw.shape
+
+
+def test_rays_tsdf_image_vs_golden(mini, gm):
+    g = mini.golden('rays')
+    ro, rd = common.get_rays(mini.H, mini.W, mini.fx, mini.fy, mini.cx, mini.cy, mini.c2w.to(DEV), DEV)
+    assert np.array_equal(ro.cpu().numpy(), g['get_rays_o'])
+    assert np.abs(rd.cpu().numpy() - g['get_rays_d']).max() <= 1.2e-7 * np.abs(g['get_rays_d']).max()
+    t = gm.rend.eval_points_tsdf(mini.query_points.to(DEV), gm.tsdf, DEV)
+    assert tuple(t.shape) == g['tsdf_q'].shape
+    assert np.abs(t.cpu().numpy() - g['tsdf_q']).max() <= 5e-7
+    gm.rend.ray_batch_size = int(g['img_ray_batch_size'])
+    try:
+        di, ui, ci = gm.rend.render_img(gm.c, gm.dec, mini.c2w.to(DEV), DEV, gm.tsdf, gm.tsdf_bnds, 'color',
+                                        gt_depth=mini.depth_img.to(DEV))
+    finally:
+        gm.rend.ray_batch_size = 100000
+    assert di.dtype == torch.float64 and tuple(di.shape) == (mini.H, mini.W) and tuple(ci.shape) == (mini.H, mini.W, 3)
+    assert_close(di, g['img_depth'], TOL, 'img depth')
+    assert_close(ci, g['img_color'], TOL, 'img color')
+    mse = float(((ci.cpu().double() - torch.from_numpy(g['img_color']).double()) ** 2).mean())
+    rng = float(np.abs(g['img_color']).max())
+    psnr = 10 * np.log10(rng * rng / max(mse, 1e-30))
+    assert psnr > 80.0, psnr
+
+
+# --------------------------------------------------------------------------- oracle, seeded
+@pytest.mark.parametrize('n_samples,n_surface', [(48, 16), (96, 32), (17, 5), (64, 0), (1, 1)])
+@pytest.mark.parametrize('stage', ['low', 'color'])
+def test_sample_counts_vs_oracle(mini, gm, stage, n_samples, n_surface):
+    """S = 64 (benchmark), 128 (config 5), ragged, no surface samples, degenerate."""
+    dec, rend = build(mini, mini.sd, n_samples, n_surface)
+    with torch.no_grad():
+        d, u, c, w = rend.render_batch_ray(gm.c, dec, gm.rays_d, gm.rays_o, DEV, gm.tsdf, gm.tsdf_bnds, stage,
+                                           gt_depth=gm.gt_depth)
+    od, ou, oc, ow = O.render_batch_ray(mini.sd, mini.c, mini.rays_d, mini.rays_o, mini.tsdf_volume, mini.tsdf_bnds,
+                                        mini.bound, stage, mini.gt_depth, n_samples, n_surface)
+    assert tuple(w.shape) == tuple(ow.shape)
+    assert_close(d, od, TOL, 'depth')
+    assert_close(c, oc, TOL, 'color')
+    assert_close(w, ow, TOL, 'weight')
+
+
+@pytest.mark.parametrize('kw', [{'perturb': 1.0}, {'lindisp': True}])
+def test_sampler_variants_vs_oracle(mini, gm, kw):
+    dec, rend = build(mini, mini.sd, 32, 16, **kw)
+    keep = mini.gt_depth > 0 if kw.get('lindisp') else torch.ones_like(mini.gt_depth, dtype=torch.bool)
+    ro, rd, gd = mini.rays_o[keep], mini.rays_d[keep], mini.gt_depth[keep]
+    torch.manual_seed(21)
+    with torch.no_grad():
+        d, u, c, w = rend.render_batch_ray(gm.c, dec, rd.to(DEV), ro.to(DEV), DEV, gm.tsdf, gm.tsdf_bnds, 'color',
+                                           gt_depth=gd.to(DEV))
+    torch.manual_seed(21)
+    t_rand = torch.rand(ro.shape[0], 32) if kw.get('perturb') else None
+    od, ou, oc, ow = O.render_batch_ray(mini.sd, mini.c, rd, ro, mini.tsdf_volume, mini.tsdf_bnds, mini.bound,
+                                        'color', gd, 32, 16, lindisp=kw.get('lindisp', False),
+                                        perturb=kw.get('perturb', 0.0), t_rand=t_rand)
+    assert_close(d, od, TOL, 'depth')
+    assert_close(c, oc, TOL, 'color')
+
+
+def test_second_seed_and_larger_scene_vs_oracle():
+    """A different weight seed on the 'tiny' scene (2.8 m room, 1/25 m TSDF, default-init grids)."""
+    sc = synthetic.Scene('tiny', H=60, W=80, fx=72.2, fy=72.2, cx=39.5, cy=29.5, voxel=0.04, grid_std_scale=20.0,
+                         seed=7)
+    sc.c['grid_high'] = sc.c['grid_high'] * 100
+    sd = O.random_state_dict(seed=11)
+    ro, rd, gd, col = synthetic.make_ray_batch(sc, 600, seed=2, poses=3)
+    dec, rend = build(sc, sd, 48, 16)
+    with torch.no_grad():
+        d, u, c, w = rend.render_batch_ray(to_dev(sc.c, DEV), dec, rd.to(DEV), ro.to(DEV), DEV,
+                                           sc.tsdf_volume.to(DEV), sc.tsdf_bnds.to(DEV), 'color', gt_depth=gd.to(DEV))
+    od, ou, oc, ow = O.render_batch_ray(sd, sc.c, rd, ro, sc.tsdf_volume, sc.tsdf_bnds, sc.bound, 'color', gd, 48, 16)
+    flips = int(((w.cpu() == 1) != (ow == 1)).sum())
+    assert flips <= 2, flips
+    assert_close(d, od, TOL, 'depth')
+    assert_close(c, oc, TOL, 'color')
+    assert_close(u, ou, 5 * TOL, 'uncertainty')
+
+
+def test_composite_entry_vs_oracle(mini):
+    g = torch.Generator().manual_seed(0)
+    raw = torch.randn(333, 70, 4, generator=g) * 0.3
+    raw[5, :, 3] = 100.0
+    raw[6, :, 3] = -100.0
+    z = torch.sort(torch.rand(333, 70, generator=g, dtype=torch.float64) * 5, dim=1)[0]
+    d, v, rgb, wts = common.raw2outputs_nerf_color(raw.to(DEV), z.to(DEV), None, occupancy=True, device=DEV)
+    od, ov, orgb, ow = O.raw2outputs(raw.clone(), z)
+    assert_close(d, od, 1e-6, 'depth')
+    assert_close(rgb, orgb, 1e-5, 'rgb')
+    assert_close(wts, ow, 1e-5, 'weights')
+    assert_close(v, ov, 1e-5, 'var')
+
+
+def test_relayout_round_trip(gm):
+    from attentive_dfprior_amd import _lib
+    L = _lib.lib()
+    g = torch.randn(1, 32, 7, 9, 11, device=DEV)
+    cl = torch.empty(7, 9, 11, 32, device=DEV)
+    back = torch.empty_like(g)
+    st = _lib.current_stream(torch.device(DEV))
+    assert L.adfp_relayout_grid(_lib.ptr(g), _lib.ptr(cl), 32, 7, 9, 11, st) == 0
+    assert L.adfp_relayout_grid_back(_lib.ptr(cl), _lib.ptr(back), 32, 7, 9, 11, st) == 0
+    assert torch.equal(cl, g[0].permute(1, 2, 3, 0).contiguous())
+    assert torch.equal(back, g)
+
+
+# --------------------------------------------------------------------------- edge cases
+def test_empty_and_single_ray(mini, gm):
+    with torch.no_grad():
+        d, u, c, w = gm.rend.render_batch_ray(gm.c, gm.dec, gm.rays_d[:0], gm.rays_o[:0], DEV, gm.tsdf, gm.tsdf_bnds,
+                                              'color', gt_depth=gm.gt_depth[:0])
+        assert d.shape == (0,) and c.shape == (0, 3) and w.shape == (0, 48, 1)
+        d, u, c, w = gm.rend.render_batch_ray(gm.c, gm.dec, gm.rays_d[:1], gm.rays_o[:1], DEV, gm.tsdf, gm.tsdf_bnds,
+                                              'color', gt_depth=gm.gt_depth[:1])
+    od, ou, oc, ow = O.render_batch_ray(mini.sd, mini.c, mini.rays_d[:1], mini.rays_o[:1], mini.tsdf_volume,
+                                        mini.tsdf_bnds, mini.bound, 'color', mini.gt_depth[:1], 32, 16)
+    assert_close(d, od, TOL, 'depth')
+    assert_close(c, oc, TOL, 'color')
+    raw, w = gm.rend.eval_points(mini.query_points[:0].to(DEV), gm.dec, gm.tsdf, gm.tsdf_bnds, gm.c, 'color', DEV)
+    assert raw.shape == (0, 4)
+
+
+def test_all_zero_depth_and_rays_leaving_bound(mini, gm):
+    """Zero-depth rays sample 0.001..max(gt_depth) (Renderer.py:191-201); rays that start outside
+    the bound get occ = 100 on every sample."""
+    n = 40
+    ro = mini.rays_o[:n].clone()
+    ro[n // 2:] += torch.tensor([5.0, 0.0, 0.0])          # outside the scene bound
+    gd = torch.zeros(n)
+    gd[0] = 0.7
+    with torch.no_grad():
+        d, u, c, w = gm.rend.render_batch_ray(gm.c, gm.dec, gm.rays_d[:n], ro.to(DEV), DEV, gm.tsdf, gm.tsdf_bnds,
+                                              'color', gt_depth=gd.to(DEV))
+    od, ou, oc, ow = O.render_batch_ray(mini.sd, mini.c, mini.rays_d[:n], ro, mini.tsdf_volume, mini.tsdf_bnds,
+                                        mini.bound, 'color', gd, 32, 16)
+    assert torch.isfinite(d).all() and torch.isfinite(c).all()
+    assert_close(d, od, TOL, 'depth')
+    assert_close(c, oc, TOL, 'color')
+    assert_close(w, ow, TOL, 'weight')
+
+
+def test_deterministic_and_order_invariant(gm):
+    """Bitwise reproducible across launches (the in-band list order is not, the outputs are) and
+    independent of how rays are tiled: a permuted batch gives the permuted outputs bit for bit."""
+    with torch.no_grad():
+        a = gm.rend.render_batch_ray(gm.c, gm.dec, gm.rays_d, gm.rays_o, DEV, gm.tsdf, gm.tsdf_bnds, 'color',
+                                     gt_depth=gm.gt_depth)
+        b = gm.rend.render_batch_ray(gm.c, gm.dec, gm.rays_d, gm.rays_o, DEV, gm.tsdf, gm.tsdf_bnds, 'color',
+                                     gt_depth=gm.gt_depth)
+        perm = torch.randperm(gm.rays_o.shape[0], device=DEV)
+        p = gm.rend.render_batch_ray(gm.c, gm.dec, gm.rays_d[perm], gm.rays_o[perm], DEV, gm.tsdf, gm.tsdf_bnds,
+                                     'color', gt_depth=gm.gt_depth[perm])
+    for x, y, z in zip(a, b, p):
+        assert torch.equal(x, y)
+        assert torch.equal(x[perm], z)
+
+
+def test_sharded_render_equals_whole(gm):
+    """Two ray shards given the full-batch depth max reproduce the unsharded render bit for bit
+    (what attentive_dfprior_amd.dist relies on); without it the far clamp differs."""
+    n = gm.rays_o.shape[0]
+    h = n // 3
+    with torch.no_grad():
+        whole = gm.rend.render_batch_ray(gm.c, gm.dec, gm.rays_d, gm.rays_o, DEV, gm.tsdf, gm.tsdf_bnds, 'color',
+                                         gt_depth=gm.gt_depth)
+        dmax = gm.gt_depth.max().reshape(1)
+        parts = [gm.rend.render_batch_ray(gm.c, gm.dec, gm.rays_d[s], gm.rays_o[s], DEV, gm.tsdf, gm.tsdf_bnds,
+                                          'color', gt_depth=gm.gt_depth[s], depth_max=dmax)
+                 for s in (slice(0, h), slice(h, n))]
+    for k in range(4):
+        assert torch.equal(whole[k], torch.cat([parts[0][k], parts[1][k]], dim=0))
+
+
+def test_weight_update_invalidates_packed_cache(mini, gm):
+    dec, rend = build(mini, mini.sd)
+    with torch.no_grad():
+        a = rend.render_batch_ray(gm.c, dec, gm.rays_d, gm.rays_o, DEV, gm.tsdf, gm.tsdf_bnds, 'color', gt_depth=gm.gt_depth)
+        dec.color_decoder.output_linear.bias.add_(0.25)       # in-place, like optimizer.step()
+        b = rend.render_batch_ray(gm.c, dec, gm.rays_d, gm.rays_o, DEV, gm.tsdf, gm.tsdf_bnds, 'color', gt_depth=gm.gt_depth)
+        c2 = {k: v.clone() for k, v in gm.c.items()}
+        c2['grid_color'] += 0.05
+        c3 = rend.render_batch_ray(c2, dec, gm.rays_d, gm.rays_o, DEV, gm.tsdf, gm.tsdf_bnds, 'color', gt_depth=gm.gt_depth)
+    assert torch.equal(a[0], b[0]) and not torch.equal(a[2], b[2])
+    assert not torch.equal(b[2], c3[2])
+
+
+# --------------------------------------------------------------------------- full size (config 2)
+def test_full_frame_room0_properties():
+    """640x480, 64 samples/ray on the room0-sized scene: size-independent properties + a ray subset
+    against the oracle."""
+    sc = synthetic.Scene('room0', device=DEV, grid_std_scale=20.0)
+    sc.c['grid_high'] = sc.c['grid_high'] * 100
+    sd = O.random_state_dict(seed=0)
+    dec, rend = build(sc, sd, 48, 16)
+    c2w = sc.default_c2w()
+    gd = sc.depth_image(c2w)
+    di, ui, ci = rend.render_img(sc.c, dec, c2w, DEV, sc.tsdf_volume, sc.tsdf_bnds, 'color', gt_depth=gd)
+    assert torch.isfinite(di).all() and torch.isfinite(ci).all() and (ui >= -1e-9).all()
+    assert (di >= 0).all() and float(di.max()) <= 1.2 * float(gd.max()) + 0.02
+    # subset of rays of the first render_img batch through the oracle (same per-batch depth max)
+    ro, rd = common.get_rays(sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2w, DEV)
+    ro, rd, g = ro.reshape(-1, 3)[:100000], rd.reshape(-1, 3)[:100000], gd.reshape(-1)[:100000]
+    pick = torch.arange(0, 100000, 997, device=DEV)
+    pick[0] = int(torch.argmax(g))                       # keep the batch max so the far clamp is identical
+    cpu = {k: v.cpu() for k, v in sc.c.items()}
+    od, ou, oc, ow = O.render_batch_ray(sd, cpu, rd[pick].cpu(), ro[pick].cpu(), sc.tsdf_volume.cpu(),
+                                        sc.tsdf_bnds, sc.bound, 'color', g[pick].cpu(), 48, 16)
+    assert_close(di.reshape(-1)[pick], od, TOL, 'depth')
+    assert_close(ci.reshape(-1, 3)[pick], oc, TOL, 'color')

@@ -1,0 +1,109 @@
+"""CPU: host-side mirror of the reference interface (module tree, parameter names, config
+handling, CPU ray helpers, no-fallback behaviour)."""
+import copy
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import attentive_dfprior_amd as A
+from attentive_dfprior_amd import common, synthetic
+from oracle import adfp_oracle as O
+from conftest import make_cfg
+
+
+def test_state_dict_names_and_shapes_match_reference():
+    m = A.DF()
+    want = O.decoder_param_shapes()
+    got = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert got == [(k, tuple(s)) for k, s in want]
+    assert sum(p.numel() for p in m.parameters()) == 86029
+
+
+def test_load_state_dict_deepcopy_pickle(mini):
+    m = A.DF()
+    m.load_state_dict(mini.sd)
+    m.bound = mini.bound
+    m2 = copy.deepcopy(m)                       # src/Tracker.py:144
+    assert m2._packed == {} and torch.equal(m2.mlp.output_linear.weight, m.mlp.output_linear.weight)
+    m3 = pickle.loads(pickle.dumps(m))          # mp.spawn, src/DF_Prior.py:302-311
+    assert torch.equal(m3.low_decoder.embedder._B, m.low_decoder.embedder._B)
+    for name in ('low_decoder', 'high_decoder', 'color_decoder', 'mlp'):
+        assert len(list(getattr(m, name).parameters())) > 0   # src/Mapper.py:364-371
+    m.share_memory()                            # src/DF_Prior.py:108-110
+
+
+def test_get_model_uses_reference_config_keys():
+    cfg = {'data': {'dim': 3}, 'grid_len': {'low': 0.32, 'high': 0.16, 'color': 0.16},
+           'model': {'c_dim': 32, 'pos_embedding_method': 'fourier'}}
+    m = A.get_model(cfg)
+    assert isinstance(m, A.DF) and m.high_decoder.c_dim == 64 and m.color_decoder.color
+    cfg['model']['pos_embedding_method'] = 'nerf'
+    with pytest.raises(NotImplementedError):
+        A.get_model(cfg)
+
+
+def test_renderer_reads_cfg_like_reference(mini):
+    r = A.Renderer(make_cfg(48, 16), None, mini)
+    assert (r.N_samples, r.N_surface, r.ray_batch_size, r.points_batch_size) == (48, 16, 100000, 500000)
+    assert r.bound is mini.bound and r.tsdf_bnds is mini.vol_bnds
+    cfg = make_cfg()
+    cfg['rendering']['N_importance'] = 8
+    with pytest.raises(NotImplementedError):
+        A.Renderer(cfg, None, mini)
+    cfg = make_cfg()
+    cfg['occupancy'] = False
+    with pytest.raises(NotImplementedError):
+        A.Renderer(cfg, None, mini)
+
+
+def test_no_cpu_fallback(mini):
+    """The product path must fail loudly on CPU tensors instead of computing somewhere else."""
+    m = A.DF()
+    m.load_state_dict(mini.sd)
+    m.bound = mini.bound
+    r = A.Renderer(make_cfg(), None, mini)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        r.render_batch_ray(mini.c, m, mini.rays_d, mini.rays_o, 'cpu', mini.tsdf_volume, mini.tsdf_bnds, 'color',
+                           mini.gt_depth)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m(mini.query_points.unsqueeze(0), c_grid=mini.c, tsdf_volume=mini.tsdf_volume, tsdf_bnds=mini.tsdf_bnds,
+          stage='high')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        common.raw2outputs_nerf_color(torch.zeros(2, 4, 4), torch.zeros(2, 4), None, occupancy=True)
+
+
+def test_cpu_ray_helpers_match_golden(mini):
+    g = mini.golden('rays')
+    ro, rd = common.get_rays(mini.H, mini.W, mini.fx, mini.fy, mini.cx, mini.cy, mini.c2w, 'cpu')
+    assert np.abs(rd.numpy() - g['get_rays_d']).max() <= 1e-6
+    assert np.array_equal(ro.contiguous().numpy(), g['get_rays_o'])
+    ro2, rd2 = common.get_rays_from_uv(torch.from_numpy(g['uv_i']), torch.from_numpy(g['uv_j']), mini.c2w,
+                                       mini.H, mini.W, mini.fx, mini.fy, mini.cx, mini.cy, 'cpu')
+    assert np.abs(rd2.numpy() - g['uv_rays_d']).max() <= 1e-6
+
+
+def test_get_samples_uses_torch_randint_stream(mini):
+    depth = mini.depth_img
+    color = torch.rand(mini.H, mini.W, 3)
+    torch.manual_seed(4)
+    ro, rd, d, c = common.get_samples(0, mini.H, 0, mini.W, 50, mini.H, mini.W, mini.fx, mini.fy, mini.cx, mini.cy,
+                                      mini.c2w, depth, color, 'cpu')
+    torch.manual_seed(4)
+    idx = torch.randint(mini.H * mini.W, (50,))
+    assert torch.equal(d, depth.reshape(-1)[idx]) and torch.equal(c, color.reshape(-1, 3)[idx])
+    i, j, d2, c2 = O.select_uv(0, mini.H, 0, mini.W, idx, depth, color)
+    _, rd_ref = O.get_rays_from_uv(i, j, mini.c2w, mini.fx, mini.fy, mini.cx, mini.cy)
+    assert (rd - rd_ref).abs().max().item() <= 1e-6
+
+
+def test_synthetic_scene_shapes_follow_reference_formulas():
+    b = synthetic.scene_bound(synthetic.SCENE_BOUNDS['room0'])
+    assert torch.allclose(b[:, 1], torch.tensor([8.94, 5.76, 3.54], dtype=torch.float64), atol=1e-9)
+    assert synthetic.grid_shape(b, 0.16)[2:] == [43, 56, 74]
+    assert synthetic.grid_shape(b, 0.32)[2:] == [21, 28, 37]
+    sc = synthetic.mini_scene()
+    assert sc.tsdf_volume.shape[:2] == (1, 1) and not sc.tsdf_volume.is_contiguous()
+    assert sc.tsdf_volume.stride(2) == 1                           # Z fastest, as get_tsdf.py:95-97
+    assert float(sc.tsdf_volume.min()) == -1.0 and float(sc.tsdf_volume.max()) == 1.0

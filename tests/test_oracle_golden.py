@@ -1,0 +1,115 @@
+"""CPU: the oracle (oracle/adfp_oracle.py) against the golden vectors generated from the
+reference's own modules (tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import adfp_oracle as O
+
+
+def _eq(a, b, tol=0.0):
+    a = torch.as_tensor(a)
+    b = torch.as_tensor(b)
+    assert a.dtype == b.dtype, (a.dtype, b.dtype)
+    assert a.shape == b.shape
+    d = (a.double() - b.double()).abs().max().item() if a.numel() else 0.0
+    assert d <= tol, d
+
+
+@pytest.mark.parametrize('stage', O.STAGES)
+def test_render_batch_ray_matches_reference(mini, stage):
+    g = mini.golden(stage)
+    d, u, c, w, aux = O.render_batch_ray(mini.sd, mini.c, mini.rays_d, mini.rays_o, mini.tsdf_volume, mini.tsdf_bnds,
+                                         mini.bound, stage, mini.gt_depth, mini.n_samples, mini.n_surface,
+                                         return_aux=True)
+    _eq(aux['z_vals'], g['z_vals'])
+    _eq(d, g['depth'], 1e-12)
+    _eq(u, g['uncertainty'], 1e-12)
+    _eq(c, g['color'], 1e-6)
+    _eq(w, g['weight'], 1e-6)
+    assert d.dtype == torch.float64 and u.dtype == torch.float64 and c.dtype == torch.float32
+    assert tuple(w.shape) == (mini.rays_o.shape[0], mini.n_samples + mini.n_surface, 1)
+
+
+@pytest.mark.parametrize('stage', O.STAGES)
+def test_render_without_sensor_depth(mini, stage):
+    g = mini.golden(stage)
+    d, u, c, w, aux = O.render_batch_ray(mini.sd, mini.c, mini.rays_d, mini.rays_o, mini.tsdf_volume, mini.tsdf_bnds,
+                                         mini.bound, stage, None, mini.n_samples, mini.n_surface, return_aux=True)
+    _eq(aux['z_vals'], g['nd_z_vals'])
+    _eq(d, g['nd_depth'], 1e-12)
+    _eq(c, g['nd_color'], 1e-6)
+    assert w.shape[1] == mini.n_samples
+
+
+@pytest.mark.parametrize('stage', O.STAGES)
+def test_eval_points_and_df_forward(mini, stage):
+    g = mini.golden(stage)
+    raw, w = O.eval_points(mini.sd, mini.query_points, mini.c, mini.tsdf_volume, mini.tsdf_bnds, mini.bound, stage)
+    _eq(raw, g['q_raw'], 1e-6)
+    _eq(w, g['q_w'], 1e-6)
+    raw2, w2 = O.df_forward(mini.sd, mini.query_points, mini.c, mini.tsdf_volume, mini.tsdf_bnds, mini.bound, stage)
+    _eq(raw2, g['df_raw'], 1e-6)
+    _eq(w2, g['df_w'], 1e-6)
+    # the query set really contains out-of-bound points (occ forced to 100, Renderer.py:64)
+    assert (torch.as_tensor(g['q_raw'])[:, 3] == 100).any()
+
+
+@pytest.mark.parametrize('stage', O.STAGES)
+@pytest.mark.parametrize('tag,warm', [('g', False), ('gw', True)])
+def test_mapper_loss_gradients(mini, stage, tag, warm):
+    g = mini.golden(stage)
+    c = {k: v.clone().requires_grad_(True) for k, v in mini.c.items()}
+    sd = {k: v.clone().requires_grad_(True) for k, v in mini.sd.items()}
+    d, u, col, w = O.render_batch_ray(sd, c, mini.rays_d, mini.rays_o, mini.tsdf_volume, mini.tsdf_bnds, mini.bound,
+                                      stage, mini.gt_depth, mini.n_samples, mini.n_surface)
+    loss = O.mapper_loss(d, col, w, mini.gt_depth, mini.gt_color, stage, warm)
+    loss.backward()
+    assert abs(loss.item() - float(g[tag + '.loss'])) <= 1e-9 * abs(float(g[tag + '.loss']))
+    for k, v in c.items():
+        got = v.grad if v.grad is not None else torch.zeros_like(v)
+        ref = torch.from_numpy(g[f'{tag}.{k}'])
+        assert (got - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    for k, v in sd.items():
+        got = v.grad if v.grad is not None else torch.zeros_like(v)
+        ref = torch.from_numpy(g[f'{tag}.sd.{k}'])
+        assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), k
+
+
+def test_rays_tsdf_and_image(mini):
+    g = mini.golden('rays')
+    ro, rd = O.get_rays(mini.H, mini.W, mini.fx, mini.fy, mini.cx, mini.cy, mini.c2w)
+    _eq(ro.contiguous(), g['get_rays_o'])
+    _eq(rd, g['get_rays_d'])
+    ro2, rd2 = O.get_rays_from_uv(torch.from_numpy(g['uv_i']), torch.from_numpy(g['uv_j']), mini.c2w,
+                                  mini.fx, mini.fy, mini.cx, mini.cy)
+    _eq(rd2, g['uv_rays_d'])
+    t = O.trilerp(mini.tsdf_volume, mini.query_points, mini.tsdf_bnds)
+    _eq(t, g['tsdf_q'])
+    di, ui, ci = O.render_img(mini.sd, mini.c, mini.c2w, mini.H, mini.W, mini.fx, mini.fy, mini.cx, mini.cy,
+                              mini.tsdf_volume, mini.tsdf_bnds, mini.bound, 'color', mini.depth_img,
+                              mini.n_samples, mini.n_surface, ray_batch_size=int(g['img_ray_batch_size']))
+    _eq(di, g['img_depth'], 1e-12)
+    _eq(ui, g['img_uncertainty'], 1e-12)
+    _eq(ci, g['img_color'], 1e-6)
+
+
+def test_trilerp_explicit_is_grid_sample(mini):
+    """The corner-by-corner restatement the HIP kernels implement == F.grid_sample, including
+    points outside the volume (border clamp) and the permuted TSDF view."""
+    a = O.trilerp(mini.tsdf_volume, mini.query_points, mini.tsdf_bnds)
+    b = O.trilerp_explicit(mini.tsdf_volume, mini.query_points, mini.tsdf_bnds)
+    assert (a - b).abs().max().item() <= 2e-7
+    a = O.trilerp(mini.c['grid_high'], mini.query_points, mini.bound)
+    b = O.trilerp_explicit(mini.c['grid_high'], mini.query_points, mini.bound)
+    assert (a - b).abs().max().item() <= 1e-6 * a.abs().max().item()
+
+
+def test_fixture_covers_edge_cases(mini):
+    g = mini.golden('color')
+    assert (mini.gt_depth == 0).sum() >= 5                      # zero-depth rays (Renderer.py:179-201)
+    raw = torch.from_numpy(g['raw'])
+    assert (raw[..., 3] == 100).any()                           # samples leaving the bound
+    w = torch.from_numpy(g['weight'])
+    frac = (w != 1).float().mean().item()
+    assert 0.05 < frac < 0.95                                   # both in-band and out-of-band samples
