@@ -76,6 +76,8 @@ SYMBOLS = [
     ('adfp_render_forward', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpRenderArgs), C.c_void_p]),
     ('adfp_tsdf_stage', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_decode_stage', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
 ]
 
 _lib = None

@@ -837,6 +837,31 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
     return 0;
 }
 
+// bench hook: ONE decoder kernel (LOW or COLOR) over every point, nothing else.
+extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, int kind, float* raw, float* w, void* stream) {
+    if (!sc || !pts || !raw || !w) return ADFP_E_ARG;
+    if (kind != ADFP_DEC_LOW && kind != ADFP_DEC_COLOR) return ADFP_E_UNSUPPORTED;
+    PtsDev P; int rc = make_pts(pts, &P); if (rc) return rc;
+    if (P.n == 0) return 0;
+    DecodeArgs a;
+    a.P = P; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
+    a.list = nullptr; a.count_ptr = nullptr; a.flags = nullptr;
+    a.raw = raw; a.w = w; a.att_occ = nullptr; a.write_w = 1; a.apply_bound = 1;
+    const int ntiles = (P.n + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == ADFP_DEC_LOW) {
+        if (!sc->low.data || !sc->w_low) return ADFP_E_ARG;
+        a.g0 = make_grid(sc->low); a.g1 = a.g0; a.packed = sc->w_low;
+        hipLaunchKernelGGL((k_decode<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+    } else {
+        if (!sc->color.data || !sc->w_color) return ADFP_E_ARG;
+        a.g0 = make_grid(sc->color); a.g1 = a.g0; a.packed = sc->w_color;
+        hipLaunchKernelGGL((k_decode<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+    }
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
 static int check_scene(const adfp_scene* sc, int stage) {
     if (!sc) return ADFP_E_ARG;
     if (stage < ADFP_STAGE_LOW || stage > ADFP_STAGE_COLOR) return ADFP_E_ARG;

@@ -179,3 +179,29 @@ def make_ray_batch(scene, n_rays, seed=1, zero_frac=0.1, noise=0.02, poses=2, de
     depth = torch.where(zero, torch.zeros_like(depth), depth)
     color = torch.rand(n_rays, 3, generator=g)
     return rays_o.to(device), rays_d.to(device), depth.to(device), color.to(device)
+
+
+def seeded_state_dict(seed=0, bias_scale=0.05, occ_bias=-0.5, out_scale=0.15):
+    """Seeded decoder weights (pretrained/low_high.pt is missing from the reference snapshot):
+    the reference's init distributions (xavier-uniform DenseLayers, N(0,25^2) Fourier matrices,
+    nn.Linear-default fc_c) with small non-zero biases; the occupancy heads are damped and biased
+    negative so that free space is mostly transparent, as with trained decoders."""
+    from .decoder import DF
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, v in DF().state_dict().items():
+        shp = tuple(v.shape)
+        if k.endswith('_B'):
+            sd[k] = torch.randn(shp, generator=g) * 25
+        elif k.endswith('weight'):
+            fan_out, fan_in = shp
+            gain = 1.0 if 'output_linear' in k else 2 ** 0.5
+            a = (1.0 / fan_in) ** 0.5 if 'fc_c' in k else gain * (6.0 / (fan_in + fan_out)) ** 0.5
+            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * a
+        else:
+            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * bias_scale
+    for name in ('low', 'high'):
+        sd[f'{name}_decoder.output_linear.weight'] *= out_scale
+    sd['low_decoder.output_linear.bias'] += occ_bias
+    sd['color_decoder.output_linear.weight'][3] *= out_scale
+    return sd

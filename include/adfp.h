@@ -171,6 +171,10 @@ int adfp_render_forward(const adfp_scene* scene /*host*/, const adfp_render_args
 int adfp_tsdf_stage(const adfp_scene* scene, const adfp_points* pts, unsigned char* flags,
                     int* list, float* att_u, float* w, int* counter, void* stream);
 
+/* Per-stage timing hook for bench.py: runs ONLY one decoder kernel (kind = ADFP_DEC_LOW or
+ * ADFP_DEC_COLOR) over every point and writes its output channel(s) of raw. */
+int adfp_decode_stage(const adfp_scene* scene, const adfp_points* pts, int kind, float* raw, float* w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
