@@ -106,8 +106,9 @@ ADFP_DEV float trilerp_scalar(const TsdfDev& t, const float pn[3]) {
     return o;
 }
 
-// 16 of the 32 channels of a channels-last feature voxel grid: lane-half `h` takes channels
-// [16h, 16h+16), i.e. half of each 128-B voxel line (4 x dwordx4 per corner).
+// 16 of the 32 channels of a channels-last feature voxel grid: lane-half `h` takes the channels
+// kmapH(r,h) = 8q+4h .. 8q+4h+3 (q = 0..3), i.e. four 16-B pieces of each 128-B voxel line; the
+// two halves of a lane pair cover the whole line (c[r] <-> channel kmapH(r, h)).
 ADFP_DEV void gather16(const GridDev& g, const float pn[3], int h, float* __restrict__ c) {
     int xi[2], yi[2], zi[2]; float wx[2], wy[2], wz[2];
     tri_axis(pn[0], g.X, xi[0], xi[1], wx[0], wx[1]);
@@ -123,10 +124,10 @@ ADFP_DEV void gather16(const GridDev& g, const float pn[3], int h, float* __rest
             for (int dx = 0; dx < 2; ++dx) {
                 const float w = (wx[dx] * wy[dy]) * wz[dz];
                 const long long vox = ((long long)zi[dz] * g.Y + yi[dy]) * g.X + xi[dx];
-                const f32x4* src = (const f32x4*)(g.data + vox * 32 + 16 * h);
+                const f32x4* src = (const f32x4*)(g.data + vox * 32 + 4 * h);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const f32x4 t = src[v];
+                    const f32x4 t = src[2 * v];
                     c[4 * v + 0] = fmaf(t.x, w, c[4 * v + 0]);
                     c[4 * v + 1] = fmaf(t.y, w, c[4 * v + 1]);
                     c[4 * v + 2] = fmaf(t.z, w, c[4 * v + 2]);
@@ -173,24 +174,52 @@ ADFP_DEV float inv_tsdf(float t) {
 // ------------------------------------------------------------------------------------
 // MFMA f32 32x32x2 chains.
 //   D[row = out unit][col = point] += A[row][k] * B[k][col]
-//   A operand: lane (i = l&31, h = l>>5) holds W[i][kmap(s,h)]   (from the packed LDS image)
-//   B operand: lane (p = l&31, h)        holds x[kmap(s,h)] of point p
-//   D: lane (p, h) reg r holds row (r&3) + 8*(r>>2) + 4*h of point p
-// so a layer's 16 accumulator registers ARE the next layer's 16 B operands with
-// kmapH(s,h) = (s&3) + 8*(s>>2) + 4*h  -- no lane movement, no LDS round trip.
-// Packed chain image: [KS/4][2][32][4] floats; lane reads one float4 per 4 k-steps.
+//   A operand: lane (i = l&31, h = l>>5) holds W[i][unit(s,h)]   (from the packed LDS image)
+//   B operand: lane (p = l&31, h)        holds x[unit(s,h)] of point p
+//   D: lane (p, h) reg r holds row kmapH(r,h) = (r&3) + 8*(r>>2) + 4*h of point p
+// so a layer's 16 accumulator registers ARE the next layer's 16 B operands -- no lane
+// movement, no LDS round trip.  ONE unit mapping is used everywhere (hidden units, Fourier
+// features, grid channels): k-step s of lane-half h carries unit  32*(s>>4) + kmapH(s&15, h).
+//
+// Packed chain image of a [32 out x K in] block: K/4 step-groups; a step-group is 2 row-groups
+// (h = 0,1) of 32 rows x 4 consecutive k-steps, each row-group padded from 128 to RG = 132
+// floats.  Forward: lane reads one float4 per 4 k-steps (ds_read_b128, conflict-free).
+// Backward (transposed operand W^T): lane j reads W[out][j] one float per MFMA
+// (ds_read_b32); the padding makes the 32 lanes hit 32 different banks.
 // ------------------------------------------------------------------------------------
+#define ADFP_RG 132
+#define ADFP_SG (2 * ADFP_RG)
+
+__host__ __device__ constexpr int kmapH(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
+// unit carried by (k-step s, lane-half h)
+__host__ __device__ constexpr int unit_of(int s, int h) { return 32 * (s >> 4) + kmapH(s & 15, h); }
+
 template <int KS, typename BT>
-ADFP_DEV void mfma_chain(f32x16& acc, const float* __restrict__ w, int lane_off4, const BT& b, const int boff = 0) {
+ADFP_DEV void mfma_chain(f32x16& acc, const float* __restrict__ w, int lane_off, const BT& b, const int boff = 0) {
 #pragma unroll
     for (int s4 = 0; s4 < KS / 4; ++s4) {
-        const f32x4 a = *(const f32x4*)(w + s4 * 256 + lane_off4);
+        const f32x4 a = *(const f32x4*)(w + s4 * ADFP_SG + lane_off);      // lane_off = h*RG + i*4
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[boff + 4 * s4 + 0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[boff + 4 * s4 + 1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[boff + 4 * s4 + 2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[boff + 4 * s4 + 3], acc, 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting the next chain's LDS reads
+}
+
+// Transposed chain: acc[in unit j][point] += sum_out W[out][j] * g[out][point] for ONE 32-wide
+// in-block of a [32 out x K in] image.  `w` = image base + the in-block's first step-group
+// (16 k-steps = 4 step-groups per in-block); lane_off_t = ((j>>3)*2 + ((j>>2)&1))*RG + (j&3)
+// for lane row j (the position of in-unit j inside its in-block); g = the 16 registers of the
+// out-block's gradient in D layout.
+template <typename BT>
+ADFP_DEV void mfma_chain_T(f32x16& acc, const float* __restrict__ w, int lane_off_t, int h, const BT& g, const int goff = 0) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float a = w[lane_off_t + 4 * kmapH(s, 0) + 16 * h];              // row kmapH(s,h) = kmapH(s,0) + 4h
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, g[goff + s], acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // acc[r] = bias[row(r,h)]: rows 8q+4h .. 8q+4h+3 are one float4
@@ -211,8 +240,12 @@ ADFP_DEV void relu_bias(f32x16& acc, const float* __restrict__ bias, int h) {
         acc[4 * q + 3] = fmaxf(acc[4 * q + 3], 0.f) + t.w;
     }
 }
-
-__host__ __device__ constexpr int kmapH(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
+ADFP_DEV unsigned pos_mask(const f32x16& acc) {
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m |= (acc[r] > 0.f) ? (1u << r) : 0u;
+    return m;
+}
 
 // ------------------------------------------------------------------------------------
 // Layouts: flat (state_dict order) and packed (MFMA operand order) images of one decoder.
@@ -225,6 +258,7 @@ struct DecLayout {
     static constexpr int KSC = CDIM / 2;      // k-steps of fc_c
     __host__ __device__ static constexpr int in_dim(int i) { return i == 0 ? 93 : (i == 3 ? 125 : 32); }
     __host__ __device__ static constexpr int ks(int i) { return i == 0 ? KSE : (i == 3 ? KSE + 16 : 16); }
+    __host__ __device__ static constexpr int chain_floats(int ksteps) { return (ksteps / 4) * ADFP_SG; }
     // ---- flat
     __host__ __device__ static constexpr int F_FC(int i) { return i * (32 * CDIM + 32); }
     static constexpr int F_EB = 5 * (32 * CDIM + 32);
@@ -237,23 +271,19 @@ struct DecLayout {
     static constexpr int F_OB = F_OW + NOUT * 32;
     static constexpr int F_TOTAL = F_OB + NOUT;
     // ---- packed
-    static constexpr int P_BM = 0;                                  // [96][4]
-    __host__ __device__ static constexpr int layer_floats(int i) { return ks(i) * 64 + 32 + KSC * 64 + 32; }
+    static constexpr int P_BM = 0;                                  // [96][4], feature-index order
+    __host__ __device__ static constexpr int layer_floats(int i) { return chain_floats(ks(i)) + 32 + chain_floats(KSC) + 32; }
     __host__ __device__ static constexpr int P_WP(int i) {
         int o = 384;
         for (int k = 0; k < i; ++k) o += layer_floats(k);
         return o;
     }
-    __host__ __device__ static constexpr int P_BP(int i) { return P_WP(i) + ks(i) * 64; }
+    __host__ __device__ static constexpr int P_BP(int i) { return P_WP(i) + chain_floats(ks(i)); }
     __host__ __device__ static constexpr int P_WC(int i) { return P_BP(i) + 32; }
-    __host__ __device__ static constexpr int P_BC(int i) { return P_WC(i) + KSC * 64; }
+    __host__ __device__ static constexpr int P_BC(int i) { return P_WC(i) + chain_floats(KSC); }
     static constexpr int P_WO = P_WP(5);                             // [2][NOUT][16]
     static constexpr int P_BO = P_WO + 2 * NOUT * 16;                // [4]
     static constexpr int P_TOTAL = P_BO + 4;
-    // channel handled by lane-half h at fc_c k-step s
-    __host__ __device__ static constexpr int cmap(int s, int h) {
-        return s < 16 ? 16 * h + s : 32 + 16 * h + (s - 16);
-    }
 };
 
 // mlp_tsdf: 2 -> 64 -> 128 -> 128 -> 64 -> 2  (decoder.py:212-228)
@@ -266,13 +296,15 @@ struct AttLayout {
     static constexpr int F_WO = F_B3 + 64, F_BO = F_WO + 2 * 64;      // [2][64]
     static constexpr int F_TOTAL = F_BO + 2;
     // packed
-    static constexpr int P_A0 = 0;                                    // [64][4] = (w0, w1, b, 0)
-    static constexpr int P_W1 = 256;                                  // 4 blocks x 32 steps x 64
-    static constexpr int P_B1 = P_W1 + 4 * 32 * 64;
-    static constexpr int P_W2 = P_B1 + 128;                           // 4 blocks x 64 steps x 64
-    static constexpr int P_B2 = P_W2 + 4 * 64 * 64;
-    static constexpr int P_W3 = P_B2 + 128;                           // 2 blocks x 64 steps x 64
-    static constexpr int P_B3 = P_W3 + 2 * 64 * 64;
+    static constexpr int BLK1 = (32 / 4) * ADFP_SG;                   // one 32-row out-block, K = 64
+    static constexpr int BLK2 = (64 / 4) * ADFP_SG;                   // K = 128
+    static constexpr int P_A0 = 0;                                    // [64][4] = (w0, w1, b, 0), unit order
+    static constexpr int P_W1 = 256;                                  // 4 out-blocks
+    static constexpr int P_B1 = P_W1 + 4 * BLK1;
+    static constexpr int P_W2 = P_B1 + 128;                           // 4 out-blocks
+    static constexpr int P_B2 = P_W2 + 4 * BLK2;
+    static constexpr int P_W3 = P_B2 + 128;                           // 2 out-blocks
+    static constexpr int P_B3 = P_W3 + 2 * BLK2;
     static constexpr int P_WO = P_B3 + 64;                            // [2 h][2 o][32]
     static constexpr int P_BO = P_WO + 128;
     static constexpr int P_TOTAL = P_BO + 4;

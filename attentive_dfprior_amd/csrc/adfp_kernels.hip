@@ -67,6 +67,15 @@ __global__ __launch_bounds__(256) void k_relayout_cl_to_cm(const float* __restri
 // =====================================================================================
 // weight packing: flat state_dict order -> MFMA operand order
 // =====================================================================================
+// position inside a padded chain image -> (k-step s, lane-half h, out row); row < 0 = padding
+__device__ __forceinline__ void chain_pos(int u, int& s, int& h, int& row) {
+    const int s4 = u / ADFP_SG, rem = u % ADFP_SG;
+    h = rem / ADFP_RG;
+    const int r2 = rem % ADFP_RG;
+    row = r2 < 128 ? (r2 >> 2) : -1;
+    s = s4 * 4 + (r2 & 3);
+}
+
 template <int CDIM, int NOUT>
 __device__ int dec_src_index(int t) {
     using L = DecLayout<CDIM, NOUT>;
@@ -77,21 +86,18 @@ __device__ int dec_src_index(int t) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         if (t < L::P_BP(i)) {                       // pts_linears.i weight chain
-            const int u = t - L::P_WP(i);
-            const int s = (u >> 8) * 4 + (u & 3), h = (u >> 7) & 1, row = (u >> 2) & 31;
-            int col;
-            if (i == 0) { col = 2 * s + h; if (col >= 93) col = -1; }
-            else if (i == 3) {
-                if (s < L::KSE) { col = 2 * s + h; if (col >= 93) col = -1; }
-                else col = 93 + kmapH(s - L::KSE, h);
-            } else col = kmapH(s, h);
-            return col < 0 ? -1 : L::F_PL(i) + row * L::in_dim(i) + col;
+            int s, h, row; chain_pos(t - L::P_WP(i), s, h, row);
+            if (row < 0) return -1;
+            int col = unit_of(s, h);                 // layer 0: feature; 1,2,4: hidden; 3: [feature(96 pad), hidden]
+            if (i == 0) { if (col >= 93) return -1; }
+            else if (i == 3) { if (col < 96) { if (col >= 93) return -1; } else col = 93 + (col - 96); }
+            return L::F_PL(i) + row * L::in_dim(i) + col;
         }
         if (t < L::P_WC(i)) return L::F_PL(i) + 32 * L::in_dim(i) + (t - L::P_BP(i));
         if (t < L::P_BC(i)) {                       // fc_c.i weight chain
-            const int u = t - L::P_WC(i);
-            const int s = (u >> 8) * 4 + (u & 3), h = (u >> 7) & 1, row = (u >> 2) & 31;
-            return L::F_FC(i) + row * CDIM + L::cmap(s, h);
+            int s, h, row; chain_pos(t - L::P_WC(i), s, h, row);
+            if (row < 0) return -1;
+            return L::F_FC(i) + row * CDIM + unit_of(s, h);
         }
         if (t < L::P_BC(i) + 32) return L::F_FC(i) + 32 * CDIM + (t - L::P_BC(i));
     }
@@ -111,6 +117,15 @@ __global__ void k_pack_decoder(const float* __restrict__ flat, float* __restrict
     const int s = dec_src_index<CDIM, NOUT>(t);
     packed[t] = s < 0 ? 0.f : flat[s];
 }
+// gradient of the packed image -> gradient of the flat parameters (every flat element has
+// exactly one packed position)
+template <int CDIM, int NOUT>
+__global__ void k_unpack_decoder_grad(const float* __restrict__ packed, float* __restrict__ flat) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= DecLayout<CDIM, NOUT>::P_TOTAL) return;
+    const int s = dec_src_index<CDIM, NOUT>(t);
+    if (s >= 0) flat[s] = packed[t];
+}
 
 __device__ int att_src_index(int t) {
     using A = AttLayout;
@@ -118,27 +133,27 @@ __device__ int att_src_index(int t) {
         const int k = t >> 2, c = t & 3;
         return c < 2 ? A::F_W0 + k * 2 + c : (c == 2 ? A::F_B0 + k : -1);
     }
-    if (t < A::P_B1) {                              // 64 -> 128, input k = 2s + h
-        const int u = t - A::P_W1, blk = u / 2048, v = u % 2048;
-        const int s = (v >> 8) * 4 + (v & 3), h = (v >> 7) & 1, row = (v >> 2) & 31;
-        return A::F_W1 + (blk * 32 + row) * 64 + (2 * s + h);
+    if (t < A::P_B1) {                              // 64 -> 128
+        const int u = t - A::P_W1, blk = u / A::BLK1;
+        int s, h, row; chain_pos(u % A::BLK1, s, h, row);
+        return row < 0 ? -1 : A::F_W1 + (blk * 32 + row) * 64 + unit_of(s, h);
     }
     if (t < A::P_W2) return A::F_B1 + (t - A::P_B1);
-    if (t < A::P_B2) {                              // 128 -> 128, input k = 32*(s>>4) + kmapH(s&15,h)
-        const int u = t - A::P_W2, blk = u / 4096, v = u % 4096;
-        const int s = (v >> 8) * 4 + (v & 3), h = (v >> 7) & 1, row = (v >> 2) & 31;
-        return A::F_W2 + (blk * 32 + row) * 128 + 32 * (s >> 4) + kmapH(s & 15, h);
+    if (t < A::P_B2) {                              // 128 -> 128
+        const int u = t - A::P_W2, blk = u / A::BLK2;
+        int s, h, row; chain_pos(u % A::BLK2, s, h, row);
+        return row < 0 ? -1 : A::F_W2 + (blk * 32 + row) * 128 + unit_of(s, h);
     }
     if (t < A::P_W3) return A::F_B2 + (t - A::P_B2);
-    if (t < A::P_B3) {
-        const int u = t - A::P_W3, blk = u / 4096, v = u % 4096;
-        const int s = (v >> 8) * 4 + (v & 3), h = (v >> 7) & 1, row = (v >> 2) & 31;
-        return A::F_W3 + (blk * 32 + row) * 128 + 32 * (s >> 4) + kmapH(s & 15, h);
+    if (t < A::P_B3) {                              // 128 -> 64
+        const int u = t - A::P_W3, blk = u / A::BLK2;
+        int s, h, row; chain_pos(u % A::BLK2, s, h, row);
+        return row < 0 ? -1 : A::F_W3 + (blk * 32 + row) * 128 + unit_of(s, h);
     }
     if (t < A::P_WO) return A::F_B3 + (t - A::P_B3);
-    if (t < A::P_BO) {                              // [h][o][32]: hidden 32*(j>>4) + kmapH(j&15,h)
+    if (t < A::P_BO) {                              // [h][o][32]: entry j <-> unit_of(j, h)
         const int u = t - A::P_WO, h = u >> 6, o = (u >> 5) & 1, j = u & 31;
-        return A::F_WO + o * 64 + 32 * (j >> 4) + kmapH(j & 15, h);
+        return A::F_WO + o * 64 + unit_of(j, h);
     }
     const int o = t - A::P_BO;
     return o < 2 ? A::F_BO + o : -1;
@@ -383,7 +398,7 @@ __global__ __launch_bounds__(NT, 2) void k_decode(DecodeArgs a) {
     __syncthreads();
 
     const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
-    const int lane_off4 = (h * 32 + p) * 4;
+    const int lane_off4 = h * ADFP_RG + p * 4;
     const int wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * (NT / 64);
     const int count = (ROLE == ROLE_HIGH) ? *a.count_ptr : a.P.n;
@@ -404,11 +419,11 @@ __global__ __launch_bounds__(NT, 2) void k_decode(DecodeArgs a) {
         gather16(a.g0, pn, h, c);
         if (CDIM == 64) gather16(a.g1, pn, h, c + 16);
 
-        // Fourier features sin(p @ B), feature j = 2s + h (decoder.py:26-30)
+        // Fourier features sin(p @ B); k-step s carries feature unit_of(s, h) (decoder.py:26-30)
         float e[L::KSE];
 #pragma unroll
         for (int s = 0; s < L::KSE; ++s) {
-            const f32x4 bm = *(const f32x4*)(lds + L::P_BM + (2 * s + h) * 4);
+            const f32x4 bm = *(const f32x4*)(lds + L::P_BM + (unit_of(s, 0) + 4 * h) * 4);
             const float arg = fmaf(pf[2], bm.z, fmaf(pf[1], bm.y, pf[0] * bm.x));
             e[s] = adfp_sinf(arg);
         }
@@ -425,7 +440,7 @@ __global__ __launch_bounds__(NT, 2) void k_decode(DecodeArgs a) {
             bias_init(acc, lds + L::P_BP(i), h);
             if (i == 3) {
                 mfma_chain<L::KSE>(acc, lds + L::P_WP(i), lane_off4, e);
-                mfma_chain<16>(acc, lds + L::P_WP(i) + L::KSE * 64, lane_off4, hcur);
+                mfma_chain<16>(acc, lds + L::P_WP(i) + L::chain_floats(L::KSE), lane_off4, hcur);
             } else {
                 mfma_chain<16>(acc, lds + L::P_WP(i), lane_off4, hcur);
             }
@@ -478,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void k_attention(AttArgs a) {
     for (int i = threadIdx.x; i < A::P_TOTAL / 4; i += 512) ((f32x4*)lds)[i] = ((const f32x4*)a.packed)[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
-    const int lane_off4 = (h * 32 + p) * 4;
+    const int lane_off4 = h * ADFP_RG + p * 4;
     const int wave = blockIdx.x * 8 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 8;
     const int count = *a.count_ptr;
@@ -488,11 +503,11 @@ __global__ __launch_bounds__(512, 2) void k_attention(AttArgs a) {
         const bool valid = idx < count;
         const int ii = valid ? idx : 0;
         const float occ = a.att_occ[ii], u = a.att_u[ii];
-        // layer 0 (2 -> 64) on the VALU; unit k = 2s + h
+        // layer 0 (2 -> 64) on the VALU; k-step s carries unit unit_of(s, h)
         float h0[32];
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
-            const f32x4 t = *(const f32x4*)(lds + A::P_A0 + (2 * s + h) * 4);
+            const f32x4 t = *(const f32x4*)(lds + A::P_A0 + (unit_of(s, 0) + 4 * h) * 4);
             h0[s] = fmaxf(fmaf(u, t.y, fmaf(occ, t.x, t.z)), 0.f);
         }
         // layer 1: 64 -> 128
@@ -501,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void k_attention(AttArgs a) {
         for (int ob = 0; ob < 4; ++ob) {
             f32x16 acc;
             bias_init(acc, lds + A::P_B1 + 32 * ob, h);
-            mfma_chain<32>(acc, lds + A::P_W1 + ob * 2048, lane_off4, h0);
+            mfma_chain<32>(acc, lds + A::P_W1 + ob * A::BLK1, lane_off4, h0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) h1[16 * ob + r] = fmaxf(acc[r], 0.f);
         }
@@ -511,7 +526,7 @@ __global__ __launch_bounds__(512, 2) void k_attention(AttArgs a) {
         for (int ob = 0; ob < 4; ++ob) {
             f32x16 acc;
             bias_init(acc, lds + A::P_B2 + 32 * ob, h);
-            mfma_chain<64>(acc, lds + A::P_W2 + ob * 4096, lane_off4, h1);
+            mfma_chain<64>(acc, lds + A::P_W2 + ob * A::BLK2, lane_off4, h1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) h2[16 * ob + r] = fmaxf(acc[r], 0.f);
         }
@@ -521,7 +536,7 @@ __global__ __launch_bounds__(512, 2) void k_attention(AttArgs a) {
         for (int ob = 0; ob < 2; ++ob) {
             f32x16 acc;
             bias_init(acc, lds + A::P_B3 + 32 * ob, h);
-            mfma_chain<64>(acc, lds + A::P_W3 + ob * 4096, lane_off4, h2);
+            mfma_chain<64>(acc, lds + A::P_W3 + ob * A::BLK2, lane_off4, h2);
             const float* w0 = lds + A::P_WO + (h * 2 + 0) * 32 + 16 * ob;
             const float* w1 = lds + A::P_WO + (h * 2 + 1) * 32 + 16 * ob;
 #pragma unroll
