@@ -38,6 +38,11 @@ class AdfpPoints(C.Structure):
                 ('rays_o', C.c_void_p), ('rays_d', C.c_void_p), ('z_vals', C.c_void_p), ('S', C.c_int)]
 
 
+class AdfpTrainState(C.Structure):
+    _fields_ = [('flags', C.c_void_p), ('list', C.c_void_p), ('counter', C.c_void_p),
+                ('att_occ', C.c_void_p), ('att_u', C.c_void_p)]
+
+
 class AdfpRenderArgs(C.Structure):
     _fields_ = [('stage', C.c_int), ('n_rays', C.c_int), ('n_samples', C.c_int), ('n_surface', C.c_int),
                 ('lindisp', C.c_int), ('perturb', C.c_float),
@@ -45,7 +50,17 @@ class AdfpRenderArgs(C.Structure):
                 ('t_rand', C.c_void_p), ('depth_max', C.c_void_p),
                 ('depth', C.c_void_p), ('uncertainty', C.c_void_p), ('color', C.c_void_p),
                 ('weight', C.c_void_p), ('z_vals', C.c_void_p), ('raw', C.c_void_p),
-                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('state', C.POINTER(AdfpTrainState))]
+
+
+class AdfpBackwardArgs(C.Structure):
+    _fields_ = [('stage', C.c_int), ('n_rays', C.c_int), ('S', C.c_int),
+                ('rays_o', C.c_void_p), ('rays_d', C.c_void_p), ('z_vals', C.c_void_p), ('raw', C.c_void_p),
+                ('state', AdfpTrainState),
+                ('g_depth', C.c_void_p), ('g_uncertainty', C.c_void_p), ('g_color', C.c_void_p), ('g_weight', C.c_void_p),
+                ('g_grid_low', C.c_void_p), ('g_grid_high', C.c_void_p), ('g_grid_color', C.c_void_p),
+                ('g_flat_low', C.c_void_p), ('g_flat_high', C.c_void_p), ('g_flat_color', C.c_void_p),
+                ('g_flat_att', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 
 Bound = (C.c_double * 2) * 3
@@ -76,6 +91,8 @@ SYMBOLS = [
     ('adfp_render_forward', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpRenderArgs), C.c_void_p]),
     ('adfp_tsdf_stage', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_backward_workspace_bytes', C.c_size_t, [C.c_longlong]),
+    ('adfp_render_backward', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpBackwardArgs), C.c_void_p]),
     ('adfp_decode_stage', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
 ]

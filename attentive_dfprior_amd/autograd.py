@@ -1,5 +1,76 @@
-"""Autograd bridge for Renderer.render_batch_ray (training path of src/Mapper.py:451-473)."""
+"""Autograd bridge for Renderer.render_batch_ray: the training path of src/Mapper.py:451-473.
+
+Forward = adfp_render_forward with a caller-owned training state; backward = adfp_render_backward
+(include/adfp.h).  Gradients are produced for the three feature grids (dense, in the shape of
+``c[key]``, which may be an autograd non-leaf built by index_put, src/Mapper.py:382-388) and for every
+decoder parameter that requires grad.  Gradients w.r.t. the rays (camera pose, src/Tracker.py) are
+not implemented.
+"""
+import torch
+
+_GRIDS = (('low', 'grid_low'), ('high', 'grid_high'), ('color', 'grid_color'))
+_NETS = (('low', 'low_decoder'), ('high', 'high_decoder'), ('color', 'color_decoder'), ('att', 'mlp'))
 
 
-def render_with_grad(*args, **kwargs):
-    raise NotImplementedError('backward pass not built yet')
+class _RenderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, bundle, grid_low, grid_high, grid_color, *params):
+        (engine, decoders, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, n_samples, n_surface,
+         lindisp, perturb, t_rand, depth_max) = bundle
+        c = {'grid_low': grid_low, 'grid_high': grid_high, 'grid_color': grid_color}
+        depth, unc, color, weight, saved = engine.render_forward(
+            decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, n_samples, n_surface,
+            lindisp, perturb, t_rand, depth_max, train=True)
+        ctx.bundle = bundle
+        ctx.saved = saved
+        ctx.c = c
+        ctx.n_params = [len(list(getattr(decoders, attr).parameters())) for _, attr in _NETS]
+        ctx.set_materialize_grads(False)
+        return depth, unc, color, weight
+
+    @staticmethod
+    def backward(ctx, g_depth, g_unc, g_color, g_weight):
+        (engine, decoders, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, *_rest) = ctx.bundle
+        used = {'low': ('low',), 'high': ('low', 'high', 'att'), 'color': ('low', 'high', 'color', 'att')}[stage]
+        need_grid = {name: bool(ctx.needs_input_grad[1 + k]) and name in used for k, (name, _) in enumerate(_GRIDS)}
+        need_flat, off = {}, 4
+        for (name, attr), n in zip(_NETS, ctx.n_params):
+            need_flat[name] = name in used and any(ctx.needs_input_grad[off:off + n])
+            off += n
+        if g_weight is not None:
+            g_weight = g_weight.reshape(g_weight.shape[0], -1)
+        grids, flats = engine.render_backward(decoders, ctx.c, tsdf_volume, tsdf_bnds, bound, stage, ctx.saved,
+                                              g_depth, g_unc, g_color, g_weight, need_grid, need_flat)
+        out = [None]
+        for k, (name, key) in enumerate(_GRIDS):
+            g = grids.get(name)
+            if g is not None and ctx.c[key].dtype != g.dtype:
+                g = g.to(ctx.c[key].dtype)
+            out.append(g)
+        off = 4
+        for (name, attr), n in zip(_NETS, ctx.n_params):
+            flat = flats.get(name)
+            pos = 0
+            for p in getattr(decoders, attr).parameters():
+                if flat is not None and ctx.needs_input_grad[off]:
+                    out.append(flat[pos:pos + p.numel()].reshape(p.shape).to(p.dtype))
+                else:
+                    out.append(None)
+                pos += p.numel()
+                off += 1
+        ctx.saved = None
+        return tuple(out)
+
+
+def render_with_grad(engine, decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, n_samples,
+                     n_surface, lindisp, perturb, t_rand, depth_max):
+    if rays_o.requires_grad or rays_d.requires_grad:
+        raise NotImplementedError('gradients w.r.t. rays (camera tracking, src/Tracker.py:112-133) are not built yet')
+    if n_samples + (n_surface if gt_depth is not None else 0) > 256:
+        raise NotImplementedError('training path supports at most 256 samples per ray')
+    bundle = (engine, decoders, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, n_samples, n_surface,
+              lindisp, perturb, t_rand, depth_max)
+    params = []
+    for _, attr in _NETS:
+        params += list(getattr(decoders, attr).parameters())
+    return _RenderFn.apply(bundle, c['grid_low'], c['grid_high'], c['grid_color'], *params)

@@ -1,0 +1,550 @@
+// adfp_backward.h -- backward kernels of the render path (Mapper loss -> grids + decoder
+// parameters, reference src/Mapper.py:457-473 through autograd).  Included by adfp_kernels.hip.
+//
+//   k_composite_bwd    d(depth, uncertainty, colour)/d(raw)               common.py:234-251
+//   k_attention_bwd    mlp_tsdf backward on the in-band list              decoder.py:240-258
+//   k_decode_bwd<...>  decoder backward: recompute forward (ReLU masks), transposed MFMA chains
+//                      out of the SAME padded LDS image, feature-gradient scatter into the
+//                      channels-last grid gradient with 128-B shaped float atomics
+//   k_outer            weight gradients: dW = sum_points g (x) input as 32x32 MFMA outer
+//                      products over point-major staging rows, atomically added to the flat
+//                      (state_dict order) gradient
+#pragma once
+#include "adfp_device.h"
+
+// ------------------------------------------------------------------------------------------
+// composite backward.  One wave per ray, lane = sample, up to 4 chunks of 64 samples.
+//   w_s = a_s T_s, T_s = prod_{j<s} f_j, f = 1 - a + 1e-10, a = sigmoid(10 occ)
+//   dL/da_s = G_s T_s - (sum_{j>s} G_j w_j) / f_s        (cumprod backward, no zeros: f >= 1e-10)
+//   G_s = gD' z_s + gV (z_s - depth)^2 + gC . c_s,  gD' = gD - 2 gV (swz - depth sw)
+// ------------------------------------------------------------------------------------------
+#define CB_MAXC 4
+__global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__ raw, const double* __restrict__ z, int n_rays, int S,
+                                                       const double* __restrict__ g_depth, const double* __restrict__ g_var,
+                                                       const float* __restrict__ g_color, float* __restrict__ g_raw) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const int nc = (S + 63) >> 6;
+    float alpha[CB_MAXC], T[CB_MAXC], w[CB_MAXC], f[CB_MAXC];
+    f32x4 r[CB_MAXC];
+    double zz[CB_MAXC];
+    float carry = 1.f;
+    double sw = 0.0, swz = 0.0;
+#pragma unroll
+    for (int c = 0; c < CB_MAXC; ++c) {
+        alpha[c] = 0.f; T[c] = 0.f; w[c] = 0.f; f[c] = 1.f; zz[c] = 0.0; r[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < nc) {
+            const int s = c * 64 + lane;
+            const bool ok = s < S;
+            if (ok) { r[c] = *(const f32x4*)(raw + ((long long)ray * S + s) * 4); zz[c] = z[(long long)ray * S + s]; }
+            alpha[c] = ok ? sigmoidf_(10.f * r[c].w) : 0.f;
+            f[c] = ok ? (1.f - alpha[c] + 1e-10f) : 1.f;
+            float incl = f[c];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float v = __shfl_up(incl, o);
+                if (lane >= o) incl *= v;
+            }
+            float excl = __shfl_up(incl, 1);
+            if (lane == 0) excl = 1.f;
+            T[c] = carry * excl;
+            w[c] = alpha[c] * T[c];
+            carry *= __shfl(incl, 63);
+            sw += (double)w[c]; swz += (double)w[c] * zz[c];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sw += __shfl_xor(sw, o); swz += __shfl_xor(swz, o); }
+    const double depth = swz;
+    const double gD = g_depth ? g_depth[ray] : 0.0;
+    const double gV = g_var ? g_var[ray] : 0.0;
+    const double gDe = gD - 2.0 * gV * (swz - depth * sw);
+    float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f;
+    if (g_color) { gc0 = g_color[3 * ray]; gc1 = g_color[3 * ray + 1]; gc2 = g_color[3 * ray + 2]; }
+    float suffix = 0.f;          // sum of G_j w_j over later chunks
+#pragma unroll
+    for (int c = CB_MAXC - 1; c >= 0; --c) {
+        if (c < nc) {
+            const int s = c * 64 + lane;
+            const bool ok = s < S;
+            const double dz = zz[c] - depth;
+            const float G = (float)(gDe * zz[c] + gV * dz * dz) + (gc0 * r[c].x + gc1 * r[c].y + gc2 * r[c].z);
+            const float gw = ok ? G * w[c] : 0.f;
+            // inclusive suffix sum across the wave (lanes above)
+            float inc = gw;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float v = __shfl_down(inc, o);
+                if (lane + o < 64) inc += v;
+            }
+            const float R = (inc - gw) + suffix;                  // sum_{j>s} G_j w_j
+            suffix += __shfl(inc, 0);
+            const float ga = G * T[c] - R / f[c];
+            const float gocc = ga * 10.f * alpha[c] * (1.f - alpha[c]);
+            if (ok) {
+                f32x4 o4 = {w[c] * gc0, w[c] * gc1, w[c] * gc2, gocc};
+                *(f32x4*)(g_raw + ((long long)ray * S + s) * 4) = o4;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// staging rows (point-major, one row per point of the current chunk) for the weight gradients
+// ------------------------------------------------------------------------------------------
+template <int CDIM>
+struct DecStage {
+    static constexpr int SX = 0;                       // [x, y, z, 1, 0 ...]
+    static constexpr int SE = 32;                      // Fourier features (96)
+    static constexpr int SC = 128;                     // grid features (CDIM)
+    __host__ __device__ static constexpr int SH(int i) { return 128 + CDIM + 32 * i; }     // h_0..h_4
+    __host__ __device__ static constexpr int SGP(int i) { return SH(5) + 32 * i; }          // d/d pre_i
+    __host__ __device__ static constexpr int SGH(int i) { return SGP(5) + 32 * i; }         // d/d h_i
+    static constexpr int SGA = SGH(5);                 // d/d (p @ B) (96)
+    static constexpr int SGO = SGA + 96;               // d/d out (32, first NOUT used)
+    static constexpr int NCOLS = SGO + 32;
+};
+struct AttStage {
+    static constexpr int AX = 0;                       // [occ_in, u, 1, 0 ...]
+    static constexpr int AH0 = 32, AH1 = 96, AH2 = 224, AH3 = 352;
+    static constexpr int AG0 = 416, AG1 = 480, AG2 = 608, AG3 = 736;
+    static constexpr int AGL = 800;                    // d/d logits (2 used)
+    static constexpr int NCOLS = 832;
+};
+
+// 16 registers of a D-layout block -> columns col + kmapH(r,h) of the point's staging row
+template <typename VT>
+ADFP_DEV void stage_block(float* __restrict__ row, int col, int h, const VT& v, const int voff = 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 t = {v[voff + 4 * q + 0], v[voff + 4 * q + 1], v[voff + 4 * q + 2], v[voff + 4 * q + 3]};
+        *(f32x4*)(row + col + 8 * q + 4 * h) = t;
+    }
+}
+// a block whose only non-zero entries are columns 0..3 (x, y, z, 1 / g_out / occ, u, 1)
+ADFP_DEV void stage_head(float* __restrict__ row, int col, int h, f32x4 head) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 t = (q == 0 && h == 0) ? head : f32x4{0.f, 0.f, 0.f, 0.f};
+        *(f32x4*)(row + col + 8 * q + 4 * h) = t;
+    }
+}
+
+ADFP_DEV void adfp_sincosf(float x, float& sn, float& cs) {
+    const float k = rintf(x * 0.636619772f);
+    float r = fmaf(k, -1.57079601e+00f, x);
+    r = fmaf(k, -3.13916473e-07f, r);
+    r = fmaf(k, -5.39030253e-15f, r);
+    const int n = (int)k;
+    const float r2 = r * r;
+    float s = fmaf(r2, 2.86567956e-6f, -1.98559923e-4f);
+    s = fmaf(s, r2, 8.33338592e-3f);
+    s = fmaf(s, r2, -1.66666672e-1f);
+    s = fmaf(s * r2, r, r);
+    float c = fmaf(r2, 2.44677067e-5f, -1.38877297e-3f);
+    c = fmaf(c, r2, 4.16666567e-2f);
+    c = fmaf(c, r2, -0.5f);
+    c = fmaf(c, r2, 1.0f);
+    float vs = (n & 1) ? c : s;
+    float vc = (n & 1) ? -s : c;
+    sn = (n & 2) ? -vs : vs;
+    cs = (n & 2) ? -vc : vc;
+}
+
+// ------------------------------------------------------------------------------------------
+// decoder backward
+// ------------------------------------------------------------------------------------------
+struct DecodeBwdArgs {
+    PtsDev P; NormDev nb; double b[6];
+    GridDev g0, g1;
+    const float* packed;
+    const int* list; const int* count_ptr;
+    const float* g_raw;        // [P,4] cotangent of raw (LOW: .w, COLOR: .xyz)
+    const float* att_g;        // HIGH: cotangent per list entry
+    float* g_grid;             // channels-last gradient of the OWN grid (or NULL)
+    float* stage;              // staging rows of this chunk (WGRAD) or NULL
+    int chunk_lo, chunk_hi;    // point / list-entry range handled by this launch
+};
+
+// lane row j of a transposed chain -> offset of in-unit j inside its in-block of the image
+ADFP_DEV int lane_off_T(int j) { return ((j >> 3) * 2 + ((j >> 2) & 1)) * ADFP_RG + (j & 3); }
+
+template <int CDIM, int NOUT, int ROLE, bool WGRAD, int NT>
+__global__ __launch_bounds__(NT) void k_decode_bwd(DecodeBwdArgs a) {
+    using L = DecLayout<CDIM, NOUT>;
+    using ST = DecStage<CDIM>;
+    constexpr int NW = NT / 64;
+    __shared__ __attribute__((aligned(16))) float lds[L::P_TOTAL];
+    __shared__ float s_tr[NW][32 * 33];          // g_c transpose: [point][channel]
+    __shared__ int s_vox[NW][32 * 8];            // corner voxel index per point
+    __shared__ float s_cw[NW][32 * 8];           // corner weight per point
+    for (int i = threadIdx.x; i < L::P_TOTAL / 4; i += NT) ((f32x4*)lds)[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+    const int lane_off = h * ADFP_RG + p * 4;
+    const int loT = lane_off_T(p);
+    const int wave = blockIdx.x * NW + wv;
+    const int nwaves = gridDim.x * NW;
+    int hi = a.chunk_hi;
+    if (ROLE == ROLE_HIGH) { const int cnt = *a.count_ptr; hi = hi < cnt ? hi : cnt; }
+    const int count = hi - a.chunk_lo;
+    const int ntiles = count > 0 ? (count + 31) >> 5 : 0;
+
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int loc = tile * 32 + p;                 // row inside the chunk
+        const bool valid = loc < count;
+        const int idx = a.chunk_lo + (valid ? loc : 0);
+        const int q = (ROLE == ROLE_HIGH) ? a.list[idx] : idx;
+        float* srow = WGRAD ? a.stage + (long long)loc * ST::NCOLS : nullptr;
+
+        double pt[3]; float pn[3], pf[3];
+        load_point(a.P, q, pt);
+        normalize3(a.nb, pt, pn);
+        pf[0] = (float)pt[0]; pf[1] = (float)pt[1]; pf[2] = (float)pt[2];
+
+        // ---------------- forward recompute (ReLU masks; stage inputs when WGRAD) ----------------
+        float c[L::KSC];
+        gather16(a.g0, pn, h, c);
+        if (CDIM == 64) gather16(a.g1, pn, h, c + 16);
+        float e[L::KSE], ce[WGRAD ? L::KSE : 1];
+#pragma unroll
+        for (int s = 0; s < L::KSE; ++s) {
+            const f32x4 bm = *(const f32x4*)(lds + L::P_BM + (unit_of(s, 0) + 4 * h) * 4);
+            const float arg = fmaf(pf[2], bm.z, fmaf(pf[1], bm.y, pf[0] * bm.x));
+            if constexpr (WGRAD) adfp_sincosf(arg, e[s], ce[s]); else e[s] = adfp_sinf(arg);
+        }
+        if (WGRAD && valid) {
+            stage_head(srow, ST::SX, h, f32x4{pf[0], pf[1], pf[2], 1.f});
+            stage_block(srow, ST::SE, h, e, 0); stage_block(srow, ST::SE + 32, h, e, 16); stage_block(srow, ST::SE + 64, h, e, 32);
+            stage_block(srow, ST::SC, h, c, 0);
+            if (CDIM == 64) stage_block(srow, ST::SC + 32, h, c, 16);
+        }
+        unsigned mask[5];
+        f32x16 hcur, acc;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            bias_init(acc, lds + L::P_BP(i), h);
+            if (i == 0) mfma_chain<L::KSE>(acc, lds + L::P_WP(0), lane_off, e);
+            else if (i == 3) {
+                mfma_chain<L::KSE>(acc, lds + L::P_WP(3), lane_off, e);
+                mfma_chain<16>(acc, lds + L::P_WP(3) + L::chain_floats(L::KSE), lane_off, hcur);
+            } else mfma_chain<16>(acc, lds + L::P_WP(i), lane_off, hcur);
+            mask[i] = pos_mask(acc);
+            relu_bias(acc, lds + L::P_BC(i), h);
+            mfma_chain<L::KSC>(acc, lds + L::P_WC(i), lane_off, c);
+            hcur = acc;
+            if (WGRAD && valid) stage_block(srow, ST::SH(i), h, hcur);
+        }
+
+        // ---------------- cotangent of the decoder output ----------------
+        float go[4] = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            if (ROLE == ROLE_LOW) go[0] = a.g_raw[4ll * q + 3];
+            else if (ROLE == ROLE_COLOR) { go[0] = a.g_raw[4ll * q]; go[1] = a.g_raw[4ll * q + 1]; go[2] = a.g_raw[4ll * q + 2]; }
+            else go[0] = a.att_g[idx];
+        }
+        if (WGRAD && valid) stage_head(srow, ST::SGO, h, f32x4{go[0], go[1], go[2], go[3]});
+
+        // d/d h_4 = Wo^T g_out
+        f32x16 gh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) s = fmaf(lds[L::P_WO + (h * NOUT + o) * 16 + r], go[o], s);
+            gh[r] = s;
+        }
+        f32x16 gc, ge0, ge1, ge2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { gc[r] = 0.f; ge0[r] = 0.f; ge1[r] = 0.f; ge2[r] = 0.f; }
+
+#pragma unroll
+        for (int i = 4; i >= 0; --i) {
+            if (WGRAD && valid) stage_block(srow, ST::SGH(i), h, gh);
+            // through fc_c[i]: d/d c += Wc_i^T gh   (own-grid channels = in-block 0 only)
+            mfma_chain_T(gc, lds + L::P_WC(i), loT, h, gh);
+            // through relu
+            f32x16 gp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gp[r] = (mask[i] >> r) & 1u ? gh[r] : 0.f;
+            if (WGRAD && valid) stage_block(srow, ST::SGP(i), h, gp);
+            if (i == 0) {
+                if (WGRAD) {
+                    mfma_chain_T(ge0, lds + L::P_WP(0), loT, h, gp);
+                    mfma_chain_T(ge1, lds + L::P_WP(0) + 4 * ADFP_SG, loT, h, gp);
+                    mfma_chain_T(ge2, lds + L::P_WP(0) + 8 * ADFP_SG, loT, h, gp);
+                }
+            } else {
+                f32x16 gn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gn[r] = 0.f;
+                if (i == 3) {
+                    if (WGRAD) {
+                        mfma_chain_T(ge0, lds + L::P_WP(3), loT, h, gp);
+                        mfma_chain_T(ge1, lds + L::P_WP(3) + 4 * ADFP_SG, loT, h, gp);
+                        mfma_chain_T(ge2, lds + L::P_WP(3) + 8 * ADFP_SG, loT, h, gp);
+                    }
+                    mfma_chain_T(gn, lds + L::P_WP(3) + L::chain_floats(L::KSE), loT, h, gp);
+                } else mfma_chain_T(gn, lds + L::P_WP(i), loT, h, gp);
+                gh = gn;
+            }
+        }
+        if constexpr (WGRAD) if (valid) {       // d/d (p @ B) = d/d e * cos(p @ B)
+            f32x16 t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = ge0[r] * ce[r];
+            stage_block(srow, ST::SGA, h, t);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = ge1[r] * ce[16 + r];
+            stage_block(srow, ST::SGA + 32, h, t);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = ge2[r] * ce[32 + r];
+            stage_block(srow, ST::SGA + 64, h, t);
+        }
+
+        // ---------------- scatter d/d c into the channels-last grid gradient ----------------
+        if (a.g_grid) {
+            // corner voxels / weights of every point of the tile -> LDS (written by the h == 0 lanes)
+            if (h == 0) {
+                int xi[2], yi[2], zi[2]; float wx[2], wy[2], wz[2];
+                tri_axis(pn[0], a.g0.X, xi[0], xi[1], wx[0], wx[1]);
+                tri_axis(pn[1], a.g0.Y, yi[0], yi[1], wy[0], wy[1]);
+                tri_axis(pn[2], a.g0.Z, zi[0], zi[1], wz[0], wz[1]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+                    s_vox[wv][p * 8 + k] = (zi[dz] * a.g0.Y + yi[dy]) * a.g0.X + xi[dx];
+                    s_cw[wv][p * 8 + k] = valid ? (wx[dx] * wy[dy]) * wz[dz] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_tr[wv][p * 33 + kmapH(r, h)] = gc[r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int ch = lane & 31;
+            for (int pp = 0; pp < 32; pp += 2) {
+                const int pi = pp + (lane >> 5);
+                const float g = s_tr[wv][pi * 33 + ch];
+                if (__ballot(g != 0.f) == 0ull) continue;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float wgt = s_cw[wv][pi * 8 + k];
+                    const float v = g * wgt;
+                    if (v != 0.f) atomicAdd(a.g_grid + (long long)s_vox[wv][pi * 8 + k] * 32 + ch, v);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// attention (mlp_tsdf) backward on the in-band list
+// ------------------------------------------------------------------------------------------
+struct AttBwdArgs {
+    const float* packed; const int* list; const int* count_ptr;
+    const float* att_occ; const float* att_u;
+    const float* g_weight;     // [P] cotangent of the attention weight output (or NULL)
+    float* g_raw;              // [P,4]: .w read as cotangent of the fused occupancy, then overwritten
+                               //        with d/d(high+low) for the LOW backward
+    float* att_g;              // per list entry: d/d(high+low) for the HIGH backward
+    float* stage;
+    int chunk_lo, chunk_hi;
+};
+
+template <bool WGRAD>
+__global__ __launch_bounds__(256) void k_attention_bwd(AttBwdArgs a) {
+    using A = AttLayout;
+    using ST = AttStage;
+    __shared__ __attribute__((aligned(16))) float lds[A::P_TOTAL];
+    for (int i = threadIdx.x; i < A::P_TOTAL / 4; i += 256) ((f32x4*)lds)[i] = ((const f32x4*)a.packed)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+    const int lane_off = h * ADFP_RG + p * 4;
+    const int loT = lane_off_T(p);
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const int cnt = *a.count_ptr;
+    const int hi = a.chunk_hi < cnt ? a.chunk_hi : cnt;
+    const int count = hi - a.chunk_lo;
+    const int ntiles = count > 0 ? (count + 31) >> 5 : 0;
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int loc = tile * 32 + p;
+        const bool valid = loc < count;
+        const int idx = a.chunk_lo + (valid ? loc : 0);
+        const int q = a.list[idx];
+        float* srow = WGRAD ? a.stage + (long long)loc * ST::NCOLS : nullptr;
+        const float occ = a.att_occ[idx], u = a.att_u[idx];
+        // ---- forward recompute with ReLU masks
+        float h0[32];
+        unsigned m0 = 0;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const f32x4 t = *(const f32x4*)(lds + A::P_A0 + (unit_of(s, 0) + 4 * h) * 4);
+            h0[s] = fmaxf(fmaf(u, t.y, fmaf(occ, t.x, t.z)), 0.f);
+            m0 |= h0[s] > 0.f ? (1u << s) : 0u;
+        }
+        if (WGRAD && valid) {
+            stage_head(srow, ST::AX, h, f32x4{occ, u, 1.f, 0.f});
+            stage_block(srow, ST::AH0, h, h0, 0); stage_block(srow, ST::AH0 + 32, h, h0, 16);
+        }
+        float h1[64]; unsigned m1[4];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            f32x16 acc;
+            bias_init(acc, lds + A::P_B1 + 32 * ob, h);
+            mfma_chain<32>(acc, lds + A::P_W1 + ob * A::BLK1, lane_off, h0);
+            m1[ob] = pos_mask(acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h1[16 * ob + r] = fmaxf(acc[r], 0.f);
+            if (WGRAD && valid) stage_block(srow, ST::AH1 + 32 * ob, h, h1, 16 * ob);
+        }
+        float h2[64]; unsigned m2[4];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            f32x16 acc;
+            bias_init(acc, lds + A::P_B2 + 32 * ob, h);
+            mfma_chain<64>(acc, lds + A::P_W2 + ob * A::BLK2, lane_off, h1);
+            m2[ob] = pos_mask(acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h2[16 * ob + r] = fmaxf(acc[r], 0.f);
+            if (WGRAD && valid) stage_block(srow, ST::AH2 + 32 * ob, h, h2, 16 * ob);
+        }
+        float l0 = 0.f, l1 = 0.f; unsigned m3[2];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+            f32x16 acc;
+            bias_init(acc, lds + A::P_B3 + 32 * ob, h);
+            mfma_chain<64>(acc, lds + A::P_W3 + ob * A::BLK2, lane_off, h2);
+            m3[ob] = pos_mask(acc);
+            const float* w0 = lds + A::P_WO + (h * 2 + 0) * 32 + 16 * ob;
+            const float* w1 = lds + A::P_WO + (h * 2 + 1) * 32 + 16 * ob;
+            f32x16 h3;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                h3[r] = fmaxf(acc[r], 0.f);
+                l0 = fmaf(h3[r], w0[r], l0);
+                l1 = fmaf(h3[r], w1[r], l1);
+            }
+            if (WGRAD && valid) stage_block(srow, ST::AH3 + 32 * ob, h, h3);
+        }
+        l0 += __shfl_xor(l0, 32); l1 += __shfl_xor(l1, 32);
+        l0 += lds[A::P_BO]; l1 += lds[A::P_BO + 1];
+        const float mx = fmaxf(l0, l1);
+        const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+        const float den = e0 + e1;
+        const float a0 = e0 / den, a1 = e1 / den;
+        // ---- backward: out = a0 occ + a1 u, w = a1
+        const float g_out = valid ? a.g_raw[4ll * q + 3] : 0.f;
+        const float g_w = (valid && a.g_weight) ? a.g_weight[q] : 0.f;
+        const float ga0 = g_out * occ, ga1 = g_out * u + g_w;
+        const float dot = a0 * ga0 + a1 * ga1;
+        const float gl0 = a0 * (ga0 - dot), gl1 = a1 * (ga1 - dot);
+        if (WGRAD && valid) stage_head(srow, ST::AGL, h, f32x4{gl0, gl1, 0.f, 0.f});
+        float gp3[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float g = fmaf(lds[A::P_WO + (h * 2 + 0) * 32 + j], gl0, lds[A::P_WO + (h * 2 + 1) * 32 + j] * gl1);
+            gp3[j] = (m3[j >> 4] >> (j & 15)) & 1u ? g : 0.f;
+        }
+        if (WGRAD && valid) { stage_block(srow, ST::AG3, h, gp3, 0); stage_block(srow, ST::AG3 + 32, h, gp3, 16); }
+        float gp2[64];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+                mfma_chain_T(acc, lds + A::P_W3 + ob * A::BLK2 + ib * 4 * ADFP_SG, loT, h, gp3, 16 * ob);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gp2[16 * ib + r] = (m2[ib] >> r) & 1u ? acc[r] : 0.f;
+            if (WGRAD && valid) stage_block(srow, ST::AG2 + 32 * ib, h, gp2, 16 * ib);
+        }
+        float gp1[64];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob)
+                mfma_chain_T(acc, lds + A::P_W2 + ob * A::BLK2 + ib * 4 * ADFP_SG, loT, h, gp2, 16 * ob);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gp1[16 * ib + r] = (m1[ib] >> r) & 1u ? acc[r] : 0.f;
+            if (WGRAD && valid) stage_block(srow, ST::AG1 + 32 * ib, h, gp1, 16 * ib);
+        }
+        float gx = 0.f;
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob)
+                mfma_chain_T(acc, lds + A::P_W1 + ob * A::BLK1 + ib * 4 * ADFP_SG, loT, h, gp1, 16 * ob);
+            f32x16 g0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                g0[r] = (m0 >> (16 * ib + r)) & 1u ? acc[r] : 0.f;
+                gx = fmaf(lds[A::P_A0 + (32 * ib + kmapH(r, h)) * 4], g0[r], gx);     // d/d occ_in through layer 0
+            }
+            if (WGRAD && valid) stage_block(srow, ST::AG0 + 32 * ib, h, g0);
+        }
+        gx += __shfl_xor(gx, 32);
+        const float g_in = a0 * g_out + gx;
+        if (valid && h == 0) { a.att_g[idx] = g_in; a.g_raw[4ll * q + 3] = g_in; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradients: one 32x32 outer-product block per (job, point-chunk) wave
+// ------------------------------------------------------------------------------------------
+struct OuterJob { int colA, colB, dst, rs, cs, nr, j0, nc; };
+#define OUTER_MAX_JOBS 56
+struct OuterArgs {
+    const float* stage; int ncols;
+    const int* count_ptr; int chunk_lo, chunk_hi;   // rows = min(chunk_hi, *count_ptr) - chunk_lo
+    float* flat;                                    // flat gradient (state_dict order)
+    int njobs; int rows_per_wave;
+    OuterJob jobs[OUTER_MAX_JOBS];
+};
+__global__ __launch_bounds__(64) void k_outer(OuterArgs a) {
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    int hi = a.chunk_hi;
+    if (a.count_ptr) { const int cnt = *a.count_ptr; hi = hi < cnt ? hi : cnt; }
+    const int rows = hi - a.chunk_lo;
+    const int m0 = blockIdx.x * a.rows_per_wave;
+    if (m0 >= rows) return;
+    const int m1 = (m0 + a.rows_per_wave < rows) ? m0 + a.rows_per_wave : rows;
+    const OuterJob jb = a.jobs[blockIdx.y];
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int m = m0; m < m1; m += 32) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int pt = m + 2 * s + h;
+            float va = 0.f, vb = 0.f;
+            if (pt < m1) {
+                const float* row = a.stage + (long long)pt * a.ncols;
+                va = row[jb.colA + i];
+                vb = row[jb.colB + i];
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vb, acc, 0, 0, 0);
+        }
+    }
+    const int j = i - jb.j0;
+    if (j >= 0 && j < jb.nc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = kmapH(r, h);
+            if (row < jb.nr && acc[r] != 0.f) atomicAdd(a.flat + jb.dst + row * jb.rs + j * jb.cs, acc[r]);
+        }
+    }
+}

@@ -462,14 +462,14 @@ __global__ __launch_bounds__(NT, 2) void k_decode(DecodeArgs a) {
         }
 
         if (valid && h == 0) {
-            if (ROLE == ROLE_LOW) {
+            if constexpr (ROLE == ROLE_LOW) {
                 const bool inb = in_bound(pt, a.b);
                 const unsigned f = a.flags ? a.flags[q] : 0u;
                 // in-band points keep the true value for the HIGH pass; the attention pass
                 // overwrites them (and applies the bound rule) afterwards.
                 a.raw[4ll * q + 3] = ((f & ADFP_F_BAND) || inb || !a.apply_bound) ? out[0] : 100.f;   // Renderer.py:64
                 if (a.write_w) a.w[q] = 1.f;
-            } else if (ROLE == ROLE_COLOR) {
+            } else if constexpr (ROLE == ROLE_COLOR) {
                 a.raw[4ll * q + 0] = out[0]; a.raw[4ll * q + 1] = out[1]; a.raw[4ll * q + 2] = out[2];
             } else {
                 a.att_occ[idx] = out[0] + a.raw[4ll * q + 3];                        // high + low, decoder.py:342
@@ -612,6 +612,8 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
         color[3 * ray + 0] = cr; color[3 * ray + 1] = cg; color[3 * ray + 2] = cb;
     }
 }
+
+#include "adfp_backward.h"
 
 // =====================================================================================
 // host side: C ABI
@@ -810,8 +812,14 @@ static int decode_grid(int ntiles, int waves_per_wg, int wg_per_cu) {
     return g < 1 ? 1 : g;
 }
 
-static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, int apply_bound, float* raw, float* w, Workspace& ws, hipStream_t st) {
+static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, int apply_bound, float* raw, float* w, Workspace& ws_in, hipStream_t st,
+                            const adfp_train_state* state = nullptr) {
     if (P.n == 0) return 0;
+    Workspace ws = ws_in;
+    if (state) {       // training: the backward needs these buffers after the call returns
+        ws.flags = state->flags; ws.list = state->list; ws.counter = state->counter;
+        ws.att_occ = state->att_occ; ws.att_u = state->att_u;
+    }
     hipError_t e;
     const bool fuse = stage != ADFP_STAGE_LOW;
     if (stage != ADFP_STAGE_COLOR) {           // rgb = 0 in stages low/high (decoder.py:317, :323)
@@ -911,6 +919,8 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
     int rc = check_scene(scene, r->stage); if (rc) return rc;
     if (!r->rays_o || !r->rays_d || !r->depth || !r->uncertainty || !r->color || !r->weight || !r->workspace) return ADFP_E_ARG;
     if (r->n_rays < 0 || r->n_samples <= 0 || r->n_surface < 0) return ADFP_E_ARG;
+    if (r->state && r->stage != ADFP_STAGE_LOW &&
+        (!r->state->flags || !r->state->list || !r->state->counter || !r->state->att_occ || !r->state->att_u)) return ADFP_E_ARG;
     const int S = r->n_samples + (r->gt_depth ? r->n_surface : 0);
     if (S > ADFP_MAX_SAMPLES) return ADFP_E_UNSUPPORTED;
     const long long Pn = (long long)r->n_rays * S;
@@ -926,9 +936,188 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
     if (rc) return rc;
     PtsDev P;
     P.mode = ADFP_PTS_RAYS; P.S = S; P.n = (int)Pn; P.pts = nullptr; P.ro = r->rays_o; P.rd = r->rays_d; P.z = z;
-    rc = eval_points_impl(scene, P, r->stage, 1, raw, r->weight, ws, st);
+    rc = eval_points_impl(scene, P, r->stage, 1, raw, r->weight, ws, st, r->state);
     if (rc) return rc;
     return adfp_composite(raw, z, r->n_rays, S, r->depth, r->uncertainty, r->color, nullptr, stream);
 }
 
+
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------
+#define STG_ROWS_MAX 65536
+
+struct BwdWorkspace { float* g_raw; float* att_g; float* stage; int stage_rows; size_t bytes; };
+static BwdWorkspace carve_bwd(void* base, long long P) {
+    BwdWorkspace w; size_t o = 0; char* b = (char*)base;
+    w.g_raw = (float*)(b + o); o += align256((size_t)P * 16);
+    w.att_g = (float*)(b + o); o += align256((size_t)P * 4);
+    w.stage_rows = (int)(P < STG_ROWS_MAX ? P : STG_ROWS_MAX);
+    if (w.stage_rows < 32) w.stage_rows = 32;
+    w.stage = (float*)(b + o); o += align256((size_t)w.stage_rows * AttStage::NCOLS * 4);
+    w.bytes = o;
+    return w;
+}
+extern "C" size_t adfp_backward_workspace_bytes(long long n_points) {
+    if (n_points < 0) return 0;
+    return carve_bwd(nullptr, n_points).bytes;
+}
+
+static void add_job(OuterArgs& a, int colA, int colB, int dst, int rs, int cs, int nr, int j0, int nc) {
+    OuterJob j; j.colA = colA; j.colB = colB; j.dst = dst; j.rs = rs; j.cs = cs; j.nr = nr; j.j0 = j0; j.nc = nc;
+    a.jobs[a.njobs++] = j;
+}
+template <int CDIM, int NOUT>
+static void decoder_jobs(OuterArgs& a) {
+    using L = DecLayout<CDIM, NOUT>;
+    using ST = DecStage<CDIM>;
+    a.njobs = 0; a.ncols = ST::NCOLS;
+    for (int i = 0; i < 5; ++i) {
+        const int ind = L::in_dim(i);
+        if (i == 0 || i == 3) {
+            for (int b = 0; b < 3; ++b) add_job(a, ST::SGP(i), ST::SE + 32 * b, L::F_PL(i) + 32 * b, ind, 1, 32, 0, b < 2 ? 32 : 29);
+            if (i == 3) add_job(a, ST::SGP(3), ST::SH(2), L::F_PL(3) + 93, ind, 1, 32, 0, 32);
+        } else add_job(a, ST::SGP(i), ST::SH(i - 1), L::F_PL(i), ind, 1, 32, 0, 32);
+        add_job(a, ST::SGP(i), ST::SX, L::F_PL(i) + 32 * ind, 1, 0, 32, 3, 1);                 // bias: column "1" of X
+        for (int cb = 0; cb < CDIM / 32; ++cb) add_job(a, ST::SGH(i), ST::SC + 32 * cb, L::F_FC(i) + 32 * cb, CDIM, 1, 32, 0, 32);
+        add_job(a, ST::SGH(i), ST::SX, L::F_FC(i) + 32 * CDIM, 1, 0, 32, 3, 1);
+    }
+    for (int b = 0; b < 3; ++b) add_job(a, ST::SGA + 32 * b, ST::SX, L::F_EB + 32 * b, 1, 93, b < 2 ? 32 : 29, 0, 3);   // embedder._B [3][93]
+    add_job(a, ST::SGO, ST::SH(4), L::F_OW, 32, 1, NOUT, 0, 32);
+    add_job(a, ST::SGO, ST::SX, L::F_OB, 1, 0, NOUT, 3, 1);
+}
+static void attention_jobs(OuterArgs& a) {
+    using A = AttLayout;
+    using ST = AttStage;
+    a.njobs = 0; a.ncols = ST::NCOLS;
+    for (int ob = 0; ob < 2; ++ob) {
+        add_job(a, ST::AG0 + 32 * ob, ST::AX, A::F_W0 + 64 * ob, 2, 1, 32, 0, 2);
+        add_job(a, ST::AG0 + 32 * ob, ST::AX, A::F_B0 + 32 * ob, 1, 0, 32, 2, 1);
+    }
+    for (int ob = 0; ob < 4; ++ob) {
+        for (int ib = 0; ib < 2; ++ib) add_job(a, ST::AG1 + 32 * ob, ST::AH0 + 32 * ib, A::F_W1 + 32 * ob * 64 + 32 * ib, 64, 1, 32, 0, 32);
+        add_job(a, ST::AG1 + 32 * ob, ST::AX, A::F_B1 + 32 * ob, 1, 0, 32, 2, 1);
+        for (int ib = 0; ib < 4; ++ib) add_job(a, ST::AG2 + 32 * ob, ST::AH1 + 32 * ib, A::F_W2 + 32 * ob * 128 + 32 * ib, 128, 1, 32, 0, 32);
+        add_job(a, ST::AG2 + 32 * ob, ST::AX, A::F_B2 + 32 * ob, 1, 0, 32, 2, 1);
+    }
+    for (int ob = 0; ob < 2; ++ob) {
+        for (int ib = 0; ib < 4; ++ib) add_job(a, ST::AG3 + 32 * ob, ST::AH2 + 32 * ib, A::F_W3 + 32 * ob * 128 + 32 * ib, 128, 1, 32, 0, 32);
+        add_job(a, ST::AG3 + 32 * ob, ST::AX, A::F_B3 + 32 * ob, 1, 0, 32, 2, 1);
+        add_job(a, ST::AGL, ST::AH3 + 32 * ob, A::F_WO + 32 * ob, 64, 1, 2, 0, 32);
+    }
+    add_job(a, ST::AGL, ST::AX, A::F_BO, 1, 0, 2, 2, 1);
+}
+
+static int launch_outer(OuterArgs& oa, const float* stage, const int* count_ptr, int lo, int hi, float* flat, hipStream_t st) {
+    oa.stage = stage; oa.count_ptr = count_ptr; oa.chunk_lo = lo; oa.chunk_hi = hi; oa.flat = flat;
+    oa.rows_per_wave = 512;
+    const int rows = hi - lo;
+    hipLaunchKernelGGL(k_outer, dim3((rows + oa.rows_per_wave - 1) / oa.rows_per_wave, oa.njobs), dim3(64), 0, st, oa);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int CDIM, int NOUT, int ROLE>
+static int run_decode_bwd(DecodeBwdArgs a, int total, const int* count_ptr, float* flat, BwdWorkspace& bw, hipStream_t st) {
+    if (total == 0) return 0;
+    if (!flat) {
+        a.stage = nullptr; a.chunk_lo = 0; a.chunk_hi = total;
+        const int ntiles = (total + 31) / 32;
+        hipLaunchKernelGGL((k_decode_bwd<CDIM, NOUT, ROLE, false, 256>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, a);
+        ADFP_CHECK_LAUNCH();
+        return 0;
+    }
+    OuterArgs oa; decoder_jobs<CDIM, NOUT>(oa);
+    a.stage = bw.stage;
+    const int rows_cap = (int)((size_t)bw.stage_rows * AttStage::NCOLS / DecStage<CDIM>::NCOLS);
+    for (int lo = 0; lo < total; lo += rows_cap) {
+        const int hi = lo + rows_cap < total ? lo + rows_cap : total;
+        a.chunk_lo = lo; a.chunk_hi = hi;
+        const int ntiles = (hi - lo + 31) / 32;
+        hipLaunchKernelGGL((k_decode_bwd<CDIM, NOUT, ROLE, true, 256>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, a);
+        ADFP_CHECK_LAUNCH();
+        int rc = launch_outer(oa, bw.stage, count_ptr, lo, hi, flat, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_args* r, void* stream) {
+    if (!r) return ADFP_E_ARG;
+    int rc = check_scene(sc, r->stage); if (rc) return rc;
+    if (!r->rays_o || !r->rays_d || !r->z_vals || !r->raw || !r->workspace || r->n_rays < 0 || r->S <= 0) return ADFP_E_ARG;
+    if (r->S > 64 * CB_MAXC) return ADFP_E_UNSUPPORTED;
+    const long long Pn = (long long)r->n_rays * r->S;
+    if (Pn > 0x7fffffffll) return ADFP_E_UNSUPPORTED;
+    BwdWorkspace bw = carve_bwd(r->workspace, Pn);
+    if (r->workspace_bytes < bw.bytes) return ADFP_E_WORKSPACE;
+    const bool fuse = r->stage != ADFP_STAGE_LOW;
+    if (fuse && (!r->state.flags || !r->state.list || !r->state.counter || !r->state.att_occ || !r->state.att_u)) return ADFP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+    // zero the outputs this call accumulates into
+    struct { float* p; size_t n; } zs[7] = {
+        {r->g_grid_low, (size_t)sc->low.Z * sc->low.Y * sc->low.X * 32},
+        {r->g_grid_high, (size_t)sc->high.Z * sc->high.Y * sc->high.X * 32},
+        {r->g_grid_color, (size_t)sc->color.Z * sc->color.Y * sc->color.X * 32},
+        {r->g_flat_low, (size_t)DecLayout<32, 1>::F_TOTAL}, {r->g_flat_high, (size_t)DecLayout<64, 1>::F_TOTAL},
+        {r->g_flat_color, (size_t)DecLayout<32, 4>::F_TOTAL}, {r->g_flat_att, (size_t)AttLayout::F_TOTAL}};
+    for (int k = 0; k < 7; ++k)
+        if (zs[k].p) { e = hipMemsetAsync(zs[k].p, 0, zs[k].n * 4, st); if (e != hipSuccess) return (int)e; }
+    if (r->n_rays == 0) return 0;
+    const int P = (int)Pn;
+
+    hipLaunchKernelGGL(k_composite_bwd, dim3((r->n_rays + 3) / 4), dim3(256), 0, st, r->raw, r->z_vals, r->n_rays, r->S,
+                       r->g_depth, r->g_uncertainty, r->g_color, bw.g_raw);
+    ADFP_CHECK_LAUNCH();
+
+    PtsDev Pd;
+    Pd.mode = ADFP_PTS_RAYS; Pd.S = r->S; Pd.n = P; Pd.pts = nullptr; Pd.ro = r->rays_o; Pd.rd = r->rays_d; Pd.z = r->z_vals;
+    DecodeBwdArgs a;
+    a.P = Pd; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
+    a.list = nullptr; a.count_ptr = nullptr; a.g_raw = bw.g_raw; a.att_g = nullptr; a.stage = nullptr;
+
+    if (fuse) {
+        AttBwdArgs t;
+        t.packed = sc->w_att; t.list = r->state.list; t.count_ptr = r->state.counter; t.att_occ = r->state.att_occ;
+        t.att_u = r->state.att_u; t.g_weight = r->g_weight; t.g_raw = bw.g_raw; t.att_g = bw.att_g; t.stage = bw.stage;
+        OuterArgs oa; attention_jobs(oa);
+        for (int lo = 0; lo < P; lo += bw.stage_rows) {
+            const int hi = lo + bw.stage_rows < P ? lo + bw.stage_rows : P;
+            t.chunk_lo = lo; t.chunk_hi = hi;
+            const int ntiles = (hi - lo + 31) / 32;
+            if (r->g_flat_att) {
+                hipLaunchKernelGGL((k_attention_bwd<true>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
+                ADFP_CHECK_LAUNCH();
+                rc = launch_outer(oa, bw.stage, r->state.counter, lo, hi, r->g_flat_att, st);
+                if (rc) return rc;
+            } else {
+                hipLaunchKernelGGL((k_attention_bwd<false>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
+                ADFP_CHECK_LAUNCH();
+            }
+        }
+        if (r->g_grid_high || r->g_flat_high) {
+            DecodeBwdArgs hgh = a;
+            hgh.g0 = make_grid(sc->high); hgh.g1 = make_grid(sc->low); hgh.packed = sc->w_high;
+            hgh.list = r->state.list; hgh.count_ptr = r->state.counter; hgh.att_g = bw.att_g; hgh.g_grid = r->g_grid_high;
+            rc = run_decode_bwd<64, 1, ROLE_HIGH>(hgh, P, r->state.counter, r->g_flat_high, bw, st);
+            if (rc) return rc;
+        }
+    }
+    if (r->g_grid_low || r->g_flat_low) {
+        DecodeBwdArgs lw = a;
+        lw.g0 = make_grid(sc->low); lw.g1 = lw.g0; lw.packed = sc->w_low; lw.g_grid = r->g_grid_low;
+        rc = run_decode_bwd<32, 1, ROLE_LOW>(lw, P, nullptr, r->g_flat_low, bw, st);
+        if (rc) return rc;
+    }
+    if (r->stage == ADFP_STAGE_COLOR && (r->g_grid_color || r->g_flat_color)) {
+        DecodeBwdArgs cl = a;
+        cl.g0 = make_grid(sc->color); cl.g1 = cl.g0; cl.packed = sc->w_color; cl.g_grid = r->g_grid_color;
+        rc = run_decode_bwd<32, 4, ROLE_COLOR>(cl, P, nullptr, r->g_flat_color, bw, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+

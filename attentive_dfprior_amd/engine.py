@@ -171,7 +171,7 @@ class Engine(object):
     # ---- a4..a13 ---------------------------------------------------------------------------
     def render_forward(self, decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage,
                        n_samples, n_surface, lindisp=False, perturb=0.0, t_rand=None, depth_max=None,
-                       want_aux=False):
+                       want_aux=False, train=False):
         _lib.require_cuda(rays_o, 'rays_o')
         dev = rays_o.device
         with torch.cuda.device(dev):
@@ -210,13 +210,78 @@ class Engine(object):
             a.uncertainty = unc.data_ptr()
             a.color = color.data_ptr()
             a.weight = weight.data_ptr()
-            if want_aux:
+            if want_aux or train:
                 aux = {'z_vals': torch.empty((N, S), dtype=torch.float64, device=dev),
                        'raw': torch.empty((N, S, 4), dtype=torch.float32, device=dev)}
                 a.z_vals = aux['z_vals'].data_ptr()
                 a.raw = aux['raw'].data_ptr()
+            if train:
+                # buffers the backward reads after this call returns (never the shared workspace)
+                P = N * S
+                aux.update(flags=torch.empty((P,), dtype=torch.uint8, device=dev),
+                           list=torch.empty((P,), dtype=torch.int32, device=dev),
+                           counter=torch.zeros((4,), dtype=torch.int32, device=dev),
+                           att_occ=torch.empty((P,), dtype=torch.float32, device=dev),
+                           att_u=torch.empty((P,), dtype=torch.float32, device=dev),
+                           rays_o=ro, rays_d=rd, S=S)
+                st = _lib.AdfpTrainState()
+                st.flags, st.list, st.counter = aux['flags'].data_ptr(), aux['list'].data_ptr(), aux['counter'].data_ptr()
+                st.att_occ, st.att_u = aux['att_occ'].data_ptr(), aux['att_u'].data_ptr()
+                aux['_state'] = st
+                a.state = C.pointer(st)
             ws = self.workspace(N * S, dev)
             a.workspace = ws.data_ptr()
             a.workspace_bytes = ws.numel()
             check(lib().adfp_render_forward(C.byref(sc), C.byref(a), _lib.current_stream(dev)), 'adfp_render_forward')
         return depth, unc, color, weight, aux
+
+    # ---- a15 -------------------------------------------------------------------------------
+    def render_backward(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, saved, g_depth, g_unc, g_color,
+                        g_weight, need_grid, need_flat):
+        """saved: the aux dict of render_forward(train=True).  need_grid / need_flat: dicts of bools.
+        Returns (grid grads dict in the reference's [1,32,Z,Y,X] layout, flat parameter grads dict)."""
+        ro = saved['rays_o']
+        dev = ro.device
+        L = lib()
+        with torch.cuda.device(dev):
+            N, S = ro.shape[0], saved['S']
+            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage)
+            a = _lib.AdfpBackwardArgs()
+            a.stage = _lib.STAGE[stage]
+            a.n_rays, a.S = N, S
+            a.rays_o, a.rays_d = ro.data_ptr(), saved['rays_d'].data_ptr()
+            a.z_vals, a.raw = saved['z_vals'].data_ptr(), saved['raw'].data_ptr()
+            a.state = saved['_state']
+
+            def prep(t, dtype):
+                if t is None:
+                    return None
+                return t.detach().to(dev, dtype).contiguous()
+            gd, gu, gc, gw = prep(g_depth, torch.float64), prep(g_unc, torch.float64), prep(g_color, torch.float32), \
+                prep(g_weight, torch.float32)
+            a.g_depth, a.g_uncertainty = _lib.ptr(gd), _lib.ptr(gu)
+            a.g_color, a.g_weight = _lib.ptr(gc), _lib.ptr(gw)
+            grids_cl, flats = {}, {}
+            for name, key in (('low', 'grid_low'), ('high', 'grid_high'), ('color', 'grid_color')):
+                if need_grid.get(name):
+                    Z, Y, X = c[key].shape[2:]
+                    grids_cl[name] = torch.empty((Z, Y, X, 32), dtype=torch.float32, device=dev)
+                    setattr(a, 'g_grid_' + name, grids_cl[name].data_ptr())
+            sizes = {'low': L.adfp_decoder_flat_floats(0), 'high': L.adfp_decoder_flat_floats(1),
+                     'color': L.adfp_decoder_flat_floats(2), 'att': L.adfp_attention_flat_floats()}
+            for name in ('low', 'high', 'color', 'att'):
+                if need_flat.get(name):
+                    flats[name] = torch.empty((sizes[name],), dtype=torch.float32, device=dev)
+                    setattr(a, 'g_flat_' + name, flats[name].data_ptr())
+            need = L.adfp_backward_workspace_bytes(N * S)
+            ws = torch.empty(int(need) + 1024, dtype=torch.uint8, device=dev)
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            stream = _lib.current_stream(dev)
+            check(L.adfp_render_backward(C.byref(sc), C.byref(a), stream), 'adfp_render_backward')
+            grids = {}
+            for name, g in grids_cl.items():
+                Z, Y, X = g.shape[:3]
+                out = torch.empty((1, 32, Z, Y, X), dtype=torch.float32, device=dev)
+                check(L.adfp_relayout_grid_back(ptr(g), ptr(out), 32, Z, Y, X, stream), 'adfp_relayout_grid_back')
+                grids[name] = out
+        return grids, flats

@@ -143,6 +143,16 @@ int adfp_composite(const float* raw /*[N,S,4]*/, const double* z_vals /*[N,S]*/,
                    double* depth, double* uncertainty, float* color /*[N,3]*/,
                    float* weights /*[N,S] or NULL*/, void* stream);
 
+/* Buffers the backward needs from the forward (training only).  Caller-owned, sized for P points:
+ * flags P bytes, list P ints, counter >= 4 bytes, att_occ / att_u P floats. */
+typedef struct adfp_train_state {
+    unsigned char* flags;
+    int* list;
+    int* counter;
+    float* att_occ;
+    float* att_u;
+} adfp_train_state;
+
 /* ---- a4..a13 in one call: Renderer.render_batch_ray (Renderer.py:110-255) ------------- */
 typedef struct adfp_render_args {
     int stage;
@@ -163,9 +173,43 @@ typedef struct adfp_render_args {
     float* raw;                 /* [N,S,4] out, optional */
     void* workspace;
     size_t workspace_bytes;
+    const adfp_train_state* state;  /* NULL for inference; else the forward leaves its state here */
 } adfp_render_args;
 
 int adfp_render_forward(const adfp_scene* scene /*host*/, const adfp_render_args* args /*host*/, void* stream);
+
+/* ---- a15: backward of render_batch_ray (autograd of src/Mapper.py:457-473) -------------- */
+/* Cotangents of (depth, uncertainty, color, weight) -> gradients of the three feature grids
+ * (channels-last, converted back by adfp_relayout_grid_back) and of the decoder parameters (flat
+ * state_dict order).  Any output pointer may be NULL (= not needed: frozen decoder, lr 0 grid).
+ * z_vals, raw and `state` are the ones the forward call wrote.  Every non-NULL output is zeroed
+ * and then accumulated with float atomics (results are not bitwise reproducible run to run).
+ * Gradients w.r.t. the rays (Tracker, src/Tracker.py:112-133) are not produced. */
+typedef struct adfp_backward_args {
+    int stage;
+    int n_rays;
+    int S;                       /* samples per ray of the forward call */
+    const float* rays_o;
+    const float* rays_d;
+    const double* z_vals;        /* [N,S] from the forward */
+    const float* raw;            /* [N,S,4] from the forward */
+    adfp_train_state state;
+    const double* g_depth;       /* [N] or NULL */
+    const double* g_uncertainty; /* [N] or NULL */
+    const float* g_color;        /* [N,3] or NULL */
+    const float* g_weight;       /* [N,S] or NULL */
+    float* g_grid_low;           /* [Z,Y,X,32] channels-last, or NULL */
+    float* g_grid_high;
+    float* g_grid_color;
+    float* g_flat_low;           /* adfp_decoder_flat_floats(kind) floats, or NULL */
+    float* g_flat_high;
+    float* g_flat_color;
+    float* g_flat_att;           /* adfp_attention_flat_floats() floats, or NULL */
+    void* workspace;
+    size_t workspace_bytes;
+} adfp_backward_args;
+size_t adfp_backward_workspace_bytes(long long n_points);
+int adfp_render_backward(const adfp_scene* scene /*host*/, const adfp_backward_args* args /*host*/, void* stream);
 
 /* Per-stage timing hook for bench.py: runs ONLY the TSDF trilerp + band-mask kernel (a10). */
 int adfp_tsdf_stage(const adfp_scene* scene, const adfp_points* pts, unsigned char* flags,

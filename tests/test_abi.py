@@ -65,13 +65,15 @@ def test_ctypes_struct_layout_matches_c(tmp_path):
 #include <stddef.h>
 #include "adfp.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu\\n", sizeof(adfp_grid), sizeof(adfp_tsdf), sizeof(adfp_scene), sizeof(adfp_points),
-         sizeof(adfp_render_args));
+  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(adfp_grid), sizeof(adfp_tsdf), sizeof(adfp_scene), sizeof(adfp_points),
+         sizeof(adfp_render_args), sizeof(adfp_train_state), sizeof(adfp_backward_args));
   printf("%zu %zu %zu %zu\\n", offsetof(adfp_scene, low), offsetof(adfp_scene, tsdf), offsetof(adfp_scene, w_low),
          offsetof(adfp_scene, w_att));
   printf("%zu %zu %zu\\n", offsetof(adfp_points, pts), offsetof(adfp_points, z_vals), offsetof(adfp_points, S));
-  printf("%zu %zu %zu %zu\\n", offsetof(adfp_render_args, perturb), offsetof(adfp_render_args, rays_o),
-         offsetof(adfp_render_args, workspace), offsetof(adfp_render_args, workspace_bytes));
+  printf("%zu %zu %zu %zu %zu\\n", offsetof(adfp_render_args, perturb), offsetof(adfp_render_args, rays_o),
+         offsetof(adfp_render_args, workspace), offsetof(adfp_render_args, workspace_bytes), offsetof(adfp_render_args, state));
+  printf("%zu %zu %zu %zu %zu\\n", offsetof(adfp_backward_args, rays_o), offsetof(adfp_backward_args, state),
+         offsetof(adfp_backward_args, g_depth), offsetof(adfp_backward_args, g_flat_att), offsetof(adfp_backward_args, workspace_bytes));
   return 0;
 }''')
     exe = tmp_path / 'layout'
@@ -79,11 +81,15 @@ int main(void) {
     out = subprocess.check_output([str(exe)]).decode().split('\n')
     sz = list(map(int, out[0].split()))
     assert sz == [ctypes.sizeof(_lib.AdfpGrid), ctypes.sizeof(_lib.AdfpTsdf), ctypes.sizeof(_lib.AdfpScene),
-                  ctypes.sizeof(_lib.AdfpPoints), ctypes.sizeof(_lib.AdfpRenderArgs)]
+                  ctypes.sizeof(_lib.AdfpPoints), ctypes.sizeof(_lib.AdfpRenderArgs),
+                  ctypes.sizeof(_lib.AdfpTrainState), ctypes.sizeof(_lib.AdfpBackwardArgs)]
     S = _lib.AdfpScene
     assert list(map(int, out[1].split())) == [S.low.offset, S.tsdf.offset, S.w_low.offset, S.w_att.offset]
     P = _lib.AdfpPoints
     assert list(map(int, out[2].split())) == [P.pts.offset, P.z_vals.offset, P.S.offset]
     R = _lib.AdfpRenderArgs
     assert list(map(int, out[3].split())) == [R.perturb.offset, R.rays_o.offset, R.workspace.offset,
-                                              R.workspace_bytes.offset]
+                                              R.workspace_bytes.offset, R.state.offset]
+    B = _lib.AdfpBackwardArgs
+    assert list(map(int, out[4].split())) == [B.rays_o.offset, B.state.offset, B.g_depth.offset, B.g_flat_att.offset,
+                                              B.workspace_bytes.offset]

@@ -1,0 +1,171 @@
+"""GPU (MI355X): backward of render_batch_ray (the Mapper's training step, src/Mapper.py:451-473)
+through the HIP kernels against the gradients the REFERENCE's autograd produced
+(tests/golden/mini_<stage>.npz, keys g.* / gw.*) and against the oracle's autograd."""
+import numpy as np
+import pytest
+import torch
+
+import attentive_dfprior_amd as A
+from attentive_dfprior_amd import synthetic
+from oracle import adfp_oracle as O
+from conftest import make_cfg, to_dev
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+GTOL = 2e-4          # gradients: relative to the largest entry of each tensor
+
+
+def mapper_loss(depth, color, weight, gt_depth, gt_color, stage, warm):
+    m = gt_depth > 0
+    loss = torch.abs(gt_depth[m] - depth[m]).sum()
+    if warm:
+        loss = loss + torch.abs(weight - torch.ones(weight.shape, device=weight.device)).sum()
+    if stage == 'color':
+        loss = loss + 0.2 * torch.abs(gt_color - color).sum()
+    return loss
+
+
+def grad_close(got, ref, what, tol=GTOL):
+    got = got.detach().double().cpu()
+    ref = torch.as_tensor(ref).double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    assert err <= tol * max(scale, 1e-12) + 1e-9, f'{what}: max abs diff {err:.3e} vs scale {scale:.3e}'
+
+
+def run(mini, stage, warm, sd=None, n_samples=None, n_surface=None, rays=None):
+    sd = mini.sd if sd is None else sd
+    dec = A.DF()
+    dec.load_state_dict(sd)
+    dec.bound = mini.bound
+    dec = dec.to(DEV)
+    for p in dec.parameters():
+        p.requires_grad_(True)
+    rend = A.Renderer(make_cfg(n_samples or mini.n_samples, n_surface if n_surface is not None else mini.n_surface),
+                      None, mini)
+    c = {k: v.to(DEV).clone().requires_grad_(True) for k, v in mini.c.items()}
+    ro, rd, gd, gc = rays if rays is not None else (mini.rays_o, mini.rays_d, mini.gt_depth, mini.gt_color)
+    ro, rd, gd, gc = ro.to(DEV), rd.to(DEV), gd.to(DEV), gc.to(DEV)
+    d, u, col, w = rend.render_batch_ray(c, dec, rd, ro, DEV, mini.tsdf_volume.to(DEV), mini.tsdf_bnds.to(DEV), stage,
+                                         gt_depth=gd)
+    loss = mapper_loss(d, col, w, gd, gc, stage, warm)
+    loss.backward()
+    return loss, c, dec
+
+
+@pytest.mark.parametrize('stage', O.STAGES)
+@pytest.mark.parametrize('tag,warm', [('g', False), ('gw', True)])
+def test_mapper_gradients_vs_reference_golden(mini, stage, tag, warm):
+    g = mini.golden(stage)
+    loss, c, dec = run(mini, stage, warm)
+    assert abs(loss.item() - float(g[tag + '.loss'])) <= 1e-5 * abs(float(g[tag + '.loss']))
+    for k, v in c.items():
+        ref = g[f'{tag}.{k}']
+        if v.grad is None:
+            assert np.abs(ref).max() == 0, k
+            continue
+        assert v.grad.shape == v.shape
+        grad_close(v.grad, ref, f'{stage}/{tag} d/d {k}')
+    for name, p in dec.named_parameters():
+        ref = g[f'{tag}.sd.{name}']
+        if p.grad is None:
+            assert np.abs(ref).max() == 0, name
+            continue
+        grad_close(p.grad, ref, f'{stage}/{tag} d/d {name}')
+
+
+def test_gradients_second_seed_64_samples_vs_oracle(mini):
+    """S = 64 (benchmark sampling), other weights, more rays, against the oracle's autograd."""
+    sd = O.random_state_dict(seed=17)
+    sc = synthetic.mini_scene()
+    rays = synthetic.make_ray_batch(sc, 300, seed=8, poses=3)
+    loss, c, dec = run(mini, 'color', True, sd=sd, n_samples=48, n_surface=16, rays=rays)
+    c_or = {k: v.clone().requires_grad_(True) for k, v in mini.c.items()}
+    sd_or = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    d2, u2, col2, w2 = O.render_batch_ray(sd_or, c_or, rays[1], rays[0], mini.tsdf_volume, mini.tsdf_bnds, mini.bound,
+                                          'color', rays[2], 48, 16)
+    loss2 = O.mapper_loss(d2, col2, w2, rays[2], rays[3], 'color', True)
+    loss2.backward()
+    assert abs(loss.item() - loss2.item()) <= 1e-5 * abs(loss2.item())
+    for k in c:
+        grad_close(c[k].grad, c_or[k].grad, k)
+    for name, p in dec.named_parameters():
+        ref = sd_or[name].grad if sd_or[name].grad is not None else torch.zeros_like(sd_or[name])
+        grad_close(p.grad if p.grad is not None else torch.zeros_like(p), ref, name)
+
+
+def test_uncertainty_cotangent_vs_oracle(mini):
+    """The Tracker's loss divides by sqrt(uncertainty) (src/Tracker.py:116-121); the Mapper never
+    differentiates it, so it is pinned here against the oracle."""
+    dec = A.DF()
+    dec.load_state_dict(mini.sd)
+    dec.bound = mini.bound
+    dec = dec.to(DEV)
+    rend = A.Renderer(make_cfg(mini.n_samples, mini.n_surface), None, mini)
+    c = {k: v.to(DEV).clone().requires_grad_(True) for k, v in mini.c.items()}
+    d, u, col, w = rend.render_batch_ray(c, dec, mini.rays_d.to(DEV), mini.rays_o.to(DEV), DEV,
+                                         mini.tsdf_volume.to(DEV), mini.tsdf_bnds.to(DEV), 'high', gt_depth=mini.gt_depth.to(DEV))
+    (u.sum() * 3.0 + d.sum()).backward()
+    c_or = {k: v.clone().requires_grad_(True) for k, v in mini.c.items()}
+    d2, u2, col2, w2 = O.render_batch_ray(mini.sd, c_or, mini.rays_d, mini.rays_o, mini.tsdf_volume, mini.tsdf_bnds,
+                                          mini.bound, 'high', mini.gt_depth, mini.n_samples, mini.n_surface)
+    (u2.sum() * 3.0 + d2.sum()).backward()
+    for k in ('grid_low', 'grid_high'):
+        grad_close(c[k].grad, c_or[k].grad, k)
+
+
+def test_frozen_decoders_and_index_put_grids(mini):
+    """Mapper configuration: low decoder never optimised, high frozen (fix_high), grids are autograd
+    non-leafs made by index_put (src/Mapper.py:364-388); gradients must arrive at the masked leaf."""
+    dec = A.DF()
+    dec.load_state_dict(mini.sd)
+    dec.bound = mini.bound
+    dec = dec.to(DEV)
+    for p in list(dec.low_decoder.parameters()) + list(dec.high_decoder.parameters()):
+        p.requires_grad_(False)
+    rend = A.Renderer(make_cfg(mini.n_samples, mini.n_surface), None, mini)
+    c = {}
+    leaves = {}
+    for k, v in mini.c.items():
+        val = v.to(DEV).clone()
+        mask = torch.rand(val.shape, device=DEV) < 0.6
+        leaf = val[mask].clone().requires_grad_(True)
+        val[mask] = leaf
+        c[k], leaves[k] = val, (leaf, mask)
+    gd, gc = mini.gt_depth.to(DEV), mini.gt_color.to(DEV)
+    d, u, col, w = rend.render_batch_ray(c, dec, mini.rays_d.to(DEV), mini.rays_o.to(DEV), DEV,
+                                         mini.tsdf_volume.to(DEV), mini.tsdf_bnds.to(DEV), 'color', gt_depth=gd)
+    mapper_loss(d, col, w, gd, gc, 'color', False).backward()
+    g = mini.golden('color')
+    for k, (leaf, mask) in leaves.items():
+        ref = torch.from_numpy(g[f'g.{k}'])[mask.cpu()]
+        grad_close(leaf.grad, ref, f'masked leaf of {k}')
+    assert all(p.grad is None for p in dec.low_decoder.parameters())
+    assert all(p.grad is None for p in dec.high_decoder.parameters())
+    assert all(p.grad is not None for p in dec.color_decoder.parameters())
+    grad_close(dec.mlp.pts_linears[2].weight.grad, g['g.sd.mlp.pts_linears.2.weight'], 'mlp W2')
+
+
+def test_adam_steps_reduce_loss(mini):
+    """A few Mapper-style iterations (fresh Adam, stage color) run and reduce the loss."""
+    dec = A.DF()
+    dec.load_state_dict(mini.sd)
+    dec.bound = mini.bound
+    dec = dec.to(DEV)
+    rend = A.Renderer(make_cfg(mini.n_samples, mini.n_surface), None, mini)
+    c = {k: v.to(DEV).clone().requires_grad_(True) for k, v in mini.c.items()}
+    opt = torch.optim.Adam([{'params': list(dec.color_decoder.parameters()) + list(dec.mlp.parameters()), 'lr': 0.005},
+                            {'params': list(c.values()), 'lr': 0.005}])
+    gd, gc = mini.gt_depth.to(DEV), mini.gt_color.to(DEV)
+    tsdf, bnds = mini.tsdf_volume.to(DEV), mini.tsdf_bnds.to(DEV)
+    losses = []
+    for it in range(12):
+        opt.zero_grad()
+        d, u, col, w = rend.render_batch_ray(c, dec, mini.rays_d.to(DEV), mini.rays_o.to(DEV), DEV, tsdf, bnds, 'color',
+                                             gt_depth=gd)
+        loss = mapper_loss(d, col, w, gd, gc, 'color', False)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < 0.8 * losses[0], losses
