@@ -70,9 +70,11 @@ def select_uv(H0, H1, W0, W1, indices, depth, color):
 # a4: sampler  (src/utils/Renderer.py:134-225)
 # ----------------------------------------------------------------------------------
 def sample_z(rays_o, rays_d, gt_depth, bound, N_samples, N_surface, lindisp=False, perturb=0.0,
-             t_rand=None):
+             t_rand=None, depth_max=None):
     """z_vals [N, S] (f64 when bound is f64) -- src/utils/Renderer.py:134-221.
-    ``t_rand`` replaces the reference's torch.rand draw (Renderer.py:216) when perturb > 0."""
+    ``t_rand`` replaces the reference's torch.rand draw (Renderer.py:216) when perturb > 0.
+    ``depth_max`` (not in the reference) replaces max(gt_depth) of Renderer.py:159/:195 so that a
+    ray shard can be sampled exactly like the full batch it was cut from."""
     if gt_depth is None:
         N_surface = 0
         near = 0.01
@@ -86,7 +88,8 @@ def sample_z(rays_o, rays_d, gt_depth, bound, N_samples, N_surface, lindisp=Fals
     far_bb = far_bb.unsqueeze(-1)
     far_bb = far_bb + 0.01
     if gt_depth is not None:
-        far = torch.clamp(far_bb, 0, torch.max(gt_depth * 1.2))            # Renderer.py:159
+        dmax = torch.max(gt_depth) if depth_max is None else depth_max.reshape(()).to(gt_depth.dtype)
+        far = torch.clamp(far_bb, 0, dmax * 1.2)                           # Renderer.py:159
     else:
         far = far_bb
     if N_surface > 0:
@@ -97,7 +100,7 @@ def sample_z(rays_o, rays_d, gt_depth, bound, N_samples, N_surface, lindisp=Fals
         z_surf = torch.zeros(gt_depth.shape[0], N_surface).double()
         nz = nz.squeeze(-1)
         z_surf[nz, :] = z_nz
-        far_surface = torch.max(gt_depth)
+        far_surface = dmax
         z_zero = 0.001 * (1. - ts) + far_surface * ts                      # Renderer.py:196
         z_surf[~nz, :] = z_zero
     t_vals = torch.linspace(0., 1., steps=N_samples)
@@ -279,10 +282,11 @@ def raw2outputs(raw, z_vals):
 # a4..a13: render_batch_ray  (src/utils/Renderer.py:110-255) and a14 render_img (:258-327)
 # ----------------------------------------------------------------------------------
 def render_batch_ray(sd, c_grid, rays_d, rays_o, tsdf_volume, tsdf_bnds, bound, stage, gt_depth,
-                     N_samples, N_surface, lindisp=False, perturb=0.0, t_rand=None, return_aux=False):
+                     N_samples, N_surface, lindisp=False, perturb=0.0, t_rand=None, return_aux=False,
+                     depth_max=None):
     """Returns (depth f64 [N], uncertainty f64 [N], color f32 [N,3], weight f32 [N,S,1])."""
     N = rays_o.shape[0]
-    z_vals = sample_z(rays_o, rays_d, gt_depth, bound, N_samples, N_surface, lindisp, perturb, t_rand)
+    z_vals = sample_z(rays_o, rays_d, gt_depth, bound, N_samples, N_surface, lindisp, perturb, t_rand, depth_max)
     S = z_vals.shape[1]
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]   # Renderer.py:223
     res = eval_points(sd, pts.reshape(-1, 3), c_grid, tsdf_volume, tsdf_bnds, bound, stage, return_aux)

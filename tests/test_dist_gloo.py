@@ -1,0 +1,107 @@
+"""CPU, world_size 2, gloo: the N>1 path of attentive_dfprior_amd.dist (ray sharding, full-batch
+depth max, output all-gather, flat-bucket gradient all-reduce).  The render function plugged in is
+the oracle, so these tests pin the sharding LOGIC; the HIP kernels behind the same logic are covered
+by tests/test_gpu_parity.py::test_sharded_render_equals_whole."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from attentive_dfprior_amd import dist as adist
+from conftest import Mini
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from oracle import adfp_oracle as O
+    mini = Mini()
+    n = 61                                   # odd: uneven shards
+    ro, rd, gd, gc = mini.rays_o[:n], mini.rays_d[:n], mini.gt_depth[:n], mini.gt_color[:n]
+
+    def render_fn(o, d, z, m):
+        return O.render_batch_ray(mini.sd, mini.c, d, o, mini.tsdf_volume, mini.tsdf_bnds, mini.bound, 'color', z,
+                                  mini.n_samples, mini.n_surface, depth_max=m)
+    with torch.no_grad():
+        outs = adist.render_rays_sharded(render_fn, ro, rd, gd)
+        whole = render_fn(ro, rd, gd, None)
+    ok_render = all(torch.equal(a, b) for a, b in zip(outs, whole))
+
+    # global_depth_max for callers holding only their shard
+    lo, hi = adist.shard_range(n, rank, world)
+    gmax = adist.global_depth_max(gd[lo:hi])
+    ok_max = float(gmax) == float(gd.max())
+
+    # gradient all-reduce: shard losses are plain sums, so summed shard grads == full-batch grads
+    c = {k: v.clone().requires_grad_(True) for k, v in mini.c.items()}
+    sd = {k: v.clone().requires_grad_(True) for k, v in mini.sd.items()}
+    d, u, col, w = O.render_batch_ray(sd, c, rd[lo:hi], ro[lo:hi], mini.tsdf_volume, mini.tsdf_bnds, mini.bound,
+                                      'color', gd[lo:hi], mini.n_samples, mini.n_surface, depth_max=gd.max())
+    O.mapper_loss(d, col, w, gd[lo:hi], gc[lo:hi], 'color', True).backward()
+    tensors = list(c.values()) + [sd[k] for k in sd]
+    adist.allreduce_grads(tensors)
+    c2 = {k: v.clone().requires_grad_(True) for k, v in mini.c.items()}
+    sd2 = {k: v.clone().requires_grad_(True) for k, v in mini.sd.items()}
+    d2, u2, col2, w2 = O.render_batch_ray(sd2, c2, rd, ro, mini.tsdf_volume, mini.tsdf_bnds, mini.bound, 'color', gd,
+                                          mini.n_samples, mini.n_surface)
+    O.mapper_loss(d2, col2, w2, gd, gc, 'color', True).backward()
+    worst = 0.0
+    for a, b in zip(tensors, list(c2.values()) + [sd2[k] for k in sd2]):
+        gb = b.grad if b.grad is not None else torch.zeros_like(b)
+        worst = max(worst, ((a.grad - gb).abs().max() / gb.abs().max().clamp_min(1e-12)).item())
+    q.put((rank, ok_render, ok_max, worst))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 61, 307200):
+        for world in (1, 2, 3, 8):
+            cuts = [adist.shard_range(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_passthrough(mini):
+    calls = []
+
+    def render_fn(o, d, z, m):
+        calls.append((o.shape[0], float(m)))
+        return (o[:, 0].clone(), d.clone())
+    out = adist.render_rays_sharded(render_fn, mini.rays_o, mini.rays_d, mini.gt_depth)
+    assert calls == [(mini.rays_o.shape[0], float(mini.gt_depth.max()))]
+    assert out[1].shape == mini.rays_d.shape
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_render, ok_max, worst in res:
+        assert ok_render, f'rank {rank}: sharded render != whole render'
+        assert ok_max
+        assert worst < 1e-5, worst
