@@ -82,7 +82,11 @@ ADFP_DEV void tri_axis(float pn, int size, int& i0, int& i1, float& w0, float& w
     if (i1 > size - 1) { i1 = size - 1; w1 = 0.f; }   // out-of-range corner contributes zero
 }
 
-// one scalar volume (the TSDF), arbitrary element strides
+// one scalar volume (the TSDF), arbitrary element strides.  The reference's volume is a permuted
+// view whose fastest dimension is Z (get_tsdf.py:95-97): then the two z-corners of each (y,x)
+// column are adjacent floats and are fetched with ONE 8-byte load (4 loads per point, not 8) --
+// the stage is bound by the number of distinct cache lines the address unit walks per wave.
+typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
 ADFP_DEV float trilerp_scalar(const TsdfDev& t, const float pn[3]) {
     int x0, x1, y0, y1, z0, z1; float wx0, wx1, wy0, wy1, wz0, wz1;
     tri_axis(pn[0], t.X, x0, x1, wx0, wx1);
@@ -90,11 +94,25 @@ ADFP_DEV float trilerp_scalar(const TsdfDev& t, const float pn[3]) {
     tri_axis(pn[2], t.Z, z0, z1, wz0, wz1);
     const float* d = t.data;
     const long long ox0 = x0 * t.sX, ox1 = x1 * t.sX, oy0 = y0 * t.sY, oy1 = y1 * t.sY;
-    const long long oz0 = z0 * t.sZ, oz1 = z1 * t.sZ;
-    const float v000 = d[oz0 + oy0 + ox0], v001 = d[oz0 + oy0 + ox1];
-    const float v010 = d[oz0 + oy1 + ox0], v011 = d[oz0 + oy1 + ox1];
-    const float v100 = d[oz1 + oy0 + ox0], v101 = d[oz1 + oy0 + ox1];
-    const float v110 = d[oz1 + oy1 + ox0], v111 = d[oz1 + oy1 + ox1];
+    float v000, v001, v010, v011, v100, v101, v110, v111;
+    if (t.sZ == 1 && t.Z >= 2) {
+        const int zb = z0 < t.Z - 1 ? z0 : t.Z - 2;       // pair (zb, zb+1) always inside the volume
+        const bool lo = z0 == zb;                          // false only when z0 = Z-1 (then z1 = z0, weight 0)
+        const f32x2_u p00 = *(const f32x2_u*)(d + zb + oy0 + ox0);
+        const f32x2_u p01 = *(const f32x2_u*)(d + zb + oy0 + ox1);
+        const f32x2_u p10 = *(const f32x2_u*)(d + zb + oy1 + ox0);
+        const f32x2_u p11 = *(const f32x2_u*)(d + zb + oy1 + ox1);
+        v000 = lo ? p00.x : p00.y; v100 = p00.y;
+        v001 = lo ? p01.x : p01.y; v101 = p01.y;
+        v010 = lo ? p10.x : p10.y; v110 = p10.y;
+        v011 = lo ? p11.x : p11.y; v111 = p11.y;
+    } else {
+        const long long oz0 = z0 * t.sZ, oz1 = z1 * t.sZ;
+        v000 = d[oz0 + oy0 + ox0]; v001 = d[oz0 + oy0 + ox1];
+        v010 = d[oz0 + oy1 + ox0]; v011 = d[oz0 + oy1 + ox1];
+        v100 = d[oz1 + oy0 + ox0]; v101 = d[oz1 + oy0 + ox1];
+        v110 = d[oz1 + oy1 + ox0]; v111 = d[oz1 + oy1 + ox1];
+    }
     float o = v000 * ((wx0 * wy0) * wz0);          // tnw, tne, tsw, tse, bnw, bne, bsw, bse
     o = fmaf(v001, (wx1 * wy0) * wz0, o);
     o = fmaf(v010, (wx0 * wy1) * wz0, o);

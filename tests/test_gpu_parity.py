@@ -317,3 +317,21 @@ def test_full_frame_room0_properties():
                                         sc.tsdf_bnds, sc.bound, 'color', g[pick].cpu(), 48, 16)
     assert_close(di.reshape(-1)[pick], od, TOL, 'depth')
     assert_close(ci.reshape(-1, 3)[pick], oc, TOL, 'color')
+
+
+def test_tsdf_generic_strides_path(mini, gm):
+    """A contiguous [1,1,Z,Y,X] TSDF (X fastest) takes the strided 8-load path; the permuted view of
+    the reference (Z fastest) takes the paired-load path.  Same values either way."""
+    qp = mini.query_points.to(DEV)
+    a = gm.rend.eval_points_tsdf(qp, gm.tsdf, DEV)
+    b = gm.rend.eval_points_tsdf(qp, gm.tsdf.contiguous(), DEV)
+    assert torch.equal(a, b)
+    # top z boundary (z0 = Z-1) and beyond: border clamp
+    lo, hi = mini.tsdf_bnds[:, 0], mini.tsdf_bnds[:, 1]
+    edge = torch.stack([lo + (hi - lo) * torch.tensor([0.3, 0.6, 1.0], dtype=torch.float64),
+                        lo + (hi - lo) * torch.tensor([0.5, 0.5, 1.2], dtype=torch.float64),
+                        lo + (hi - lo) * torch.tensor([1.0, 1.0, 1.0], dtype=torch.float64),
+                        lo + (hi - lo) * torch.tensor([0.0, 0.0, 0.0], dtype=torch.float64)])
+    got = gm.rend.eval_points_tsdf(edge.to(DEV), gm.tsdf, DEV).cpu().reshape(-1)
+    ref = O.trilerp(mini.tsdf_volume, edge, mini.tsdf_bnds).reshape(-1)
+    assert (got - ref).abs().max().item() <= 5e-7
