@@ -30,7 +30,8 @@ class AdfpTsdf(C.Structure):
 class AdfpScene(C.Structure):
     _fields_ = [('bound', (C.c_double * 2) * 3), ('tsdf_bnds', (C.c_double * 2) * 3),
                 ('low', AdfpGrid), ('high', AdfpGrid), ('color', AdfpGrid), ('tsdf', AdfpTsdf),
-                ('w_low', C.c_void_p), ('w_high', C.c_void_p), ('w_color', C.c_void_p), ('w_att', C.c_void_p)]
+                ('w_low', C.c_void_p), ('w_high', C.c_void_p), ('w_color', C.c_void_p), ('w_att', C.c_void_p),
+                ('h_low', C.c_void_p), ('h_high', C.c_void_p), ('h_color', C.c_void_p)]
 
 
 class AdfpPoints(C.Structure):
@@ -77,6 +78,8 @@ SYMBOLS = [
     ('adfp_relayout_grid_back', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ('adfp_pack_decoder', C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_pack_attention', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_decoder_packed_h_words', C.c_longlong, [C.c_int]),
+    ('adfp_pack_decoder_h', C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_get_rays', C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_sample_rays', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Bound),

@@ -131,27 +131,6 @@ ADFP_DEV void stage_head(float* __restrict__ row, int col, int h, f32x4 head) {
     }
 }
 
-ADFP_DEV void adfp_sincosf(float x, float& sn, float& cs) {
-    const float k = rintf(x * 0.636619772f);
-    float r = fmaf(k, -1.57079601e+00f, x);
-    r = fmaf(k, -3.13916473e-07f, r);
-    r = fmaf(k, -5.39030253e-15f, r);
-    const int n = (int)k;
-    const float r2 = r * r;
-    float s = fmaf(r2, 2.86567956e-6f, -1.98559923e-4f);
-    s = fmaf(s, r2, 8.33338592e-3f);
-    s = fmaf(s, r2, -1.66666672e-1f);
-    s = fmaf(s * r2, r, r);
-    float c = fmaf(r2, 2.44677067e-5f, -1.38877297e-3f);
-    c = fmaf(c, r2, 4.16666567e-2f);
-    c = fmaf(c, r2, -0.5f);
-    c = fmaf(c, r2, 1.0f);
-    float vs = (n & 1) ? c : s;
-    float vc = (n & 1) ? -s : c;
-    sn = (n & 2) ? -vs : vs;
-    cs = (n & 2) ? -vc : vc;
-}
-
 // ------------------------------------------------------------------------------------------
 // decoder backward
 // ------------------------------------------------------------------------------------------

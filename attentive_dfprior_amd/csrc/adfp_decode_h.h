@@ -1,0 +1,238 @@
+// adfp_decode_h.h -- decoder kernel with the MLP on v_mfma_f32_32x32x16_f16 using a 3-product
+// split of every f32 operand:  a = a_hi + a_lo (a_hi = a truncated to 11 significant bits, a_lo the
+// f16-rounded remainder),  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  accumulated in fp32.
+//
+// Why.  Measured on MI355X (tools/micro/mfma_valu_*.hip): VALU instructions do NOT hide behind
+// MFMAs on a SIMD -- neither another wave's (a VALU-only partner wave gets ~2 % of its issue rate
+// next to a dependent MFMA chain) nor the wave's own (64 -> 89 cycles per MFMA with 8 independent
+// v_fma behind it).  The decoder's time is therefore  64 cyc x 240 f32 MFMAs + ~3.5 cyc x 1800 VALU
+// per 32-point tile; the MFMA term is 70 % of it and f32-input MFMA runs at 1/16 of the f16 rate.
+// Three f16 MFMAs per 16 k-values replace eight f32 MFMAs: 90 x ~35 cycles instead of 240 x 64.
+//
+// Accuracy (tools/micro/f16x3_accuracy.hip, K = 128): max error relative to the largest output
+// 3.6e-7 for O(1) operands and 9.5e-7 for O(0.03) operands, against 3.6e-7 / 2.5e-7 for the exact f32
+// MFMA; f16 products are exact in fp32 and f16 subnormal inputs are not flushed on gfx950.  The
+// dropped a_lo*b_lo term is 2^-22 relative.  Operands must stay below 65504 in magnitude (hidden
+// activations of this network are O(1..10)).  The exact-f32 kernel (k_decode) stays available
+// (ADFP_MATH=f32) and is what the backward uses.
+#pragma once
+#include "adfp_device.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// "H" image of one decoder: Fourier matrix / biases / output layer in f32, weight chains in f16.
+// A chain block [32 out x K in] is K/16 k-steps; a k-step is [hi|lo][h][32 rows][8 j] halves
+// (1024 halves = 2 KB): lane (i,h) reads its 8 hi and 8 lo halves with two ds_read_b128.
+// k-step ks, lane-half h, element j carries unit 32*(ks>>1) + kmapH(8*(ks&1) + j, h): the 16
+// accumulator registers of a layer, split in two groups of 8, are the next layer's two k-steps.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int unit_of_h(int ks, int h, int j) { return 32 * (ks >> 1) + kmapH(8 * (ks & 1) + j, h); }
+
+template <int CDIM, int NOUT>
+struct DecLayoutH {
+    using F = DecLayout<CDIM, NOUT>;                 // flat (state_dict) offsets are shared
+    static constexpr int KS_E = 6;                   // k-steps of the 96 (93) Fourier features
+    static constexpr int KS_C = CDIM / 16;
+    __host__ __device__ static constexpr int ks(int i) { return i == 0 ? KS_E : (i == 3 ? KS_E + 2 : 2); }
+    // offsets in 32-bit words (a k-step = 512 words)
+    static constexpr int P_BM = 0;                                   // [96][4] f32
+    __host__ __device__ static constexpr int layer_words(int i) { return ks(i) * 512 + 32 + KS_C * 512 + 32; }
+    __host__ __device__ static constexpr int P_WP(int i) {
+        int o = 384;
+        for (int k = 0; k < i; ++k) o += layer_words(k);
+        return o;
+    }
+    __host__ __device__ static constexpr int P_BP(int i) { return P_WP(i) + ks(i) * 512; }
+    __host__ __device__ static constexpr int P_WC(int i) { return P_BP(i) + 32; }
+    __host__ __device__ static constexpr int P_BC(int i) { return P_WC(i) + KS_C * 512; }
+    static constexpr int P_WO = P_WP(5);                              // [2][NOUT][16] f32
+    static constexpr int P_BO = P_WO + 2 * NOUT * 16;
+    static constexpr int P_TOTAL = P_BO + 4;
+};
+
+// source of 32-bit word t of the H image: either one f32 of the flat buffer (kind 0) or a pair of
+// halves (kind 1 = hi parts, kind 2 = lo parts) of two flat weights
+struct HSrc { int kind, s0, s1; };
+template <int CDIM, int NOUT>
+__device__ HSrc dec_h_src(int t) {
+    using L = DecLayoutH<CDIM, NOUT>;
+    using F = DecLayout<CDIM, NOUT>;
+    if (t < 384) {
+        const int j = t >> 2, c = t & 3;
+        return HSrc{0, (j < 93 && c < 3) ? F::F_EB + c * 93 + j : -1, -1};
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        if (t < L::P_BP(i) || (t >= L::P_WC(i) && t < L::P_BC(i))) {
+            const bool fc = t >= L::P_WC(i);
+            const int u = t - (fc ? L::P_WC(i) : L::P_WP(i));
+            const int ks = u >> 9, part = (u >> 8) & 1, h = (u >> 7) & 1, row = (u >> 2) & 31, jp = (u & 3) * 2;
+            int src[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                int col = unit_of_h(ks, h, jp + e);
+                if (fc) src[e] = F::F_FC(i) + row * CDIM + col;
+                else {
+                    if (i == 0) { if (col >= 93) col = -1; }
+                    else if (i == 3) { if (col < 96) { if (col >= 93) col = -1; } else col = 93 + (col - 96); }
+                    src[e] = col < 0 ? -1 : F::F_PL(i) + row * F::in_dim(i) + col;
+                }
+            }
+            return HSrc{1 + part, src[0], src[1]};
+        }
+        if (t < L::P_WC(i)) return HSrc{0, F::F_PL(i) + 32 * F::in_dim(i) + (t - L::P_BP(i)), -1};
+        if (t < L::P_BC(i) + 32) return HSrc{0, F::F_FC(i) + 32 * CDIM + (t - L::P_BC(i)), -1};
+    }
+    if (t < L::P_BO) {
+        const int u = t - L::P_WO;
+        const int h = u / (NOUT * 16), o = (u >> 4) % NOUT, r = u & 15;
+        return HSrc{0, F::F_OW + o * 32 + kmapH(r, h), -1};
+    }
+    const int o = t - L::P_BO;
+    return HSrc{0, o < NOUT ? F::F_OB + o : -1, -1};
+}
+
+__device__ __forceinline__ float f16_hi_part(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFFE000u); }
+
+template <int CDIM, int NOUT>
+__global__ void k_pack_decoder_h(const float* __restrict__ flat, unsigned* __restrict__ packed) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= DecLayoutH<CDIM, NOUT>::P_TOTAL) return;
+    const HSrc s = dec_h_src<CDIM, NOUT>(t);
+    if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(flat[s.s0]); return; }
+    const float a = s.s0 < 0 ? 0.f : flat[s.s0], b = s.s1 < 0 ? 0.f : flat[s.s1];
+    const float ah = f16_hi_part(a), bh = f16_hi_part(b);
+    _Float16 x, y;
+    if (s.kind == 1) { x = (_Float16)ah; y = (_Float16)bh; }
+    else { x = (_Float16)(a - ah); y = (_Float16)(b - bh); }
+    packed[t] = (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+
+// 8 f32 -> 8 hi halves + 8 lo halves (3 VALU per value: and, sub, 2 x cvt_pkrtz per pair)
+ADFP_DEV void split8(const float* __restrict__ x, f16x8& hi, f16x8& lo) {
+    u32x4 uh, ul;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = x[2 * j], b = x[2 * j + 1];
+        const float ah = f16_hi_part(a), bh = f16_hi_part(b);
+        uh[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ah, bh));
+        ul[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - ah, b - bh));
+    }
+    hi = __builtin_bit_cast(f16x8, uh);
+    lo = __builtin_bit_cast(f16x8, ul);
+}
+
+// NK k-steps of a chain: acc += W[:, units of k-step] * x   with the 3-product split
+template <int NK>
+ADFP_DEV void mfma_chain_h(f32x16& acc, const unsigned* __restrict__ w, int lane_off, const f16x8* __restrict__ xh, const f16x8* __restrict__ xl) {
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const f16x8 ah = __builtin_bit_cast(f16x8, *(const u32x4*)(w + ks * 512 + lane_off));
+        const f16x8 al = __builtin_bit_cast(f16x8, *(const u32x4*)(w + ks * 512 + 256 + lane_off));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[ks], acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting the next chain's LDS reads
+}
+
+template <int CDIM, int NOUT, int ROLE, int NT>
+__global__ __launch_bounds__(NT, 2) void k_decode_h(DecodeArgs a) {
+    using L = DecLayoutH<CDIM, NOUT>;
+    __shared__ __attribute__((aligned(16))) unsigned ldsu[L::P_TOTAL];
+    for (int i = threadIdx.x; i < L::P_TOTAL / 4; i += NT) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lds = (const float*)ldsu;
+
+    const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+    const int lane_off = h * 128 + p * 4;            // words: [h][32 rows][4 words = 8 halves]
+    const int wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (NT / 64);
+    const int count = (ROLE == ROLE_HIGH) ? *a.count_ptr : a.P.n;
+    const int ntiles = (count + 31) >> 5;
+
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int idx = tile * 32 + p;
+        const bool valid = idx < count;
+        int q = valid ? idx : 0;
+        if (ROLE == ROLE_HIGH) q = a.list[q];
+
+        double pt[3]; float pn[3], pf[3];
+        load_point(a.P, q, pt);
+        normalize3(a.nb, pt, pn);
+        pf[0] = (float)pt[0]; pf[1] = (float)pt[1]; pf[2] = (float)pt[2];   // p.float() decoder.py:189
+
+        // grid features -> split halves (k-steps of fc_c)
+        f16x8 ch[L::KS_C], cl[L::KS_C];
+        {
+            float c[CDIM / 2];
+            gather16(a.g0, pn, h, c);
+            if (CDIM == 64) gather16(a.g1, pn, h, c + 16);
+#pragma unroll
+            for (int ks = 0; ks < L::KS_C; ++ks) split8(c + 8 * ks, ch[ks], cl[ks]);
+        }
+        // Fourier features sin(p @ B) (decoder.py:26-30) -> split halves (6 k-steps)
+        f16x8 eh[L::KS_E], el[L::KS_E];
+#pragma unroll
+        for (int ks = 0; ks < L::KS_E; ++ks) {
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 bm = *(const f32x4*)(lds + L::P_BM + unit_of_h(ks, h, j) * 4);
+                const float arg = fmaf(pf[2], bm.z, fmaf(pf[1], bm.y, pf[0] * bm.x));
+                e[j] = adfp_sinf(arg);
+            }
+            split8(e, eh[ks], el[ks]);
+        }
+
+        __builtin_amdgcn_sched_barrier(0);
+        // h = relu(W_i h + b_i) + (Wc_i c + bc_i); skip-concat [emb, h] feeds layer 3 (decoder.py:192-199)
+        f32x16 acc;
+        f16x8 hh[2], hl[2];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            bias_init(acc, lds + L::P_BP(i), h);
+            if (i == 0) mfma_chain_h<L::KS_E>(acc, ldsu + L::P_WP(0), lane_off, eh, el);
+            else if (i == 3) {
+                mfma_chain_h<L::KS_E>(acc, ldsu + L::P_WP(3), lane_off, eh, el);
+                mfma_chain_h<2>(acc, ldsu + L::P_WP(3) + L::KS_E * 512, lane_off, hh, hl);
+            } else mfma_chain_h<2>(acc, ldsu + L::P_WP(i), lane_off, hh, hl);
+            relu_bias(acc, lds + L::P_BC(i), h);
+            mfma_chain_h<L::KS_C>(acc, ldsu + L::P_WC(i), lane_off, ch, cl);
+            if (i < 4) {
+                float t[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = acc[r];
+                split8(t, hh[0], hl[0]);
+                split8(t + 8, hh[1], hl[1]);
+            }
+        }
+
+        // output_linear on the VALU in f32: each half holds 16 of the 32 hidden units
+        float out[NOUT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const float* wo = lds + L::P_WO + (h * NOUT + o) * 16;
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s = fmaf(acc[r], wo[r], s);
+            s += __shfl_xor(s, 32);
+            out[o] = s + lds[L::P_BO + o];
+        }
+
+        if (valid && h == 0) {
+            if constexpr (ROLE == ROLE_LOW) {
+                const bool inb = in_bound(pt, a.b);
+                const unsigned f = a.flags ? a.flags[q] : 0u;
+                a.raw[4ll * q + 3] = ((f & ADFP_F_BAND) || inb || !a.apply_bound) ? out[0] : 100.f;   // Renderer.py:64
+                if (a.write_w) a.w[q] = 1.f;
+            } else if constexpr (ROLE == ROLE_COLOR) {
+                a.raw[4ll * q + 0] = out[0]; a.raw[4ll * q + 1] = out[1]; a.raw[4ll * q + 2] = out[2];
+            } else {
+                a.att_occ[idx] = out[0] + a.raw[4ll * q + 3];                        // high + low, decoder.py:342
+            }
+        }
+    }
+}

@@ -155,10 +155,23 @@ ADFP_DEV void gather16(const GridDev& g, const float pn[3], int h, float* __rest
 }
 
 // ------------------------------------------------------------------------------------
-// sin for Fourier features with |x| up to ~1e3 rad (B ~ N(0,25^2), decoder.py:21-22):
-// 3-constant Cody-Waite reduction by pi/2 carried by fma (exact product), then minimax
-// polynomials on [-pi/4, pi/4].  ~1 ulp; the hardware v_sin_f32 is far too coarse here.
+// sin for Fourier features with |x| up to ~1e3 rad (B ~ N(0,25^2), decoder.py:21-22).
+// The argument is reduced EXACTLY first -- k = rint(x / 2pi), r = x - k*2pi by three fmas with a
+// 3-constant split of 2pi (the products are exact inside the fma) -- and only the reduced turn
+// fraction r / 2pi in [-0.5, 0.5] goes to the hardware v_sin_f32 (which computes sin(2 pi t)).
+// Measured on MI355X over |x| < 3000 (tools/micro/sin_variants.hip): max abs error 3.9e-7, against
+// 6.9e-8 for a full software sin/cos-polynomial version that costs 15 more VALU issue slots per
+// feature; v_sin_f32 on the UNREDUCED argument would be off by ~1e-4.  VALU instructions do not
+// hide behind MFMAs on this machine, so those slots are wall time (279 sines per sample).
 // ------------------------------------------------------------------------------------
+ADFP_DEV float adfp_turns(float x) {
+    const float k = rintf(x * 0.159154943f);
+    float r = fmaf(k, -6.28318405e+00f, x);
+    r = fmaf(k, -1.25566589e-06f, r);
+    r = fmaf(k, -2.15612101e-14f, r);
+    return r * 0.159154943f;
+}
+#ifdef ADFP_SIN_POLY
 ADFP_DEV float adfp_sinf(float x) {
     const float k = rintf(x * 0.636619772f);
     float r = fmaf(k, -1.57079601e+00f, x);
@@ -166,7 +179,6 @@ ADFP_DEV float adfp_sinf(float x) {
     r = fmaf(k, -5.39030253e-15f, r);
     const int n = (int)k;
     const float r2 = r * r;
-    // sin(r) = r + r^3 * S(r2);  cos(r) = 1 - r2/2 + r2^2 * C(r2)
     float s = fmaf(r2, 2.86567956e-6f, -1.98559923e-4f);
     s = fmaf(s, r2, 8.33338592e-3f);
     s = fmaf(s, r2, -1.66666672e-1f);
@@ -178,6 +190,21 @@ ADFP_DEV float adfp_sinf(float x) {
     float v = (n & 1) ? c : s;
     return (n & 2) ? -v : v;
 }
+#else
+ADFP_DEV float adfp_sinf(float x) { return __builtin_amdgcn_sinf(adfp_turns(x)); }
+#endif
+ADFP_DEV void adfp_sincosf(float x, float& sn, float& cs) {
+    const float t = adfp_turns(x);
+    sn = __builtin_amdgcn_sinf(t);
+    cs = __builtin_amdgcn_cosf(t);
+}
+
+// relu as ONE integer instruction: max(bits(x), 0) keeps every positive float and maps every
+// negative one (sign bit = negative int, -0.0 included) to +0.  fmaxf() on an MFMA result costs two
+// VALU instructions (the compiler puts a canonicalising v_max in front of it, and folds fmed3 back
+// into the same pair).  No inline asm on purpose: the compiler does not pad the MFMA-result hazard
+// for an asm statement, and an asm v_max read half-finished accumulators.
+ADFP_DEV float relu_f(float x) { const int b = __float_as_int(x); return __int_as_float(b > 0 ? b : 0); }
 
 ADFP_DEV float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -252,10 +279,10 @@ ADFP_DEV void relu_bias(f32x16& acc, const float* __restrict__ bias, int h) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x4 t = *(const f32x4*)(bias + 8 * q + 4 * h);
-        acc[4 * q + 0] = fmaxf(acc[4 * q + 0], 0.f) + t.x;
-        acc[4 * q + 1] = fmaxf(acc[4 * q + 1], 0.f) + t.y;
-        acc[4 * q + 2] = fmaxf(acc[4 * q + 2], 0.f) + t.z;
-        acc[4 * q + 3] = fmaxf(acc[4 * q + 3], 0.f) + t.w;
+        acc[4 * q + 0] = relu_f(acc[4 * q + 0]) + t.x;
+        acc[4 * q + 1] = relu_f(acc[4 * q + 1]) + t.y;
+        acc[4 * q + 2] = relu_f(acc[4 * q + 2]) + t.z;
+        acc[4 * q + 3] = relu_f(acc[4 * q + 3]) + t.w;
     }
 }
 ADFP_DEV unsigned pos_mask(const f32x16& acc) {

@@ -478,6 +478,8 @@ __global__ __launch_bounds__(NT, 2) void k_decode(DecodeArgs a) {
     }
 }
 
+#include "adfp_decode_h.h"
+
 // =====================================================================================
 // attention fusion mlp_tsdf (a11) on the in-band list
 // =====================================================================================
@@ -734,6 +736,33 @@ int adfp_pack_decoder(int kind, const float* flat, float* packed, void* stream) 
     ADFP_CHECK_LAUNCH();
     return 0;
 }
+long long adfp_decoder_packed_h_words(int kind) {
+    switch (kind) {
+        case ADFP_DEC_LOW: return DecLayoutH<32, 1>::P_TOTAL;
+        case ADFP_DEC_HIGH: return DecLayoutH<64, 1>::P_TOTAL;
+        case ADFP_DEC_COLOR: return DecLayoutH<32, 4>::P_TOTAL;
+    }
+    return ADFP_E_ARG;
+}
+int adfp_pack_decoder_h(int kind, const float* flat, void* packed, void* stream) {
+    if (!flat || !packed) return ADFP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* out = (unsigned*)packed;
+    switch (kind) {
+        case ADFP_DEC_LOW:
+            hipLaunchKernelGGL((k_pack_decoder_h<32, 1>), dim3((DecLayoutH<32, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out);
+            break;
+        case ADFP_DEC_HIGH:
+            hipLaunchKernelGGL((k_pack_decoder_h<64, 1>), dim3((DecLayoutH<64, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out);
+            break;
+        case ADFP_DEC_COLOR:
+            hipLaunchKernelGGL((k_pack_decoder_h<32, 4>), dim3((DecLayoutH<32, 4>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out);
+            break;
+        default: return ADFP_E_ARG;
+    }
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
 int adfp_pack_attention(const float* flat, float* packed, void* stream) {
     if (!flat || !packed) return ADFP_E_ARG;
     hipLaunchKernelGGL(k_pack_attention, dim3((AttLayout::P_TOTAL + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat, packed);
@@ -838,18 +867,36 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
     a.raw = raw; a.w = w; a.att_occ = nullptr; a.write_w = fuse ? 0 : 1; a.apply_bound = apply_bound;
     const int ntiles = (P.n + 31) / 32;
     // LOW on every point
-    a.g0 = make_grid(sc->low); a.g1 = a.g0; a.packed = sc->w_low;
-    hipLaunchKernelGGL((k_decode<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+    a.g0 = make_grid(sc->low); a.g1 = a.g0;
+    if (sc->h_low) {
+        a.packed = (const float*)sc->h_low;
+        hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+    } else {
+        a.packed = sc->w_low;
+        hipLaunchKernelGGL((k_decode<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+    }
     ADFP_CHECK_LAUNCH();
     if (stage == ADFP_STAGE_COLOR) {
-        a.g0 = make_grid(sc->color); a.g1 = a.g0; a.packed = sc->w_color;
-        hipLaunchKernelGGL((k_decode<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+        a.g0 = make_grid(sc->color); a.g1 = a.g0;
+        if (sc->h_color) {
+            a.packed = (const float*)sc->h_color;
+            hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+        } else {
+            a.packed = sc->w_color;
+            hipLaunchKernelGGL((k_decode<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+        }
         ADFP_CHECK_LAUNCH();
     }
     if (fuse) {
-        a.g0 = make_grid(sc->high); a.g1 = make_grid(sc->low); a.packed = sc->w_high;
+        a.g0 = make_grid(sc->high); a.g1 = make_grid(sc->low);
         a.list = ws.list; a.count_ptr = ws.counter; a.att_occ = ws.att_occ;
-        hipLaunchKernelGGL((k_decode<64, 1, ROLE_HIGH, 512>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
+        if (sc->h_high) {
+            a.packed = (const float*)sc->h_high;
+            hipLaunchKernelGGL((k_decode_h<64, 1, ROLE_HIGH, 256>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, a);
+        } else {
+            a.packed = sc->w_high;
+            hipLaunchKernelGGL((k_decode<64, 1, ROLE_HIGH, 512>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
+        }
         ADFP_CHECK_LAUNCH();
         AttArgs t;
         t.packed = sc->w_att; t.list = ws.list; t.count_ptr = ws.counter; t.att_occ = ws.att_occ; t.att_u = ws.att_u;
@@ -873,13 +920,25 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
     const int ntiles = (P.n + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if (kind == ADFP_DEC_LOW) {
-        if (!sc->low.data || !sc->w_low) return ADFP_E_ARG;
-        a.g0 = make_grid(sc->low); a.g1 = a.g0; a.packed = sc->w_low;
-        hipLaunchKernelGGL((k_decode<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+        if (!sc->low.data || !(sc->w_low || sc->h_low)) return ADFP_E_ARG;
+        a.g0 = make_grid(sc->low); a.g1 = a.g0;
+        if (sc->h_low) {
+            a.packed = (const float*)sc->h_low;
+            hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+        } else {
+            a.packed = sc->w_low;
+            hipLaunchKernelGGL((k_decode<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+        }
     } else {
-        if (!sc->color.data || !sc->w_color) return ADFP_E_ARG;
-        a.g0 = make_grid(sc->color); a.g1 = a.g0; a.packed = sc->w_color;
-        hipLaunchKernelGGL((k_decode<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+        if (!sc->color.data || !(sc->w_color || sc->h_color)) return ADFP_E_ARG;
+        a.g0 = make_grid(sc->color); a.g1 = a.g0;
+        if (sc->h_color) {
+            a.packed = (const float*)sc->h_color;
+            hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+        } else {
+            a.packed = sc->w_color;
+            hipLaunchKernelGGL((k_decode<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+        }
     }
     ADFP_CHECK_LAUNCH();
     return 0;
@@ -888,9 +947,9 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
 static int check_scene(const adfp_scene* sc, int stage) {
     if (!sc) return ADFP_E_ARG;
     if (stage < ADFP_STAGE_LOW || stage > ADFP_STAGE_COLOR) return ADFP_E_ARG;
-    if (!sc->low.data || !sc->w_low) return ADFP_E_ARG;
-    if (stage >= ADFP_STAGE_HIGH && (!sc->high.data || !sc->w_high || !sc->w_att || !sc->tsdf.data)) return ADFP_E_ARG;
-    if (stage == ADFP_STAGE_COLOR && (!sc->color.data || !sc->w_color)) return ADFP_E_ARG;
+    if (!sc->low.data || !(sc->w_low || sc->h_low)) return ADFP_E_ARG;
+    if (stage >= ADFP_STAGE_HIGH && (!sc->high.data || !(sc->w_high || sc->h_high) || !sc->w_att || !sc->tsdf.data)) return ADFP_E_ARG;
+    if (stage == ADFP_STAGE_COLOR && (!sc->color.data || !(sc->w_color || sc->h_color))) return ADFP_E_ARG;
     return 0;
 }
 
@@ -1047,6 +1106,7 @@ static int run_decode_bwd(DecodeBwdArgs a, int total, const int* count_ptr, floa
 extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_args* r, void* stream) {
     if (!r) return ADFP_E_ARG;
     int rc = check_scene(sc, r->stage); if (rc) return rc;
+    if (!sc->w_low || (r->stage >= ADFP_STAGE_HIGH && !sc->w_high) || (r->stage == ADFP_STAGE_COLOR && !sc->w_color)) return ADFP_E_ARG;   // exact-f32 images
     if (!r->rays_o || !r->rays_d || !r->z_vals || !r->raw || !r->workspace || r->n_rays < 0 || r->S <= 0) return ADFP_E_ARG;
     if (r->S > 64 * CB_MAXC) return ADFP_E_UNSUPPORTED;
     const long long Pn = (long long)r->n_rays * r->S;

@@ -138,15 +138,29 @@ class DF(nn.Module):
         self._engine = None
 
     # ---- weight images for the kernels -------------------------------------------------
-    def packed_weights(self, name):
+    def packed_weights(self, name, fmt='f32'):
         """Packed (MFMA operand order) image of one sub-network, rebuilt only when a parameter
-        changed (optimizer step bumps Parameter._version)."""
+        changed (optimizer step bumps Parameter._version).  fmt 'f32' = exact f32-input MFMA image,
+        'h' = f16 hi/lo split image of the forward decoders (adfp_pack_decoder_h)."""
         module = {'low': self.low_decoder, 'high': self.high_decoder, 'color': self.color_decoder,
                   'att': self.mlp}[name]
         key = _version_key(module)
-        hit = self._packed.get(name)
+        slot = name if fmt == 'f32' else name + '.h'
+        hit = self._packed.get(slot)
         if hit is not None and hit[0] == key:
             return hit[1]
+        if fmt == 'h':
+            flat = _flat_params(module)
+            _lib.require_cuda(flat, f'{name} decoder parameters')
+            L = lib()
+            dev = flat.device
+            with torch.cuda.device(dev):
+                kind = _lib.DEC_KIND[name]
+                packed = torch.empty(L.adfp_decoder_packed_h_words(kind), dtype=torch.int32, device=dev)
+                _lib.check(L.adfp_pack_decoder_h(kind, _lib.ptr(flat), _lib.ptr(packed), _lib.current_stream(dev)),
+                           'adfp_pack_decoder_h')
+            self._packed[slot] = (key, packed)
+            return packed
         flat = _flat_params(module)
         _lib.require_cuda(flat, f'{name} decoder parameters')
         L = lib()

@@ -24,6 +24,16 @@ def _host_bound(t):
     return [[float(v) for v in row] for row in t.detach().to('cpu', torch.float64).tolist()]
 
 
+def math_mode():
+    """ADFP_MATH=f16x3 (default): forward decoders on f16 MFMA with a 3-product operand split;
+    ADFP_MATH=f32: exact f32-input MFMA everywhere."""
+    import os
+    m = os.environ.get('ADFP_MATH', 'f16x3')
+    if m not in ('f16x3', 'f32'):
+        raise RuntimeError(f'ADFP_MATH={m}: expected f16x3 or f32')
+    return m
+
+
 class Engine(object):
     def __init__(self):
         self._ws = None
@@ -70,8 +80,10 @@ class Engine(object):
         return dst
 
     # ---- descriptor ----------------------------------------------------------------------
-    def scene(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage):
-        """Returns (AdfpScene, keepalive list)."""
+    def scene(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=False):
+        """Returns (AdfpScene, keepalive list).  The forward takes the f16-split decoder images unless
+        ADFP_MATH=f32; the backward always takes the exact f32 images."""
+        use_h = (not backward) and math_mode() == 'f16x3'
         sc = _lib.AdfpScene()
         keep = []
         _lib.fill_bound(sc.bound, self.host_bound(bound, 'bound'))
@@ -86,14 +98,23 @@ class Engine(object):
             gd = getattr(sc, field)
             gd.data = g.data_ptr()
             gd.Z, gd.Y, gd.X = g.shape[0], g.shape[1], g.shape[2]
-        sc.w_low = decoders.packed_weights('low').data_ptr()
+        if use_h:
+            sc.h_low = decoders.packed_weights('low', 'h').data_ptr()
+        else:
+            sc.w_low = decoders.packed_weights('low').data_ptr()
         if stage != 'low':
-            sc.w_high = decoders.packed_weights('high').data_ptr()
+            if use_h:
+                sc.h_high = decoders.packed_weights('high', 'h').data_ptr()
+            else:
+                sc.w_high = decoders.packed_weights('high').data_ptr()
             sc.w_att = decoders.packed_weights('att').data_ptr()
             _lib.fill_bound(sc.tsdf_bnds, self.host_bound(tsdf_bnds, 'tsdf_bnds'))
             self.fill_tsdf(sc.tsdf, tsdf_volume, keep)
         if stage == 'color':
-            sc.w_color = decoders.packed_weights('color').data_ptr()
+            if use_h:
+                sc.h_color = decoders.packed_weights('color', 'h').data_ptr()
+            else:
+                sc.w_color = decoders.packed_weights('color').data_ptr()
         return sc, keep
 
     @staticmethod
@@ -245,7 +266,7 @@ class Engine(object):
         L = lib()
         with torch.cuda.device(dev):
             N, S = ro.shape[0], saved['S']
-            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage)
+            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=True)
             a = _lib.AdfpBackwardArgs()
             a.stage = _lib.STAGE[stage]
             a.n_rays, a.S = N, S

@@ -77,6 +77,12 @@ typedef struct adfp_scene {
     const float* w_high;
     const float* w_color;
     const float* w_att;
+    /* optional "H" images (adfp_pack_decoder_h): when non-NULL the FORWARD decoders run their MLP on
+     * f16 MFMA with a 3-product split of every f32 operand (fp32-grade accuracy);
+     * NULL = exact f32-input MFMA from w_*.  The backward always uses w_*. */
+    const void* h_low;
+    const void* h_high;
+    const void* h_color;
 } adfp_scene;
 
 typedef struct adfp_points {
@@ -105,6 +111,9 @@ int adfp_relayout_grid(const float* src_cm, float* dst_cl, int C, int Z, int Y, 
 int adfp_relayout_grid_back(const float* src_cl, float* dst_cm, int C, int Z, int Y, int X, void* stream);
 /* flat state_dict-order parameters -> packed MFMA image (MLP: decoder.py:91-203) */
 int adfp_pack_decoder(int kind, const float* flat, float* packed, void* stream);
+/* same parameters -> "H" image (f16 hi/lo halves of every weight), adfp_decoder_packed_h_words(kind) 32-bit words */
+long long adfp_decoder_packed_h_words(int kind);
+int adfp_pack_decoder_h(int kind, const float* flat, void* packed, void* stream);
 /* mlp_tsdf parameters (decoder.py:206-258) */
 int adfp_pack_attention(const float* flat, float* packed, void* stream);
 
