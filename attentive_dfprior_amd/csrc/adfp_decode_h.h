@@ -110,7 +110,8 @@ __global__ void k_pack_decoder_h(const float* __restrict__ flat, unsigned* __res
     packed[t] = (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
 
-// 8 f32 -> 8 hi halves + 8 lo halves (3 VALU per value: and, sub, 2 x cvt_pkrtz per pair)
+// 8 f32 -> 8 hi halves + 8 lo halves (3 VALU per value: and, sub, 2 x cvt_pkrtz per pair).
+// hi = x truncated to 11 significant bits (a mask; exactly representable in f16), lo = x - hi.
 ADFP_DEV void split8(const float* __restrict__ x, f16x8& hi, f16x8& lo) {
     u32x4 uh, ul;
 #pragma unroll

@@ -156,20 +156,19 @@ ADFP_DEV void gather16(const GridDev& g, const float pn[3], int h, float* __rest
 
 // ------------------------------------------------------------------------------------
 // sin for Fourier features with |x| up to ~1e3 rad (B ~ N(0,25^2), decoder.py:21-22).
-// The argument is reduced EXACTLY first -- k = rint(x / 2pi), r = x - k*2pi by three fmas with a
-// 3-constant split of 2pi (the products are exact inside the fma) -- and only the reduced turn
-// fraction r / 2pi in [-0.5, 0.5] goes to the hardware v_sin_f32 (which computes sin(2 pi t)).
-// Measured on MI355X over |x| < 3000 (tools/micro/sin_variants.hip): max abs error 3.9e-7, against
+// The argument is reduced EXACTLY first, in turns: t = x/(2pi) - rint(x/(2pi)) by two fmas with a
+// 2-constant split of 1/(2pi) (the product is exact inside the fma), and only the reduced turn
+// fraction in [-0.5, 0.5] goes to the hardware v_sin_f32 (which computes sin(2 pi t)).
+// Measured on MI355X over |x| < 3000 (tools/micro/sin_variants.hip): max abs error 3.2e-7, against
 // 6.9e-8 for a full software sin/cos-polynomial version that costs 15 more VALU issue slots per
 // feature; v_sin_f32 on the UNREDUCED argument would be off by ~1e-4.  VALU instructions do not
 // hide behind MFMAs on this machine, so those slots are wall time (279 sines per sample).
 // ------------------------------------------------------------------------------------
 ADFP_DEV float adfp_turns(float x) {
-    const float k = rintf(x * 0.159154943f);
-    float r = fmaf(k, -6.28318405e+00f, x);
-    r = fmaf(k, -1.25566589e-06f, r);
-    r = fmaf(k, -2.15612101e-14f, r);
-    return r * 0.159154943f;
+    // 1/(2 pi) = C_HI + C_LO; x*C_HI - k is exact inside the fma (k = the nearest integer of it)
+    const float k = rintf(x * 0.15915494f);
+    float t = fmaf(x, 0.15915494f, -k);
+    return fmaf(x, 6.4206382432985265e-09f, t);
 }
 #ifdef ADFP_SIN_POLY
 ADFP_DEV float adfp_sinf(float x) {

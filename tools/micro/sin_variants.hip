@@ -29,9 +29,15 @@ __device__ float sinC(float x) {
     float r = fmaf(k, -6.28318405e+00f, x); r = fmaf(k, -1.25566589e-06f, r); r = fmaf(k, -2.15612101e-14f, r);
     return __builtin_amdgcn_sinf(r * 0.159154943f);
 }
+__device__ float sinD(float x) {
+    const float k = rintf(x * 0.15915494f);
+    float t = fmaf(x, 0.15915494f, -k);
+    t = fmaf(x, 6.4206382432985265e-09f, t);
+    return __builtin_amdgcn_sinf(t);
+}
 __global__ void k(const float* x, float* a, float* b, float* c, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
-    a[i] = sinA(x[i]); b[i] = sinB(x[i]); c[i] = sinC(x[i]);
+    a[i] = sinA(x[i]); b[i] = sinD(x[i]); c[i] = sinC(x[i]);
 }
 int main() {
     const int n = 1 << 22; float *x, *a, *b, *c; hipMalloc(&x, n * 4); hipMalloc(&a, n * 4); hipMalloc(&b, n * 4); hipMalloc(&c, n * 4);
@@ -39,7 +45,7 @@ int main() {
     srand(3); for (int i = 0; i < n; ++i) hx[i] = ((float)rand() / RAND_MAX * 2 - 1) * 3000.f;
     hipMemcpy(x, hx, n * 4, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k, dim3(n / 256), dim3(256), 0, 0, x, a, b, c, n);
-    float* outs[3] = {a, b, c}; const char* names[3] = {"A pi/2 + sin/cos polys", "B pi + odd poly deg 11 ", "C 2pi + v_sin_f32      "};
+    float* outs[3] = {a, b, c}; const char* names[3] = {"A pi/2 + sin/cos polys", "D turns by 2 fma + v_sin", "C 2pi + v_sin_f32      "};
     for (int m = 0; m < 3; ++m) {
         hipMemcpy(h, outs[m], n * 4, hipMemcpyDeviceToHost);
         double e = 0; for (int i = 0; i < n; ++i) e = fmax(e, fabs((double)h[i] - sin((double)hx[i])));
