@@ -31,7 +31,7 @@ class AdfpScene(C.Structure):
     _fields_ = [('bound', (C.c_double * 2) * 3), ('tsdf_bnds', (C.c_double * 2) * 3),
                 ('low', AdfpGrid), ('high', AdfpGrid), ('color', AdfpGrid), ('tsdf', AdfpTsdf),
                 ('w_low', C.c_void_p), ('w_high', C.c_void_p), ('w_color', C.c_void_p), ('w_att', C.c_void_p),
-                ('h_low', C.c_void_p), ('h_high', C.c_void_p), ('h_color', C.c_void_p)]
+                ('h_low', C.c_void_p), ('h_high', C.c_void_p), ('h_color', C.c_void_p), ('h_att', C.c_void_p)]
 
 
 class AdfpPoints(C.Structure):
@@ -80,6 +80,8 @@ SYMBOLS = [
     ('adfp_pack_attention', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_decoder_packed_h_words', C.c_longlong, [C.c_int]),
     ('adfp_pack_decoder_h', C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_attention_packed_h_words', C.c_longlong, []),
+    ('adfp_pack_attention_h', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_get_rays', C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_sample_rays', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Bound),

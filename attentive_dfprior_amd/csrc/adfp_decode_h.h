@@ -140,7 +140,7 @@ ADFP_DEV void mfma_chain_h(f32x16& acc, const unsigned* __restrict__ w, int lane
 }
 
 template <int CDIM, int NOUT, int ROLE, int NT>
-__global__ __launch_bounds__(NT, 2) void k_decode_h(DecodeArgs a) {
+__global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 : 2))) void k_decode_h(DecodeArgs a) {
     using L = DecLayoutH<CDIM, NOUT>;
     __shared__ __attribute__((aligned(16))) unsigned ldsu[L::P_TOTAL];
     for (int i = threadIdx.x; i < L::P_TOTAL / 4; i += NT) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed)[i];
@@ -234,6 +234,150 @@ __global__ __launch_bounds__(NT, 2) void k_decode_h(DecodeArgs a) {
             } else {
                 a.att_occ[idx] = out[0] + a.raw[4ll * q + 3];                        // high + low, decoder.py:342
             }
+        }
+    }
+}
+
+// =============================================================================================
+// attention fusion mlp_tsdf (a11) on f16 MFMA with the same 3-product split
+// =============================================================================================
+struct AttLayoutH {
+    using F = AttLayout;
+    // words
+    static constexpr int P_A0 = 0;                               // [64][4] f32 = (w0, w1, b, 0), unit order
+    static constexpr int P_W1 = 256;                             // 4 out-blocks x 4 k-steps
+    static constexpr int P_B1 = P_W1 + 4 * 4 * 512;
+    static constexpr int P_W2 = P_B1 + 128;                      // 4 out-blocks x 8 k-steps
+    static constexpr int P_B2 = P_W2 + 4 * 8 * 512;
+    static constexpr int P_W3 = P_B2 + 128;                      // 2 out-blocks x 8 k-steps
+    static constexpr int P_B3 = P_W3 + 2 * 8 * 512;
+    static constexpr int P_WO = P_B3 + 64;                       // [2 h][2 o][32] f32
+    static constexpr int P_BO = P_WO + 128;
+    static constexpr int P_TOTAL = P_BO + 4;
+};
+
+__device__ HSrc att_h_src(int t) {
+    using L = AttLayoutH;
+    using F = AttLayout;
+    if (t < L::P_W1) {
+        const int k = t >> 2, c = t & 3;
+        return HSrc{0, c < 2 ? F::F_W0 + k * 2 + c : (c == 2 ? F::F_B0 + k : -1), -1};
+    }
+    auto chain = [](int u, int nks, int base, int ld) {
+        const int blk = u / (nks * 512), v = u % (nks * 512);
+        const int ks = v >> 9, part = (v >> 8) & 1, h = (v >> 7) & 1, row = (v >> 2) & 31, jp = (v & 3) * 2;
+        return HSrc{1 + part, base + (blk * 32 + row) * ld + unit_of_h(ks, h, jp), base + (blk * 32 + row) * ld + unit_of_h(ks, h, jp + 1)};
+    };
+    if (t < L::P_B1) return chain(t - L::P_W1, 4, F::F_W1, 64);
+    if (t < L::P_W2) return HSrc{0, F::F_B1 + (t - L::P_B1), -1};
+    if (t < L::P_B2) return chain(t - L::P_W2, 8, F::F_W2, 128);
+    if (t < L::P_W3) return HSrc{0, F::F_B2 + (t - L::P_B2), -1};
+    if (t < L::P_B3) return chain(t - L::P_W3, 8, F::F_W3, 128);
+    if (t < L::P_WO) return HSrc{0, F::F_B3 + (t - L::P_B3), -1};
+    if (t < L::P_BO) {                                            // entry j of lane-half h <-> unit_of(j, h)
+        const int u = t - L::P_WO, h = u >> 6, o = (u >> 5) & 1, j = u & 31;
+        return HSrc{0, F::F_WO + o * 64 + unit_of(j, h), -1};
+    }
+    const int o = t - L::P_BO;
+    return HSrc{0, o < 2 ? F::F_BO + o : -1, -1};
+}
+__global__ void k_pack_attention_h(const float* __restrict__ flat, unsigned* __restrict__ packed) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= AttLayoutH::P_TOTAL) return;
+    const HSrc s = att_h_src(t);
+    if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(flat[s.s0]); return; }
+    const float a = flat[s.s0], b = flat[s.s1];
+    const float ah = f16_hi_part(a), bh = f16_hi_part(b);
+    _Float16 x, y;
+    if (s.kind == 1) { x = (_Float16)ah; y = (_Float16)bh; }
+    else { x = (_Float16)(a - ah); y = (_Float16)(b - bh); }
+    packed[t] = (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+
+__global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
+    using A = AttLayoutH;
+    __shared__ __attribute__((aligned(16))) unsigned ldsu[A::P_TOTAL];
+    for (int i = threadIdx.x; i < A::P_TOTAL / 4; i += 512) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed)[i];
+    __syncthreads();
+    const float* lds = (const float*)ldsu;
+    const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+    const int lane_off = h * 128 + p * 4;
+    const int wave = blockIdx.x * 8 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 8;
+    const int count = *a.count_ptr;
+    const int ntiles = (count + 31) >> 5;
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int idx = tile * 32 + p;
+        const bool valid = idx < count;
+        const int ii = valid ? idx : 0;
+        const float occ = a.att_occ[ii], u = a.att_u[ii];
+        // layer 0 (2 -> 64) on the VALU
+        f16x8 xh[8], xl[8];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float t8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 t = *(const f32x4*)(lds + A::P_A0 + unit_of_h(ks, h, j) * 4);
+                t8[j] = relu_f(fmaf(u, t.y, fmaf(occ, t.x, t.z)));
+            }
+            split8(t8, xh[ks], xl[ks]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // layer 1: 64 -> 128
+        f16x8 yh[8], yl[8];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            f32x16 acc;
+            bias_init(acc, lds + A::P_B1 + 32 * ob, h);
+            mfma_chain_h<4>(acc, ldsu + A::P_W1 + ob * 4 * 512, lane_off, xh, xl);
+            float t[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = relu_f(acc[r]);
+            split8(t, yh[2 * ob], yl[2 * ob]);
+            split8(t + 8, yh[2 * ob + 1], yl[2 * ob + 1]);
+        }
+        // layer 2: 128 -> 128
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            f32x16 acc;
+            bias_init(acc, lds + A::P_B2 + 32 * ob, h);
+            mfma_chain_h<8>(acc, ldsu + A::P_W2 + ob * 8 * 512, lane_off, yh, yl);
+            float t[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = relu_f(acc[r]);
+            split8(t, xh[2 * ob], xl[2 * ob]);
+            split8(t + 8, xh[2 * ob + 1], xl[2 * ob + 1]);
+        }
+        // layer 3: 128 -> 64, output 64 -> 2 on the VALU in f32
+        float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+            f32x16 acc;
+            bias_init(acc, lds + A::P_B3 + 32 * ob, h);
+            mfma_chain_h<8>(acc, ldsu + A::P_W3 + ob * 8 * 512, lane_off, xh, xl);
+            const float* w0 = lds + A::P_WO + (h * 2 + 0) * 32 + 16 * ob;
+            const float* w1 = lds + A::P_WO + (h * 2 + 1) * 32 + 16 * ob;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = relu_f(acc[r]);
+                l0 = fmaf(v, w0[r], l0);
+                l1 = fmaf(v, w1[r], l1);
+            }
+        }
+        l0 += __shfl_xor(l0, 32); l1 += __shfl_xor(l1, 32);
+        l0 += lds[A::P_BO]; l1 += lds[A::P_BO + 1];
+        // softmax over 2, convex blend (decoder.py:255-258)
+        const float m = fmaxf(l0, l1);
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+        const float den = e0 + e1;
+        const float a0 = e0 / den, a1 = e1 / den;
+        const float fused = a0 * occ + a1 * u;
+        if (valid && h == 0) {
+            const int q = a.list[ii];
+            const bool inb = (a.flags[q] & ADFP_F_INBOUND) != 0;
+            a.raw[4ll * q + 3] = (inb || !a.apply_bound) ? fused : 100.f;   // Renderer.py:64
+            a.w[q] = a1;
         }
     }
 }

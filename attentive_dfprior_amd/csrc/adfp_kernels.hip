@@ -321,29 +321,66 @@ struct TsdfArgs {
     PtsDev P; NormDev nt; TsdfDev t; double b[6];
     unsigned char* flags; int* list; float* att_u; float* w; int* counter; float* tsdf_out;
 };
+#ifndef TSDF_CHUNK
 #define TSDF_CHUNK 2048
+#endif
+// In ray mode a block owns RB consecutive rays (RB * S <= 2048 points) and walks them TRANSPOSED:
+// consecutive lanes take the SAME sample index of consecutive rays.  Neighbouring pixels' samples of
+// equal index are millimetres apart, so the 64 lanes of a load instruction fall into a few cache lines
+// instead of 64 (consecutive samples of ONE ray are ~5 voxels apart) -- the stage is bound by the
+// lines the address unit walks, not by bytes.  z_vals come in and flags / w go out through LDS so
+// that global traffic stays coalesced.
 __global__ __launch_bounds__(256) void k_tsdf(TsdfArgs a) {
     __shared__ int s_q[TSDF_CHUNK];
     __shared__ float s_u[TSDF_CHUNK];
+    __shared__ double s_z[TSDF_CHUNK + 64];
+    __shared__ unsigned char s_f[TSDF_CHUNK];
+    __shared__ float s_ray[64 * 6];
     __shared__ int s_cnt, s_base;
     if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int q0 = blockIdx.x * TSDF_CHUNK;
+    const bool rays = a.P.mode == ADFP_PTS_RAYS;
+    const int S = a.P.S;
+    int RB = 1, q0, npts, rb = 1;
+    if (rays) {
+        while (RB * 2 * S <= TSDF_CHUNK && RB < 64) RB *= 2;
+        const int r0 = blockIdx.x * RB;
+        const int nr = a.P.n / S;
+        rb = (r0 + RB <= nr) ? RB : nr - r0;
+        q0 = r0 * S; npts = rb * S;
+        for (int i = threadIdx.x; i < npts; i += 256) { const int row = i / S, col = i - row * S; s_z[row * (S + 1) + col] = a.P.z[q0 + i]; }
+        for (int i = threadIdx.x; i < rb * 6; i += 256) {
+            const int row = i / 6, k = i - row * 6;
+            s_ray[i] = k < 3 ? a.P.ro[3 * (r0 + row) + k] : a.P.rd[3 * (r0 + row) + k - 3];
+        }
+    } else {
+        q0 = blockIdx.x * TSDF_CHUNK;
+        npts = a.P.n - q0 < TSDF_CHUNK ? a.P.n - q0 : TSDF_CHUNK;
+    }
+    __syncthreads();
 #pragma unroll 2
-    for (int it = 0; it < TSDF_CHUNK / 256; ++it) {
-        const int q = q0 + it * 256 + threadIdx.x;
-        bool band = false; float u = 0.f;
-        if (q < a.P.n) {
+    for (int i0 = 0; i0 < npts; i0 += 256) {          // block-uniform trip count (ballot below)
+        const int i = i0 + threadIdx.x;
+        bool band = false; float u = 0.f; int q = 0;
+        if (i < npts) {
             double p[3]; float pn[3];
-            load_point(a.P, q, p);
-            normalize3(a.nt, p, pn);
-            const float t = trilerp_scalar(a.t, pn);
-            if (a.tsdf_out) a.tsdf_out[q] = t;
-            band = (t > (float)(-1.0 + 1e-4)) & (t < (float)(1.0 - 1e-4));
-            if (a.flags) a.flags[q] = (unsigned char)((in_bound(p, a.b) ? ADFP_F_INBOUND : 0u) | (band ? ADFP_F_BAND : 0u));
-            if (a.w) a.w[q] = 1.f;
-            if (band) u = inv_tsdf(t);
+            int loc = i;
+            if (rays) {
+                const int col = (int)((unsigned)i / (unsigned)rb), row = i - col * rb;   // transposed walk: lane <-> ray
+                loc = row * S + col;
+                const double z = s_z[row * (S + 1) + col];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) p[k] = __dadd_rn((double)s_ray[row * 6 + k], __dmul_rn((double)s_ray[row * 6 + 3 + k], z));
+            } else load_point(a.P, q0 + i, p);
+            if (loc >= 0) {
+                q = q0 + loc;
+                normalize3(a.nt, p, pn);
+                const float t = trilerp_scalar(a.t, pn);
+                if (a.tsdf_out) a.tsdf_out[q] = t;
+                band = (t > (float)(-1.0 + 1e-4)) & (t < (float)(1.0 - 1e-4));
+                s_f[loc] = (unsigned char)((in_bound(p, a.b) ? ADFP_F_INBOUND : 0u) | (band ? ADFP_F_BAND : 0u));
+                if (band) u = inv_tsdf(t);
+            }
         }
         if (a.list) {
             const unsigned long long m = __ballot(band);
@@ -358,8 +395,12 @@ __global__ __launch_bounds__(256) void k_tsdf(TsdfArgs a) {
             }
         }
     }
-    if (!a.list) return;
     __syncthreads();
+    for (int i = threadIdx.x; i < npts; i += 256) {
+        if (a.flags) a.flags[q0 + i] = s_f[i];
+        if (a.w) a.w[q0 + i] = 1.f;
+    }
+    if (!a.list) return;
     const int n = s_cnt;
     if (n == 0) return;
     if (threadIdx.x == 0) s_base = atomicAdd(a.counter, n);
@@ -478,16 +519,23 @@ __global__ __launch_bounds__(NT, 2) void k_decode(DecodeArgs a) {
     }
 }
 
-#include "adfp_decode_h.h"
-
-// =====================================================================================
-// attention fusion mlp_tsdf (a11) on the in-band list
-// =====================================================================================
 struct AttArgs {
     const float* packed; const int* list; const int* count_ptr;
     const float* att_occ; const float* att_u; const unsigned char* flags;
     float* raw; float* w; int apply_bound;
 };
+
+// workgroup shape of the dense f16x3 decoder kernels: 256 threads x 2 workgroups per CU, or one
+// workgroup of 512 / 768 / 1024 threads per CU (2 / 3 / 4 waves per SIMD sharing one weight image)
+#ifndef ADFP_DECH_NT
+#define ADFP_DECH_NT 768
+#endif
+#define ADFP_DECH_WG (ADFP_DECH_NT == 256 ? 2 : 1)
+#include "adfp_decode_h.h"
+
+// =====================================================================================
+// attention fusion mlp_tsdf (a11) on the in-band list
+// =====================================================================================
 
 __global__ __launch_bounds__(512, 2) void k_attention(AttArgs a) {
     using A = AttLayout;
@@ -763,6 +811,13 @@ int adfp_pack_decoder_h(int kind, const float* flat, void* packed, void* stream)
     ADFP_CHECK_LAUNCH();
     return 0;
 }
+long long adfp_attention_packed_h_words(void) { return AttLayoutH::P_TOTAL; }
+int adfp_pack_attention_h(const float* flat, void* packed, void* stream) {
+    if (!flat || !packed) return ADFP_E_ARG;
+    hipLaunchKernelGGL(k_pack_attention_h, dim3((AttLayoutH::P_TOTAL + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat, (unsigned*)packed);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
 int adfp_pack_attention(const float* flat, float* packed, void* stream) {
     if (!flat || !packed) return ADFP_E_ARG;
     hipLaunchKernelGGL(k_pack_attention, dim3((AttLayout::P_TOTAL + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat, packed);
@@ -810,7 +865,15 @@ static int launch_tsdf(const adfp_scene* sc, const PtsDev& P, unsigned char* fla
     a.P = P; a.nt = make_norm(sc->tsdf_bnds); a.t = make_tsdf(sc->tsdf); fill_bound(a.b, sc->bound);
     a.flags = flags; a.list = list; a.att_u = att_u; a.w = w; a.counter = counter; a.tsdf_out = tsdf_out;
     if (P.n == 0) return 0;
-    hipLaunchKernelGGL(k_tsdf, dim3((P.n + TSDF_CHUNK - 1) / TSDF_CHUNK), dim3(256), 0, st, a);
+    int blocks = (P.n + TSDF_CHUNK - 1) / TSDF_CHUNK;
+    if (P.mode == ADFP_PTS_RAYS) {
+        if (P.S > TSDF_CHUNK) return ADFP_E_UNSUPPORTED;
+        int RB = 1;
+        while (RB * 2 * P.S <= TSDF_CHUNK && RB < 64) RB *= 2;
+        const int nr = P.n / P.S;
+        blocks = (nr + RB - 1) / RB;
+    }
+    hipLaunchKernelGGL(k_tsdf, dim3(blocks), dim3(256), 0, st, a);
     ADFP_CHECK_LAUNCH();
     return 0;
 }
@@ -870,7 +933,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
     a.g0 = make_grid(sc->low); a.g1 = a.g0;
     if (sc->h_low) {
         a.packed = (const float*)sc->h_low;
-        hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
     } else {
         a.packed = sc->w_low;
         hipLaunchKernelGGL((k_decode<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
@@ -880,7 +943,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         a.g0 = make_grid(sc->color); a.g1 = a.g0;
         if (sc->h_color) {
             a.packed = (const float*)sc->h_color;
-            hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+            hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
         } else {
             a.packed = sc->w_color;
             hipLaunchKernelGGL((k_decode<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
@@ -899,9 +962,15 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         }
         ADFP_CHECK_LAUNCH();
         AttArgs t;
-        t.packed = sc->w_att; t.list = ws.list; t.count_ptr = ws.counter; t.att_occ = ws.att_occ; t.att_u = ws.att_u;
+        t.list = ws.list; t.count_ptr = ws.counter; t.att_occ = ws.att_occ; t.att_u = ws.att_u;
         t.flags = ws.flags; t.raw = raw; t.w = w; t.apply_bound = apply_bound;
-        hipLaunchKernelGGL(k_attention, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
+        if (sc->h_att) {
+            t.packed = (const float*)sc->h_att;
+            hipLaunchKernelGGL(k_attention_h, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
+        } else {
+            t.packed = sc->w_att;
+            hipLaunchKernelGGL(k_attention, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
+        }
         ADFP_CHECK_LAUNCH();
     }
     return 0;
@@ -924,7 +993,7 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
         a.g0 = make_grid(sc->low); a.g1 = a.g0;
         if (sc->h_low) {
             a.packed = (const float*)sc->h_low;
-            hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+            hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
         } else {
             a.packed = sc->w_low;
             hipLaunchKernelGGL((k_decode<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
@@ -934,7 +1003,7 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
         a.g0 = make_grid(sc->color); a.g1 = a.g0;
         if (sc->h_color) {
             a.packed = (const float*)sc->h_color;
-            hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
+            hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
         } else {
             a.packed = sc->w_color;
             hipLaunchKernelGGL((k_decode<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
@@ -948,7 +1017,7 @@ static int check_scene(const adfp_scene* sc, int stage) {
     if (!sc) return ADFP_E_ARG;
     if (stage < ADFP_STAGE_LOW || stage > ADFP_STAGE_COLOR) return ADFP_E_ARG;
     if (!sc->low.data || !(sc->w_low || sc->h_low)) return ADFP_E_ARG;
-    if (stage >= ADFP_STAGE_HIGH && (!sc->high.data || !(sc->w_high || sc->h_high) || !sc->w_att || !sc->tsdf.data)) return ADFP_E_ARG;
+    if (stage >= ADFP_STAGE_HIGH && (!sc->high.data || !(sc->w_high || sc->h_high) || !(sc->w_att || sc->h_att) || !sc->tsdf.data)) return ADFP_E_ARG;
     if (stage == ADFP_STAGE_COLOR && (!sc->color.data || !(sc->w_color || sc->h_color))) return ADFP_E_ARG;
     return 0;
 }
@@ -1106,7 +1175,7 @@ static int run_decode_bwd(DecodeBwdArgs a, int total, const int* count_ptr, floa
 extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_args* r, void* stream) {
     if (!r) return ADFP_E_ARG;
     int rc = check_scene(sc, r->stage); if (rc) return rc;
-    if (!sc->w_low || (r->stage >= ADFP_STAGE_HIGH && !sc->w_high) || (r->stage == ADFP_STAGE_COLOR && !sc->w_color)) return ADFP_E_ARG;   // exact-f32 images
+    if (!sc->w_low || (r->stage >= ADFP_STAGE_HIGH && (!sc->w_high || !sc->w_att)) || (r->stage == ADFP_STAGE_COLOR && !sc->w_color)) return ADFP_E_ARG;   // exact-f32 images
     if (!r->rays_o || !r->rays_d || !r->z_vals || !r->raw || !r->workspace || r->n_rays < 0 || r->S <= 0) return ADFP_E_ARG;
     if (r->S > 64 * CB_MAXC) return ADFP_E_UNSUPPORTED;
     const long long Pn = (long long)r->n_rays * r->S;

@@ -105,9 +105,10 @@ class Engine(object):
         if stage != 'low':
             if use_h:
                 sc.h_high = decoders.packed_weights('high', 'h').data_ptr()
+                sc.h_att = decoders.packed_weights('att', 'h').data_ptr()
             else:
                 sc.w_high = decoders.packed_weights('high').data_ptr()
-            sc.w_att = decoders.packed_weights('att').data_ptr()
+                sc.w_att = decoders.packed_weights('att').data_ptr()
             _lib.fill_bound(sc.tsdf_bnds, self.host_bound(tsdf_bnds, 'tsdf_bnds'))
             self.fill_tsdf(sc.tsdf, tsdf_volume, keep)
         if stage == 'color':

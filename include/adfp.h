@@ -83,6 +83,7 @@ typedef struct adfp_scene {
     const void* h_low;
     const void* h_high;
     const void* h_color;
+    const void* h_att;        /* adfp_pack_attention_h */
 } adfp_scene;
 
 typedef struct adfp_points {
@@ -114,6 +115,8 @@ int adfp_pack_decoder(int kind, const float* flat, float* packed, void* stream);
 /* same parameters -> "H" image (f16 hi/lo halves of every weight), adfp_decoder_packed_h_words(kind) 32-bit words */
 long long adfp_decoder_packed_h_words(int kind);
 int adfp_pack_decoder_h(int kind, const float* flat, void* packed, void* stream);
+long long adfp_attention_packed_h_words(void);
+int adfp_pack_attention_h(const float* flat, void* packed, void* stream);
 /* mlp_tsdf parameters (decoder.py:206-258) */
 int adfp_pack_attention(const float* flat, float* packed, void* stream);
 
