@@ -38,6 +38,8 @@ if ROOT not in sys.path:
 MAC_LOW, MAC_HIGH, MAC_COLOR, MAC_ATT = 15479, 20599, 15575, 33024
 TSDF_BYTES_PER_SAMPLE = 32
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, spec
+PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA, spec
+F16X3_FLOP_COLOR = 90 * 32 * 32 * 16 * 2 / 32.0   # executed f16 MFMA FLOP per sample: 90 x 32x32x16 per 32-point tile
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
 
 
@@ -123,7 +125,7 @@ def main():
         'metric': 'rendered rays/sec (64 samples/ray), Replica room0',
         'value': value, 'unit': 'rays/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': 'f32', 'data': 'synthetic', 'math': os.environ.get('ADFP_MATH', 'f16x3'),
         'config': {'workload': f'{args.scene} synthetic box room, 640x480 full-frame render_img, stage color, '
                                '64 samples/ray (N_samples 48 + N_surface 16), ray_batch_size 100000, '
                                'one frame per GPU per step',
@@ -206,11 +208,24 @@ def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, N
     ach = fl_color / t_color / 1e12
     by = float(TSDF_BYTES_PER_SAMPLE) * pts_per_launch
     useful = 2.0 * (MAC_LOW + MAC_COLOR + band_frac * (MAC_HIGH + MAC_ATT)) * pts_per_launch
+    from attentive_dfprior_amd.engine import math_mode
+    if math_mode() == 'f32':
+        roof = {'kernel': 'k_decode<32,4,COLOR> (colour decoder, exact f32-input MFMA)', 'bound': 'mfma',
+                'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
+                'traffic': None}
+    else:
+        ex = F16X3_FLOP_COLOR * pts_per_launch / t_color / 1e12
+        roof = {'kernel': 'k_decode_h<32,4,COLOR> (colour decoder, f16 MFMA with 3-product f32 operand split)',
+                'bound': 'mfma', 'achieved': ex, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ex / PEAK_F16_MFMA_TFLOPS, 'traffic': None,
+                'note': 'executed f16 MFMA FLOP (3 products per f32 product); the kernel is VALU-issue bound: '
+                        'VALU does not overlap MFMA on a CDNA4 SIMD (tools/micro), see DESIGN.md section 5',
+                'algorithmic_f32_tflops': ach, 'f32_mfma_peak_tflops': PEAK_F32_MFMA_TFLOPS,
+                'frac_of_f32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS}
+    roof.update({'algorithmic_flop_per_launch': fl_color, 'avg_launch_ms': t_color * 1e3, 'launches_per_frame': nl,
+                 'points_per_launch': pts_per_launch})
     return {
-        'roofline': {'kernel': 'k_decode<32,4,COLOR> (colour decoder)', 'bound': 'mfma',
-                     'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
-                     'traffic': None, 'flop_per_launch': fl_color, 'avg_launch_ms': t_color * 1e3,
-                     'launches_per_frame': nl, 'points_per_launch': pts_per_launch},
+        'roofline': roof,
         'roofline_tsdf': {'kernel': 'k_tsdf (TSDF trilerp + band mask + compaction)', 'bound': 'hbm',
                           'achieved': by / t_tsdf / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
                           'frac': by / t_tsdf / 1e9 / PEAK_HBM_GBPS, 'traffic': None, 'bytes_per_launch': by,

@@ -1,0 +1,62 @@
+"""Config 5 smoke (BASELINE.json configs[4], one GPU's share): 16 m cube, 1024^3 TSDF (4.3 GB),
+128 samples/ray (96 + 32), rays from several poses.  Prints rays/s and checks a ray subset against the
+oracle.  Not part of the driver contract."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import attentive_dfprior_amd as A                      # noqa: E402
+from attentive_dfprior_amd import synthetic            # noqa: E402
+from attentive_dfprior_amd.common import get_rays      # noqa: E402
+
+
+def main(n_rays=131072, check=300):
+    dev = torch.device('cuda:0')
+    sc = synthetic.Scene('cube16', device=dev, grid_std_scale=20.0, voxel=16.0 / 1024, inset=2.0)
+    sc.c['grid_high'] = sc.c['grid_high'] * 100
+    assert sc.tsdf_volume.numel() >= 1000 ** 3
+    sd = synthetic.seeded_state_dict(0)
+    dec = A.DF(); dec.load_state_dict(sd); dec.bound = sc.bound; dec = dec.to(dev)
+    cfg = {'rendering': {'lindisp': False, 'perturb': 0.0, 'N_samples': 96, 'N_surface': 32, 'N_importance': 0},
+           'scale': 1, 'occupancy': True, 'meshing': {'resolution': 256}}
+    rend = A.Renderer(cfg, None, sc)
+    tsdf_bnds = sc.tsdf_bnds.to(dev)
+    ros, rds, gds = [], [], []
+    for k in range(8):
+        c2w = sc.default_c2w(offset=(0.5 * k - 2, 0.3 * k - 1, 0.2 * k), yaw=0.7 * k, pitch=-0.2 + 0.05 * k)
+        gd = sc.depth_image(c2w)
+        ro, rd = get_rays(sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2w, dev)
+        pick = torch.randperm(sc.H * sc.W, device=dev)[:n_rays // 8]
+        ros.append(ro.reshape(-1, 3)[pick]); rds.append(rd.reshape(-1, 3)[pick]); gds.append(gd.reshape(-1)[pick])
+    ro, rd, gd = torch.cat(ros), torch.cat(rds), torch.cat(gds)
+    with torch.no_grad():
+        out = rend.render_batch_ray(sc.c, dec, rd, ro, dev, sc.tsdf_volume, tsdf_bnds, 'color', gt_depth=gd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            out = rend.render_batch_ray(sc.c, dec, rd, ro, dev, sc.tsdf_volume, tsdf_bnds, 'color', gt_depth=gd)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+    d, u, c, w = out
+    assert torch.isfinite(d).all() and torch.isfinite(c).all()
+    res = {'config': '1024^3 TSDF, 128 samples/ray', 'rays': ro.shape[0], 'ms': dt * 1e3, 'rays_per_s': ro.shape[0] / dt,
+           'tsdf_GB': sc.tsdf_volume.numel() * 4 / 1e9, 'in_band_fraction': float((w != 1).float().mean())}
+    if check:
+        from oracle import adfp_oracle as O
+        idx = torch.arange(0, ro.shape[0], ro.shape[0] // check, device=dev)[:check]
+        idx[0] = int(torch.argmax(gd))
+        cpu = {k: v.cpu() for k, v in sc.c.items()}
+        od, ou, oc, ow = O.render_batch_ray(sd, cpu, rd[idx].cpu(), ro[idx].cpu(), sc.tsdf_volume.cpu(), sc.tsdf_bnds, sc.bound,
+                                            'color', gd[idx].cpu(), 96, 32)
+        res['max_rel_depth'] = float((d[idx].cpu() - od).abs().max() / od.abs().max())
+        res['max_rel_color'] = float((c[idx].cpu() - oc).abs().max() / oc.abs().max())
+        res['band_flips'] = int(((w[idx].cpu() == 1) != (ow == 1)).sum())
+    print(json.dumps(res))
+
+
+if __name__ == '__main__':
+    main()
