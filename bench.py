@@ -59,9 +59,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    if world > 1 or os.environ.get('ADFP_BENCH_FORCE_DIST') == '1':     # the env knob exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
     else:
