@@ -61,7 +61,8 @@ class AdfpBackwardArgs(C.Structure):
                 ('g_depth', C.c_void_p), ('g_uncertainty', C.c_void_p), ('g_color', C.c_void_p), ('g_weight', C.c_void_p),
                 ('g_grid_low', C.c_void_p), ('g_grid_high', C.c_void_p), ('g_grid_color', C.c_void_p),
                 ('g_flat_low', C.c_void_p), ('g_flat_high', C.c_void_p), ('g_flat_color', C.c_void_p),
-                ('g_flat_att', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+                ('g_flat_att', C.c_void_p), ('g_rays_o', C.c_void_p), ('g_rays_d', C.c_void_p),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 
 Bound = (C.c_double * 2) * 3

@@ -3,8 +3,8 @@
 Forward = adfp_render_forward with a caller-owned training state; backward = adfp_render_backward
 (include/adfp.h).  Gradients are produced for the three feature grids (dense, in the shape of
 ``c[key]``, which may be an autograd non-leaf built by index_put, src/Mapper.py:382-388) and for every
-decoder parameter that requires grad.  Gradients w.r.t. the rays (camera pose, src/Tracker.py) are
-not implemented.
+decoder parameter that requires grad, and for the rays (``rays_o`` / ``rays_d``: the camera pose of
+src/Tracker.py:112-133 reaches the renderer only through them).
 """
 import torch
 
@@ -14,8 +14,8 @@ _NETS = (('low', 'low_decoder'), ('high', 'high_decoder'), ('color', 'color_deco
 
 class _RenderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, bundle, grid_low, grid_high, grid_color, *params):
-        (engine, decoders, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, n_samples, n_surface,
+    def forward(ctx, bundle, rays_o, rays_d, grid_low, grid_high, grid_color, *params):
+        (engine, decoders, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, n_samples, n_surface,
          lindisp, perturb, t_rand, depth_max) = bundle
         c = {'grid_low': grid_low, 'grid_high': grid_high, 'grid_color': grid_color}
         depth, unc, color, weight, saved = engine.render_forward(
@@ -30,24 +30,25 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_depth, g_unc, g_color, g_weight):
-        (engine, decoders, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, *_rest) = ctx.bundle
+        (engine, decoders, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, *_rest) = ctx.bundle
         used = {'low': ('low',), 'high': ('low', 'high', 'att'), 'color': ('low', 'high', 'color', 'att')}[stage]
-        need_grid = {name: bool(ctx.needs_input_grad[1 + k]) and name in used for k, (name, _) in enumerate(_GRIDS)}
-        need_flat, off = {}, 4
+        need_rays = bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        need_grid = {name: bool(ctx.needs_input_grad[3 + k]) and name in used for k, (name, _) in enumerate(_GRIDS)}
+        need_flat, off = {}, 6
         for (name, attr), n in zip(_NETS, ctx.n_params):
             need_flat[name] = name in used and any(ctx.needs_input_grad[off:off + n])
             off += n
         if g_weight is not None:
             g_weight = g_weight.reshape(g_weight.shape[0], -1)
-        grids, flats = engine.render_backward(decoders, ctx.c, tsdf_volume, tsdf_bnds, bound, stage, ctx.saved,
-                                              g_depth, g_unc, g_color, g_weight, need_grid, need_flat)
-        out = [None]
+        grids, flats, g_rays = engine.render_backward(decoders, ctx.c, tsdf_volume, tsdf_bnds, bound, stage, ctx.saved,
+                                                      g_depth, g_unc, g_color, g_weight, need_grid, need_flat, need_rays)
+        out = [None, g_rays[0] if ctx.needs_input_grad[1] else None, g_rays[1] if ctx.needs_input_grad[2] else None]
         for k, (name, key) in enumerate(_GRIDS):
             g = grids.get(name)
             if g is not None and ctx.c[key].dtype != g.dtype:
                 g = g.to(ctx.c[key].dtype)
             out.append(g)
-        off = 4
+        off = 6
         for (name, attr), n in zip(_NETS, ctx.n_params):
             flat = flats.get(name)
             pos = 0
@@ -64,13 +65,11 @@ class _RenderFn(torch.autograd.Function):
 
 def render_with_grad(engine, decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, n_samples,
                      n_surface, lindisp, perturb, t_rand, depth_max):
-    if rays_o.requires_grad or rays_d.requires_grad:
-        raise NotImplementedError('gradients w.r.t. rays (camera tracking, src/Tracker.py:112-133) are not built yet')
     if n_samples + (n_surface if gt_depth is not None else 0) > 256:
         raise NotImplementedError('training path supports at most 256 samples per ray')
-    bundle = (engine, decoders, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, n_samples, n_surface,
+    bundle = (engine, decoders, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, n_samples, n_surface,
               lindisp, perturb, t_rand, depth_max)
     params = []
     for _, attr in _NETS:
         params += list(getattr(decoders, attr).parameters())
-    return _RenderFn.apply(bundle, c['grid_low'], c['grid_high'], c['grid_color'], *params)
+    return _RenderFn.apply(bundle, rays_o, rays_d, c['grid_low'], c['grid_high'], c['grid_color'], *params)

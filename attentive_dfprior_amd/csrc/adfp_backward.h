@@ -132,6 +132,39 @@ ADFP_DEV void stage_head(float* __restrict__ row, int col, int h, f32x4 head) {
 }
 
 // ------------------------------------------------------------------------------------------
+// derivatives w.r.t. the sample position (camera tracking, src/Tracker.py:112-133): the trilinear
+// lookup is differentiable in its coordinates (grid_sample backward, 'border' padding zeroes the
+// gradient of clipped coordinates) and so is sin(p @ B).
+// ------------------------------------------------------------------------------------------
+// tri_axis + d(unnormalised, clipped coordinate)/d(world coordinate); dn = d p_n / d p = 2 / (hi - lo)
+ADFP_DEV void tri_axis_d(float pn, int size, float dn, int& i0, int& i1, float& w0, float& w1, float& dc) {
+    const float c = ((pn + 1.f) / 2.f) * (float)(size - 1);
+    tri_axis(pn, size, i0, i1, w0, w1);
+    dc = (c <= 0.f || c >= (float)(size - 1)) ? 0.f : 0.5f * (float)(size - 1) * dn;   // clip_coordinates_set_grad
+}
+
+// TSDF value and its gradient w.r.t. the world position
+ADFP_DEV float trilerp_scalar_grad(const TsdfDev& t, const float pn[3], const float dn[3], float g[3]) {
+    int xi[2], yi[2], zi[2]; float wx[2], wy[2], wz[2], dx, dy, dz;
+    tri_axis_d(pn[0], t.X, dn[0], xi[0], xi[1], wx[0], wx[1], dx);
+    tri_axis_d(pn[1], t.Y, dn[1], yi[0], yi[1], wy[0], wy[1], dy);
+    tri_axis_d(pn[2], t.Z, dn[2], zi[0], zi[1], wz[0], wz[1], dz);
+    float o = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int a = k & 1, b = (k >> 1) & 1, c = k >> 2;
+        const float v = t.data[zi[c] * t.sZ + yi[b] * t.sY + xi[a] * t.sX];
+        o = fmaf(v, (wx[a] * wy[b]) * wz[c], o);
+        gx = fmaf(v, (a ? 1.f : -1.f) * wy[b] * wz[c], gx);
+        gy = fmaf(v, (b ? 1.f : -1.f) * wx[a] * wz[c], gy);
+        gz = fmaf(v, (c ? 1.f : -1.f) * wx[a] * wy[b], gz);
+    }
+    // a corner clamped onto its neighbour (i1 == i0 at the far face) has weight 0 and a clipped coordinate
+    g[0] = gx * dx; g[1] = gy * dy; g[2] = gz * dz;
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------
 // decoder backward
 // ------------------------------------------------------------------------------------------
 struct DecodeBwdArgs {
@@ -143,14 +176,16 @@ struct DecodeBwdArgs {
     const float* att_g;        // HIGH: cotangent per list entry
     float* g_grid;             // channels-last gradient of the OWN grid (or NULL)
     float* stage;              // staging rows of this chunk (WGRAD) or NULL
+    float* g_pts;              // [P,3] d/d sample position, accumulated (PGRAD) or NULL
     int chunk_lo, chunk_hi;    // point / list-entry range handled by this launch
 };
 
 // lane row j of a transposed chain -> offset of in-unit j inside its in-block of the image
 ADFP_DEV int lane_off_T(int j) { return ((j >> 3) * 2 + ((j >> 2) & 1)) * ADFP_RG + (j & 3); }
 
-template <int CDIM, int NOUT, int ROLE, bool WGRAD, int NT>
+template <int CDIM, int NOUT, int ROLE, bool WGRAD, bool PGRAD, int NT>
 __global__ __launch_bounds__(NT) void k_decode_bwd(DecodeBwdArgs a) {
+    constexpr bool NEED_E = WGRAD || PGRAD;
     using L = DecLayout<CDIM, NOUT>;
     using ST = DecStage<CDIM>;
     constexpr int NW = NT / 64;
@@ -187,12 +222,12 @@ __global__ __launch_bounds__(NT) void k_decode_bwd(DecodeBwdArgs a) {
         float c[L::KSC];
         gather16(a.g0, pn, h, c);
         if (CDIM == 64) gather16(a.g1, pn, h, c + 16);
-        float e[L::KSE], ce[WGRAD ? L::KSE : 1];
+        float e[L::KSE], ce[NEED_E ? L::KSE : 1];
 #pragma unroll
         for (int s = 0; s < L::KSE; ++s) {
             const f32x4 bm = *(const f32x4*)(lds + L::P_BM + (unit_of(s, 0) + 4 * h) * 4);
             const float arg = fmaf(pf[2], bm.z, fmaf(pf[1], bm.y, pf[0] * bm.x));
-            if constexpr (WGRAD) adfp_sincosf(arg, e[s], ce[s]); else e[s] = adfp_sinf(arg);
+            if constexpr (NEED_E) adfp_sincosf(arg, e[s], ce[s]); else e[s] = adfp_sinf(arg);
         }
         if (WGRAD && valid) {
             stage_head(srow, ST::SX, h, f32x4{pf[0], pf[1], pf[2], 1.f});
@@ -250,7 +285,7 @@ __global__ __launch_bounds__(NT) void k_decode_bwd(DecodeBwdArgs a) {
             for (int r = 0; r < 16; ++r) gp[r] = (mask[i] >> r) & 1u ? gh[r] : 0.f;
             if (WGRAD && valid) stage_block(srow, ST::SGP(i), h, gp);
             if (i == 0) {
-                if (WGRAD) {
+                if (NEED_E) {
                     mfma_chain_T(ge0, lds + L::P_WP(0), loT, h, gp);
                     mfma_chain_T(ge1, lds + L::P_WP(0) + 4 * ADFP_SG, loT, h, gp);
                     mfma_chain_T(ge2, lds + L::P_WP(0) + 8 * ADFP_SG, loT, h, gp);
@@ -260,7 +295,7 @@ __global__ __launch_bounds__(NT) void k_decode_bwd(DecodeBwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gn[r] = 0.f;
                 if (i == 3) {
-                    if (WGRAD) {
+                    if (NEED_E) {
                         mfma_chain_T(ge0, lds + L::P_WP(3), loT, h, gp);
                         mfma_chain_T(ge1, lds + L::P_WP(3) + 4 * ADFP_SG, loT, h, gp);
                         mfma_chain_T(ge2, lds + L::P_WP(3) + 8 * ADFP_SG, loT, h, gp);
@@ -283,6 +318,45 @@ __global__ __launch_bounds__(NT) void k_decode_bwd(DecodeBwdArgs a) {
             stage_block(srow, ST::SGA + 64, h, t);
         }
 
+        if constexpr (PGRAD) {
+            // through the Fourier features: d/dp_k = sum_j B[k][j] cos(p @ B)_j d/d e_j
+            float gp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < L::KSE; ++s) {
+                const f32x4 bm = *(const f32x4*)(lds + L::P_BM + (unit_of(s, 0) + 4 * h) * 4);
+                const float ga = (s < 16 ? ge0[s] : (s < 32 ? ge1[s - 16] : ge2[s - 32])) * ce[s];
+                gp[0] = fmaf(ga, bm.x, gp[0]); gp[1] = fmaf(ga, bm.y, gp[1]); gp[2] = fmaf(ga, bm.z, gp[2]);
+            }
+            // through the trilinear feature lookup of the OWN grid (the high decoder's low-grid features
+            // are under no_grad in the reference, decoder.py:182-187)
+            int xi[2], yi[2], zi[2]; float wx[2], wy[2], wz[2], dcx, dcy, dcz;
+            tri_axis_d(pn[0], a.g0.X, (float)(2.0 * a.nb.inv[0]), xi[0], xi[1], wx[0], wx[1], dcx);
+            tri_axis_d(pn[1], a.g0.Y, (float)(2.0 * a.nb.inv[1]), yi[0], yi[1], wy[0], wy[1], dcy);
+            tri_axis_d(pn[2], a.g0.Z, (float)(2.0 * a.nb.inv[2]), zi[0], zi[1], wz[0], wz[1], dcz);
+            float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int ka = k & 1, kb = (k >> 1) & 1, kc = k >> 2;
+                const long long vox = ((long long)zi[kc] * a.g0.Y + yi[kb]) * a.g0.X + xi[ka];
+                const f32x4* src = (const f32x4*)(a.g0.data + vox * 32 + 4 * h);
+                float sdot = 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const f32x4 t = src[2 * v];
+                    sdot = fmaf(t.x, gc[4 * v + 0], sdot); sdot = fmaf(t.y, gc[4 * v + 1], sdot);
+                    sdot = fmaf(t.z, gc[4 * v + 2], sdot); sdot = fmaf(t.w, gc[4 * v + 3], sdot);
+                }
+                gx = fmaf(sdot, (ka ? 1.f : -1.f) * wy[kb] * wz[kc], gx);
+                gy = fmaf(sdot, (kb ? 1.f : -1.f) * wx[ka] * wz[kc], gy);
+                gz = fmaf(sdot, (kc ? 1.f : -1.f) * wx[ka] * wy[kb], gz);
+            }
+            gp[0] = fmaf(gx, dcx, gp[0]); gp[1] = fmaf(gy, dcy, gp[1]); gp[2] = fmaf(gz, dcz, gp[2]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gp[k] += __shfl_xor(gp[k], 32);
+            if (valid && h == 0) {
+                a.g_pts[3ll * q + 0] += gp[0]; a.g_pts[3ll * q + 1] += gp[1]; a.g_pts[3ll * q + 2] += gp[2];
+            }
+        }
         // ---------------- scatter d/d c into the channels-last grid gradient ----------------
         if (a.g_grid) {
             // corner voxels / weights of every point of the tile -> LDS (written by the h == 0 lanes)
@@ -334,9 +408,11 @@ struct AttBwdArgs {
     float* att_g;              // per list entry: d/d(high+low) for the HIGH backward
     float* stage;
     int chunk_lo, chunk_hi;
+    // PGRAD: the fused occupancy depends on the sample position through u = inv_tsdf(tsdf(p)) (decoder.py:241-248)
+    PtsDev P; NormDev nt; TsdfDev t; float* g_pts;
 };
 
-template <bool WGRAD>
+template <bool WGRAD, bool PGRAD>
 __global__ __launch_bounds__(256) void k_attention_bwd(AttBwdArgs a) {
     using A = AttLayout;
     using ST = AttStage;
@@ -458,7 +534,7 @@ __global__ __launch_bounds__(256) void k_attention_bwd(AttBwdArgs a) {
             for (int r = 0; r < 16; ++r) gp1[16 * ib + r] = (m1[ib] >> r) & 1u ? acc[r] : 0.f;
             if (WGRAD && valid) stage_block(srow, ST::AG1 + 32 * ib, h, gp1, 16 * ib);
         }
-        float gx = 0.f;
+        float gx = 0.f, gxu = 0.f;
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
             f32x16 acc;
@@ -472,12 +548,34 @@ __global__ __launch_bounds__(256) void k_attention_bwd(AttBwdArgs a) {
             for (int r = 0; r < 16; ++r) {
                 g0[r] = (m0 >> (16 * ib + r)) & 1u ? acc[r] : 0.f;
                 gx = fmaf(lds[A::P_A0 + (32 * ib + kmapH(r, h)) * 4], g0[r], gx);     // d/d occ_in through layer 0
+                if (PGRAD) gxu = fmaf(lds[A::P_A0 + (32 * ib + kmapH(r, h)) * 4 + 1], g0[r], gxu);   // d/d u
             }
             if (WGRAD && valid) stage_block(srow, ST::AG0 + 32 * ib, h, g0);
         }
         gx += __shfl_xor(gx, 32);
         const float g_in = a0 * g_out + gx;
         if (valid && h == 0) { a.att_g[idx] = g_in; a.g_raw[4ll * q + 3] = g_in; }
+        if constexpr (PGRAD) {
+            gxu += __shfl_xor(gxu, 32);
+            const float g_u = a1 * g_out + gxu;
+            if (valid && h == 0) {
+                double pt[3]; float pn[3], dn[3], gt[3];
+                load_point(a.P, q, pt);
+                normalize3(a.nt, pt, pn);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dn[k] = (float)(2.0 * a.nt.inv[k]);
+                const float tv = trilerp_scalar_grad(a.t, pn, dn, gt);
+                // u = clamp(-0.1 log(1/(s + 1e-8) - 1 + 1e-7), +-100), s = clamp(1 - (t + 1)/2, 0, 1)
+                const float sr = 1.f - (tv + 1.f) / 2.f;
+                const float sc = fminf(fmaxf(sr, 0.f), 1.f);
+                const float se = sc + 1e-8f;
+                const float vv = (1.f / se) - 1.f + 1e-7f;
+                const float ur = -0.1f * logf(vv);
+                float du_dt = (sr > 0.f && sr < 1.f && ur > -100.f && ur < 100.f) ? -0.05f / (vv * se * se) : 0.f;
+                const float g_t = g_u * du_dt;
+                a.g_pts[3ll * q + 0] += g_t * gt[0]; a.g_pts[3ll * q + 1] += g_t * gt[1]; a.g_pts[3ll * q + 2] += g_t * gt[2];
+            }
+        }
     }
 }
 
@@ -525,5 +623,28 @@ __global__ __launch_bounds__(64) void k_outer(OuterArgs a) {
             const int row = kmapH(r, h);
             if (row < jb.nr && acc[r] != 0.f) atomicAdd(a.flat + jb.dst + row * jb.rs + j * jb.cs, acc[r]);
         }
+    }
+}
+
+// d/d rays_o = sum_s d/dp_s,  d/d rays_d = sum_s z_s d/dp_s   (p = o + d z, Renderer.py:223)
+__global__ __launch_bounds__(256) void k_rays_grad(const float* __restrict__ g_pts, const double* __restrict__ z, int n_rays, int S,
+                                                   float* __restrict__ g_o, float* __restrict__ g_d) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    double so[3] = {0, 0, 0}, sd[3] = {0, 0, 0};
+    for (int s = lane; s < S; s += 64) {
+        const long long q = (long long)ray * S + s;
+        const double zz = z[q];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double g = (double)g_pts[3 * q + k]; so[k] += g; sd[k] += g * zz; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { so[k] += __shfl_xor(so[k], o); sd[k] += __shfl_xor(sd[k], o); }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { if (g_o) g_o[3 * ray + k] = (float)so[k]; if (g_d) g_d[3 * ray + k] = (float)sd[k]; }
     }
 }

@@ -1099,11 +1099,12 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
 // ---------------------------------------------------------------------------------------
 #define STG_ROWS_MAX 65536
 
-struct BwdWorkspace { float* g_raw; float* att_g; float* stage; int stage_rows; size_t bytes; };
+struct BwdWorkspace { float* g_raw; float* att_g; float* g_pts; float* stage; int stage_rows; size_t bytes; };
 static BwdWorkspace carve_bwd(void* base, long long P) {
     BwdWorkspace w; size_t o = 0; char* b = (char*)base;
     w.g_raw = (float*)(b + o); o += align256((size_t)P * 16);
     w.att_g = (float*)(b + o); o += align256((size_t)P * 4);
+    w.g_pts = (float*)(b + o); o += align256((size_t)P * 12);
     w.stage_rows = (int)(P < STG_ROWS_MAX ? P : STG_ROWS_MAX);
     if (w.stage_rows < 32) w.stage_rows = 32;
     w.stage = (float*)(b + o); o += align256((size_t)w.stage_rows * AttStage::NCOLS * 4);
@@ -1169,13 +1170,13 @@ static int launch_outer(OuterArgs& oa, const float* stage, const int* count_ptr,
     return 0;
 }
 
-template <int CDIM, int NOUT, int ROLE>
-static int run_decode_bwd(DecodeBwdArgs a, int total, const int* count_ptr, float* flat, BwdWorkspace& bw, hipStream_t st) {
+template <int CDIM, int NOUT, int ROLE, bool PGRAD>
+static int run_decode_bwd_p(DecodeBwdArgs a, int total, const int* count_ptr, float* flat, BwdWorkspace& bw, hipStream_t st) {
     if (total == 0) return 0;
     if (!flat) {
         a.stage = nullptr; a.chunk_lo = 0; a.chunk_hi = total;
         const int ntiles = (total + 31) / 32;
-        hipLaunchKernelGGL((k_decode_bwd<CDIM, NOUT, ROLE, false, 256>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_decode_bwd<CDIM, NOUT, ROLE, false, PGRAD, 256>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, a);
         ADFP_CHECK_LAUNCH();
         return 0;
     }
@@ -1186,12 +1187,17 @@ static int run_decode_bwd(DecodeBwdArgs a, int total, const int* count_ptr, floa
         const int hi = lo + rows_cap < total ? lo + rows_cap : total;
         a.chunk_lo = lo; a.chunk_hi = hi;
         const int ntiles = (hi - lo + 31) / 32;
-        hipLaunchKernelGGL((k_decode_bwd<CDIM, NOUT, ROLE, true, 256>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_decode_bwd<CDIM, NOUT, ROLE, true, PGRAD, 256>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, a);
         ADFP_CHECK_LAUNCH();
         int rc = launch_outer(oa, bw.stage, count_ptr, lo, hi, flat, st);
         if (rc) return rc;
     }
     return 0;
+}
+template <int CDIM, int NOUT, int ROLE>
+static int run_decode_bwd(DecodeBwdArgs a, int total, const int* count_ptr, float* flat, BwdWorkspace& bw, hipStream_t st) {
+    return a.g_pts ? run_decode_bwd_p<CDIM, NOUT, ROLE, true>(a, total, count_ptr, flat, bw, st)
+                   : run_decode_bwd_p<CDIM, NOUT, ROLE, false>(a, total, count_ptr, flat, bw, st);
 }
 
 extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_args* r, void* stream) {
@@ -1229,27 +1235,33 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
     DecodeBwdArgs a;
     a.P = Pd; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
     a.list = nullptr; a.count_ptr = nullptr; a.g_raw = bw.g_raw; a.att_g = nullptr; a.stage = nullptr;
+    const bool pgrad = r->g_rays_o || r->g_rays_d;
+    a.g_pts = pgrad ? bw.g_pts : nullptr;
+    if (pgrad) { e = hipMemsetAsync(bw.g_pts, 0, (size_t)P * 12, st); if (e != hipSuccess) return (int)e; }
 
     if (fuse) {
         AttBwdArgs t;
         t.packed = sc->w_att; t.list = r->state.list; t.count_ptr = r->state.counter; t.att_occ = r->state.att_occ;
         t.att_u = r->state.att_u; t.g_weight = r->g_weight; t.g_raw = bw.g_raw; t.att_g = bw.att_g; t.stage = bw.stage;
+        t.P = Pd; t.nt = make_norm(sc->tsdf_bnds); t.t = make_tsdf(sc->tsdf); t.g_pts = a.g_pts;
         OuterArgs oa; attention_jobs(oa);
         for (int lo = 0; lo < P; lo += bw.stage_rows) {
             const int hi = lo + bw.stage_rows < P ? lo + bw.stage_rows : P;
             t.chunk_lo = lo; t.chunk_hi = hi;
             const int ntiles = (hi - lo + 31) / 32;
             if (r->g_flat_att) {
-                hipLaunchKernelGGL((k_attention_bwd<true>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
+                if (pgrad) hipLaunchKernelGGL((k_attention_bwd<true, true>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
+                else hipLaunchKernelGGL((k_attention_bwd<true, false>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
                 ADFP_CHECK_LAUNCH();
                 rc = launch_outer(oa, bw.stage, r->state.counter, lo, hi, r->g_flat_att, st);
                 if (rc) return rc;
             } else {
-                hipLaunchKernelGGL((k_attention_bwd<false>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
+                if (pgrad) hipLaunchKernelGGL((k_attention_bwd<false, true>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
+                else hipLaunchKernelGGL((k_attention_bwd<false, false>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
                 ADFP_CHECK_LAUNCH();
             }
         }
-        if (r->g_grid_high || r->g_flat_high) {
+        if (r->g_grid_high || r->g_flat_high || pgrad) {
             DecodeBwdArgs hgh = a;
             hgh.g0 = make_grid(sc->high); hgh.g1 = make_grid(sc->low); hgh.packed = sc->w_high;
             hgh.list = r->state.list; hgh.count_ptr = r->state.counter; hgh.att_g = bw.att_g; hgh.g_grid = r->g_grid_high;
@@ -1257,17 +1269,22 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
             if (rc) return rc;
         }
     }
-    if (r->g_grid_low || r->g_flat_low) {
+    if (r->g_grid_low || r->g_flat_low || pgrad) {
         DecodeBwdArgs lw = a;
         lw.g0 = make_grid(sc->low); lw.g1 = lw.g0; lw.packed = sc->w_low; lw.g_grid = r->g_grid_low;
         rc = run_decode_bwd<32, 1, ROLE_LOW>(lw, P, nullptr, r->g_flat_low, bw, st);
         if (rc) return rc;
     }
-    if (r->stage == ADFP_STAGE_COLOR && (r->g_grid_color || r->g_flat_color)) {
+    if (r->stage == ADFP_STAGE_COLOR && (r->g_grid_color || r->g_flat_color || pgrad)) {
         DecodeBwdArgs cl = a;
         cl.g0 = make_grid(sc->color); cl.g1 = cl.g0; cl.packed = sc->w_color; cl.g_grid = r->g_grid_color;
         rc = run_decode_bwd<32, 4, ROLE_COLOR>(cl, P, nullptr, r->g_flat_color, bw, st);
         if (rc) return rc;
+    }
+    if (pgrad) {
+        hipLaunchKernelGGL(k_rays_grad, dim3((r->n_rays + 3) / 4), dim3(256), 0, st, bw.g_pts, r->z_vals, r->n_rays, r->S,
+                           r->g_rays_o, r->g_rays_d);
+        ADFP_CHECK_LAUNCH();
     }
     return 0;
 }

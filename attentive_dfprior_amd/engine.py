@@ -259,7 +259,7 @@ class Engine(object):
 
     # ---- a15 -------------------------------------------------------------------------------
     def render_backward(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, saved, g_depth, g_unc, g_color,
-                        g_weight, need_grid, need_flat):
+                        g_weight, need_grid, need_flat, need_rays=False):
         """saved: the aux dict of render_forward(train=True).  need_grid / need_flat: dicts of bools.
         Returns (grid grads dict in the reference's [1,32,Z,Y,X] layout, flat parameter grads dict)."""
         ro = saved['rays_o']
@@ -295,6 +295,11 @@ class Engine(object):
                 if need_flat.get(name):
                     flats[name] = torch.empty((sizes[name],), dtype=torch.float32, device=dev)
                     setattr(a, 'g_flat_' + name, flats[name].data_ptr())
+            g_ro = g_rd = None
+            if need_rays:
+                g_ro = torch.empty((N, 3), dtype=torch.float32, device=dev)
+                g_rd = torch.empty((N, 3), dtype=torch.float32, device=dev)
+                a.g_rays_o, a.g_rays_d = g_ro.data_ptr(), g_rd.data_ptr()
             need = L.adfp_backward_workspace_bytes(N * S)
             ws = torch.empty(int(need) + 1024, dtype=torch.uint8, device=dev)
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
@@ -306,4 +311,4 @@ class Engine(object):
                 out = torch.empty((1, 32, Z, Y, X), dtype=torch.float32, device=dev)
                 check(L.adfp_relayout_grid_back(ptr(g), ptr(out), 32, Z, Y, X, stream), 'adfp_relayout_grid_back')
                 grids[name] = out
-        return grids, flats
+        return grids, flats, (g_ro, g_rd)

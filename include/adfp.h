@@ -196,7 +196,8 @@ int adfp_render_forward(const adfp_scene* scene /*host*/, const adfp_render_args
  * state_dict order).  Any output pointer may be NULL (= not needed: frozen decoder, lr 0 grid).
  * z_vals, raw and `state` are the ones the forward call wrote.  Every non-NULL output is zeroed
  * and then accumulated with float atomics (results are not bitwise reproducible run to run).
- * Gradients w.r.t. the rays (Tracker, src/Tracker.py:112-133) are not produced. */
+ * g_rays_o / g_rays_d: gradients w.r.t. the rays (p = o + d z; through the trilinear coordinates of the
+ * feature grids and the TSDF and through sin(p @ B)) for the Tracker, src/Tracker.py:112-133. */
 typedef struct adfp_backward_args {
     int stage;
     int n_rays;
@@ -217,6 +218,8 @@ typedef struct adfp_backward_args {
     float* g_flat_high;
     float* g_flat_color;
     float* g_flat_att;           /* adfp_attention_flat_floats() floats, or NULL */
+    float* g_rays_o;             /* [N,3] or NULL: camera tracking (src/Tracker.py:112-133) */
+    float* g_rays_d;             /* [N,3] or NULL */
     void* workspace;
     size_t workspace_bytes;
 } adfp_backward_args;

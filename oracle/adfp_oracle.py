@@ -332,6 +332,19 @@ def mapper_loss(depth, color, weight, gt_depth, gt_color, stage, warmup=False, w
     return loss
 
 
+def tracker_loss(depth, uncertainty, color, gt_depth, gt_color, handle_dynamic=True, w_color_loss=0.5):
+    """Camera-tracking loss, src/Tracker.py:116-129 (use_color_in_tracking: True)."""
+    uncertainty = uncertainty.detach()
+    if handle_dynamic:
+        tmp = torch.abs(gt_depth - depth) / torch.sqrt(uncertainty + 1e-10)
+        mask = (tmp < 10 * tmp.median()) & (gt_depth > 0)
+    else:
+        mask = gt_depth > 0
+    loss = (torch.abs(gt_depth - depth) / torch.sqrt(uncertainty + 1e-10))[mask].sum()
+    loss = loss + w_color_loss * torch.abs(gt_color - color)[mask].sum()
+    return loss
+
+
 # ----------------------------------------------------------------------------------
 # helpers shared by tests / bench (synthetic scene of SURVEY.md section 8d)
 # ----------------------------------------------------------------------------------

@@ -16,6 +16,7 @@ Files
                      render without sensor depth (nd_*), eval_points on explicit points,
                      Mapper-loss gradients w.r.t. the grids and every decoder parameter
                      (plain loss and the warm-up variant with the |w-1| term)
+  mini_tracker.npz   Tracker loss (src/Tracker.py:116-129) and its gradients w.r.t. rays_o / rays_d
   mini_rays.npz      get_rays / get_rays_from_uv vectors, TSDF point samples, render_img tile
 """
 import os
@@ -110,6 +111,22 @@ def main():
                 p.requires_grad_(False)
         np.savez_compressed(os.path.join(OUT, f'mini_{stage}.npz'), **out)
         print(stage, 'depth', out['depth'][:4], 'loss', out['g.loss'])
+
+    # Tracker: gradients w.r.t. the rays from the REFERENCE (src/Tracker.py:112-133)
+    tr = {}
+    ro_g = rays_o.clone().requires_grad_(True)
+    rd_g = rays_d.clone().requires_grad_(True)
+    d, u, col, w = rend.render_batch_ray(scene.c, df, rd_g, ro_g, 'cpu', scene.tsdf_volume, scene.tsdf_bnds, 'color',
+                                         gt_depth=depth)
+    u = u.detach()
+    tmp = torch.abs(depth - d) / torch.sqrt(u + 1e-10)
+    m = (tmp < 10 * tmp.median()) & (depth > 0)
+    loss = (torch.abs(depth - d) / torch.sqrt(u + 1e-10))[m].sum() + 0.5 * torch.abs(color - col)[m].sum()
+    loss.backward()
+    tr['loss'] = np.array(loss.item())
+    tr['g_rays_o'], tr['g_rays_d'] = ro_g.grad.numpy(), rd_g.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'mini_tracker.npz'), **tr)
+    print('tracker loss', tr['loss'], 'max |g_o|', np.abs(tr['g_rays_o']).max(), 'max |g_d|', np.abs(tr['g_rays_d']).max())
 
     # rays + tsdf samples + full image tile
     rr = {}

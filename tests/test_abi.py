@@ -73,7 +73,7 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu\\n", offsetof(adfp_render_args, perturb), offsetof(adfp_render_args, rays_o),
          offsetof(adfp_render_args, workspace), offsetof(adfp_render_args, workspace_bytes), offsetof(adfp_render_args, state));
   printf("%zu %zu %zu %zu %zu\\n", offsetof(adfp_backward_args, rays_o), offsetof(adfp_backward_args, state),
-         offsetof(adfp_backward_args, g_depth), offsetof(adfp_backward_args, g_flat_att), offsetof(adfp_backward_args, workspace_bytes));
+         offsetof(adfp_backward_args, g_depth), offsetof(adfp_backward_args, g_rays_d), offsetof(adfp_backward_args, workspace_bytes));
   return 0;
 }''')
     exe = tmp_path / 'layout'
@@ -91,5 +91,5 @@ int main(void) {
     assert list(map(int, out[3].split())) == [R.perturb.offset, R.rays_o.offset, R.workspace.offset,
                                               R.workspace_bytes.offset, R.state.offset]
     B = _lib.AdfpBackwardArgs
-    assert list(map(int, out[4].split())) == [B.rays_o.offset, B.state.offset, B.g_depth.offset, B.g_flat_att.offset,
+    assert list(map(int, out[4].split())) == [B.rays_o.offset, B.state.offset, B.g_depth.offset, B.g_rays_d.offset,
                                               B.workspace_bytes.offset]

@@ -169,3 +169,66 @@ def test_adam_steps_reduce_loss(mini):
         opt.step()
         losses.append(loss.item())
     assert all(np.isfinite(losses)) and losses[-1] < 0.8 * losses[0], losses
+
+
+def tracker_loss(depth, unc, color, gt_depth, gt_color):
+    unc = unc.detach()
+    tmp = torch.abs(gt_depth - depth) / torch.sqrt(unc + 1e-10)
+    mask = (tmp < 10 * tmp.median()) & (gt_depth > 0)
+    return (torch.abs(gt_depth - depth) / torch.sqrt(unc + 1e-10))[mask].sum() + 0.5 * torch.abs(gt_color - color)[mask].sum()
+
+
+def test_tracker_ray_gradients_vs_reference_golden(mini):
+    """Camera tracking (src/Tracker.py:112-133): gradients w.r.t. rays_o / rays_d through the trilinear
+    coordinates of the three feature grids and of the TSDF and through sin(p @ B), against the reference's."""
+    g = mini.golden('tracker')
+    dec = A.DF()
+    dec.load_state_dict(mini.sd)
+    dec.bound = mini.bound
+    dec = dec.to(DEV)
+    for p in dec.parameters():
+        p.requires_grad_(False)
+    rend = A.Renderer(make_cfg(mini.n_samples, mini.n_surface), None, mini)
+    c = to_dev(mini.c, DEV)
+    ro = mini.rays_o.to(DEV).clone().requires_grad_(True)
+    rd = mini.rays_d.to(DEV).clone().requires_grad_(True)
+    gd, gc = mini.gt_depth.to(DEV), mini.gt_color.to(DEV)
+    d, u, col, w = rend.render_batch_ray(c, dec, rd, ro, DEV, mini.tsdf_volume.to(DEV), mini.tsdf_bnds.to(DEV), 'color',
+                                         gt_depth=gd)
+    loss = tracker_loss(d, u, col, gd, gc)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= 2e-5 * abs(float(g['loss']))
+    grad_close(ro.grad, g['g_rays_o'], 'd/d rays_o', tol=5e-4)
+    grad_close(rd.grad, g['g_rays_d'], 'd/d rays_d', tol=5e-4)
+
+
+def test_pose_gradient_through_get_rays_from_uv(mini):
+    """End to end like Tracker.optimize_cam_in_batch: a c2w matrix that requires grad -> rays -> render -> loss;
+    the pose gradient equals the oracle's."""
+    from attentive_dfprior_amd import common
+    dec = A.DF()
+    dec.load_state_dict(mini.sd)
+    dec.bound = mini.bound
+    dec = dec.to(DEV)
+    for p in dec.parameters():
+        p.requires_grad_(False)
+    rend = A.Renderer(make_cfg(mini.n_samples, mini.n_surface), None, mini)
+    c = to_dev(mini.c, DEV)
+    gen = torch.Generator().manual_seed(3)
+    i = torch.randint(4, mini.W - 4, (120,), generator=gen).float()
+    j = torch.randint(4, mini.H - 4, (120,), generator=gen).float()
+    gd = mini.depth_img[j.long(), i.long()]
+    gcol = torch.rand(120, 3, generator=gen)
+
+    c2w = mini.c2w.to(DEV).clone().requires_grad_(True)
+    ro, rd = common.get_rays_from_uv(i.to(DEV), j.to(DEV), c2w, mini.H, mini.W, mini.fx, mini.fy, mini.cx, mini.cy, DEV)
+    d, u, col, w = rend.render_batch_ray(c, dec, rd, ro, DEV, mini.tsdf_volume.to(DEV), mini.tsdf_bnds.to(DEV), 'color',
+                                         gt_depth=gd.to(DEV))
+    tracker_loss(d, u, col, gd.to(DEV), gcol.to(DEV)).backward()
+
+    c2w_o = mini.c2w.clone().requires_grad_(True)
+    ro2, rd2 = O.get_rays_from_uv(i, j, c2w_o, mini.fx, mini.fy, mini.cx, mini.cy)
+    d2, u2, col2, w2 = O.render_batch_ray(mini.sd, mini.c, rd2, ro2, mini.tsdf_volume, mini.tsdf_bnds, mini.bound, 'color',
+                                          gd, mini.n_samples, mini.n_surface)
+    O.tracker_loss(d2, u2, col2, gd, gcol).backward()
+    grad_close(c2w.grad[:3], c2w_o.grad[:3], 'd/d c2w', tol=5e-4)

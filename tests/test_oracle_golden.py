@@ -113,3 +113,17 @@ def test_fixture_covers_edge_cases(mini):
     w = torch.from_numpy(g['weight'])
     frac = (w != 1).float().mean().item()
     assert 0.05 < frac < 0.95                                   # both in-band and out-of-band samples
+
+
+def test_tracker_ray_gradients(mini):
+    """d(Tracker loss)/d(rays) of the oracle == the reference's (tests/golden/mini_tracker.npz)."""
+    g = mini.golden('tracker')
+    ro = mini.rays_o.clone().requires_grad_(True)
+    rd = mini.rays_d.clone().requires_grad_(True)
+    d, u, c, w = O.render_batch_ray(mini.sd, mini.c, rd, ro, mini.tsdf_volume, mini.tsdf_bnds, mini.bound, 'color',
+                                    mini.gt_depth, mini.n_samples, mini.n_surface)
+    loss = O.tracker_loss(d, u, c, mini.gt_depth, mini.gt_color)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= 1e-9 * abs(float(g['loss']))
+    assert (ro.grad - torch.from_numpy(g['g_rays_o'])).abs().max().item() <= 1e-4
+    assert (rd.grad - torch.from_numpy(g['g_rays_d'])).abs().max().item() <= 1e-4
