@@ -92,6 +92,9 @@ SYMBOLS = [
                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ('adfp_sample_tsdf', C.c_int, [C.POINTER(AdfpTsdf), C.POINTER(Bound), C.POINTER(AdfpPoints),
                                    C.c_void_p, C.c_void_p]),
+    ('adfp_tsdf_integrate', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float * 3),
+                                      C.c_float, C.POINTER(C.c_float * 9), C.POINTER(C.c_float * 16), C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     ('adfp_composite', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_render_forward', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpRenderArgs), C.c_void_p]),

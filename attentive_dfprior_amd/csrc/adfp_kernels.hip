@@ -220,11 +220,13 @@ struct SampleArgs {
     double* z;
 };
 
-// torch.linspace(0, 1, n) for float32 (ATen RangeFactories: symmetric fill)
+// torch.linspace(0, 1, n) for float32 (ATen RangeFactories: symmetric fill).  The upper half is
+// end - step * (n - 1 - i); PyTorch's CPU build contracts it into one fma (the golden z_vals generated
+// from the reference are reproduced to the last bit only with the fma), so it is an explicit fmaf here.
 ADFP_DEV float linspace01(int i, int n) {
     if (n == 1) return 0.f;
     const float step = 1.0f / (float)(n - 1);
-    return (i < n / 2) ? __fmul_rn(step, (float)i) : __fsub_rn(1.0f, __fmul_rn(step, (float)(n - i - 1)));
+    return (i < n / 2) ? step * (float)i : fmaf(-step, (float)(n - i - 1), 1.0f);
 }
 
 struct RaySampler {
@@ -686,6 +688,7 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
 }
 
 #include "adfp_backward.h"
+#include "adfp_fusion.h"
 
 // =====================================================================================
 // host side: C ABI
@@ -871,7 +874,7 @@ int adfp_sample_rays(const float* rays_o, const float* rays_d, const float* gt_d
         if (!scratch) return ADFP_E_ARG;
         hipError_t e = hipMemsetAsync(scratch, 0, 16, st);
         if (e != hipSuccess) return (int)e;
-        int blocks = (n_rays + 255) / 256; if (blocks > 1024) blocks = 1024;
+        int blocks = (n_rays + 2047) / 2048; if (blocks > 64) blocks = 64;     // few blocks: the cost is the atomics' latency
         hipLaunchKernelGGL(k_depth_max, dim3(blocks), dim3(256), 0, st, gt_depth, n_rays, (unsigned*)scratch);
         ADFP_CHECK_LAUNCH();
         a.dmax_ord = (const unsigned*)scratch;
@@ -1052,6 +1055,25 @@ int adfp_eval_points(const adfp_scene* scene, const adfp_points* pts, int stage,
     Workspace ws = carve(workspace, P.n);
     if (workspace_bytes < ws.bytes) return ADFP_E_WORKSPACE;
     return eval_points_impl(scene, P, stage, (flags & ADFP_EVAL_APPLY_BOUND) ? 1 : 0, raw, w, ws, (hipStream_t)stream);
+}
+
+int adfp_tsdf_integrate(float* tsdf, float* weight, float* color, int dim_x, int dim_y, int dim_z, const float origin[3], float voxel_size,
+                        const float cam_intr[9], const float cam_pose[16], const float* color_im, const float* depth_im, int im_h, int im_w,
+                        float trunc_margin, float obs_weight, void* stream) {
+    if (!tsdf || !weight || !origin || !cam_intr || !cam_pose || !depth_im || (color && !color_im)) return ADFP_E_ARG;
+    if (dim_x <= 0 || dim_y <= 0 || dim_z <= 0 || im_h <= 0 || im_w <= 0 || !(voxel_size > 0) || !(trunc_margin > 0)) return ADFP_E_ARG;
+    const long long n = (long long)dim_x * dim_y * dim_z;
+    if (n > 0x7fffffffll) return ADFP_E_UNSUPPORTED;
+    FusionArgs a;
+    a.tsdf = tsdf; a.weight = weight; a.color = color; a.dx = dim_x; a.dy = dim_y; a.dz = dim_z;
+    for (int k = 0; k < 3; ++k) a.origin[k] = origin[k];
+    a.voxel = voxel_size;
+    for (int k = 0; k < 9; ++k) a.intr[k] = cam_intr[k];
+    for (int k = 0; k < 16; ++k) a.pose[k] = cam_pose[k];
+    a.color_im = color_im; a.depth_im = depth_im; a.im_h = im_h; a.im_w = im_w; a.trunc = trunc_margin; a.obs_w = obs_weight;
+    hipLaunchKernelGGL(k_tsdf_integrate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    ADFP_CHECK_LAUNCH();
+    return 0;
 }
 
 int adfp_composite(const float* raw, const double* z_vals, int n_rays, int S, double* depth, double* uncertainty, float* color,

@@ -226,6 +226,15 @@ typedef struct adfp_backward_args {
 size_t adfp_backward_workspace_bytes(long long n_points);
 int adfp_render_backward(const adfp_scene* scene /*host*/, const adfp_backward_args* args /*host*/, void* stream);
 
+/* ---- TSDF fusion of one RGB-D frame (src/fusion.py:69-142 CUDA kernel, launch :226-251) ---- */
+/* tsdf / weight / color: device volumes in the reference's physical order [X][Y][Z] (Z fastest), updated in
+ * place; color may be NULL.  origin, cam_intr (3x3) and cam_pose (4x4 camera-to-world, already in the
+ * OpenCV convention of get_tsdf.py:79-80) are HOST arrays; color_im is the packed b*65536+g*256+r image
+ * (src/fusion.py:223), depth_im the depth image, both [H,W] fp32 on the device. */
+int adfp_tsdf_integrate(float* tsdf, float* weight, float* color, int dim_x, int dim_y, int dim_z, const float origin[3],
+                        float voxel_size, const float cam_intr[9], const float cam_pose[16], const float* color_im,
+                        const float* depth_im, int im_h, int im_w, float trunc_margin, float obs_weight, void* stream);
+
 /* Per-stage timing hook for bench.py: runs ONLY the TSDF trilerp + band-mask kernel (a10). */
 int adfp_tsdf_stage(const adfp_scene* scene, const adfp_points* pts, unsigned char* flags,
                     int* list, float* att_u, float* w, int* counter, void* stream);

@@ -396,3 +396,63 @@ def random_state_dict(seed=0, bias_scale=0.05, occ_bias=-0.5, out_scale=0.15):
     sd['low_decoder.output_linear.bias'] += occ_bias
     sd['color_decoder.output_linear.weight'][3] *= out_scale
     return sd
+
+
+# ----------------------------------------------------------------------------------
+# TSDF fusion: numpy restatement of the reference's CUDA kernel
+# src/fusion.py:69-142 in float32, statement by statement.  PARITY UNPINNED for this function: neither
+# pycuda nor numba exists in the build container, so the reference's fusion cannot be executed here and
+# it ships no vectors; the restatement is checked only by reading.
+# ----------------------------------------------------------------------------------
+def tsdf_integrate_np(tsdf, weight, color, origin, voxel, cam_intr, cam_pose, color_im_packed, depth_im, trunc, obs_w):
+    import numpy as np
+    f = np.float32
+    dx, dy, dz = tsdf.shape
+    n = dx * dy * dz
+    idx = np.arange(n, dtype=np.int32)
+    vx = np.floor(idx.astype(f) / f(dy * dz)).astype(f)                                   # fusion.py:92
+    vy = np.floor((idx - vx.astype(np.int32) * (dy * dz)).astype(f) / f(dz)).astype(f)       # :93
+    vz = (idx - vx.astype(np.int32) * (dy * dz) - vy.astype(np.int32) * dz).astype(f)        # :94
+    origin = np.asarray(origin, f); P = np.asarray(cam_pose, f).reshape(4, 4); K = np.asarray(cam_intr, f).reshape(3, 3)
+    voxel = f(voxel); trunc = f(trunc); obs_w = f(obs_w)
+    px, py, pz = origin[0] + vx * voxel, origin[1] + vy * voxel, origin[2] + vz * voxel
+    tx, ty, tz = px - P[0, 3], py - P[1, 3], pz - P[2, 3]
+    cx = P[0, 0] * tx + P[1, 0] * ty + P[2, 0] * tz                                          # :104-106
+    cy = P[0, 1] * tx + P[1, 1] * ty + P[2, 1] * tz
+    cz = P[0, 2] * tx + P[1, 2] * ty + P[2, 2] * tz
+
+    def roundf(x):                                                                            # C roundf: half away from zero
+        return np.where(x >= 0, np.floor(x + f(0.5)), np.ceil(x - f(0.5))).astype(f)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        ux = K[0, 0] * (cx / cz) + K[0, 2]
+        uy = K[1, 1] * (cy / cz) + K[1, 2]
+    # roundf of x + 0.5 can differ from true roundf when x + 0.5 rounds up; use exact comparison instead
+    def c_roundf(x):
+        r = np.trunc(x)
+        frac = np.abs(x - r)
+        return (r + np.sign(x) * (frac >= f(0.5))).astype(f)
+    h, w = depth_im.shape
+    with np.errstate(invalid='ignore'):
+        pix_x = np.nan_to_num(c_roundf(ux), nan=-1e9, posinf=1e9, neginf=-1e9).clip(-2e9, 2e9).astype(np.int64)
+        pix_y = np.nan_to_num(c_roundf(uy), nan=-1e9, posinf=1e9, neginf=-1e9).clip(-2e9, 2e9).astype(np.int64)
+    ok = (pix_x >= 0) & (pix_x < w) & (pix_y >= 0) & (pix_y < h) & ~(cz < 0)
+    dval = np.zeros(n, f)
+    dval[ok] = depth_im[pix_y[ok], pix_x[ok]]
+    ok &= dval != 0
+    diff = dval - cz
+    ok &= ~(diff < -trunc)
+    dist = np.minimum(f(1.0), diff / trunc)
+    t, wt, col = tsdf.reshape(-1).copy(), weight.reshape(-1).copy(), color.reshape(-1).copy()
+    w_old = wt[ok]
+    w_new = w_old + obs_w
+    wt[ok] = w_new
+    t[ok] = (t[ok] * w_old + obs_w * dist[ok]) / w_new
+    oc = col[ok]
+    ob = np.floor(oc / f(65536)); og = np.floor((oc - ob * f(65536)) / f(256)); orr = oc - ob * f(65536) - og * f(256)
+    nc = color_im_packed[pix_y[ok], pix_x[ok]].astype(f)
+    nb = np.floor(nc / f(65536)); ng = np.floor((nc - nb * f(65536)) / f(256)); nr = nc - nb * f(65536) - ng * f(256)
+    nb = np.minimum(c_roundf((ob * w_old + obs_w * nb) / w_new), f(255))
+    ng = np.minimum(c_roundf((og * w_old + obs_w * ng) / w_new), f(255))
+    nr = np.minimum(c_roundf((orr * w_old + obs_w * nr) / w_new), f(255))
+    col[ok] = nb * f(65536) + ng * f(256) + nr
+    return t.reshape(tsdf.shape), wt.reshape(tsdf.shape), col.reshape(tsdf.shape)
