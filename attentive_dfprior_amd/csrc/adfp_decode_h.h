@@ -139,22 +139,29 @@ ADFP_DEV void mfma_chain_h(f32x16& acc, const unsigned* __restrict__ w, int lane
     __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting the next chain's LDS reads
 }
 
+#ifdef ADFP_STAMPS
+__device__ unsigned long long g_stamps[2 * 8192];     // debug build only: per-wave start/end wall clock (100 MHz)
+#endif
+
 template <int CDIM, int NOUT, int ROLE, int NT>
 __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 : 2))) void k_decode_h(DecodeArgs a) {
     using L = DecLayoutH<CDIM, NOUT>;
+#ifdef ADFP_STAMPS
+    const unsigned long long stamp0 = wall_clock64();
+#endif
     __shared__ __attribute__((aligned(16))) unsigned ldsu[L::P_TOTAL];
+    __shared__ int s_next;
     for (int i = threadIdx.x; i < L::P_TOTAL / 4; i += NT) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed)[i];
+    if (threadIdx.x == 0) s_next = NT / 64;
     __syncthreads();
     const float* lds = (const float*)ldsu;
 
     const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
     const int lane_off = h * 128 + p * 4;            // words: [h][32 rows][4 words = 8 halves]
-    const int wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * (NT / 64);
     const int count = (ROLE == ROLE_HIGH) ? *a.count_ptr : a.P.n;
     const int ntiles = (count + 31) >> 5;
 
-    for (int tile = wave; tile < ntiles; tile += nwaves) {
+    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<NT / 64>(j, &s_next, ntiles)) >= 0;) {
         const int idx = tile * 32 + p;
         const bool valid = idx < count;
         int q = valid ? idx : 0;
@@ -236,6 +243,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
             }
         }
     }
+#ifdef ADFP_STAMPS
+    const int wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (lane == 0 && wave < 8192) { g_stamps[2 * wave] = stamp0; g_stamps[2 * wave + 1] = wall_clock64(); }
+#endif
 }
 
 // =============================================================================================
@@ -297,16 +308,16 @@ __global__ void k_pack_attention_h(const float* __restrict__ flat, unsigned* __r
 __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
     using A = AttLayoutH;
     __shared__ __attribute__((aligned(16))) unsigned ldsu[A::P_TOTAL];
+    __shared__ int s_next;
     for (int i = threadIdx.x; i < A::P_TOTAL / 4; i += 512) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed)[i];
+    if (threadIdx.x == 0) s_next = 8;
     __syncthreads();
     const float* lds = (const float*)ldsu;
     const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
     const int lane_off = h * 128 + p * 4;
-    const int wave = blockIdx.x * 8 + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * 8;
     const int count = *a.count_ptr;
     const int ntiles = (count + 31) >> 5;
-    for (int tile = wave; tile < ntiles; tile += nwaves) {
+    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<8>(j, &s_next, ntiles)) >= 0;) {
         const int idx = tile * 32 + p;
         const bool valid = idx < count;
         const int ii = valid ? idx : 0;

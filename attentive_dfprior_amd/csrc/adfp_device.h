@@ -353,3 +353,26 @@ struct AttLayout {
     static constexpr int P_BO = P_WO + 128;
     static constexpr int P_TOTAL = P_BO + 4;
 };
+
+// ---------------------------------------------------------------------------------------------
+// Tile hand-out inside a workgroup.  A workgroup of NWW waves owns the tiles
+//   wg_tile(j) = blockIdx.x * NWW + (j % NWW) + (j / NWW) * (gridDim.x * NWW),   j = 0, 1, 2, ...
+// (the same set a fixed wave-strided split would give it) and its waves take slots j from an LDS
+// ticket.  The SIMD arbiter favours the oldest wave, so with a fixed split the young waves of every
+// SIMD finished ~20 % after the old ones (measured per-wave end stamps, tools/ab_stage.py).
+// *s_next must be initialised to NWW before the barrier that precedes the loop; wave w starts at j = w.
+// Returns the tile of slot j (or -1 when the workgroup's tiles are exhausted) and advances j.
+// ---------------------------------------------------------------------------------------------
+template <int NWW>
+ADFP_DEV int claim_tile(int& j, int* s_next, int ntiles) {
+    const int tile = blockIdx.x * NWW + (j % NWW) + (j / NWW) * (gridDim.x * NWW);
+    if (tile >= ntiles) return -1;
+#ifdef ADFP_STATIC_TILES        // A/B switch: the fixed split
+    j += NWW;
+#else
+    int jn = 0;
+    if ((threadIdx.x & 63) == 0) jn = atomicAdd(s_next, 1);
+    j = __builtin_amdgcn_readfirstlane(jn);
+#endif
+    return tile;
+}

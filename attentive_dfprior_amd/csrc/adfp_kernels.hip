@@ -922,6 +922,12 @@ int adfp_sample_tsdf(const adfp_tsdf* tsdf, const double tsdf_bnds[3][2], const 
     return launch_tsdf(&sc, P, nullptr, nullptr, nullptr, nullptr, nullptr, out, (hipStream_t)stream);
 }
 
+#ifdef ADFP_STAMPS
+extern "C" int adfp_debug_stamps(unsigned long long* host_out, int n_waves) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), (size_t)n_waves * 16);
+}
+#endif
+
 static int decode_grid(int ntiles, int waves_per_wg, int wg_per_cu) {
     int g = (ntiles + waves_per_wg - 1) / waves_per_wg;
     const int cap = num_cu() * wg_per_cu;

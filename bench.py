@@ -43,6 +43,23 @@ F16X3_FLOP_COLOR = 90 * 32 * 32 * 16 * 2 / 32.0   # executed f16 MFMA FLOP per s
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
 
 
+def pmc_traffic(kernel_prefix, samples_per_launch):
+    """HBM bytes per launch of one kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE, separate runs, profiles/r01_pmc_hbm_traffic.csv holds bytes per sample): the counters
+    cannot be read from inside this process, so the figure is the profiled bytes/sample x this run's samples
+    per launch.  None when the file is absent."""
+    import csv
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.csv')
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rows = [r for r in csv.reader(l for l in f if not l.startswith('#'))]
+    for r in rows[1:]:
+        if r[0].startswith(kernel_prefix):
+            return (float(r[3]) + float(r[4])) * samples_per_launch
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -225,13 +242,19 @@ def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, N
                         'VALU does not overlap MFMA on a CDNA4 SIMD (tools/micro), see DESIGN.md section 5',
                 'algorithmic_f32_tflops': ach, 'f32_mfma_peak_tflops': PEAK_F32_MFMA_TFLOPS,
                 'frac_of_f32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS}
+    kname = 'void k_decode<32, 4, 2' if math_mode() == 'f32' else 'void k_decode_h<32, 4, 2'
+    roof['traffic'] = pmc_traffic(kname, pts_per_launch)
+    roof['traffic_note'] = ('HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) per sample of profiles/r01_pmc_hbm_traffic.csv '
+                            '(separate --pmc passes) x samples per launch; stores are 16-B/lane streams (exact), '
+                            'gather fetches are uncalibrated on gfx950 (MI355X_MICROARCH.md, HBM)')
     roof.update({'algorithmic_flop_per_launch': fl_color, 'avg_launch_ms': t_color * 1e3, 'launches_per_frame': nl,
                  'points_per_launch': pts_per_launch})
     return {
         'roofline': roof,
         'roofline_tsdf': {'kernel': 'k_tsdf (TSDF trilerp + band mask + compaction)', 'bound': 'hbm',
                           'achieved': by / t_tsdf / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
-                          'frac': by / t_tsdf / 1e9 / PEAK_HBM_GBPS, 'traffic': None, 'bytes_per_launch': by,
+                          'frac': by / t_tsdf / 1e9 / PEAK_HBM_GBPS, 'traffic': pmc_traffic('k_tsdf', pts_per_launch),
+                          'bytes_per_launch': by,
                           'avg_launch_ms': t_tsdf * 1e3},
         'stage_avg_launch_ms': {'color_decoder': t_color * 1e3, 'low_decoder': t_low * 1e3, 'tsdf': t_tsdf * 1e3,
                                 'whole_render_batch_ray': t_all * 1e3},

@@ -68,6 +68,27 @@ def main(reps=8):
     res['color_tflops'] = 2.0 * 15575 * P / (res['color_ms'][0] * 1e-3) / 1e12
     res['tsdf_gbps'] = 32.0 * P / (res['tsdf_ms'][0] * 1e-3) / 1e9
     print(json.dumps(res))
+    if hasattr(L, 'adfp_debug_stamps') or os.environ.get('ADFP_STAMPS'):
+        # debug build (-DADFP_STAMPS): per-wave start/end wall clock of the last k_decode_h launch
+        import numpy as np
+        L.adfp_decode_stage(C.byref(sc), C.byref(ap), 2, _lib.ptr(raw), _lib.ptr(wb), st)
+        torch.cuda.synchronize()
+        nw = 256 * 12
+        buf = (C.c_ulonglong * (2 * nw))()
+        L.adfp_debug_stamps.argtypes = [C.c_void_p, C.c_int]
+        assert L.adfp_debug_stamps(buf, nw) == 0
+        a = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 2).astype(np.int64)
+        t0 = a[:, 0].min()
+        s0, e0 = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0          # us
+        print('wave start us: min %.1f p50 %.1f max %.1f' % (s0.min(), np.median(s0), s0.max()))
+        print('wave end   us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f mean %.1f' % (
+            e0.min(), np.percentile(e0, 10), np.median(e0), np.percentile(e0, 90), e0.max(), e0.mean()))
+        wg_end = e0.reshape(256, 12).max(1)
+        print('per-workgroup end us (sorted, every 16th):', np.sort(wg_end)[::16].round(1).tolist())
+        print('within-WG spread us (max-min of wave ends): mean %.1f max %.1f' % (
+            (e0.reshape(256, 12).max(1) - e0.reshape(256, 12).min(1)).mean(), (e0.reshape(256, 12).max(1) - e0.reshape(256, 12).min(1)).max()))
+        x = wg_end.reshape(32, 8)      # blockIdx % 8 = XCD
+        print('per-XCD mean WG end us:', x.mean(0).round(1).tolist())
 
 
 if __name__ == '__main__':
