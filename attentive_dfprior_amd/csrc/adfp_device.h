@@ -124,6 +124,41 @@ ADFP_DEV float trilerp_scalar(const TsdfDev& t, const float pn[3]) {
     return o;
 }
 
+// The same lookup split in two so that a caller can put the loads of SEVERAL points in flight before
+// it consumes any of them (unit z stride only): prepare = indices, weights, 4 addresses; finish = blend.
+struct TriPair {
+    const f32x2_u* a00; const f32x2_u* a01; const f32x2_u* a10; const f32x2_u* a11;   // (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+    float wx0, wx1, wy0, wy1, wz0, wz1;
+    bool lo;
+};
+ADFP_DEV void trilerp_pair_prepare(const TsdfDev& t, const float pn[3], TriPair& r) {
+    int x0, x1, y0, y1, z0, z1;
+    tri_axis(pn[0], t.X, x0, x1, r.wx0, r.wx1);
+    tri_axis(pn[1], t.Y, y0, y1, r.wy0, r.wy1);
+    tri_axis(pn[2], t.Z, z0, z1, r.wz0, r.wz1);
+    const long long ox0 = x0 * t.sX, ox1 = x1 * t.sX, oy0 = y0 * t.sY, oy1 = y1 * t.sY;
+    const int zb = z0 < t.Z - 1 ? z0 : t.Z - 2;       // pair (zb, zb+1) always inside the volume
+    r.lo = z0 == zb;                                   // false only when z0 = Z-1 (then z1 = z0, weight 0)
+    const float* d = t.data + zb;
+    r.a00 = (const f32x2_u*)(d + oy0 + ox0); r.a01 = (const f32x2_u*)(d + oy0 + ox1);
+    r.a10 = (const f32x2_u*)(d + oy1 + ox0); r.a11 = (const f32x2_u*)(d + oy1 + ox1);
+}
+ADFP_DEV float trilerp_pair_finish(const TriPair& r, f32x2_u p00, f32x2_u p01, f32x2_u p10, f32x2_u p11) {
+    const float v000 = r.lo ? p00.x : p00.y, v100 = p00.y;
+    const float v001 = r.lo ? p01.x : p01.y, v101 = p01.y;
+    const float v010 = r.lo ? p10.x : p10.y, v110 = p10.y;
+    const float v011 = r.lo ? p11.x : p11.y, v111 = p11.y;
+    float o = v000 * ((r.wx0 * r.wy0) * r.wz0);          // same order as trilerp_scalar
+    o = fmaf(v001, (r.wx1 * r.wy0) * r.wz0, o);
+    o = fmaf(v010, (r.wx0 * r.wy1) * r.wz0, o);
+    o = fmaf(v011, (r.wx1 * r.wy1) * r.wz0, o);
+    o = fmaf(v100, (r.wx0 * r.wy0) * r.wz1, o);
+    o = fmaf(v101, (r.wx1 * r.wy0) * r.wz1, o);
+    o = fmaf(v110, (r.wx0 * r.wy1) * r.wz1, o);
+    o = fmaf(v111, (r.wx1 * r.wy1) * r.wz1, o);
+    return o;
+}
+
 // 16 of the 32 channels of a channels-last feature voxel grid: lane-half `h` takes the channels
 // kmapH(r,h) = 8q+4h .. 8q+4h+3 (q = 0..3), i.e. four 16-B pieces of each 128-B voxel line; the
 // two halves of a lane pair cover the whole line (c[r] <-> channel kmapH(r, h)).

@@ -354,7 +354,16 @@ struct TsdfArgs {
 // instead of 64 (consecutive samples of ONE ray are ~5 voxels apart) -- the stage is bound by the
 // lines the address unit walks, not by bytes.  z_vals come in and flags / w go out through LDS so
 // that global traffic stays coalesced.
-__global__ __launch_bounds__(256) void k_tsdf(TsdfArgs a) {
+#ifndef TSDF_UB
+#define TSDF_UB 4
+#endif
+#ifndef TSDF_MINW
+#define TSDF_MINW 4
+#endif
+__global__ __launch_bounds__(256, TSDF_MINW) void k_tsdf(TsdfArgs a) {
+    constexpr int PER = TSDF_CHUNK / 256;            // points per thread
+    constexpr int UB = TSDF_UB;                      // points whose loads are in flight together
+    static_assert(PER % UB == 0, "TSDF_CHUNK must be a multiple of 256 * UB");
     __shared__ int s_q[TSDF_CHUNK];
     __shared__ float s_u[TSDF_CHUNK];
     __shared__ double s_z[TSDF_CHUNK + 64];
@@ -372,58 +381,89 @@ __global__ __launch_bounds__(256) void k_tsdf(TsdfArgs a) {
         const int nr = a.P.n / S;
         rb = (r0 + RB <= nr) ? RB : nr - r0;
         q0 = r0 * S; npts = rb * S;
-        for (int i = threadIdx.x; i < npts; i += 256) { const int row = i / S, col = i - row * S; s_z[row * (S + 1) + col] = a.P.z[q0 + i]; }
-        for (int i = threadIdx.x; i < rb * 6; i += 256) {
-            const int row = i / 6, k = i - row * 6;
-            s_ray[i] = k < 3 ? a.P.ro[3 * (r0 + row) + k] : a.P.rd[3 * (r0 + row) + k - 3];
+        double zr[PER];                              // all of the thread's z loads in flight at once
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { const int i = threadIdx.x + 256 * k; zr[k] = i < npts ? a.P.z[q0 + i] : 0.0; }
+        float rr[2] = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < rb * 6) { const int row = i / 6, c = i - row * 6; rr[k] = c < 3 ? a.P.ro[3 * (r0 + row) + c] : a.P.rd[3 * (r0 + row) + c - 3]; }
         }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < npts) { const int row = (int)((unsigned)i / (unsigned)S), col = i - row * S; s_z[row * (S + 1) + col] = zr[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { const int i = threadIdx.x + 256 * k; if (i < rb * 6) s_ray[i] = rr[k]; }
     } else {
         q0 = blockIdx.x * TSDF_CHUNK;
         npts = a.P.n - q0 < TSDF_CHUNK ? a.P.n - q0 : TSDF_CHUNK;
     }
     __syncthreads();
-#pragma unroll 2
-    for (int i0 = 0; i0 < npts; i0 += 256) {          // block-uniform trip count (ballot below)
-        const int i = i0 + threadIdx.x;
-        bool band = false; float u = 0.f; int q = 0;
-        if (i < npts) {
-            double p[3]; float pn[3];
-            int loc = i;
+    const bool paired = a.t.sZ == 1 && a.t.Z >= 2;   // the reference's layout: z fastest
+    for (int i0 = 0; i0 < npts; i0 += 256 * UB) {    // block-uniform trip count (ballots below)
+        double p[UB][3]; float pn[UB][3]; int loc[UB]; bool ok[UB]; float tv[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = i0 + 256 * u + threadIdx.x;
+            ok[u] = i < npts;
+            const int ic = ok[u] ? i : npts - 1;     // clamped: every lane does valid loads, results masked
+            loc[u] = ic;
             if (rays) {
-                const int col = (int)((unsigned)i / (unsigned)rb), row = i - col * rb;   // transposed walk: lane <-> ray
-                loc = row * S + col;
+                const int col = (int)((unsigned)ic / (unsigned)rb), row = ic - col * rb;   // transposed walk: lane <-> ray
+                loc[u] = row * S + col;
                 const double z = s_z[row * (S + 1) + col];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) p[k] = __dadd_rn((double)s_ray[row * 6 + k], __dmul_rn((double)s_ray[row * 6 + 3 + k], z));
-            } else load_point(a.P, q0 + i, p);
-            if (loc >= 0) {
-                q = q0 + loc;
-                normalize3(a.nt, p, pn);
-                const float t = trilerp_scalar(a.t, pn);
-                if (a.tsdf_out) a.tsdf_out[q] = t;
-                band = (t > (float)(-1.0 + 1e-4)) & (t < (float)(1.0 - 1e-4));
-                s_f[loc] = (unsigned char)((in_bound(p, a.b) ? ADFP_F_INBOUND : 0u) | (band ? ADFP_F_BAND : 0u));
-                if (band) u = inv_tsdf(t);
-            }
+                for (int k = 0; k < 3; ++k) p[u][k] = __dadd_rn((double)s_ray[row * 6 + k], __dmul_rn((double)s_ray[row * 6 + 3 + k], z));
+            } else load_point(a.P, q0 + ic, p[u]);
+            normalize3(a.nt, p[u], pn[u]);
         }
-        if (a.list) {
-            const unsigned long long m = __ballot(band);
-            if (m) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_cnt, __popcll(m));
-                base = __shfl(base, 0);
-                if (band) {
-                    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-                    s_q[pos] = q; s_u[pos] = u;
+        if (paired) {
+            TriPair tp[UB]; f32x2_u v[UB][4];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) trilerp_pair_prepare(a.t, pn[u], tp[u]);
+#pragma unroll
+            for (int u = 0; u < UB; ++u) { v[u][0] = *tp[u].a00; v[u][1] = *tp[u].a01; v[u][2] = *tp[u].a10; v[u][3] = *tp[u].a11; }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) tv[u] = trilerp_pair_finish(tp[u], v[u][0], v[u][1], v[u][2], v[u][3]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) tv[u] = trilerp_scalar(a.t, pn[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const float t = tv[u];
+            const int q = q0 + loc[u];
+            const bool band = ok[u] & (t > (float)(-1.0 + 1e-4)) & (t < (float)(1.0 - 1e-4));
+            if (ok[u]) {
+                if (a.tsdf_out) a.tsdf_out[q] = t;
+                s_f[loc[u]] = (unsigned char)((in_bound(p[u], a.b) ? ADFP_F_INBOUND : 0u) | (band ? ADFP_F_BAND : 0u));
+            }
+            if (a.list) {
+                const unsigned long long m = __ballot(band);
+                if (m) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&s_cnt, __popcll(m));
+                    base = __shfl(base, 0);
+                    if (band) {
+                        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                        s_q[pos] = q; s_u[pos] = inv_tsdf(t);
+                    }
                 }
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < npts; i += 256) {
-        if (a.flags) a.flags[q0 + i] = s_f[i];
-        if (a.w) a.w[q0 + i] = 1.f;
+    if (a.flags) {
+        if (((q0 | npts) & 3) == 0) {                // whole block 4-byte aligned: 4 flags per store
+            for (int i = threadIdx.x; i < (npts >> 2); i += 256) ((unsigned*)(a.flags + q0))[i] = ((const unsigned*)s_f)[i];
+        } else {
+            for (int i = threadIdx.x; i < npts; i += 256) a.flags[q0 + i] = s_f[i];
+        }
     }
+    if (a.w) for (int i = threadIdx.x; i < npts; i += 256) a.w[q0 + i] = 1.f;
     if (!a.list) return;
     const int n = s_cnt;
     if (n == 0) return;
@@ -952,13 +992,13 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
     if (fuse) {
         e = hipMemsetAsync(ws.counter, 0, 4, st);
         if (e != hipSuccess) return (int)e;
-        int rc = launch_tsdf(sc, P, ws.flags, ws.list, ws.att_u, w, ws.counter, nullptr, st);
+        int rc = launch_tsdf(sc, P, ws.flags, ws.list, ws.att_u, nullptr, ws.counter, nullptr, st);   // w = 1 comes from the LOW decoder
         if (rc) return rc;
     }
     DecodeArgs a;
     a.P = P; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
     a.list = nullptr; a.count_ptr = nullptr; a.flags = fuse ? ws.flags : nullptr;
-    a.raw = raw; a.w = w; a.att_occ = nullptr; a.write_w = fuse ? 0 : 1; a.apply_bound = apply_bound;
+    a.raw = raw; a.w = w; a.att_occ = nullptr; a.write_w = 1; a.apply_bound = apply_bound;   // attention overwrites w on the band
     const int ntiles = (P.n + 31) / 32;
     // LOW on every point
     a.g0 = make_grid(sc->low); a.g1 = a.g0;

@@ -220,7 +220,7 @@ def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, N
     t_color = timed(lambda b: _lib.check(L.adfp_decode_stage(C.byref(sc), C.byref(b[0]), 2, _lib.ptr(raw), _lib.ptr(wbuf), st), 'decode'))
     t_low = timed(lambda b: _lib.check(L.adfp_decode_stage(C.byref(sc), C.byref(b[0]), 0, _lib.ptr(raw), _lib.ptr(wbuf), st), 'decode'))
     t_tsdf = timed(lambda b: _lib.check(L.adfp_tsdf_stage(C.byref(sc), C.byref(b[0]), _lib.ptr(flags), _lib.ptr(lst), _lib.ptr(attu),
-                                                          _lib.ptr(wbuf), _lib.ptr(cnt), st), 'tsdf'))
+                                                          None, _lib.ptr(cnt), st), 'tsdf'))
     t_all = timed(lambda b: eng.render_forward(dec, scene.c, b[1], b[2], b[3], scene.tsdf_volume, tsdf_bnds, scene.bound,
                                                'color', NS, NF))
     pts_per_launch = n_pts / nl

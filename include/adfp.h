@@ -235,7 +235,8 @@ int adfp_tsdf_integrate(float* tsdf, float* weight, float* color, int dim_x, int
                         float voxel_size, const float cam_intr[9], const float cam_pose[16], const float* color_im,
                         const float* depth_im, int im_h, int im_w, float trunc_margin, float obs_weight, void* stream);
 
-/* Per-stage timing hook for bench.py: runs ONLY the TSDF trilerp + band-mask kernel (a10). */
+/* Per-stage timing hook for bench.py: runs ONLY the TSDF trilerp + band-mask kernel (a10).
+ * w may be NULL (that is the render path's launch: there the LOW decoder writes w = 1). */
 int adfp_tsdf_stage(const adfp_scene* scene, const adfp_points* pts, unsigned char* flags,
                     int* list, float* att_u, float* w, int* counter, void* stream);
 

@@ -63,7 +63,7 @@ def main(reps=8):
     res['color_ms'] = timed(lambda: L.adfp_decode_stage(C.byref(sc), C.byref(ap), 2, _lib.ptr(raw), _lib.ptr(wb), st))
     res['low_ms'] = timed(lambda: L.adfp_decode_stage(C.byref(sc), C.byref(ap), 0, _lib.ptr(raw), _lib.ptr(wb), st))
     res['tsdf_ms'] = timed(lambda: L.adfp_tsdf_stage(C.byref(sc), C.byref(ap), _lib.ptr(flags), _lib.ptr(lst), _lib.ptr(attu),
-                                                     _lib.ptr(wb), _lib.ptr(cnt), st))
+                                                     None, _lib.ptr(cnt), st))
     res['batch_ms'] = timed(lambda: eng.render_forward(dec, scene.c, ro, rd, gd, scene.tsdf_volume, tsdf_bnds, scene.bound, 'color', 48, 16))
     res['color_tflops'] = 2.0 * 15575 * P / (res['color_ms'][0] * 1e-3) / 1e12
     res['tsdf_gbps'] = 32.0 * P / (res['tsdf_ms'][0] * 1e-3) / 1e9
