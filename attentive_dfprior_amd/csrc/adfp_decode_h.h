@@ -110,8 +110,10 @@ __global__ void k_pack_decoder_h(const float* __restrict__ flat, unsigned* __res
     packed[t] = (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
 
-// 8 f32 -> 8 hi halves + 8 lo halves (3 VALU per value: and, sub, 2 x cvt_pkrtz per pair).
-// hi = x truncated to 11 significant bits (a mask; exactly representable in f16), lo = x - hi.
+// 8 f32 -> 8 hi halves + 8 lo halves.
+#ifdef ADFP_SPLIT_MASK
+// 3 VALU per value: and, sub, 2 x cvt_pkrtz per pair.  hi = x truncated to 11 significant bits (a mask;
+// exactly representable in f16), lo = x - hi.
 ADFP_DEV void split8(const float* __restrict__ x, f16x8& hi, f16x8& lo) {
     u32x4 uh, ul;
 #pragma unroll
@@ -124,6 +126,29 @@ ADFP_DEV void split8(const float* __restrict__ x, f16x8& hi, f16x8& lo) {
     hi = __builtin_bit_cast(f16x8, uh);
     lo = __builtin_bit_cast(f16x8, ul);
 }
+#else
+// 2 VALU per value: hi = cvt_pkrtz (round toward zero = the 11-bit truncation) for a pair, then
+// lo = x - hi as ONE v_fma_mix_f32 per value (the f16 half is widened inside the instruction; the
+// difference is exact), then cvt_pkrtz of the pair of remainders.
+ADFP_DEV void split8(const float* __restrict__ x, f16x8& hi, f16x8& lo) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    u32x4 uh, ul;
+    unsigned m1 = 0xBC00BC00u;                       // f16 (-1, -1), opaque to the optimiser so that the
+    asm volatile("" : "+v"(m1));                     // fma below stays fma(fpext, fpext, f32) = v_fma_mix_f32
+    const h2 neg1 = __builtin_bit_cast(h2, m1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = x[2 * j], b = x[2 * j + 1];
+        const h2 hp = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a, b));
+        const float la = __builtin_fmaf((float)hp[0], (float)neg1[0], a);
+        const float lb = __builtin_fmaf((float)hp[1], (float)neg1[0], b);
+        uh[j] = __builtin_bit_cast(unsigned, hp);
+        ul[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(la, lb));
+    }
+    hi = __builtin_bit_cast(f16x8, uh);
+    lo = __builtin_bit_cast(f16x8, ul);
+}
+#endif
 
 // NK k-steps of a chain: acc += W[:, units of k-step] * x   with the 3-product split
 template <int NK>
