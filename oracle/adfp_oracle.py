@@ -95,15 +95,15 @@ def sample_z(rays_o, rays_d, gt_depth, bound, N_samples, N_surface, lindisp=Fals
     if N_surface > 0:
         nz = gt_depth > 0                                                  # Renderer.py:179
         gt_nz = gt_depth[nz].unsqueeze(-1).repeat(1, N_surface)
-        ts = torch.linspace(0., 1., steps=N_surface).double()
+        ts = torch.linspace(0., 1., steps=N_surface, device=rays_o.device).double()
         z_nz = 0.95 * gt_nz * (1. - ts) + 1.05 * gt_nz * ts                # Renderer.py:186
-        z_surf = torch.zeros(gt_depth.shape[0], N_surface).double()
+        z_surf = torch.zeros(gt_depth.shape[0], N_surface, device=rays_o.device).double()
         nz = nz.squeeze(-1)
         z_surf[nz, :] = z_nz
         far_surface = dmax
         z_zero = 0.001 * (1. - ts) + far_surface * ts                      # Renderer.py:196
         z_surf[~nz, :] = z_zero
-    t_vals = torch.linspace(0., 1., steps=N_samples)
+    t_vals = torch.linspace(0., 1., steps=N_samples, device=rays_o.device)
     if not lindisp:
         z_vals = near * (1. - t_vals) + far * t_vals                       # Renderer.py:206
     else:
@@ -154,7 +154,7 @@ def trilerp_explicit(vol, p, bound):
     x0, y0, z0 = torch.floor(ix), torch.floor(iy), torch.floor(iz)
     tx, ty, tz = ix - x0, iy - y0, iz - z0
     x0, y0, z0 = x0.long(), y0.long(), z0.long()
-    out = torch.zeros(C, p.shape[0])
+    out = torch.zeros(C, p.shape[0], device=p.device)
     v = vol[0]
     for dz in (0, 1):
         for dy in (0, 1):
@@ -222,22 +222,22 @@ def df_forward(sd, p, c_grid, tsdf_volume, tsdf_bnds, bound, stage, return_aux=F
     low = mlp_forward(sd, 'low', p, c_grid, bound)
     aux = {}
     if stage == 'low':
-        raw = torch.zeros(P, 4)
+        raw = torch.zeros(P, 4, device=p.device)
         raw = torch.cat([raw[:, :3], low.unsqueeze(-1)], -1)
-        w = torch.ones(P)
+        w = torch.ones(P, device=p.device)
         return (raw, w, aux) if return_aux else (raw, w)
     high = mlp_forward(sd, 'high', p, c_grid, bound)
     if stage == 'color':
         rgb = mlp_forward(sd, 'color', p, c_grid, bound)[:, :3]
     else:
-        rgb = torch.zeros(P, 3)
+        rgb = torch.zeros(P, 3, device=p.device)
     f_add = high + low                                                       # decoder.py:325/:342
     t = trilerp(tsdf_volume, p, tsdf_bnds).reshape(-1)
     mask = (t > -1.0 + 1e-4) & (t < 1.0 - 1e-4)                              # decoder.py:329/:346
     fused, a1 = mlp_tsdf_forward(sd, f_add[mask], t[mask])
     occ = low.clone()
     occ[mask] = fused                                                        # unmasked keep LOW only
-    w = torch.ones(P)
+    w = torch.ones(P, device=p.device)
     w[mask] = a1
     raw = torch.cat([rgb, occ.unsqueeze(-1)], -1)
     if return_aux:
@@ -268,7 +268,7 @@ def eval_points(sd, p, c_grid, tsdf_volume, tsdf_bnds, bound, stage, return_aux=
 def raw2outputs(raw, z_vals):
     rgb = raw[..., :3]
     alpha = torch.sigmoid(10 * raw[..., 3])                                  # common.py:236
-    ones = torch.ones((alpha.shape[0], 1))
+    ones = torch.ones((alpha.shape[0], 1), device=alpha.device)
     weights = alpha.float() * torch.cumprod(
         torch.cat([ones, (1. - alpha + 1e-10).float()], -1).float(), -1)[:, :-1]
     rgb_map = torch.sum(weights[..., None] * rgb, -2)
@@ -326,7 +326,7 @@ def mapper_loss(depth, color, weight, gt_depth, gt_color, stage, warmup=False, w
     depth_mask = gt_depth > 0
     loss = torch.abs(gt_depth[depth_mask] - depth[depth_mask]).sum()
     if warmup:
-        loss = loss + torch.abs(weight - torch.ones(weight.shape)).sum()
+        loss = loss + torch.abs(weight - torch.ones(weight.shape, device=weight.device)).sum()
     if stage == 'color':
         loss = loss + w_color_loss * torch.abs(gt_color - color).sum()
     return loss
