@@ -85,6 +85,8 @@ SYMBOLS = [
     ('adfp_pack_attention_h', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_get_rays', C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_prefilter_rays', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
     ('adfp_sample_rays', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Bound),
                                    C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -78,6 +78,32 @@ def get_samples(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, c2w, depth, color, devi
     return rays_o, rays_d, sample_depth, sample_color
 
 
+def filter_rays_in_bound(batch_rays_o, batch_rays_d, batch_gt_depth, batch_gt_color, bound):
+    """The Mapper's pre-filter "should pre-filter those out of bounding box depth value"
+    (reference src/Mapper.py:438-449): keeps the rays whose sensor depth lies inside the bounding box,
+    ``min_axis max_side((bound - o) / d) >= gt_depth``, in their original order.
+
+    Returns ``(rays_o, rays_d, gt_depth, gt_color)`` like the four boolean-mask indexings of the
+    reference; the mask and its ordered compaction run in libadfp.so (``adfp_prefilter_rays``), the
+    row gather is ``index_select`` so that autograd to camera tensors (BA) is preserved.  Reading the
+    kept count synchronises the stream exactly as the reference's boolean indexing does."""
+    _lib.require_cuda(batch_rays_o, 'batch_rays_o')
+    dev = batch_rays_o.device
+    n = batch_rays_o.shape[0]
+    with torch.cuda.device(dev):
+        ro = batch_rays_o.detach().float().contiguous()
+        rd = batch_rays_d.detach().float().contiguous()
+        gd = batch_gt_depth.detach().float().contiguous()
+        b = torch.as_tensor(bound).to(dev, torch.float64).contiguous()
+        idx = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+        cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+        check(lib().adfp_prefilter_rays(ptr(ro), ptr(rd), ptr(gd), n, ptr(b), ptr(idx), ptr(cnt),
+                                        _lib.current_stream(dev)), 'adfp_prefilter_rays')
+        keep = idx[:int(cnt.item())].long()
+    return (batch_rays_o.index_select(0, keep), batch_rays_d.index_select(0, keep),
+            batch_gt_depth.index_select(0, keep), batch_gt_color.index_select(0, keep))
+
+
 def random_select(l, k):
     """k distinct indices out of range(l) (reference src/common.py:68-73)."""
     return list(np.random.permutation(np.arange(l))[:min(l, k)])

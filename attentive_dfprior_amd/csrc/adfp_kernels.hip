@@ -186,6 +186,54 @@ __global__ void k_get_rays(int H, int W, float fx, float fy, float cx, float cy,
 }
 
 // =====================================================================================
+// a3: the Mapper's bounding-box pre-filter (Mapper.py:438-449): keep ray i iff
+//   min_axis max_side((bound - o) / d) >= gt_depth          (f64, NaN compares false)
+// Order-preserving compaction of the kept ray ids by ONE workgroup: a ballot prefix inside each
+// wave, a 16-entry LDS scan across waves, a running base across 1024-ray rounds.  Mapping batches
+// are a few thousand rays, so one workgroup is the whole job.
+// =====================================================================================
+__global__ __launch_bounds__(1024) void k_prefilter(const float* __restrict__ ro, const float* __restrict__ rd,
+                                                    const float* __restrict__ depth, int n, const double* __restrict__ bnd,
+                                                    int* __restrict__ out_index, int* __restrict__ out_count) {
+    __shared__ int s_w[16];
+    __shared__ int s_base;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double b[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) b[k] = bnd[k];
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        bool keep = false;
+        if (i < n) {
+            double t = INFINITY; bool nan = false;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double o = (double)ro[3 * i + k], d = (double)rd[3 * i + k];
+                const double t0 = (b[2 * k] - o) / d, t1 = (b[2 * k + 1] - o) / d;
+                nan |= (t0 != t0) | (t1 != t1);            // torch.max / torch.min propagate NaN
+                const double tm = t0 > t1 ? t0 : t1;
+                t = tm < t ? tm : t;
+            }
+            keep = !nan && (t >= (double)depth[i]);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_w[wv] = __popcll(m);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int c = s_w[w]; before += w < wv ? c : 0; total += c; }
+        const int base = s_base;
+        if (keep) out_index[base + before + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = base + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out_count = s_base;
+}
+
+// =====================================================================================
 // a4: sampler
 // =====================================================================================
 __device__ __forceinline__ unsigned f2ord(float f) {
@@ -893,6 +941,16 @@ int adfp_pack_attention(const float* flat, float* packed, void* stream) {
 int adfp_get_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w, float* rays_o, float* rays_d, void* stream) {
     if (!c2w || !rays_o || !rays_d || H <= 0 || W <= 0) return ADFP_E_ARG;
     hipLaunchKernelGGL(k_get_rays, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, H, W, fx, fy, cx, cy, c2w, rays_o, rays_d);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
+int adfp_prefilter_rays(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double* bound_dev,
+                        int* out_index, int* out_count, void* stream) {
+    if (!out_count || n_rays < 0) return ADFP_E_ARG;
+    if (n_rays == 0) return (int)hipMemsetAsync(out_count, 0, 4, (hipStream_t)stream);
+    if (!rays_o || !rays_d || !gt_depth || !bound_dev || !out_index) return ADFP_E_ARG;
+    hipLaunchKernelGGL(k_prefilter, dim3(1), dim3(1024), 0, (hipStream_t)stream, rays_o, rays_d, gt_depth, n_rays, bound_dev, out_index, out_count);
     ADFP_CHECK_LAUNCH();
     return 0;
 }

@@ -125,6 +125,14 @@ int adfp_pack_attention(const float* flat, float* packed, void* stream);
 int adfp_get_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w,
                   float* rays_o /*[H*W,3]*/, float* rays_d /*[H*W,3]*/, void* stream);
 
+/* ---- a3: the Mapper's bounding-box pre-filter (src/Mapper.py:438-449) ------------------ */
+/* Keeps ray i iff min over axes of max over the two bound planes of (bound - o) / d >= gt_depth
+ * (f64 arithmetic on f32 rays, as the reference's f64 `self.bound` promotes it; NaN compares false).
+ * bound_dev: [3][2] float64 ON THE DEVICE.  out_index [n_rays] int32 receives the kept ray ids in
+ * ascending order (= boolean-mask indexing), *out_count (device int) their number. */
+int adfp_prefilter_rays(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays,
+                        const double* bound_dev, int* out_index, int* out_count, void* stream);
+
 /* ---- a4: sampler (src/utils/Renderer.py:134-221) ------------------------------------ */
 /* gt_depth may be NULL (then n_surface is ignored, near = 0.01).  t_rand [N,n_samples] is
  * the caller's torch.rand draw when perturb > 0 (Renderer.py:216), else NULL.

@@ -119,6 +119,18 @@ def sample_z(rays_o, rays_d, gt_depth, bound, N_samples, N_surface, lindisp=Fals
 
 
 # ----------------------------------------------------------------------------------
+# a3: the Mapper's bounding-box pre-filter  (src/Mapper.py:438-449)
+# ----------------------------------------------------------------------------------
+def prefilter_mask(rays_o, rays_d, gt_depth, bound):
+    """inside_mask of src/Mapper.py:440-445 (bound f64 [3,2], rays f32)."""
+    det_rays_o = rays_o.clone().detach().unsqueeze(-1)                     # (N, 3, 1)
+    det_rays_d = rays_d.clone().detach().unsqueeze(-1)
+    t = (bound.unsqueeze(0) - det_rays_o) / det_rays_d
+    t, _ = torch.min(torch.max(t, dim=2)[0], dim=1)
+    return t >= gt_depth
+
+
+# ----------------------------------------------------------------------------------
 # a6/a7/a10: normalisation and trilinear lookup  (src/common.py:275-290, decoder.py:168-175)
 # ----------------------------------------------------------------------------------
 def normalize_3d_coordinate(p, bound):

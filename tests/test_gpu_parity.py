@@ -335,3 +335,30 @@ def test_tsdf_generic_strides_path(mini, gm):
     got = gm.rend.eval_points_tsdf(edge.to(DEV), gm.tsdf, DEV).cpu().reshape(-1)
     ref = O.trilerp(mini.tsdf_volume, edge, mini.tsdf_bnds).reshape(-1)
     assert (got - ref).abs().max().item() <= 5e-7
+
+
+@pytest.mark.parametrize('n', [0, 1, 63, 1023, 1024, 1025, 5000, 20001])
+def test_prefilter_rays_vs_oracle(mini, n):
+    """a3 (src/Mapper.py:438-449): kept rays and their ORDER equal boolean-mask indexing; zero direction
+    components (inf / NaN in the slab test) and exact-equality depths included; autograd survives."""
+    dev = torch.device('cuda:0')
+    scene = synthetic.mini_scene()
+    ro, rd, depth, color = synthetic.make_ray_batch(scene, max(n, 1), seed=11 + n, zero_frac=0.2)
+    ro, rd, depth, color = ro[:n], rd[:n], depth[:n], color[:n]
+    g = torch.Generator().manual_seed(n)
+    depth = depth * (0.5 + 1.5 * torch.rand(depth.shape, generator=g))      # some beyond the box -> dropped
+    if n >= 63:
+        rd[3, 0] = 0.0                          # +-inf on one axis
+        rd[5] = 0.0                             # inf everywhere
+        ro[7, 1] = float(scene.bound[1, 0]); rd[7, 1] = 0.0      # 0/0 = NaN on one plane -> ray dropped
+        t = (scene.bound.unsqueeze(0) - ro[9:10].unsqueeze(-1)) / rd[9:10].unsqueeze(-1)
+        depth[9] = torch.min(torch.max(t, dim=2)[0], dim=1)[0].float()      # t == depth after f32 rounding or not
+    mask = O.prefilter_mask(ro, rd, depth, scene.bound)
+    ro_g = ro.to(dev).requires_grad_(True)
+    o, d, z, c = common.filter_rays_in_bound(ro_g, rd.to(dev), depth.to(dev), color.to(dev), scene.bound)
+    assert o.shape[0] == int(mask.sum())
+    assert torch.equal(o.detach().cpu(), ro[mask]) and torch.equal(d.cpu(), rd[mask])
+    assert torch.equal(z.cpu(), depth[mask]) and torch.equal(c.cpu(), color[mask])
+    if n:
+        o.sum().backward()
+        assert torch.equal(ro_g.grad.cpu(), mask.float().unsqueeze(-1).expand(-1, 3))

@@ -127,3 +127,17 @@ def test_tracker_ray_gradients(mini):
     assert abs(loss.item() - float(g['loss'])) <= 1e-9 * abs(float(g['loss']))
     assert (ro.grad - torch.from_numpy(g['g_rays_o'])).abs().max().item() <= 1e-4
     assert (rd.grad - torch.from_numpy(g['g_rays_d'])).abs().max().item() <= 1e-4
+
+
+def test_prefilter_mask_properties(mini):
+    """a3 restatement (src/Mapper.py:438-449; the Mapper cannot be imported here, so this function is
+    pinned by properties only): rays whose depth is the analytic ray/box distance are kept, rays
+    reported 5 % beyond the bounding box are dropped."""
+    from attentive_dfprior_amd import synthetic
+    scene = synthetic.mini_scene()
+    ro, rd, _, _ = synthetic.make_ray_batch(scene, 300, seed=4, zero_frac=0.0)
+    t = (scene.bound.unsqueeze(0) - ro.unsqueeze(-1)) / rd.unsqueeze(-1)
+    t_exit = torch.min(torch.max(t, dim=2)[0], dim=1)[0]
+    assert bool(O.prefilter_mask(ro, rd, (0.95 * t_exit).float(), scene.bound).all())
+    assert not bool(O.prefilter_mask(ro, rd, (1.05 * t_exit).float(), scene.bound).any())
+    assert bool(O.prefilter_mask(ro, rd, torch.zeros(300), scene.bound).all())
