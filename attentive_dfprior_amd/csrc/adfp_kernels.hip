@@ -1299,6 +1299,8 @@ static int launch_outer(OuterArgs& oa, const float* stage, const int* count_ptr,
 template <int CDIM, int NOUT, int ROLE, bool PGRAD>
 static int run_decode_bwd_p(DecodeBwdArgs a, int total, const int* count_ptr, float* flat, BwdWorkspace& bw, hipStream_t st) {
     if (total == 0) return 0;
+    // the scatter cache keeps its slot number in the top 5 bits of the voxel index
+    if (ROLE != ROLE_HIGH && a.g_grid && (long long)a.g0.X * a.g0.Y * a.g0.Z >= (1ll << 27)) return ADFP_E_UNSUPPORTED;
     if (!flat) {
         a.stage = nullptr; a.chunk_lo = 0; a.chunk_hi = total;
         const int ntiles = (total + 31) / 32;

@@ -31,6 +31,7 @@ def main():
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--rays', type=int, default=5000)
     ap.add_argument('--scene', default='office0')
+    ap.add_argument('--profile', action='store_true', help='synchronise after every section and print where the time goes')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     sc = synthetic.Scene(args.scene, device=dev)
@@ -50,9 +51,18 @@ def main():
     keyframes = []
     hist = []
     torch.manual_seed(0)
+    sect = {}
+
+    def tick(name, t0):
+        if args.profile:
+            torch.cuda.synchronize()
+            sect[name] = sect.get(name, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
+
     t_start = time.perf_counter()
     n_iter = 0
     for f in range(args.frames):
+        tk = time.perf_counter()
         ang = 2 * math.pi * f / args.frames
         c2w = sc.default_c2w(offset=(1.5 * math.cos(ang), 1.5 * math.sin(ang), 0.2 * math.sin(3 * ang)), yaw=ang, pitch=-0.1)
         depth = sc.depth_image(c2w)
@@ -65,6 +75,7 @@ def main():
                                 {'params': [grids['grid_low']], 'lr': 0}, {'params': [grids['grid_high']], 'lr': 0},
                                 {'params': [grids['grid_color']], 'lr': 0}])
         first = None
+        tk = tick('frame setup (pose, depth image, optimizer)', tk)
         for it in range(args.iters):
             stage = 'low' if it <= int(args.iters * 0.4) else ('high' if it <= int(args.iters * 0.6) else 'color')
             lr = STAGE_LR[stage]
@@ -77,21 +88,28 @@ def main():
                                                     kdepth, target_color, dev)
                 ros.append(ro.float()); rds.append(rd.float()); gds.append(gd.float()); gcs.append(gc.float())
             ro, rd, gd, gc = torch.cat(ros), torch.cat(rds), torch.cat(gds), torch.cat(gcs)
+            tk = tick('get_samples x frames', tk)
             with torch.no_grad():                                   # bbox pre-filter, src/Mapper.py:439-449
                 t = (bound.unsqueeze(0) - ro.unsqueeze(-1)) / rd.unsqueeze(-1)
                 t, _ = torch.min(torch.max(t, dim=2)[0], dim=1)
                 inside = t >= gd
             ro, rd, gd, gc = ro[inside], rd[inside], gd[inside], gc[inside]
+            tk = tick('bbox pre-filter', tk)
             d, u, col, w = rend.render_batch_ray(grids, dec, rd, ro, dev, sc.tsdf_volume, tsdf_bnds, stage, gd)
+            tk = tick('render forward', tk)
             m = gd > 0
             loss = torch.abs(gd[m] - d[m]).sum()
             if stage == 'color':
                 loss = loss + 0.2 * torch.abs(gc - col).sum()
+            tk = tick('loss', tk)
             loss.backward()
+            tk = tick('backward', tk)
             opt.step()
+            tk = tick('Adam', tk)
             n_iter += 1
             if first is None:
                 first = float(loss) / max(1, int(m.sum()))
+            tk = tick('bookkeeping', tk)
         c = {k: v.detach() for k, v in grids.items()}
         hist.append((first, float(loss) / max(1, int(m.sum()))))
         if not math.isfinite(hist[-1][1]):
@@ -104,6 +122,7 @@ def main():
                       'rays_per_iter': args.rays, 'iterations': n_iter, 'seconds': dt, 'ms_per_iteration': dt / n_iter * 1e3,
                       'depth_loss_per_ray_first_quarter': mean([h[1] for h in hist[:q]]),
                       'depth_loss_per_ray_last_quarter': mean([h[1] for h in hist[-q:]]),
+                      'sections_ms_per_iteration': {k: v / n_iter * 1e3 for k, v in sect.items()},
                       'all_finite': True, 'grid_absmax': {k: float(v.abs().max()) for k, v in c.items()}}))
 
 
