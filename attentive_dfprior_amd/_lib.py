@@ -100,6 +100,11 @@ SYMBOLS = [
     ('adfp_composite', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_render_forward', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpRenderArgs), C.c_void_p]),
+    ('adfp_frustum_mask', C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(Bound), C.POINTER(C.c_float * 16),
+                                    C.POINTER(C.c_float * 16), C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_masked_adam', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int,
+                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     ('adfp_tsdf_stage', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_backward_workspace_bytes', C.c_size_t, [C.c_longlong]),

@@ -777,6 +777,7 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
 
 #include "adfp_backward.h"
 #include "adfp_fusion.h"
+#include "adfp_mapping.h"
 
 // =====================================================================================
 // host side: C ABI
@@ -1176,6 +1177,45 @@ int adfp_tsdf_integrate(float* tsdf, float* weight, float* color, int dim_x, int
     for (int k = 0; k < 16; ++k) a.pose[k] = cam_pose[k];
     a.color_im = color_im; a.depth_im = depth_im; a.im_h = im_h; a.im_w = im_w; a.trunc = trunc_margin; a.obs_w = obs_weight;
     hipLaunchKernelGGL(k_tsdf_integrate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
+int adfp_frustum_mask(int X, int Y, int Z, const double bound[3][2], const float c2w[16], const float w2c[16], double fx, double fy,
+                      double cx, double cy, int H, int W, const float* depth, float* sampled, unsigned* scratch, unsigned char* mask,
+                      void* stream) {
+    if (!bound || !c2w || !w2c || !depth || !sampled || !scratch || !mask || X <= 0 || Y <= 0 || Z <= 0 || H <= 0 || W <= 0) return ADFP_E_ARG;
+    FrustumArgs a;
+    a.X = X; a.Y = Y; a.Z = Z;
+    for (int k = 0; k < 3; ++k) { a.lo[k] = bound[k][0]; a.hi[k] = bound[k][1]; a.cam[k] = c2w[4 * k + 3]; }
+    for (int k = 0; k < 16; ++k) a.w2c[k] = w2c[k];
+    a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.H = H; a.W = W; a.depth = depth;
+    a.sampled = sampled; a.dmax_ord = scratch; a.mask = mask;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(scratch, 0, 4, st);
+    if (e != hipSuccess) return (int)e;
+    const long long n = (long long)X * Y * Z;
+    long long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_frustum_depth, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    ADFP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_frustum_mask, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
+int adfp_masked_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const unsigned char* mask, long long nvox,
+                     int channels, float lr, float beta1, float beta2, float eps, int step, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || nvox < 0 || channels <= 0 || step < 1) return ADFP_E_ARG;
+    if (nvox == 0) return 0;
+    AdamArgs a;
+    a.param = param; a.grad = grad; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.mask = mask; a.nvox = nvox; a.C = channels;
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    // bias corrections in double like torch.optim (python floats), then one rounding to f32
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.step_size = (float)((double)lr / bc1);
+    a.sqrt_bc2 = (float)sqrt(bc2);
+    const long long threads = ((nvox + 3) >> 2) * channels;
+    hipLaunchKernelGGL(k_masked_adam, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     ADFP_CHECK_LAUNCH();
     return 0;
 }

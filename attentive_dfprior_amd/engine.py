@@ -53,7 +53,7 @@ class Engine(object):
         if hit is not None and hit[0] == key:
             return hit[1]
         val = _host_bound(t)
-        self._bound_cache[slot] = (key, val)
+        self._bound_cache[slot] = (key, val, t.untyped_storage())     # pins the storage, see grid_cl
         return val
 
     def grid_cl(self, name, g):
@@ -76,7 +76,9 @@ class Engine(object):
             dst = torch.empty((Z, Y, X, 32), dtype=torch.float32, device=src.device)
         check(lib().adfp_relayout_grid(ptr(src), ptr(dst), 32, Z, Y, X, _lib.current_stream(src.device)),
               'adfp_relayout_grid')
-        self._grid_cache[name] = (key, dst)
+        # the cache entry keeps the source's storage alive: (data_ptr, _version) identifies the contents only as
+        # long as the allocator cannot hand the same address to another tensor
+        self._grid_cache[name] = (key, dst, g.untyped_storage())
         return dst
 
     # ---- descriptor ----------------------------------------------------------------------

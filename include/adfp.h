@@ -243,6 +243,25 @@ int adfp_tsdf_integrate(float* tsdf, float* weight, float* color, int dim_x, int
                         float voxel_size, const float cam_intr[9], const float cam_pose[16], const float* color_im,
                         const float* depth_im, int im_h, int im_w, float trunc_margin, float obs_weight, void* stream);
 
+/* ---- Mapper bookkeeping on the device ----------------------------------- */
+/* Frustum feature selection, src/Mapper.py:90-158: which points of an X x Y x Z feature grid (point
+ * coordinates = linspace over `bound` per axis) project into the current depth image in front of the sensed
+ * surface (+0.5 m), plus the ball of radius 0.5 m around the camera centre.  The reference does this on the
+ * host with numpy and cv2.remap (bilinear, 1/32-pixel map rounding, constant-0 border -- restated here).
+ * c2w / w2c (= inverse, computed by the caller) are HOST 4x4 row-major fp32; depth is the [H,W] fp32 image on
+ * the device; sampled: X*Y*Z floats of device workspace; scratch: 4 bytes of device workspace.
+ * mask: X*Y*Z bytes written in the grid tensor's [Z][Y][X] order (the permute(2,1,0) of src/Mapper.py:345). */
+int adfp_frustum_mask(int X, int Y, int Z, const double bound[3][2], const float c2w[16], const float w2c[16],
+                      double fx, double fy, double cx, double cy, int H, int W, const float* depth,
+                      float* sampled, unsigned* scratch, unsigned char* mask, void* stream);
+/* One torch.optim.Adam step (amsgrad off, weight_decay 0; src/Mapper.py:374-378, :473) on the masked
+ * voxels of a channel-major grid [channels][nvox], in place -- instead of the reference's compact copy
+ * `val[mask]` that is index_put into the grid before and after every iteration (src/Mapper.py:347-361,
+ * :382-388, :476-482).  exp_avg / exp_avg_sq have the grid's shape and must be zero before step 1; elements
+ * outside the mask (mask == NULL: none) are not touched.  step counts from 1. */
+int adfp_masked_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const unsigned char* mask,
+                     long long nvox, int channels, float lr, float beta1, float beta2, float eps, int step, void* stream);
+
 /* Per-stage timing hook for bench.py: runs ONLY the TSDF trilerp + band-mask kernel (a10).
  * w may be NULL (that is the render path's launch: there the LOW decoder writes w = 1). */
 int adfp_tsdf_stage(const adfp_scene* scene, const adfp_points* pts, unsigned char* flags,

@@ -468,3 +468,57 @@ def tsdf_integrate_np(tsdf, weight, color, origin, voxel, cam_intr, cam_pose, co
     nr = np.minimum(c_roundf((orr * w_old + obs_w * nr) / w_new), f(255))
     col[ok] = nb * f(65536) + ng * f(256) + nr
     return t.reshape(tsdf.shape), wt.reshape(tsdf.shape), col.reshape(tsdf.shape)
+
+
+# ----------------------------------------------------------------------------------
+# frustum feature selection  (src/Mapper.py:90-158)
+# PARITY UNPINNED: src.Mapper needs cv2 / colorama, which the build container lacks, so the reference's
+# function cannot be executed here; cv2.remap is restated from OpenCV's documented algorithm
+# (imgproc remap, INTER_LINEAR: map rounded to 1/32 pixel with cvRound, weights from the 32x32 bilinear
+# table, BORDER_CONSTANT value 0 for taps outside the image).
+# ----------------------------------------------------------------------------------
+def remap_linear_np(img, u, v):
+    import numpy as np
+    H, W = img.shape
+    su = np.rint(u.astype(np.float32) * np.float32(32)).astype(np.int64)
+    sv = np.rint(v.astype(np.float32) * np.float32(32)).astype(np.int64)
+    sx = np.clip(su >> 5, -32768, 32767)
+    sy = np.clip(sv >> 5, -32768, 32767)
+    fx = ((su & 31).astype(np.float32)) * np.float32(1 / 32)
+    fy = ((sv & 31).astype(np.float32)) * np.float32(1 / 32)
+    one = np.float32(1)
+    w = [(one - fy) * (one - fx), (one - fy) * fx, fy * (one - fx), fy * fx]
+
+    def tap(yy, xx):
+        ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+        return np.where(ok, img[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)], np.float32(0)).astype(np.float32)
+    out = tap(sy, sx) * w[0] + tap(sy, sx + 1) * w[1] + tap(sy + 1, sx) * w[2] + tap(sy + 1, sx + 1) * w[3]
+    gone = (sx >= W) | (sx + 1 < 0) | (sy >= H) | (sy + 1 < 0)
+    return np.where(gone, np.float32(0), out).astype(np.float32)
+
+
+def frustum_mask_np(c2w, val_shape, depth_np, bound, H, W, fx, fy, cx, cy):
+    """Mapper.get_mask_from_c2w; returns the bool mask in the grid tensor's [Z, Y, X] order
+    (= the reference's [X, Y, Z] result after the permute(2, 1, 0) of src/Mapper.py:345)."""
+    import numpy as np
+    Z, Y, X = val_shape
+    gx, gy, gz = torch.meshgrid(torch.linspace(bound[0][0], bound[0][1], X), torch.linspace(bound[1][0], bound[1][1], Y),
+                                torch.linspace(bound[2][0], bound[2][1], Z), indexing='ij')      # Mapper.py:105-107
+    pts = torch.stack([gx, gy, gz], -1).reshape(-1, 3)
+    c2w = c2w.cpu().numpy()
+    w2c = np.linalg.inv(c2w)
+    homo = np.concatenate([pts.numpy(), np.ones((pts.shape[0], 1), np.float32)], 1).reshape(-1, 4, 1)
+    cam = (w2c @ homo)[:, :3]                                               # :116-117
+    K = np.array([[fx, .0, cx], [.0, fy, cy], [.0, .0, 1.0]])
+    cam[:, 0] *= -1
+    uv = K @ cam                                                            # f64 from here, :120
+    z = uv[:, -1:] + 1e-5
+    uv = (uv[:, :2] / z).astype(np.float32)
+    depths = remap_linear_np(depth_np, uv[:, 0, 0], uv[:, 1, 0]).reshape(-1, 1)
+    mask = (uv[:, 0] < W) * (uv[:, 0] > 0) * (uv[:, 1] < H) * (uv[:, 1] > 0)
+    depths[depths == 0] = np.max(depths)                                    # :138-140
+    mask = mask & (0 <= -z[:, :, 0]) & (-z[:, :, 0] <= depths + 0.5)
+    mask = mask.reshape(-1)
+    dist = pts - torch.from_numpy(c2w[:3, 3]).unsqueeze(0)                  # :146-151
+    mask = mask | (torch.sum(dist * dist, 1) < 0.5 * 0.5).numpy()
+    return np.ascontiguousarray(mask.reshape(X, Y, Z).transpose(2, 1, 0))

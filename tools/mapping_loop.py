@@ -2,8 +2,11 @@
 (training stability).  Follows the structure of Mapper.optimize_map (reference src/Mapper.py:374-473): a
 fresh Adam per frame over {decoders, mlp, low, high, color} parameter groups, the low -> high -> color stage
 schedule by iteration ratio with the per-stage learning rates of configs/df_prior.yaml:65-83, rays drawn from
-the current frame and 4 keyframes with get_samples, the bbox pre-filter, the Mapper loss.  Synthetic poses on
-a circle; ITERS iterations per frame instead of 60 to keep the run short.  Not part of the driver contract.
+the current frame and 4 keyframes with get_samples, the bbox pre-filter, the Mapper loss, frustum feature
+selection (src/Mapper.py:330-361): only the grid points in the current frustum are optimised.  The frustum
+mask, the pre-filter and the masked Adam run in libadfp.so (attentive_dfprior_amd.mapping / .common).
+Synthetic poses on a circle; ITERS iterations per frame instead of 60 to keep the run short.  Not part of
+the driver contract.
 
   python tools/mapping_loop.py [--frames 200] [--iters 10] [--rays 5000]
 """
@@ -18,7 +21,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import attentive_dfprior_amd as A                                   # noqa: E402
-from attentive_dfprior_amd import synthetic, common                 # noqa: E402
+from attentive_dfprior_amd import synthetic, common, mapping        # noqa: E402
 
 STAGE_LR = {'low': dict(mlp=0.0, dec=0.0, low=0.1, high=0.0, color=0.0),
             'high': dict(mlp=0.005, dec=0.0, low=0.005, high=0.005, color=0.0),
@@ -69,19 +72,20 @@ def main():
         if f % 5 == 0:
             keyframes.append((c2w, depth))
         frames = [(c2w, depth)] + keyframes[-4:]
-        grids = {k: v.detach().clone().requires_grad_(True) for k, v in c.items()}
+        grids = {k: v.detach().requires_grad_(True) for k, v in c.items()}
+        masks = {k: mapping.frustum_mask(c2w, tuple(v.shape[2:]), depth, sc.bound, H, W, fx, fy, cx, cy) for k, v in grids.items()}
+        opt_grids = mapping.MaskedGridAdam(grids, masks)
         opt = torch.optim.Adam([{'params': list(dec.color_decoder.parameters()), 'lr': 0},      # fix_high: True
-                                {'params': list(dec.mlp.parameters()), 'lr': 0},
-                                {'params': [grids['grid_low']], 'lr': 0}, {'params': [grids['grid_high']], 'lr': 0},
-                                {'params': [grids['grid_color']], 'lr': 0}])
+                                {'params': list(dec.mlp.parameters()), 'lr': 0}])
         first = None
         tk = tick('frame setup (pose, depth image, optimizer)', tk)
         for it in range(args.iters):
             stage = 'low' if it <= int(args.iters * 0.4) else ('high' if it <= int(args.iters * 0.6) else 'color')
             lr = STAGE_LR[stage]
-            for g, key in zip(opt.param_groups, ('dec', 'mlp', 'low', 'high', 'color')):
+            for g, key in zip(opt.param_groups, ('dec', 'mlp')):
                 g['lr'] = lr[key]
             opt.zero_grad()
+            opt_grids.zero_grad()
             ros, rds, gds, gcs = [], [], [], []
             for kc2w, kdepth in frames:
                 ro, rd, gd, gc = common.get_samples(0, H, 0, W, args.rays // len(frames), H, W, fx, fy, cx, cy, kc2w,
@@ -89,11 +93,7 @@ def main():
                 ros.append(ro.float()); rds.append(rd.float()); gds.append(gd.float()); gcs.append(gc.float())
             ro, rd, gd, gc = torch.cat(ros), torch.cat(rds), torch.cat(gds), torch.cat(gcs)
             tk = tick('get_samples x frames', tk)
-            with torch.no_grad():                                   # bbox pre-filter, src/Mapper.py:439-449
-                t = (bound.unsqueeze(0) - ro.unsqueeze(-1)) / rd.unsqueeze(-1)
-                t, _ = torch.min(torch.max(t, dim=2)[0], dim=1)
-                inside = t >= gd
-            ro, rd, gd, gc = ro[inside], rd[inside], gd[inside], gc[inside]
+            ro, rd, gd, gc = common.filter_rays_in_bound(ro, rd, gd, gc, bound)     # src/Mapper.py:439-449
             tk = tick('bbox pre-filter', tk)
             d, u, col, w = rend.render_batch_ray(grids, dec, rd, ro, dev, sc.tsdf_volume, tsdf_bnds, stage, gd)
             tk = tick('render forward', tk)
@@ -105,6 +105,7 @@ def main():
             loss.backward()
             tk = tick('backward', tk)
             opt.step()
+            opt_grids.step({'grid_low': lr['low'], 'grid_high': lr['high'], 'grid_color': lr['color']})
             tk = tick('Adam', tk)
             n_iter += 1
             if first is None:
