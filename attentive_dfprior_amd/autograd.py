@@ -24,7 +24,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.bundle = bundle
         ctx.saved = saved
         ctx.c = c
-        ctx.n_params = [len(list(getattr(decoders, attr).parameters())) for _, attr in _NETS]
+        ctx.n_params = [len(decoders.net_params(name)) for name, _ in _NETS]
         ctx.set_materialize_grads(False)
         return depth, unc, color, weight
 
@@ -51,14 +51,20 @@ class _RenderFn(torch.autograd.Function):
         off = 6
         for (name, attr), n in zip(_NETS, ctx.n_params):
             flat = flats.get(name)
-            pos = 0
-            for p in getattr(decoders, attr).parameters():
-                if flat is not None and ctx.needs_input_grad[off]:
-                    out.append(flat[pos:pos + p.numel()].reshape(p.shape).to(p.dtype))
-                else:
-                    out.append(None)
-                pos += p.numel()
-                off += 1
+            params = decoders.net_params(name)
+            if flat is None:
+                out.extend([None] * n)
+            else:
+                pieces = torch.split(flat, [p.numel() for p in params])       # views of the flat gradient
+                for p, piece in zip(params, pieces):
+                    if ctx.needs_input_grad[off]:
+                        g = piece.view(p.shape)
+                        out.append(g if g.dtype == p.dtype else g.to(p.dtype))
+                    else:
+                        out.append(None)
+                    off += 1
+                continue
+            off += n
         ctx.saved = None
         return tuple(out)
 
@@ -70,6 +76,6 @@ def render_with_grad(engine, decoders, c, rays_o, rays_d, gt_depth, tsdf_volume,
     bundle = (engine, decoders, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, n_samples, n_surface,
               lindisp, perturb, t_rand, depth_max)
     params = []
-    for _, attr in _NETS:
-        params += list(getattr(decoders, attr).parameters())
+    for name, _ in _NETS:
+        params += decoders.net_params(name)
     return _RenderFn.apply(bundle, rays_o, rays_d, c['grid_low'], c['grid_high'], c['grid_color'], *params)

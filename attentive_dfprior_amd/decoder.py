@@ -102,12 +102,15 @@ class mlp_tsdf(nn.Module):
         raise NotImplementedError('mlp_tsdf is evaluated fused inside DF.forward (libadfp.so)')
 
 
-def _flat_params(module):
-    return torch.cat([p.detach().reshape(-1).float() for p in module.parameters()])
+def _flat_params(params):
+    return torch.cat([p.detach().reshape(-1).float() for p in params])
 
 
-def _version_key(module):
-    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+def _version_key(params):
+    return tuple((p.data_ptr(), p._version) for p in params)
+
+
+_NET_ATTR = {'low': 'low_decoder', 'high': 'high_decoder', 'color': 'color_decoder', 'att': 'mlp'}
 
 
 class DF(nn.Module):
@@ -135,15 +138,32 @@ class DF(nn.Module):
                                  pos_embedding_method=pos_embedding_method)
         self.mlp = mlp_tsdf()
         self._packed = {}       # name -> (version key, packed tensor)
+        self._plists = {}       # name -> tuple of the sub-network's parameters (module walks are slow)
         self._engine = None
+
+    def net_params(self, name):
+        """The parameters of one sub-network ('low' / 'high' / 'color' / 'att') in state_dict order.  Cached:
+        nn.Module.parameters() walks the module tree (0.5 ms per training iteration when called per use);
+        conversions that may replace Parameter objects (_apply) drop the cache."""
+        hit = self._plists.get(name)
+        if hit is None:
+            hit = tuple(getattr(self, _NET_ATTR[name]).parameters())
+            self._plists[name] = hit
+        return hit
+
+    def any_requires_grad(self):
+        return any(p.requires_grad for n in _NET_ATTR for p in self.net_params(n))
+
+    def _apply(self, fn, *args, **kwargs):
+        self._plists = {}
+        return super()._apply(fn, *args, **kwargs)
 
     # ---- weight images for the kernels -------------------------------------------------
     def packed_weights(self, name, fmt='f32'):
         """Packed (MFMA operand order) image of one sub-network, rebuilt only when a parameter
         changed (optimizer step bumps Parameter._version).  fmt 'f32' = exact f32-input MFMA image,
         'h' = f16 hi/lo split image of the forward decoders (adfp_pack_decoder_h)."""
-        module = {'low': self.low_decoder, 'high': self.high_decoder, 'color': self.color_decoder,
-                  'att': self.mlp}[name]
+        module = self.net_params(name)
         key = _version_key(module)
         slot = name if fmt == 'f32' else name + '.h'
         hit = self._packed.get(slot)
@@ -191,10 +211,11 @@ class DF(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k in ('_packed', '_engine'):
+            if k in ('_packed', '_engine', '_plists'):
                 continue
             setattr(new, k, copy.deepcopy(v, memo))
         new._packed = {}
+        new._plists = {}
         new._engine = None
         return new
 
@@ -202,6 +223,7 @@ class DF(nn.Module):
         # torch.multiprocessing spawn pickles the module (src/DF_Prior.py:302-311)
         d = self.__dict__.copy()
         d['_packed'] = {}
+        d['_plists'] = {}
         d['_engine'] = None
         return d
 

@@ -137,11 +137,8 @@ class Engine(object):
     def eval_points(self, decoders, pts, c, tsdf_volume, tsdf_bnds, bound, stage, apply_bound_rule=True):
         """pts [P,3] f64/f32 on the GPU -> raw [P,4] f32, w [P] f32."""
         _lib.require_cuda(pts, 'points')
-        if torch.is_grad_enabled() and (pts.requires_grad or any(v.requires_grad for v in c.values())
-                                         or any(p.requires_grad for p in decoders.parameters())):
-            # point-wise queries are inference-only in the reference too (Mesher under no_grad,
-            # src/utils/Mesher.py:437-447); training goes through Renderer.render_batch_ray
-            pass
+        # point-wise queries are inference-only (the reference's Mesher runs them under no_grad,
+        # src/utils/Mesher.py:437-447); training goes through Renderer.render_batch_ray
         dev = pts.device
         with torch.cuda.device(dev):
             if pts.dtype == torch.float64:

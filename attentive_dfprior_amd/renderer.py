@@ -70,7 +70,7 @@ class Renderer(object):
         if self.perturb > 0.:
             t_rand = torch.rand(N, self.N_samples)                        # CPU generator, as Renderer.py:216
         needs_grad = torch.is_grad_enabled() and (
-            any(v.requires_grad for v in c.values()) or any(p.requires_grad for p in decoders.parameters())
+            any(v.requires_grad for v in c.values()) or decoders.any_requires_grad()
             or rays_o.requires_grad or rays_d.requires_grad)
         if needs_grad:
             from .autograd import render_with_grad
