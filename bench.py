@@ -156,6 +156,24 @@ def main():
 
     if rank == 0 and not args.no_stage_timing:
         result.update(stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF))
+        if os.environ.get('ADFP_MATH', 'f16x3') == 'f16x3':
+            # the same frame with every product on the exact f32-input MFMA (ADFP_MATH=f32), for reference:
+            # the f16x3 split reproduces f32 products to 2^-22, this is the bit-exact mode
+            os.environ['ADFP_MATH'] = 'f32'
+            try:
+                step()
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    out32 = step()
+                torch.cuda.synchronize(dev)
+                dt = (time.perf_counter() - t1) / 3
+            finally:
+                os.environ['ADFP_MATH'] = 'f16x3'
+            result['exact_f32_mode'] = {
+                'value': n_rays / dt, 'unit': 'rays/s', 'ms_per_step': dt * 1e3, 'n_gpus': 1,
+                'max_abs_diff_color_vs_default_mode': float((out32[2] - color_img).abs().max()),
+                'max_rel_diff_depth_vs_default_mode': float(((out32[0] - depth_img).abs() / depth_img.abs().clamp_min(1e-3)).max())}
     if rank == 0 and args.cpu_rays > 0:
         result.update(cpu_leg(rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF, args.cpu_rays))
     if rank == 0:
