@@ -644,6 +644,7 @@ struct OuterArgs {
     const float* stage; int ncols;
     const int* count_ptr; int chunk_lo, chunk_hi;   // rows = min(chunk_hi, *count_ptr) - chunk_lo
     float* flat;                                    // flat gradient (state_dict order)
+    float* partial; int part_stride;                // k_outer_lds: one private copy of the flat gradient per workgroup
     int njobs; int rows_per_wave;
     OuterJob jobs[OUTER_MAX_JOBS];
 };
@@ -680,6 +681,111 @@ __global__ __launch_bounds__(64) void k_outer(OuterArgs a) {
             if (row < jb.nr && acc[r] != 0.f) atomicAdd(a.flat + jb.dst + row * jb.rs + j * jb.cs, acc[r]);
         }
     }
+}
+
+// The same job table, staged through LDS.  k_outer reads every staging column block once per job that
+// uses it (2 x 128 B per point per job, ~7.7 KB per point for a decoder whose row is 3 KB) and runs at the
+// rate L2 delivers those 128-B pieces.  Here a 512-thread workgroup streams its rows ONCE, 16 at a time,
+// coalesced into a double-buffered LDS tile of whole staging rows, and its 8 waves split the jobs (up to 7
+// accumulator blocks per wave); every MFMA operand is a conflict-free ds_read_b32.  One barrier per 16 rows.
+// Two jobs may write the same gradient element only through DIFFERENT (row, column) sub-blocks, so within a
+// workgroup the slot updates never collide.
+#define OUTER_NW 8
+#define OUTER_JW (OUTER_MAX_JOBS / OUTER_NW)
+#define OUTER_RT 16
+#define OUTER_MAXCOLS 832
+__global__ __launch_bounds__(512) void k_outer_lds(OuterArgs a) {
+    __shared__ __attribute__((aligned(16))) float sm[2 * OUTER_RT * OUTER_MAXCOLS];
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+    int hi = a.chunk_hi;
+    if (a.count_ptr) { const int cnt = *a.count_ptr; hi = hi < cnt ? hi : cnt; }
+    const int rows = hi - a.chunk_lo;
+    const int m0 = blockIdx.x * a.rows_per_wave;          // rows_per_wave = rows per WORKGROUP here
+    if (m0 >= rows) return;
+    const int m1 = (m0 + a.rows_per_wave < rows) ? m0 + a.rows_per_wave : rows;
+    const int nc = a.ncols, n4 = OUTER_RT * nc / 4;       // float4 pieces of one 16-row tile
+    constexpr int LD = (OUTER_RT * OUTER_MAXCOLS / 4 + 511) / 512;
+    f32x16 acc[OUTER_JW];
+#pragma unroll
+    for (int j = 0; j < OUTER_JW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    int ca[OUTER_JW], cb[OUTER_JW];                        // this wave's jobs: byte-free LDS column offsets
+#pragma unroll
+    for (int j = 0; j < OUTER_JW; ++j) {
+        const int job = wv + OUTER_NW * j;
+        ca[j] = job < a.njobs ? a.jobs[job].colA + i : -1;
+        cb[j] = job < a.njobs ? a.jobs[job].colB + i : -1;
+    }
+    f32x4 ld[LD];
+    auto fetch = [&](int row0) {                           // rows row0 .. row0+15 -> registers (zeros past m1)
+        const f32x4* src = (const f32x4*)(a.stage + (long long)row0 * nc);
+        const int lim = (m1 - row0) * (nc / 4);            // float4 pieces that belong to real rows
+#pragma unroll
+        for (int k = 0; k < LD; ++k) {
+            const int e = threadIdx.x + 512 * k;
+            ld[k] = (e < n4 && e < lim) ? src[e] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stash = [&](int buf) {
+        f32x4* dst = (f32x4*)(sm + buf * OUTER_RT * OUTER_MAXCOLS);
+#pragma unroll
+        for (int k = 0; k < LD; ++k) { const int e = threadIdx.x + 512 * k; if (e < n4) dst[e] = ld[k]; }
+    };
+    fetch(m0);
+    stash(0);
+    int buf = 0;
+    for (int m = m0; m < m1; m += OUTER_RT, buf ^= 1) {
+        const bool more = m + OUTER_RT < m1;
+        if (more) fetch(m + OUTER_RT);
+        __syncthreads();                                   // tile `buf` complete; everyone is done with `buf ^ 1`
+        const float* t = sm + buf * OUTER_RT * OUTER_MAXCOLS;
+#pragma unroll
+        for (int j = 0; j < OUTER_JW; ++j) {
+            if (ca[j] >= 0) {
+#pragma unroll
+                for (int s = 0; s < OUTER_RT / 2; ++s) {
+                    const float va = t[(2 * s + h) * nc + ca[j]], vb = t[(2 * s + h) * nc + cb[j]];
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vb, acc[j], 0, 0, 0);
+                }
+            }
+        }
+        if (more) stash(buf ^ 1);
+    }
+    // The workgroup owns slot blockIdx.x of `partial` (zeroed before the network's first chunk): plain
+    // read-modify-write, no atomics -- 250+ workgroups adding 64-134 KB each into ONE copy of the gradient ran
+    // at a fraction of the atomic rate (all adders on the same few rows), and the sum is now reproducible.
+    float* part = a.partial + (long long)blockIdx.x * a.part_stride;
+#pragma unroll
+    for (int j = 0; j < OUTER_JW; ++j) {
+        const int job = wv + OUTER_NW * j;
+        if (job < a.njobs) {
+            const OuterJob jb = a.jobs[job];
+            const int c = i - jb.j0;
+            if (c >= 0 && c < jb.nc) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = kmapH(r, h);
+                    if (row < jb.nr) part[jb.dst + row * jb.rs + c * jb.cs] += acc[j][r];
+                }
+            }
+        }
+    }
+}
+
+// flat[e] += sum over the workgroup slots of partial[slot][e]
+__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partial, int nslots, int stride, int n,
+                                                         float* __restrict__ flat) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= nslots; k += 4) {
+        s0 += partial[(long long)k * stride + e]; s1 += partial[(long long)(k + 1) * stride + e];
+        s2 += partial[(long long)(k + 2) * stride + e]; s3 += partial[(long long)(k + 3) * stride + e];
+    }
+    for (; k < nslots; ++k) s0 += partial[(long long)k * stride + e];
+    flat[e] += (s0 + s1) + (s2 + s3);
 }
 
 // d/d rays_o = sum_s d/dp_s,  d/d rays_d = sum_s z_s d/dp_s   (p = o + d z, Renderer.py:223)

@@ -1265,7 +1265,8 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
 // ---------------------------------------------------------------------------------------
 #define STG_ROWS_MAX 65536
 
-struct BwdWorkspace { float* g_raw; float* att_g; float* g_pts; float* stage; int stage_rows; size_t bytes; };
+#define OUTER_NSLOT 256         // workgroups per weight-gradient launch = private gradient copies (one per CU)
+struct BwdWorkspace { float* g_raw; float* att_g; float* g_pts; float* stage; int stage_rows; float* partial; int part_stride; size_t bytes; };
 static BwdWorkspace carve_bwd(void* base, long long P) {
     BwdWorkspace w; size_t o = 0; char* b = (char*)base;
     w.g_raw = (float*)(b + o); o += align256((size_t)P * 16);
@@ -1274,6 +1275,12 @@ static BwdWorkspace carve_bwd(void* base, long long P) {
     w.stage_rows = (int)(P < STG_ROWS_MAX ? P : STG_ROWS_MAX);
     if (w.stage_rows < 32) w.stage_rows = 32;
     w.stage = (float*)(b + o); o += align256((size_t)w.stage_rows * AttStage::NCOLS * 4);
+    int fmax = DecLayout<32, 1>::F_TOTAL;
+    if (DecLayout<64, 1>::F_TOTAL > fmax) fmax = DecLayout<64, 1>::F_TOTAL;
+    if (DecLayout<32, 4>::F_TOTAL > fmax) fmax = DecLayout<32, 4>::F_TOTAL;
+    if (AttLayout::F_TOTAL > fmax) fmax = AttLayout::F_TOTAL;
+    w.part_stride = (fmax + 63) / 64 * 64;
+    w.partial = (float*)(b + o); o += align256((size_t)OUTER_NSLOT * w.part_stride * 4);
     w.bytes = o;
     return w;
 }
@@ -1327,11 +1334,39 @@ static void attention_jobs(OuterArgs& a) {
     add_job(a, ST::AGL, ST::AX, A::F_BO, 1, 0, 2, 2, 1);
 }
 
-static int launch_outer(OuterArgs& oa, const float* stage, const int* count_ptr, int lo, int hi, float* flat, hipStream_t st) {
+// weight gradients of one network: outer_begin (zero the per-workgroup copies), launch_outer per staging chunk,
+// outer_end (sum the copies into the flat gradient)
+static int outer_begin(const BwdWorkspace& bw, int n_floats, hipStream_t st) {
+#ifdef ADFP_OUTER_SIMPLE
+    return 0;
+#else
+    (void)n_floats;
+    return (int)hipMemsetAsync(bw.partial, 0, (size_t)OUTER_NSLOT * bw.part_stride * 4, st);
+#endif
+}
+static int outer_end(const BwdWorkspace& bw, int n_floats, float* flat, hipStream_t st) {
+#ifndef ADFP_OUTER_SIMPLE
+    hipLaunchKernelGGL(k_reduce_partials, dim3((n_floats + 255) / 256), dim3(256), 0, st, bw.partial, OUTER_NSLOT, bw.part_stride, n_floats, flat);
+    ADFP_CHECK_LAUNCH();
+#endif
+    return 0;
+}
+static int launch_outer(OuterArgs& oa, const BwdWorkspace& bw, const int* count_ptr, int lo, int hi, float* flat, hipStream_t st) {
+    const float* stage = bw.stage;
     oa.stage = stage; oa.count_ptr = count_ptr; oa.chunk_lo = lo; oa.chunk_hi = hi; oa.flat = flat;
-    oa.rows_per_wave = 512;
+    oa.partial = bw.partial; oa.part_stride = bw.part_stride;
     const int rows = hi - lo;
+#ifdef ADFP_OUTER_SIMPLE       // A/B switch: one wave per (job, 512 rows), operands straight from L2
+    oa.rows_per_wave = 512;
     hipLaunchKernelGGL(k_outer, dim3((rows + oa.rows_per_wave - 1) / oa.rows_per_wave, oa.njobs), dim3(64), 0, st, oa);
+#else
+    if (oa.ncols > OUTER_MAXCOLS || (oa.ncols & 3) || oa.njobs > OUTER_NW * OUTER_JW) return ADFP_E_UNSUPPORTED;
+    // rows per workgroup: at most OUTER_NSLOT workgroups (each owns one private gradient copy), at least 64 rows each
+    int per = (rows + OUTER_NSLOT - 1) / OUTER_NSLOT;
+    per = ((per < 64 ? 64 : per) + OUTER_RT - 1) / OUTER_RT * OUTER_RT;
+    oa.rows_per_wave = per;
+    hipLaunchKernelGGL(k_outer_lds, dim3((rows + per - 1) / per), dim3(512), 0, st, oa);
+#endif
     ADFP_CHECK_LAUNCH();
     return 0;
 }
@@ -1351,16 +1386,18 @@ static int run_decode_bwd_p(DecodeBwdArgs a, int total, const int* count_ptr, fl
     OuterArgs oa; decoder_jobs<CDIM, NOUT>(oa);
     a.stage = bw.stage;
     const int rows_cap = (int)((size_t)bw.stage_rows * AttStage::NCOLS / DecStage<CDIM>::NCOLS);
+    int rc = outer_begin(bw, DecLayout<CDIM, NOUT>::F_TOTAL, st);
+    if (rc) return rc;
     for (int lo = 0; lo < total; lo += rows_cap) {
         const int hi = lo + rows_cap < total ? lo + rows_cap : total;
         a.chunk_lo = lo; a.chunk_hi = hi;
         const int ntiles = (hi - lo + 31) / 32;
         hipLaunchKernelGGL((k_decode_bwd<CDIM, NOUT, ROLE, true, PGRAD, 256>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, a);
         ADFP_CHECK_LAUNCH();
-        int rc = launch_outer(oa, bw.stage, count_ptr, lo, hi, flat, st);
+        rc = launch_outer(oa, bw, count_ptr, lo, hi, flat, st);
         if (rc) return rc;
     }
-    return 0;
+    return outer_end(bw, DecLayout<CDIM, NOUT>::F_TOTAL, flat, st);
 }
 template <int CDIM, int NOUT, int ROLE>
 static int run_decode_bwd(DecodeBwdArgs a, int total, const int* count_ptr, float* flat, BwdWorkspace& bw, hipStream_t st) {
@@ -1413,6 +1450,7 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
         t.att_u = r->state.att_u; t.g_weight = r->g_weight; t.g_raw = bw.g_raw; t.att_g = bw.att_g; t.stage = bw.stage;
         t.P = Pd; t.nt = make_norm(sc->tsdf_bnds); t.t = make_tsdf(sc->tsdf); t.g_pts = a.g_pts;
         OuterArgs oa; attention_jobs(oa);
+        if (r->g_flat_att) { rc = outer_begin(bw, AttLayout::F_TOTAL, st); if (rc) return rc; }
         for (int lo = 0; lo < P; lo += bw.stage_rows) {
             const int hi = lo + bw.stage_rows < P ? lo + bw.stage_rows : P;
             t.chunk_lo = lo; t.chunk_hi = hi;
@@ -1421,7 +1459,7 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
                 if (pgrad) hipLaunchKernelGGL((k_attention_bwd<true, true>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
                 else hipLaunchKernelGGL((k_attention_bwd<true, false>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
                 ADFP_CHECK_LAUNCH();
-                rc = launch_outer(oa, bw.stage, r->state.counter, lo, hi, r->g_flat_att, st);
+                rc = launch_outer(oa, bw, r->state.counter, lo, hi, r->g_flat_att, st);
                 if (rc) return rc;
             } else {
                 if (pgrad) hipLaunchKernelGGL((k_attention_bwd<false, true>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
@@ -1429,6 +1467,7 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
                 ADFP_CHECK_LAUNCH();
             }
         }
+        if (r->g_flat_att) { rc = outer_end(bw, AttLayout::F_TOTAL, r->g_flat_att, st); if (rc) return rc; }
         if (r->g_grid_high || r->g_flat_high || pgrad) {
             DecodeBwdArgs hgh = a;
             hgh.g0 = make_grid(sc->high); hgh.g1 = make_grid(sc->low); hgh.packed = sc->w_high;
