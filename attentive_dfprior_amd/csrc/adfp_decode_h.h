@@ -166,6 +166,11 @@ ADFP_DEV void mfma_chain_h(f32x16& acc, const unsigned* __restrict__ w, int lane
 
 #ifdef ADFP_STAMPS
 __device__ unsigned long long g_stamps[2 * 8192];     // debug build only: per-wave start/end wall clock (100 MHz)
+__device__ unsigned long long g_phase[8];             // debug build only: wave-cycles per tile phase, summed over waves
+#define ADFP_PHASE(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = clock64(); \
+                           __builtin_amdgcn_sched_barrier(0); ph_[k] += now_ - last_; last_ = now_; } while (0)
+#else
+#define ADFP_PHASE(k) do {} while (0)
 #endif
 
 template <int CDIM, int NOUT, int ROLE, int NT>
@@ -186,7 +191,11 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
     const int count = (ROLE == ROLE_HIGH) ? *a.count_ptr : a.P.n;
     const int ntiles = (count + 31) >> 5;
 
+#ifdef ADFP_STAMPS
+    unsigned long long ph_[6] = {0, 0, 0, 0, 0, 0}, last_ = clock64();
+#endif
     for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<NT / 64>(j, &s_next, ntiles)) >= 0;) {
+        ADFP_PHASE(0);                                  // ticket + loop overhead
         const int idx = tile * 32 + p;
         const bool valid = idx < count;
         int q = valid ? idx : 0;
@@ -206,6 +215,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
 #pragma unroll
             for (int ks = 0; ks < L::KS_C; ++ks) split8(c + 8 * ks, ch[ks], cl[ks]);
         }
+        ADFP_PHASE(1);                                  // point, normalise, gather, split c
         // Fourier features sin(p @ B) (decoder.py:26-30) -> split halves (6 k-steps)
         f16x8 eh[L::KS_E], el[L::KS_E];
 #pragma unroll
@@ -219,6 +229,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
             }
             split8(e, eh[ks], el[ks]);
         }
+        ADFP_PHASE(2);                                  // Fourier features
 
         __builtin_amdgcn_sched_barrier(0);
         // h = relu(W_i h + b_i) + (Wc_i c + bc_i); skip-concat [emb, h] feeds layer 3 (decoder.py:192-199)
@@ -243,6 +254,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
             }
         }
 
+        ADFP_PHASE(3);                                  // 5 layers
         // output_linear on the VALU in f32: each half holds 16 of the 32 hidden units
         float out[NOUT];
 #pragma unroll
@@ -267,8 +279,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
                 a.att_occ[idx] = out[0] + a.raw[4ll * q + 3];                        // high + low, decoder.py:342
             }
         }
+        ADFP_PHASE(4);                                  // output layer + store
     }
 #ifdef ADFP_STAMPS
+    if (lane == 0) for (int k = 0; k < 5; ++k) atomicAdd(&g_phase[k], ph_[k]);
     const int wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     if (lane == 0 && wave < 8192) { g_stamps[2 * wave] = stamp0; g_stamps[2 * wave + 1] = wall_clock64(); }
 #endif

@@ -1025,6 +1025,11 @@ int adfp_sample_tsdf(const adfp_tsdf* tsdf, const double tsdf_bnds[3][2], const 
 extern "C" int adfp_debug_stamps(unsigned long long* host_out, int n_waves) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), (size_t)n_waves * 16);
 }
+extern "C" int adfp_debug_phases(unsigned long long* host_out, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase), 64);
+    if (!rc && reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, 64); }
+    return rc;
+}
 #endif
 
 static int decode_grid(int ntiles, int waves_per_wg, int wg_per_cu) {

@@ -89,6 +89,17 @@ def main(reps=8):
             (e0.reshape(256, 12).max(1) - e0.reshape(256, 12).min(1)).mean(), (e0.reshape(256, 12).max(1) - e0.reshape(256, 12).min(1)).max()))
         x = wg_end.reshape(32, 8)      # blockIdx % 8 = XCD
         print('per-XCD mean WG end us:', x.mean(0).round(1).tolist())
+        ph = (C.c_ulonglong * 8)()
+        L.adfp_debug_phases.argtypes = [C.c_void_p, C.c_int]
+        L.adfp_debug_phases(ph, 1)
+        L.adfp_decode_stage(C.byref(sc), C.byref(ap), 2, _lib.ptr(raw), _lib.ptr(wb), st)
+        torch.cuda.synchronize()
+        L.adfp_debug_phases(ph, 1)
+        tot = float(sum(ph[:5]))
+        names = ['ticket/loop', 'point+gather+split c', 'Fourier', '5 layers', 'output+store']
+        ntile = P / 32
+        print('phase shares of wave-cycles (colour decoder):', {n: round(ph[k] / tot, 3) for k, n in enumerate(names)},
+              'wave-cycles per tile:', {n: round(ph[k] / ntile) for k, n in enumerate(names)})
 
 
 if __name__ == '__main__':
