@@ -2,12 +2,14 @@
 // split of every f32 operand:  a = a_hi + a_lo (a_hi = a truncated to 11 significant bits, a_lo the
 // f16-rounded remainder),  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  accumulated in fp32.
 //
-// Why.  Measured on MI355X (tools/micro/mfma_valu_*.hip): VALU instructions do NOT hide behind
-// MFMAs on a SIMD -- neither another wave's (a VALU-only partner wave gets ~2 % of its issue rate
-// next to a dependent MFMA chain) nor the wave's own (64 -> 89 cycles per MFMA with 8 independent
-// v_fma behind it).  The decoder's time is therefore  64 cyc x 240 f32 MFMAs + ~3.5 cyc x 1800 VALU
-// per 32-point tile; the MFMA term is 70 % of it and f32-input MFMA runs at 1/16 of the f16 rate.
-// Three f16 MFMAs per 16 k-values replace eight f32 MFMAs: 90 x ~35 cycles instead of 240 x 64.
+// Why.  Measured on MI355X (tools/micro/mfma_valu_*.hip): VALU instructions barely hide behind MFMAs on
+// a SIMD -- next to a dependent f32 MFMA chain a VALU-only partner wave gets ~2 % of its issue rate, next to
+// an f16 MFMA stream ~2 instructions per 32-cycle slot, and a wave's own fillers cost 2.5-4 cycles each.
+// The exact-f32 decoder therefore costs  64 cyc x 240 f32 MFMAs + the VALU work  per 32-point tile, the MFMA
+// term is 70 % of it and f32-input MFMA runs at 1/16 of the f16 rate.  Three f16 MFMAs per 16 k-values
+// replace eight f32 MFMAs: 90 x 32 cycles instead of 240 x 64.  Per-phase stamps of this kernel (debug build
+// -DADFP_STAMPS, tools/ab_stage.py): gather 32 %, Fourier features 25 %, the five layers 33 %, output layer +
+// store 8 % of the wave-cycles.
 //
 // Accuracy (tools/micro/f16x3_accuracy.hip, K = 128): max error relative to the largest output
 // 3.6e-7 for O(1) operands and 9.5e-7 for O(0.03) operands, against 3.6e-7 / 2.5e-7 for the exact f32
