@@ -87,6 +87,9 @@ def main():
     else:
         dist = None
     n_gpus = world
+    if args.gpus != world and rank == 0:
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run '
+              f'--nproc-per-node {args.gpus} for a {args.gpus}-GPU run (reporting n_gpus={world})', file=sys.stderr)
     dev = torch.device(f'cuda:{local_rank}')
     torch.cuda.set_device(dev)
 
