@@ -322,6 +322,52 @@ def cpu_leg(rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF, n_cpu):
             dt = time.perf_counter() - t0
             if it > 0 and (best is None or dt < best):
                 best = dt
+    # forward + backward of the Mapper loss (src/Mapper.py:457-473) on a 2 000-ray subset: the oracle with autograd on
+    # the host cores beside the product path's autograd on the GPU, same rays, gradients to grids + colour / attention nets
+    nt = min(2000, ro_c.shape[0])
+    gcol = torch.rand(nt, 3, generator=torch.Generator().manual_seed(0))
+    train = {}
+    try:
+        c_req = {k: v.clone().requires_grad_(True) for k, v in c_cpu.items()}
+        sd_req = {k: (v.clone().requires_grad_(True) if k.startswith(('color_decoder', 'mlp')) else v) for k, v in sd.items()}
+        tb = None
+        for it in range(2):
+            for v in list(c_req.values()) + [v for v in sd_req.values() if v.requires_grad]:
+                v.grad = None
+            t0 = time.perf_counter()
+            td, tu, tc, tw = O.render_batch_ray(sd_req, c_req, rd_c[:nt], ro_c[:nt], tsdf_cpu, scene.tsdf_bnds, scene.bound,
+                                                'color', gd_c[:nt], NS, NF)
+            O.mapper_loss(td, tc, tw, gd_c[:nt], gcol, 'color').backward()
+            dt = time.perf_counter() - t0
+            tb = dt if tb is None or dt < tb else tb
+        c_g = {k: v.detach().clone().requires_grad_(True) for k, v in scene.c.items()}
+        ro_t, rd_t, gd_t, gc_t = ro[:nt], rd[:nt], gd[:nt], gcol.to(dev)
+        for p_ in list(dec.low_decoder.parameters()) + list(dec.high_decoder.parameters()):
+            p_.requires_grad_(False)
+
+        def gpu_it():
+            for v in c_g.values():
+                v.grad = None
+            dd, uu, cc, ww = rend.render_batch_ray(c_g, dec, rd_t, ro_t, dev, scene.tsdf_volume, tsdf_bnds, 'color', gt_depth=gd_t)
+            m = gd_t > 0
+            (torch.abs(gd_t[m] - dd[m]).sum() + 0.2 * torch.abs(gc_t - cc).sum()).backward()
+        for _ in range(3):
+            gpu_it()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            gpu_it()
+        torch.cuda.synchronize(dev)
+        tg = (time.perf_counter() - t0) / 10
+        gl = c_g['grid_color'].grad.cpu()
+        train = {'train_fwd_bwd': {'rays': nt, 'unit': 'rays/s', 'value': nt / tg, 'ms_per_iteration': tg * 1e3,
+                                   'cpu_baseline': nt / tb, 'cpu_cores': cores,
+                                   'max_rel_grad_grid_color_vs_oracle': float((gl - c_req['grid_color'].grad).abs().max()
+                                                                              / c_req['grid_color'].grad.abs().max())}}
+        for p_ in dec.parameters():
+            p_.grad = None
+    except Exception as e:                      # the training leg is extra information, never the reason a bench fails
+        train = {'train_fwd_bwd': {'error': repr(e)[:200]}}
     mse = float(((c.cpu().double() - oc.double()) ** 2).mean())
     peak = float(oc.abs().max())
     psnr = 10.0 * torch.log10(torch.tensor(peak * peak / max(mse, 1e-300))).item()
@@ -336,6 +382,7 @@ def cpu_leg(rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF, n_cpu):
                              'max_rel_depth': float(((d.cpu() - od).abs().max() / od.abs().max())),
                              'max_rel_color': float(((c.cpu() - oc).abs().max() / oc.abs().max())),
                              'rays': len(pick)},
+        **train,
     }
 
 

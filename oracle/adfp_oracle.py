@@ -14,6 +14,12 @@ imported read-only in the build container by ``oracle/validate_against_reference
 fixtures under ``tests/golden/`` that ``tests/golden/make_golden.py`` generated from
 the reference's own modules.
 
+PARITY UNPINNED for three small restatements whose reference modules cannot be imported in the build
+container (they need pycuda / numba / skimage or cv2 / colorama) and for which the reference ships no
+vectors: ``tsdf_integrate_np`` (src/fusion.py:69-142), ``prefilter_mask`` (src/Mapper.py:440-445) and
+``frustum_mask_np`` / ``remap_linear_np`` (src/Mapper.py:90-158 with cv2.remap).  Each says so at its
+definition; everything on the render path proper (rows a1-a15) is pinned as above.
+
 Every function cites the reference file:line it follows (paths relative to the
 reference checkout).  Decoder weights are passed as a flat ``dict`` keyed exactly like
 ``DF.state_dict()`` in the reference (``low_decoder.fc_c.0.weight`` ...), so the
