@@ -400,7 +400,21 @@ struct AttLayout {
 // ---------------------------------------------------------------------------------------------
 template <int NWW>
 ADFP_DEV int claim_tile(int& j, int* s_next, int ntiles) {
+#ifdef ADFP_XCD_TILES
+    // XCD-aware variant: workgroup b runs on XCD b % 8 (round-robin dispatch); give every XCD one CONTIGUOUS
+    // eighth of the tiles (a band of image rows) so that its private L2 sees one eighth of the frustum's grid
+    // lines instead of a 1-in-8 sample of all of them.
+    int tile;
+    if ((gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, bl = blockIdx.x >> 3, gl = gridDim.x >> 3;
+        const int per = ((ntiles + 7) / 8 + NWW - 1) / NWW * NWW;            // tiles per XCD, whole slots
+        const int loc = bl * NWW + (j % NWW) + (j / NWW) * (gl * NWW);
+        if (loc >= per) return -1;
+        tile = xcd * per + loc;
+    } else tile = blockIdx.x * NWW + (j % NWW) + (j / NWW) * (gridDim.x * NWW);
+#else
     const int tile = blockIdx.x * NWW + (j % NWW) + (j / NWW) * (gridDim.x * NWW);
+#endif
     if (tile >= ntiles) return -1;
 #ifdef ADFP_STATIC_TILES        // A/B switch: the fixed split
     j += NWW;
