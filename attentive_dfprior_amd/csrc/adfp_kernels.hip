@@ -25,6 +25,30 @@
         if (e_ != hipSuccess) return (int)e_;       \
     } while (0)
 
+// Zero-fill as a KERNEL, not hipMemsetAsync: every device write of a call is then an ordinary kernel node when the
+// caller captures the call into a HIP graph (torch.cuda.graph); with memset nodes in the captured sequence, replays
+// interleaved with other allocations faulted on ROCm 7.2 (tools/graph_capture.py).  bytes must be a multiple of 4.
+__global__ __launch_bounds__(256) void k_zero(unsigned* __restrict__ p, long long n_words) {
+    const long long n4 = n_words >> 2;
+    const long long stride = (long long)gridDim.x * 256;
+    if ((((unsigned long long)p) & 15ull) == 0) {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) ((uint4*)p)[i] = uint4{0u, 0u, 0u, 0u};
+        for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n_words; i += stride) p[i] = 0u;
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_words; i += stride) p[i] = 0u;
+    }
+}
+static hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    const long long words = (long long)(bytes / 4);
+    long long blocks = (words / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_zero, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned*)p, words);
+    return hipGetLastError();
+}
+
+
 // =====================================================================================
 // layout conversion
 // =====================================================================================
@@ -949,7 +973,7 @@ int adfp_get_rays(int H, int W, float fx, float fy, float cx, float cy, const fl
 int adfp_prefilter_rays(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double* bound_dev,
                         int* out_index, int* out_count, void* stream) {
     if (!out_count || n_rays < 0) return ADFP_E_ARG;
-    if (n_rays == 0) return (int)hipMemsetAsync(out_count, 0, 4, (hipStream_t)stream);
+    if (n_rays == 0) return (int)zero_async(out_count, 4, (hipStream_t)stream);
     if (!rays_o || !rays_d || !gt_depth || !bound_dev || !out_index) return ADFP_E_ARG;
     hipLaunchKernelGGL(k_prefilter, dim3(1), dim3(1024), 0, (hipStream_t)stream, rays_o, rays_d, gt_depth, n_rays, bound_dev, out_index, out_count);
     ADFP_CHECK_LAUNCH();
@@ -971,7 +995,7 @@ int adfp_sample_rays(const float* rays_o, const float* rays_d, const float* gt_d
     a.n_rays = n_rays; a.n_samples = n_samples; a.n_surface = n_surface; a.lindisp = lindisp; a.perturb = perturb; a.z = z_vals;
     if (gt_depth && !depth_max) {
         if (!scratch) return ADFP_E_ARG;
-        hipError_t e = hipMemsetAsync(scratch, 0, 16, st);
+        hipError_t e = zero_async(scratch, 16, st);
         if (e != hipSuccess) return (int)e;
         int blocks = (n_rays + 2047) / 2048; if (blocks > 64) blocks = 64;     // few blocks: the cost is the atomics' latency
         hipLaunchKernelGGL(k_depth_max, dim3(blocks), dim3(256), 0, st, gt_depth, n_rays, (unsigned*)scratch);
@@ -1008,7 +1032,7 @@ int adfp_tsdf_stage(const adfp_scene* scene, const adfp_points* pts, unsigned ch
     if (list && (!att_u || !counter)) return ADFP_E_ARG;
     PtsDev P; int rc = make_pts(pts, &P); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (counter) { hipError_t e = hipMemsetAsync(counter, 0, 4, st); if (e != hipSuccess) return (int)e; }
+    if (counter) { hipError_t e = zero_async(counter, 4, st); if (e != hipSuccess) return (int)e; }
     return launch_tsdf(scene, P, flags, list, att_u, w, counter, nullptr, st);
 }
 
@@ -1050,11 +1074,11 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
     hipError_t e;
     const bool fuse = stage != ADFP_STAGE_LOW;
     if (stage != ADFP_STAGE_COLOR) {           // rgb = 0 in stages low/high (decoder.py:317, :323)
-        e = hipMemsetAsync(raw, 0, (size_t)P.n * 16, st);
+        e = zero_async(raw, (size_t)P.n * 16, st);
         if (e != hipSuccess) return (int)e;
     }
     if (fuse) {
-        e = hipMemsetAsync(ws.counter, 0, 4, st);
+        e = zero_async(ws.counter, 4, st);
         if (e != hipSuccess) return (int)e;
         int rc = launch_tsdf(sc, P, ws.flags, ws.list, ws.att_u, nullptr, ws.counter, nullptr, st);   // w = 1 comes from the LOW decoder
         if (rc) return rc;
@@ -1197,7 +1221,7 @@ int adfp_frustum_mask(int X, int Y, int Z, const double bound[3][2], const float
     a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.H = H; a.W = W; a.depth = depth;
     a.sampled = sampled; a.dmax_ord = scratch; a.mask = mask;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(scratch, 0, 4, st);
+    hipError_t e = zero_async(scratch, 4, st);
     if (e != hipSuccess) return (int)e;
     const long long n = (long long)X * Y * Z;
     long long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
@@ -1346,7 +1370,7 @@ static int outer_begin(const BwdWorkspace& bw, int n_floats, hipStream_t st) {
     return 0;
 #else
     (void)n_floats;
-    return (int)hipMemsetAsync(bw.partial, 0, (size_t)OUTER_NSLOT * bw.part_stride * 4, st);
+    return (int)zero_async(bw.partial, (size_t)OUTER_NSLOT * bw.part_stride * 4, st);
 #endif
 }
 static int outer_end(const BwdWorkspace& bw, int n_floats, float* flat, hipStream_t st) {
@@ -1432,7 +1456,7 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
         {r->g_flat_low, (size_t)DecLayout<32, 1>::F_TOTAL}, {r->g_flat_high, (size_t)DecLayout<64, 1>::F_TOTAL},
         {r->g_flat_color, (size_t)DecLayout<32, 4>::F_TOTAL}, {r->g_flat_att, (size_t)AttLayout::F_TOTAL}};
     for (int k = 0; k < 7; ++k)
-        if (zs[k].p) { e = hipMemsetAsync(zs[k].p, 0, zs[k].n * 4, st); if (e != hipSuccess) return (int)e; }
+        if (zs[k].p) { e = zero_async(zs[k].p, zs[k].n * 4, st); if (e != hipSuccess) return (int)e; }
     if (r->n_rays == 0) return 0;
     const int P = (int)Pn;
 
@@ -1447,7 +1471,7 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
     a.list = nullptr; a.count_ptr = nullptr; a.g_raw = bw.g_raw; a.att_g = nullptr; a.stage = nullptr;
     const bool pgrad = r->g_rays_o || r->g_rays_d;
     a.g_pts = pgrad ? bw.g_pts : nullptr;
-    if (pgrad) { e = hipMemsetAsync(bw.g_pts, 0, (size_t)P * 12, st); if (e != hipSuccess) return (int)e; }
+    if (pgrad) { e = zero_async(bw.g_pts, (size_t)P * 12, st); if (e != hipSuccess) return (int)e; }
 
     if (fuse) {
         AttBwdArgs t;
