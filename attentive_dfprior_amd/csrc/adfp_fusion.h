@@ -8,6 +8,11 @@
 // (float)voxel_idx is rounded, which puts the first few voxels of some x-slabs one slab early.  It
 // is reproduced here on purpose (results identical to the reference); the off-by-one bound test
 // `voxel_idx > N` (:89), which lets thread N touch memory past the volume, is not.
+//
+// Rounding: every product and sum below is rounded separately (as the numpy restatement in oracle/ does).
+// The reference's kernel string is compiled by nvcc, whose default -fmad=true may fuse some of these into
+// fmas; which ones is a property of that compiler run, cannot be observed here (no pycuda, no CUDA device),
+// and moves a result by at most one ulp before the pixel rounding -- part of why this entry is parity-unpinned.
 #pragma once
 #include "adfp_device.h"
 
