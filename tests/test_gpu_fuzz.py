@@ -51,3 +51,31 @@ def test_random_shapes_vs_oracle(seed, n_rays, ns, nf, stage, with_depth):
     assert_close(u, ou, 1e-4, 'uncertainty')
     assert_close(c, oc, 1e-4, 'color')
     assert_close(w, ow, 1e-4, 'weight')
+
+
+@pytest.mark.parametrize('stage', ['high', 'color'])
+def test_mesher_lattice_vs_oracle(stage):
+    """The Mesher's query (src/utils/Mesher.py:286-326): a dense lattice over the bounding box plus a margin,
+    through Renderer.eval_points in one call (the reference chunks it by 500 000 points; chunking is
+    value-neutral), checked on a strided subset against the oracle."""
+    scene = synthetic.mini_scene(seed=5)
+    sd = O.random_state_dict(seed=105)
+    dec = A.DF()
+    dec.load_state_dict(sd)
+    dec.bound = scene.bound
+    dec = dec.to(DEV)
+    rend = A.Renderer(make_cfg(32, 16), None, scene)
+    n = 96
+    lo = scene.bound[:, 0] - 0.05 * (scene.bound[:, 1] - scene.bound[:, 0])
+    hi = scene.bound[:, 1] + 0.05 * (scene.bound[:, 1] - scene.bound[:, 0])
+    ax = [torch.linspace(float(lo[k]), float(hi[k]), n, dtype=torch.float64) for k in range(3)]
+    pts = torch.stack(torch.meshgrid(*ax, indexing='ij'), -1).reshape(-1, 3)          # 884 736 points
+    c_dev = {k: v.to(DEV) for k, v in scene.c.items()}
+    with torch.no_grad():
+        raw, w = rend.eval_points(pts.to(DEV), dec, scene.tsdf_volume.to(DEV), scene.tsdf_bnds.to(DEV), c_dev, stage, DEV)
+    assert raw.shape == (pts.shape[0], 4) and w.shape == (pts.shape[0],)
+    sub = torch.arange(0, pts.shape[0], 37)
+    oraw, ow = O.eval_points(sd, pts[sub], scene.c, scene.tsdf_volume, scene.tsdf_bnds, scene.bound, stage)
+    assert bool((oraw[:, 3] == 100).any()) and bool((ow != 1).any())                   # outside points and band points present
+    assert_close(raw[sub.to(DEV)], oraw, 1e-4, 'raw')
+    assert_close(w[sub.to(DEV)], ow, 1e-4, 'w')
