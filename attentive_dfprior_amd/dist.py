@@ -89,3 +89,74 @@ def allreduce_grads(tensors, group=None):
         else:
             t.grad.copy_(g)
         off += n
+
+
+class MaskedGradBucket:
+    """All-reduce of the grid gradients restricted to the frustum-selected voxels (SURVEY.md section 8e,
+    "reduce only the frustum-masked subset"): outside the mask the Mapper never updates a grid
+    (src/Mapper.py:345-361), so those gradients need not travel.  The voxel index lists are built ONCE per
+    mapping call from the masks (identical on every rank, so the compact buckets line up); per iteration the
+    masked columns of every grid gradient and the other tensors' gradients go through one flat all-reduce.
+
+        bucket = MaskedGradBucket(c, masks, extra=list(decoders.parameters()))
+        loss.backward(); bucket.allreduce(); opt_grids.step(lrs); optimizer.step()
+    """
+
+    def __init__(self, grids, masks, extra=(), group=None):
+        self.group = group
+        self.grids = [(k, g) for k, g in grids.items() if g.requires_grad]
+        self.extra = [t for t in extra if t.requires_grad]
+        self.index = {}
+        for k, g in self.grids:
+            m = masks.get(k) if masks is not None else None
+            if m is None:
+                self.index[k] = None
+            else:
+                if tuple(m.shape) != tuple(g.shape[2:]):
+                    raise ValueError(f'{k}: mask shape {tuple(m.shape)} != grid {tuple(g.shape[2:])}')
+                self.index[k] = torch.nonzero(m.reshape(-1).to(g.device), as_tuple=False).reshape(-1)
+
+    def numel(self):
+        n = sum(t.numel() for t in self.extra)
+        for k, g in self.grids:
+            idx = self.index[k]
+            n += g.numel() if idx is None else g.shape[1] * idx.numel()
+        return n
+
+    @torch.no_grad()
+    def allreduce(self):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return
+        parts = []
+        for k, g in self.grids:
+            gr = g.grad if g.grad is not None else torch.zeros_like(g)
+            idx = self.index[k]
+            flat = gr.reshape(g.shape[1], -1)
+            parts.append((flat if idx is None else flat.index_select(1, idx)).reshape(-1).float())
+        for t in self.extra:
+            parts.append((t.grad if t.grad is not None else torch.zeros_like(t)).reshape(-1).float())
+        if not parts:
+            return
+        bucket = torch.cat(parts)
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for k, g in self.grids:
+            idx = self.index[k]
+            C = g.shape[1]
+            n = g.numel() if idx is None else C * idx.numel()
+            piece = bucket[off:off + n].reshape(C, -1).to(g.dtype)
+            if g.grad is None:
+                g.grad = torch.zeros_like(g)
+            if idx is None:
+                g.grad.copy_(piece.reshape(g.shape))
+            else:
+                g.grad.reshape(C, -1).index_copy_(1, idx, piece)     # outside the mask: the local gradient, never used
+            off += n
+        for t in self.extra:
+            n = t.numel()
+            piece = bucket[off:off + n].reshape(t.shape).to(t.dtype)
+            if t.grad is None:
+                t.grad = piece.clone()
+            else:
+                t.grad.copy_(piece)
+            off += n

@@ -62,7 +62,33 @@ def _worker(rank, world, port, q):
     for a, b in zip(tensors, list(c2.values()) + [sd2[k] for k in sd2]):
         gb = b.grad if b.grad is not None else torch.zeros_like(b)
         worst = max(worst, ((a.grad - gb).abs().max() / gb.abs().max().clamp_min(1e-12)).item())
-    q.put((rank, ok_render, ok_max, worst))
+    # masked bucket: only the selected voxels (and the extra tensors) travel; inside the mask the result is the
+    # full-batch gradient, outside it stays the rank's own
+    g = torch.Generator().manual_seed(7)
+    masks = {k: torch.rand(v.shape[2:], generator=g) < 0.4 for k, v in mini.c.items()}
+    masks['grid_low'] = None                                   # frustum selection off for this grid
+    c3 = {k: v.clone().requires_grad_(True) for k, v in mini.c.items()}
+    sd3 = {k: v.clone().requires_grad_(True) for k, v in mini.sd.items()}
+    d3, u3, col3, w3 = O.render_batch_ray(sd3, c3, rd[lo:hi], ro[lo:hi], mini.tsdf_volume, mini.tsdf_bnds, mini.bound,
+                                          'color', gd[lo:hi], mini.n_samples, mini.n_surface, depth_max=gd.max())
+    O.mapper_loss(d3, col3, w3, gd[lo:hi], gc[lo:hi], 'color', True).backward()
+    local = {k: v.grad.clone() for k, v in c3.items()}
+    extra = [sd3[k] for k in sd3 if k.startswith('mlp.')]
+    bucket = adist.MaskedGradBucket(c3, masks, extra=extra)
+    full_numel = sum(v.numel() for v in c3.values()) + sum(t.numel() for t in extra)
+    ok_small = bucket.numel() < full_numel
+    bucket.allreduce()
+    worst_m = 0.0
+    for k in c3:
+        ref = c2[k].grad
+        m = torch.ones(c3[k].shape[2:], dtype=torch.bool) if masks[k] is None else masks[k]
+        mm = m[None, None].expand(c3[k].shape)
+        worst_m = max(worst_m, ((c3[k].grad - ref)[mm].abs().max() / ref.abs().max().clamp_min(1e-12)).item())
+        ok_small = ok_small and torch.equal(c3[k].grad[~mm], local[k][~mm])
+    for k in sd3:
+        if k.startswith('mlp.'):
+            worst_m = max(worst_m, ((sd3[k].grad - sd2[k].grad).abs().max() / sd2[k].grad.abs().max().clamp_min(1e-12)).item())
+    q.put((rank, ok_render, ok_max and ok_small, max(worst, worst_m)))
     dist.barrier()
     dist.destroy_process_group()
 
