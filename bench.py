@@ -259,8 +259,10 @@ def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, N
         roof = {'kernel': 'k_decode_h<32,4,COLOR> (colour decoder, f16 MFMA with 3-product f32 operand split)',
                 'bound': 'mfma', 'achieved': ex, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': ex / PEAK_F16_MFMA_TFLOPS, 'traffic': None,
-                'note': 'executed f16 MFMA FLOP (3 products per f32 product); the kernel is VALU-issue bound: '
-                        'VALU does not overlap MFMA on a CDNA4 SIMD (tools/micro), see DESIGN.md section 5',
+                'note': 'executed f16 MFMA FLOP (3 products per f32 product) against the 2.4 GHz spec peak; the chip '
+                        'clocks this kernel at ~1.8 GHz and PMC shows the matrix pipe busy 41 % of the time '
+                        '(profiles/r01_pmc_sq_forward.csv); the rest of the issue slots go to the gather / Fourier / split '
+                        'VALU work, which barely overlaps MFMA on a CDNA4 SIMD (tools/micro, DESIGN.md sections 4.1, 5)',
                 'algorithmic_f32_tflops': ach, 'f32_mfma_peak_tflops': PEAK_F32_MFMA_TFLOPS,
                 'frac_of_f32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS}
     kname = 'void k_decode<32, 4, 2' if math_mode() == 'f32' else 'void k_decode_h<32, 4, 2'
