@@ -356,13 +356,22 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
         rs.dep = rs.has_depth ? a.depth[ray] : 0.f;
         rs.nearf = __fmul_rn(rs.dep, 0.01f);
         // far_bb = min_axis max_side (bound - o)/d + 0.01   (Renderer.py:151-156), f64
+        // The six plane distances are ONE f64 division per wave: lane l (mod 8) < 6 takes axis l >> 1, side l & 1
+        // (an f64 division is ~40 instructions; six of them in every lane were most of this kernel's VALU work).
         double far_bb = INFINITY;
+        {
+            const int sel = lane & 7, ax = sel < 6 ? sel >> 1 : 0, side = sel & 1;
+            const double o = (double)a.ro[3 * ray + ax], d = (double)a.rd[3 * ray + ax];
+            const double bk = ax == 0 ? (side ? a.b[1] : a.b[0]) : (ax == 1 ? (side ? a.b[3] : a.b[2]) : (side ? a.b[5] : a.b[4]));
+            const double t = (bk - o) / d;
+            const double tp = __shfl_xor(t, 1);
+            const double t0 = side ? tp : t, t1 = side ? t : tp;
+            const double tmk = t0 > t1 ? t0 : t1;         // torch.max propagates NaN; not reproduced
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const double o = (double)a.ro[3 * ray + k], d = (double)a.rd[3 * ray + k];
-            const double t0 = (a.b[2 * k] - o) / d, t1 = (a.b[2 * k + 1] - o) / d;
-            const double tm = t0 > t1 ? t0 : t1;          // torch.max propagates NaN; not reproduced
-            far_bb = tm < far_bb ? tm : far_bb;
+            for (int k = 0; k < 3; ++k) {
+                const double tm = __shfl(tmk, 2 * k);
+                far_bb = tm < far_bb ? tm : far_bb;
+            }
         }
         far_bb += 0.01;
         if (rs.has_depth) {
