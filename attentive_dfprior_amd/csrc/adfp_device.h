@@ -389,6 +389,51 @@ struct AttLayout {
     static constexpr int P_TOTAL = P_BO + 4;
 };
 
+
+// ---------------------------------------------------------------------------------------------
+// Wave-wide sums and an inclusive product scan on DPP (data-parallel primitives inside the VALU: no trip
+// through the LDS crossbar that __shfl / ds_bpermute takes, ~8 cycles per step instead of ~100).
+//   quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140,
+//   row_shr:n = 0x110 + n, wave_shr:1 = 0x138 (gfx9 family)
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, bool BOUND_CTRL = true>      // BOUND_CTRL false: lanes without a source keep `old`
+ADFP_DEV float dpp_f32(float v, float old = 0.f) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, BOUND_CTRL));
+}
+template <int CTRL>
+ADFP_DEV double dpp_f64(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+ADFP_DEV float readlane_f32(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+ADFP_DEV double readlane_f64(double v, int l) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// sum over the 64 lanes, valid in every lane
+ADFP_DEV float wave_sum(float v) {
+    v += dpp_f32<0xB1>(v); v += dpp_f32<0x4E>(v); v += dpp_f32<0x141>(v); v += dpp_f32<0x140>(v);      // every lane: its 16-lane row
+    return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));
+}
+ADFP_DEV double wave_sum(double v) {
+    v += dpp_f64<0xB1>(v); v += dpp_f64<0x4E>(v); v += dpp_f64<0x141>(v); v += dpp_f64<0x140>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+// inclusive product scan over the 64 lanes; `total` = product of all lanes
+ADFP_DEV float wave_scan_mul(float v, int lane, float& total) {
+    v *= dpp_f32<0x111, false>(v, 1.f); v *= dpp_f32<0x112, false>(v, 1.f);                            // inside each row of 16
+    v *= dpp_f32<0x114, false>(v, 1.f); v *= dpp_f32<0x118, false>(v, 1.f);
+    const float t0 = readlane_f32(v, 15), t1 = readlane_f32(v, 31), t2 = readlane_f32(v, 47), t3 = readlane_f32(v, 63);
+    const float p1 = t0, p2 = t0 * t1, p3 = p2 * t2;
+    const int row = lane >> 4;
+    v *= row == 0 ? 1.f : (row == 1 ? p1 : (row == 2 ? p2 : p3));
+    total = p3 * t3;
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Tile hand-out inside a workgroup.  A workgroup of NWW waves owns the tiles
 //   wg_tile(j) = blockIdx.x * NWW + (j % NWW) + (j / NWW) * (gridDim.x * NWW),   j = 0, 1, 2, ...

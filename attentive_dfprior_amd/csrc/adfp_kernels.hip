@@ -778,28 +778,20 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
         if (ok) { r = *(const f32x4*)(raw + ((long long)ray * S + s) * 4); zz = z[(long long)ray * S + s]; }
         const float alpha = ok ? sigmoidf_(10.f * r.w) : 0.f;                   // common.py:236
         float f = ok ? (1.f - alpha + 1e-10f) : 1.f;
-        // inclusive product scan across the wave
-        float incl = f;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const float v = __shfl_up(incl, o);
-            if (lane >= o) incl *= v;
-        }
-        float excl = __shfl_up(incl, 1);
-        if (lane == 0) excl = 1.f;
+        // inclusive product scan across the wave (DPP), then one lane to the right for the exclusive one
+        float total;
+        const float incl = wave_scan_mul(f, lane, total);
+        const float excl = dpp_f32<0x138, false>(incl, 1.f);                       // wave_shr:1, lane 0 <- 1
         const float T = carry * excl;
         const float w = alpha * T;                                                // common.py:244
-        carry *= __shfl(incl, 63);
+        carry *= total;
         if (ok && weights) weights[(long long)ray * S + s] = w;
         cr = fmaf(w, r.x, cr); cg = fmaf(w, r.y, cg); cb = fmaf(w, r.z, cb);
         const double wd = (double)w;
         sw += wd; swz += wd * zz; swzz += wd * zz * zz;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        cr += __shfl_xor(cr, o); cg += __shfl_xor(cg, o); cb += __shfl_xor(cb, o);
-        sw += __shfl_xor(sw, o); swz += __shfl_xor(swz, o); swzz += __shfl_xor(swzz, o);
-    }
+    cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb);
+    sw = wave_sum(sw); swz = wave_sum(swz); swzz = wave_sum(swzz);
     if (lane == 0) {
         depth[ray] = swz;
         // sum w (z - d)^2 = sum w z^2 - 2 d sum w z + d^2 sum w        (common.py:248-250)
