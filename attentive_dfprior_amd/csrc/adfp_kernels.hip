@@ -364,12 +364,12 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
             const double o = (double)a.ro[3 * ray + ax], d = (double)a.rd[3 * ray + ax];
             const double bk = ax == 0 ? (side ? a.b[1] : a.b[0]) : (ax == 1 ? (side ? a.b[3] : a.b[2]) : (side ? a.b[5] : a.b[4]));
             const double t = (bk - o) / d;
-            const double tp = __shfl_xor(t, 1);
+            const double tp = dpp_f64<0xB1>(t);              // lane ^ 1
             const double t0 = side ? tp : t, t1 = side ? t : tp;
             const double tmk = t0 > t1 ? t0 : t1;         // torch.max propagates NaN; not reproduced
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const double tm = __shfl(tmk, 2 * k);
+                const double tm = readlane_f64(tmk, 2 * k);
                 far_bb = tm < far_bb ? tm : far_bb;
             }
         }
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256, TSDF_MINW) void k_tsdf(TsdfArgs a) {
                 if (m) {
                     int base = 0;
                     if (lane == 0) base = atomicAdd(&s_cnt, __popcll(m));
-                    base = __shfl(base, 0);
+                    base = __builtin_amdgcn_readfirstlane(base);
                     if (band) {
                         const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
                         s_q[pos] = q; s_u[pos] = inv_tsdf(t);
