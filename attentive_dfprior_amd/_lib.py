@@ -9,6 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ADFP_LIB_PATH', os.path.join(_HERE, 'libadfp.so'))   # override: kernel A/B builds
 
+ABI_VERSION = 110                 # ADFP_VERSION of include/adfp.h this binding was written against
+STATUS_F16_RANGE = 1
 STAGE = {'low': 0, 'high': 1, 'color': 2}
 DEC_KIND = {'low': 0, 'high': 1, 'color': 2}
 PTS_RAYS, PTS_F64, PTS_F32 = 0, 1, 2
@@ -31,7 +33,8 @@ class AdfpScene(C.Structure):
     _fields_ = [('bound', (C.c_double * 2) * 3), ('tsdf_bnds', (C.c_double * 2) * 3),
                 ('low', AdfpGrid), ('high', AdfpGrid), ('color', AdfpGrid), ('tsdf', AdfpTsdf),
                 ('w_low', C.c_void_p), ('w_high', C.c_void_p), ('w_color', C.c_void_p), ('w_att', C.c_void_p),
-                ('h_low', C.c_void_p), ('h_high', C.c_void_p), ('h_color', C.c_void_p), ('h_att', C.c_void_p)]
+                ('h_low', C.c_void_p), ('h_high', C.c_void_p), ('h_color', C.c_void_p), ('h_att', C.c_void_p),
+                ('status', C.c_void_p)]
 
 
 class AdfpPoints(C.Structure):
@@ -80,9 +83,9 @@ SYMBOLS = [
     ('adfp_pack_decoder', C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_pack_attention', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_decoder_packed_h_words', C.c_longlong, [C.c_int]),
-    ('adfp_pack_decoder_h', C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_pack_decoder_h', C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_attention_packed_h_words', C.c_longlong, []),
-    ('adfp_pack_attention_h', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_pack_attention_h', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_get_rays', C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_prefilter_rays', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
@@ -130,6 +133,8 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        if handle.adfp_version() != ABI_VERSION:
+            raise RuntimeError(f'{LIB_PATH} is ABI version {handle.adfp_version()}, this package binds {ABI_VERSION}: rebuild it')
         _lib = handle
     return _lib
 
@@ -163,3 +168,41 @@ def require_cuda(t, name):
         raise RuntimeError(
             f'{name} is on {t.device}: attentive_dfprior_amd runs only on an MI355X through libadfp.so; '
             'there is no CPU fallback.')
+
+
+# ---- sticky status word (adfp_scene.status) -------------------------------------------------------------
+# One word of pinned host memory per process: the kernels OR into it with a system-scope atomic (pinned host
+# memory is device-visible under HIP's unified addressing), and the host reads it without synchronising.
+# Like an asynchronous HIP error, a raised bit is reported at the NEXT call into the library -- or at once
+# by check_status(sync=True).
+_status = None
+
+
+def status_word():
+    global _status
+    if _status is None:
+        import torch
+        _status = torch.zeros(4, dtype=torch.int32).pin_memory()
+    return _status
+
+
+def status_ptr():
+    return C.c_void_p(status_word().data_ptr())
+
+
+def check_status(sync=False, device=None):
+    """Raise if an earlier call left a bit in the status word (and clear it).  sync=True waits for the device first."""
+    if _status is None:
+        return
+    if sync:
+        import torch
+        torch.cuda.synchronize(device)
+    v = int(_status[0])
+    if v:
+        _status[0] = 0
+        if v & STATUS_F16_RANGE:
+            raise RuntimeError(
+                'libadfp: an operand of the f16-split (ADFP_MATH=f16x3) decoders reached |x| >= 65504 -- a weight, a '
+                'grid feature or a hidden activation; the outputs of that call are invalid.  Re-run with '
+                'ADFP_MATH=f32 (exact f32-input MFMA, no range limit).')
+        raise RuntimeError(f'libadfp: status word {v:#x}')

@@ -16,7 +16,7 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, bundle, rays_o, rays_d, grid_low, grid_high, grid_color, *params):
         (engine, decoders, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, n_samples, n_surface,
-         lindisp, perturb, t_rand, depth_max) = bundle
+         lindisp, perturb, t_rand, depth_max, need_param_grad) = bundle
         c = {'grid_low': grid_low, 'grid_high': grid_high, 'grid_color': grid_color}
         depth, unc, color, weight, saved = engine.render_forward(
             decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, n_samples, n_surface,
@@ -36,7 +36,7 @@ class _RenderFn(torch.autograd.Function):
         need_grid = {name: bool(ctx.needs_input_grad[3 + k]) and name in used for k, (name, _) in enumerate(_GRIDS)}
         need_flat, off = {}, 6
         for (name, attr), n in zip(_NETS, ctx.n_params):
-            need_flat[name] = name in used and any(ctx.needs_input_grad[off:off + n])
+            need_flat[name] = ctx.bundle[-1] and name in used and any(ctx.needs_input_grad[off:off + n])
             off += n
         if g_weight is not None:
             g_weight = g_weight.reshape(g_weight.shape[0], -1)
@@ -70,11 +70,11 @@ class _RenderFn(torch.autograd.Function):
 
 
 def render_with_grad(engine, decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, n_samples,
-                     n_surface, lindisp, perturb, t_rand, depth_max):
+                     n_surface, lindisp, perturb, t_rand, depth_max, need_param_grad=True):
     if n_samples + (n_surface if gt_depth is not None else 0) > 256:
         raise NotImplementedError('training path supports at most 256 samples per ray')
     bundle = (engine, decoders, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, n_samples, n_surface,
-              lindisp, perturb, t_rand, depth_max)
+              lindisp, perturb, t_rand, depth_max, need_param_grad)
     params = []
     for name, _ in _NETS:
         params += decoders.net_params(name)

@@ -15,8 +15,9 @@
 // 3.6e-7 for O(1) operands and 9.5e-7 for O(0.03) operands, against 3.6e-7 / 2.5e-7 for the exact f32
 // MFMA; f16 products are exact in fp32 and f16 subnormal inputs are not flushed on gfx950.  The
 // dropped a_lo*b_lo term is 2^-22 relative.  Operands must stay below 65504 in magnitude (hidden
-// activations of this network are O(1..10)).  The exact-f32 kernel (k_decode) stays available
-// (ADFP_MATH=f32) and is what the backward uses.
+// activations of this network are O(1..10)); every value that is split is range-checked and a violation raises
+// the sticky ADFP_STATUS_F16_RANGE bit of adfp_scene.status instead of passing silently.  The exact-f32
+// kernel (k_decode) stays available (ADFP_MATH=f32) and is what the backward uses.
 #pragma once
 #include "adfp_device.h"
 
@@ -99,12 +100,14 @@ __device__ HSrc dec_h_src(int t) {
 __device__ __forceinline__ float f16_hi_part(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFFE000u); }
 
 template <int CDIM, int NOUT>
-__global__ void k_pack_decoder_h(const float* __restrict__ flat, unsigned* __restrict__ packed) {
+__global__ void k_pack_decoder_h(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= DecLayoutH<CDIM, NOUT>::P_TOTAL) return;
     const HSrc s = dec_h_src<CDIM, NOUT>(t);
     if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(flat[s.s0]); return; }
     const float a = s.s0 < 0 ? 0.f : flat[s.s0], b = s.s1 < 0 ? 0.f : flat[s.s1];
+    if (status && !(fmaxf(fabsf(a), fabsf(b)) < 65504.0f))       // a weight the f16 split cannot hold
+        __hip_atomic_fetch_or(status, ADFP_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const float ah = f16_hi_part(a), bh = f16_hi_part(b);
     _Float16 x, y;
     if (s.kind == 1) { x = (_Float16)ah; y = (_Float16)bh; }
@@ -112,15 +115,20 @@ __global__ void k_pack_decoder_h(const float* __restrict__ flat, unsigned* __res
     packed[t] = (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
 
-// 8 f32 -> 8 hi halves + 8 lo halves.
+// 8 f32 -> 8 hi halves + 8 lo halves.  `amax` tracks max |x| of everything that was split (one v_max3_f32 per
+// pair): an operand at or beyond the f16 range (65504) cannot be split -- cvt_pkrtz saturates it -- so the kernels
+// raise the sticky ADFP_STATUS_F16_RANGE bit of adfp_scene.status when amax reaches it (CHECK = false for values
+// that are bounded by construction: sines).
 #ifdef ADFP_SPLIT_MASK
 // 3 VALU per value: and, sub, 2 x cvt_pkrtz per pair.  hi = x truncated to 11 significant bits (a mask;
 // exactly representable in f16), lo = x - hi.
-ADFP_DEV void split8(const float* __restrict__ x, f16x8& hi, f16x8& lo) {
+template <bool CHECK = true>
+ADFP_DEV void split8(const float* __restrict__ x, f16x8& hi, f16x8& lo, float& amax) {
     u32x4 uh, ul;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float a = x[2 * j], b = x[2 * j + 1];
+        if (CHECK) amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), amax);
         const float ah = f16_hi_part(a), bh = f16_hi_part(b);
         uh[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ah, bh));
         ul[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - ah, b - bh));
@@ -132,7 +140,8 @@ ADFP_DEV void split8(const float* __restrict__ x, f16x8& hi, f16x8& lo) {
 // 2 VALU per value: hi = cvt_pkrtz (round toward zero = the 11-bit truncation) for a pair, then
 // lo = x - hi as ONE v_fma_mix_f32 per value (the f16 half is widened inside the instruction; the
 // difference is exact), then cvt_pkrtz of the pair of remainders.
-ADFP_DEV void split8(const float* __restrict__ x, f16x8& hi, f16x8& lo) {
+template <bool CHECK = true>
+ADFP_DEV void split8(const float* __restrict__ x, f16x8& hi, f16x8& lo, float& amax) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     u32x4 uh, ul;
     unsigned m1 = 0xBC00BC00u;                       // f16 (-1, -1), opaque to the optimiser so that the
@@ -141,6 +150,7 @@ ADFP_DEV void split8(const float* __restrict__ x, f16x8& hi, f16x8& lo) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float a = x[2 * j], b = x[2 * j + 1];
+        if (CHECK) amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), amax);
         const h2 hp = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a, b));
         const float la = __builtin_fmaf((float)hp[0], (float)neg1[0], a);
         const float lb = __builtin_fmaf((float)hp[1], (float)neg1[0], b);
@@ -151,6 +161,11 @@ ADFP_DEV void split8(const float* __restrict__ x, f16x8& hi, f16x8& lo) {
     lo = __builtin_bit_cast(f16x8, ul);
 }
 #endif
+#define ADFP_F16_MAX 65504.0f
+// once per wave, after its tile loop
+ADFP_DEV void report_range(int* status, float amax) {
+    if (status && !(amax < ADFP_F16_MAX)) __hip_atomic_fetch_or(status, ADFP_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // NK k-steps of a chain: acc += W[:, units of k-step] * x   with the 3-product split
 template <int NK>
@@ -196,6 +211,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
 #ifdef ADFP_STAMPS
     unsigned long long ph_[6] = {0, 0, 0, 0, 0, 0}, last_ = clock64();
 #endif
+    float amax = 0.f;                                   // max |operand| this wave has split (f16 range guard)
     for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<NT / 64>(j, &s_next, ntiles)) >= 0;) {
         ADFP_PHASE(0);                                  // ticket + loop overhead
         const int idx = tile * 32 + p;
@@ -215,7 +231,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
             gather16(a.g0, pn, h, c);
             if (CDIM == 64) gather16(a.g1, pn, h, c + 16);
 #pragma unroll
-            for (int ks = 0; ks < L::KS_C; ++ks) split8(c + 8 * ks, ch[ks], cl[ks]);
+            for (int ks = 0; ks < L::KS_C; ++ks) split8(c + 8 * ks, ch[ks], cl[ks], amax);
         }
         ADFP_PHASE(1);                                  // point, normalise, gather, split c
         // Fourier features sin(p @ B) (decoder.py:26-30) -> split halves (6 k-steps)
@@ -229,7 +245,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
                 const float arg = fmaf(pf[2], bm.z, fmaf(pf[1], bm.y, pf[0] * bm.x));
                 e[j] = adfp_sinf(arg);
             }
-            split8(e, eh[ks], el[ks]);
+            split8<false>(e, eh[ks], el[ks], amax);     // |sin| <= 1
         }
         ADFP_PHASE(2);                                  // Fourier features
 
@@ -251,8 +267,8 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
                 float t[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) t[r] = acc[r];
-                split8(t, hh[0], hl[0]);
-                split8(t + 8, hh[1], hl[1]);
+                split8(t, hh[0], hl[0], amax);
+                split8(t + 8, hh[1], hl[1], amax);
             }
         }
 
@@ -269,6 +285,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
             out[o] = s + lds[L::P_BO + o];
         }
 
+        nan_point_outputs<NOUT>(pt, out);
         if (valid && h == 0) {
             if constexpr (ROLE == ROLE_LOW) {
                 const bool inb = in_bound(pt, a.b);
@@ -283,6 +300,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
         }
         ADFP_PHASE(4);                                  // output layer + store
     }
+    report_range(a.status, amax);
 #ifdef ADFP_STAMPS
     if (lane == 0) for (int k = 0; k < 5; ++k) atomicAdd(&g_phase[k], ph_[k]);
     const int wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
@@ -333,12 +351,14 @@ __device__ HSrc att_h_src(int t) {
     const int o = t - L::P_BO;
     return HSrc{0, o < 2 ? F::F_BO + o : -1, -1};
 }
-__global__ void k_pack_attention_h(const float* __restrict__ flat, unsigned* __restrict__ packed) {
+__global__ void k_pack_attention_h(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= AttLayoutH::P_TOTAL) return;
     const HSrc s = att_h_src(t);
     if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(flat[s.s0]); return; }
     const float a = flat[s.s0], b = flat[s.s1];
+    if (status && !(fmaxf(fabsf(a), fabsf(b)) < 65504.0f))
+        __hip_atomic_fetch_or(status, ADFP_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const float ah = f16_hi_part(a), bh = f16_hi_part(b);
     _Float16 x, y;
     if (s.kind == 1) { x = (_Float16)ah; y = (_Float16)bh; }
@@ -358,6 +378,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
     const int lane_off = h * 128 + p * 4;
     const int count = *a.count_ptr;
     const int ntiles = (count + 31) >> 5;
+    float amax = 0.f;
     for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<8>(j, &s_next, ntiles)) >= 0;) {
         const int idx = tile * 32 + p;
         const bool valid = idx < count;
@@ -373,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
                 const f32x4 t = *(const f32x4*)(lds + A::P_A0 + unit_of_h(ks, h, j) * 4);
                 t8[j] = relu_f(fmaf(u, t.y, fmaf(occ, t.x, t.z)));
             }
-            split8(t8, xh[ks], xl[ks]);
+            split8(t8, xh[ks], xl[ks], amax);
         }
         __builtin_amdgcn_sched_barrier(0);
         // layer 1: 64 -> 128
@@ -386,8 +407,8 @@ __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
             float t[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) t[r] = relu_f(acc[r]);
-            split8(t, yh[2 * ob], yl[2 * ob]);
-            split8(t + 8, yh[2 * ob + 1], yl[2 * ob + 1]);
+            split8(t, yh[2 * ob], yl[2 * ob], amax);
+            split8(t + 8, yh[2 * ob + 1], yl[2 * ob + 1], amax);
         }
         // layer 2: 128 -> 128
 #pragma unroll
@@ -398,8 +419,8 @@ __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
             float t[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) t[r] = relu_f(acc[r]);
-            split8(t, xh[2 * ob], xl[2 * ob]);
-            split8(t + 8, xh[2 * ob + 1], xl[2 * ob + 1]);
+            split8(t, xh[2 * ob], xl[2 * ob], amax);
+            split8(t + 8, xh[2 * ob + 1], xl[2 * ob + 1], amax);
         }
         // layer 3: 128 -> 64, output 64 -> 2 on the VALU in f32
         float l0 = 0.f, l1 = 0.f;
@@ -432,4 +453,5 @@ __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
             a.w[q] = a1;
         }
     }
+    report_range(a.status, amax);
 }

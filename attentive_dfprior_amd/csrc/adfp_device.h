@@ -233,6 +233,17 @@ ADFP_DEV void adfp_sincosf(float x, float& sn, float& cs) {
     cs = __builtin_amdgcn_cosf(t);
 }
 
+// A sample position with a NaN coordinate (degenerate rays: 0/0 in the slab test, src/utils/Renderer.py:151) makes every
+// Fourier feature NaN and the reference's decoders return NaN.  The integer relu below maps a NaN with the sign bit set
+// to 0 (and v_max_f32 would drop any NaN), so the kernels restore the reference's answer at the output instead of paying a
+// compare + select per hidden activation.
+template <int NOUT>
+ADFP_DEV void nan_point_outputs(const double pt[3], float* __restrict__ out) {
+    const bool pnan = (pt[0] != pt[0]) | (pt[1] != pt[1]) | (pt[2] != pt[2]);
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) out[o] = pnan ? __builtin_nanf("") : out[o];
+}
+
 // relu as ONE integer instruction: max(bits(x), 0) keeps every positive float and maps every
 // negative one (sign bit = negative int, -0.0 included) to +0.  fmaxf() on an MFMA result costs two
 // VALU instructions (the compiler puts a canonicalising v_max in front of it, and folds fmed3 back

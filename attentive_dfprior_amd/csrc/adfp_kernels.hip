@@ -366,11 +366,13 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
             const double t = (bk - o) / d;
             const double tp = dpp_f64<0xB1>(t);              // lane ^ 1
             const double t0 = side ? tp : t, t1 = side ? t : tp;
-            const double tmk = t0 > t1 ? t0 : t1;         // torch.max propagates NaN; not reproduced
+            // torch.max / torch.min propagate NaN (0/0: a zero direction component with the origin on that bound
+            // plane; inf/inf), and so does torch.clamp below -- the whole ray then samples NaN like the reference's
+            const double tmk = (t0 != t0 || t1 != t1) ? (double)NAN : (t0 > t1 ? t0 : t1);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const double tm = readlane_f64(tmk, 2 * k);
-                far_bb = tm < far_bb ? tm : far_bb;
+                far_bb = (tm != tm || far_bb != far_bb) ? (double)NAN : (tm < far_bb ? tm : far_bb);
             }
         }
         far_bb += 0.01;
@@ -391,8 +393,12 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
     // Both lists are monotone (uniform samples run near -> far, surface samples 0.95 d -> 1.05 d), so
     // the rank of an element is its own index plus a binary-search count in the OTHER list (ties:
     // uniform first, like a stable sort of the concatenation).  The O(S^2) count is kept for the
-    // degenerate descending cases (far < near when the ray leaves the bound at once).
-    const bool ascending = (v[0] <= v[rs.ns - 1]) && (v[rs.ns] <= v[S - 1]);
+    // degenerate cases: descending lists (far < near when the ray leaves the bound at once) and NaN samples
+    // (NaN far plane; lindisp with a zero sensor depth gives inf * 0 in the last uniform sample), which
+    // torch.sort orders after every number.
+    bool any_nan = false;
+    for (int e0 = 0; e0 < S; e0 += 64) { const int e = e0 + lane; any_nan |= __ballot(e < S && v[e] != v[e]) != 0ull; }
+    const bool ascending = !any_nan && (v[0] <= v[rs.ns - 1]) && (v[rs.ns] <= v[S - 1]);
     if (ascending) {
         for (int e = lane; e < S; e += 64) {
             const double val = v[e];
@@ -412,8 +418,15 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
     }
     for (int e = lane; e < S; e += 64) {
         const double val = v[e];
+        const bool vn = val != val;
         int rank = 0;
-        for (int k = 0; k < S; ++k) { const double o = v[k]; rank += (o < val) || (o == val && k < e); }
+        for (int k = 0; k < S; ++k) {
+            const double o = v[k];
+            const bool on = o != o;
+            const bool less = vn ? !on : (o < val);                  // every number sorts before a NaN
+            const bool same = vn ? on : (o == val);
+            rank += less || (same && k < e);
+        }
         zrow[rank] = val;
     }
 }
@@ -517,7 +530,10 @@ __global__ __launch_bounds__(256, TSDF_MINW) void k_tsdf(TsdfArgs a) {
         for (int u = 0; u < UB; ++u) {
             const float t = tv[u];
             const int q = q0 + loc[u];
-            const bool band = ok[u] & (t > (float)(-1.0 + 1e-4)) & (t < (float)(1.0 - 1e-4));
+            // a NaN position (degenerate ray, see k_sample) is in no band: F.grid_sample of a NaN coordinate is NaN on
+            // the reference's side and every comparison with it is false (decoder.py:329)
+            const bool pnan = (p[u][0] != p[u][0]) | (p[u][1] != p[u][1]) | (p[u][2] != p[u][2]);
+            const bool band = ok[u] & !pnan & (t > (float)(-1.0 + 1e-4)) & (t < (float)(1.0 - 1e-4));
             if (ok[u]) {
                 if (a.tsdf_out) a.tsdf_out[q] = t;
                 s_f[loc[u]] = (unsigned char)((in_bound(p[u], a.b) ? ADFP_F_INBOUND : 0u) | (band ? ADFP_F_BAND : 0u));
@@ -574,6 +590,7 @@ struct DecodeArgs {
     float* att_occ;            // HIGH: high+low per list entry
     int write_w;
     int apply_bound;           // Renderer.eval_points' ret[~mask,3] = 100 (Renderer.py:64)
+    int* status;               // adfp_scene.status (f16x3 kernels: operand range guard) or NULL
 };
 
 template <int CDIM, int NOUT, int ROLE, int NT>
@@ -647,6 +664,7 @@ __global__ __launch_bounds__(NT, 2) void k_decode(DecodeArgs a) {
             out[o] = s + lds[L::P_BO + o];
         }
 
+        nan_point_outputs<NOUT>(pt, out);
         if (valid && h == 0) {
             if constexpr (ROLE == ROLE_LOW) {
                 const bool inb = in_bound(pt, a.b);
@@ -668,6 +686,7 @@ struct AttArgs {
     const float* packed; const int* list; const int* count_ptr;
     const float* att_occ; const float* att_u; const unsigned char* flags;
     float* raw; float* w; int apply_bound;
+    int* status;
 };
 
 // workgroup shape of the dense f16x3 decoder kernels: 256 threads x 2 workgroups per CU, or one
@@ -931,19 +950,19 @@ long long adfp_decoder_packed_h_words(int kind) {
     }
     return ADFP_E_ARG;
 }
-int adfp_pack_decoder_h(int kind, const float* flat, void* packed, void* stream) {
+int adfp_pack_decoder_h(int kind, const float* flat, void* packed, int* status, void* stream) {
     if (!flat || !packed) return ADFP_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     unsigned* out = (unsigned*)packed;
     switch (kind) {
         case ADFP_DEC_LOW:
-            hipLaunchKernelGGL((k_pack_decoder_h<32, 1>), dim3((DecLayoutH<32, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out);
+            hipLaunchKernelGGL((k_pack_decoder_h<32, 1>), dim3((DecLayoutH<32, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status);
             break;
         case ADFP_DEC_HIGH:
-            hipLaunchKernelGGL((k_pack_decoder_h<64, 1>), dim3((DecLayoutH<64, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out);
+            hipLaunchKernelGGL((k_pack_decoder_h<64, 1>), dim3((DecLayoutH<64, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status);
             break;
         case ADFP_DEC_COLOR:
-            hipLaunchKernelGGL((k_pack_decoder_h<32, 4>), dim3((DecLayoutH<32, 4>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out);
+            hipLaunchKernelGGL((k_pack_decoder_h<32, 4>), dim3((DecLayoutH<32, 4>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status);
             break;
         default: return ADFP_E_ARG;
     }
@@ -951,9 +970,9 @@ int adfp_pack_decoder_h(int kind, const float* flat, void* packed, void* stream)
     return 0;
 }
 long long adfp_attention_packed_h_words(void) { return AttLayoutH::P_TOTAL; }
-int adfp_pack_attention_h(const float* flat, void* packed, void* stream) {
+int adfp_pack_attention_h(const float* flat, void* packed, int* status, void* stream) {
     if (!flat || !packed) return ADFP_E_ARG;
-    hipLaunchKernelGGL(k_pack_attention_h, dim3((AttLayoutH::P_TOTAL + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat, (unsigned*)packed);
+    hipLaunchKernelGGL(k_pack_attention_h, dim3((AttLayoutH::P_TOTAL + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat, (unsigned*)packed, status);
     ADFP_CHECK_LAUNCH();
     return 0;
 }
@@ -1088,6 +1107,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
     a.P = P; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
     a.list = nullptr; a.count_ptr = nullptr; a.flags = fuse ? ws.flags : nullptr;
     a.raw = raw; a.w = w; a.att_occ = nullptr; a.write_w = 1; a.apply_bound = apply_bound;   // attention overwrites w on the band
+    a.status = sc->status;
     const int ntiles = (P.n + 31) / 32;
     // LOW on every point
     a.g0 = make_grid(sc->low); a.g1 = a.g0;
@@ -1123,7 +1143,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         ADFP_CHECK_LAUNCH();
         AttArgs t;
         t.list = ws.list; t.count_ptr = ws.counter; t.att_occ = ws.att_occ; t.att_u = ws.att_u;
-        t.flags = ws.flags; t.raw = raw; t.w = w; t.apply_bound = apply_bound;
+        t.flags = ws.flags; t.raw = raw; t.w = w; t.apply_bound = apply_bound; t.status = sc->status;
         if (sc->h_att) {
             t.packed = (const float*)sc->h_att;
             hipLaunchKernelGGL(k_attention_h, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
@@ -1145,7 +1165,7 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
     DecodeArgs a;
     a.P = P; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
     a.list = nullptr; a.count_ptr = nullptr; a.flags = nullptr;
-    a.raw = raw; a.w = w; a.att_occ = nullptr; a.write_w = 1; a.apply_bound = 1;
+    a.raw = raw; a.w = w; a.att_occ = nullptr; a.write_w = 1; a.apply_bound = 1; a.status = sc->status;
     const int ntiles = (P.n + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if (kind == ADFP_DEC_LOW) {

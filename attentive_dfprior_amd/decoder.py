@@ -177,12 +177,13 @@ class DF(nn.Module):
             with torch.cuda.device(dev):
                 if name == 'att':
                     packed = torch.empty(L.adfp_attention_packed_h_words(), dtype=torch.int32, device=dev)
-                    _lib.check(L.adfp_pack_attention_h(_lib.ptr(flat), _lib.ptr(packed), _lib.current_stream(dev)),
+                    _lib.check(L.adfp_pack_attention_h(_lib.ptr(flat), _lib.ptr(packed), _lib.status_ptr(), _lib.current_stream(dev)),
                                'adfp_pack_attention_h')
                 else:
                     kind = _lib.DEC_KIND[name]
                     packed = torch.empty(L.adfp_decoder_packed_h_words(kind), dtype=torch.int32, device=dev)
-                    _lib.check(L.adfp_pack_decoder_h(kind, _lib.ptr(flat), _lib.ptr(packed), _lib.current_stream(dev)),
+                    _lib.check(L.adfp_pack_decoder_h(kind, _lib.ptr(flat), _lib.ptr(packed), _lib.status_ptr(),
+                                                     _lib.current_stream(dev)),
                                'adfp_pack_decoder_h')
             self._packed[slot] = (key, packed)
             return packed

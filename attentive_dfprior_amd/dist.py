@@ -66,14 +66,16 @@ def render_rays_sharded(render_fn, rays_o, rays_d, gt_depth, group=None, gather=
     return tuple(_all_gather_rows(o.contiguous(), sizes, group) for o in outs)
 
 
-def allreduce_grads(tensors, group=None):
+def allreduce_grads(tensors, group=None, skip_single=True):
     """One flat-bucket all-reduce (SUM, fp32) of the gradients of `tensors` (parameters or grids).
-    Tensors without a gradient contribute zeros so that every rank issues the same collective."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return
+    Tensors without a gradient contribute zeros so that every rank issues the same collective.
+    Returns the number of bytes that went through the collective (0 when it was skipped).
+    skip_single=False issues the collective even in a world of one rank (bench / RCCL smoke test)."""
+    if not (dist.is_available() and dist.is_initialized()) or (skip_single and dist.get_world_size(group) == 1):
+        return 0
     tensors = [t for t in tensors if t.requires_grad]
     if not tensors:
-        return
+        return 0
     flats = []
     for t in tensors:
         g = t.grad if t.grad is not None else torch.zeros_like(t)
@@ -89,6 +91,7 @@ def allreduce_grads(tensors, group=None):
         else:
             t.grad.copy_(g)
         off += n
+    return bucket.numel() * 4
 
 
 class MaskedGradBucket:
@@ -124,8 +127,8 @@ class MaskedGradBucket:
         return n
 
     @torch.no_grad()
-    def allreduce(self):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+    def allreduce(self, skip_single=True):
+        if not (dist.is_available() and dist.is_initialized()) or (skip_single and dist.get_world_size(self.group) == 1):
             return
         parts = []
         for k, g in self.grids:

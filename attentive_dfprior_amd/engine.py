@@ -86,7 +86,9 @@ class Engine(object):
         """Returns (AdfpScene, keepalive list).  The forward takes the f16-split decoder images unless
         ADFP_MATH=f32; the backward always takes the exact f32 images."""
         use_h = (not backward) and math_mode() == 'f16x3'
+        _lib.check_status()                      # an f16-range violation of an EARLIER call surfaces here
         sc = _lib.AdfpScene()
+        sc.status = _lib.status_word().data_ptr()
         keep = []
         _lib.fill_bound(sc.bound, self.host_bound(bound, 'bound'))
         grids = [('low', 'grid_low')]
@@ -137,8 +139,14 @@ class Engine(object):
     def eval_points(self, decoders, pts, c, tsdf_volume, tsdf_bnds, bound, stage, apply_bound_rule=True):
         """pts [P,3] f64/f32 on the GPU -> raw [P,4] f32, w [P] f32."""
         _lib.require_cuda(pts, 'points')
-        # point-wise queries are inference-only (the reference's Mesher runs them under no_grad,
-        # src/utils/Mesher.py:437-447); training goes through Renderer.render_batch_ray
+        # Point-wise queries are inference-only here (the reference's Mesher runs them under no_grad,
+        # src/utils/Mesher.py:437-447); training goes through Renderer.render_batch_ray.  The reference's
+        # eval_points is autograd-transparent, so a caller that expects gradients must hear about it: raise
+        # instead of returning detached tensors that silently yield zero gradients.
+        if torch.is_grad_enabled() and (pts.requires_grad or any(v.requires_grad for v in c.values())):
+            raise NotImplementedError(
+                'eval_points / DF.forward are not differentiable in libadfp: differentiate through '
+                'Renderer.render_batch_ray (grids, decoder parameters, rays), or call under torch.no_grad()')
         dev = pts.device
         with torch.cuda.device(dev):
             if pts.dtype == torch.float64:

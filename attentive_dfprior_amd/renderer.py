@@ -41,7 +41,15 @@ class Renderer(object):
         if not self.occupancy:
             raise NotImplementedError('occupancy=False (density compositing) is not used by the reference '
                                       'configs (configs/df_prior.yaml:4); not supported')
+        self.need_param_grad = True          # see render_batch_ray
         self._engine = Engine()
+
+    def check_overflow(self, device=None):
+        """Not in the reference.  The default f16-split decoders (ADFP_MATH=f16x3) cannot represent operands with
+        |x| >= 65504; the kernels raise a sticky flag instead of returning garbage silently, and -- like an
+        asynchronous HIP error -- the flag is reported by the next call into the library.  This waits for the
+        device and reports it now (RuntimeError)."""
+        _lib.check_status(sync=True, device=device)
 
     # ---- point queries --------------------------------------------------------------------
     def eval_points(self, p, decoders, tsdf_volume, tsdf_bnds, c=None, stage='color', device='cuda:0'):
@@ -50,33 +58,40 @@ class Renderer(object):
                                         apply_bound_rule=True)
 
     def sample_grid_tsdf(self, p, tsdf_volume, device='cuda:0'):
-        """Trilinear TSDF lookup of p [..., P, 3] -> [1, P] (Renderer.py:73-81)."""
-        return self._engine.sample_tsdf(p, tsdf_volume, self.tsdf_bnds).reshape(1, -1)
+        """Trilinear TSDF lookup of p [1, P, 3] -> [1, 1, P] (grid_sample's [N, C, P], Renderer.py:73-81)."""
+        return self._engine.sample_tsdf(p, tsdf_volume, self.tsdf_bnds).reshape(1, 1, -1)
 
     def eval_points_tsdf(self, p, tsdf_volume, device='cuda:0'):
-        """TSDF value of every point of p [P,3] -> [1, P] (Renderer.py:84-107)."""
-        return self.sample_grid_tsdf(p, tsdf_volume, device)
+        """TSDF value of every point of p [P,3] -> [1, P] (Renderer.py:84-107: sample_grid_tsdf(...).squeeze(0))."""
+        return self.sample_grid_tsdf(p, tsdf_volume, device).squeeze(0)
 
     # ---- rays -----------------------------------------------------------------------------
     def render_batch_ray(self, c, decoders, rays_d, rays_o, device, tsdf_volume, tsdf_bnds, stage, gt_depth=None,
-                         depth_max=None):
+                         depth_max=None, need_param_grad=None):
         """Render depth / uncertainty / colour / attention weight of a batch of rays.
 
         ``depth_max`` (not in the reference) lets a ray shard use the max sensor depth of the full
-        batch so that sharded renders reproduce the unsharded far clamp (Renderer.py:159, :195)."""
+        batch so that sharded renders reproduce the unsharded far clamp (Renderer.py:159, :195).
+        ``need_param_grad`` (not in the reference; default = ``self.need_param_grad`` = True): False skips the
+        decoder-parameter gradients in the backward.  The reference's Tracker deep-copies decoders whose
+        parameters keep requires_grad=True although only the camera pose is optimised (src/Tracker.py:144, :112-133);
+        autograd then computes weight gradients nobody reads.  A tracker sets ``renderer.need_param_grad = False``
+        (or calls ``decoders.requires_grad_(False)``) and pays for the ray gradients only."""
         _lib.require_cuda(rays_o, 'rays_o')
         N = rays_o.shape[0]
         t_rand = None
         if self.perturb > 0.:
             t_rand = torch.rand(N, self.N_samples)                        # CPU generator, as Renderer.py:216
+        if need_param_grad is None:
+            need_param_grad = self.need_param_grad
         needs_grad = torch.is_grad_enabled() and (
-            any(v.requires_grad for v in c.values()) or decoders.any_requires_grad()
+            any(v.requires_grad for v in c.values()) or (need_param_grad and decoders.any_requires_grad())
             or rays_o.requires_grad or rays_d.requires_grad)
         if needs_grad:
             from .autograd import render_with_grad
             return render_with_grad(self._engine, decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds,
                                     self.bound, stage, self.N_samples, self.N_surface, self.lindisp, self.perturb,
-                                    t_rand, depth_max)
+                                    t_rand, depth_max, need_param_grad)
         depth, unc, color, weight, _ = self._engine.render_forward(
             decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, self.bound, stage,
             self.N_samples, self.N_surface, self.lindisp, self.perturb, t_rand, depth_max)

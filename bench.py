@@ -9,26 +9,39 @@ region; the per-call layout conversions of my path (grid relayout, weight packin
 invalidated every step so that they are INSIDE the timed region.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N   (one rank per GPU)
 
-Multi-GPU: rays (here: whole frames, one pose per rank) are independent units, so ranks render
-with NO data-path collective ("weak" scaling); value = all rays of all ranks / max-over-ranks time.
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU, starts N worker
+processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, backend
+"nccl" = RCCL) and relays rank 0's JSON line.  Under ``python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N`` the environment is already there and every process is a worker.
+
+Multi-GPU headline: rays (here: whole frames, one pose per rank) are independent units, so ranks render with
+NO data-path collective ("weak" scaling); value = all rays of all ranks / max-over-ranks time.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline      dominant kernel (colour decoder, MFMA f32 bound): algorithmic FLOP per launch /
-                HIP-event time of that kernel alone on the launch stream
-  roofline_tsdf the HBM-streaming trilerp stage (k_tsdf): 32 algorithmic bytes per sample
-  cpu_baseline  the oracle (CPU PyTorch restatement == reference) timed on this host's cores on a
-                bounded ray sample of the same workload; psnr/max-rel of the GPU path vs it
+  roofline        dominant kernel (colour decoder): executed-MFMA FLOP and algorithmic FLOP per launch / HIP-event
+                  time of that kernel alone on the launch stream
+  roofline_tsdf   the HBM-side trilerp stage (k_tsdf): 32 algorithmic bytes per sample (room0: cache-resident)
+  config5         the one configuration whose TSDF streams from HBM (1024^3 = 4.3 GB, 128 samples/ray, one GPU's
+                  share of 1 M rays): rays/s and the trilerp stage's roofline there
+  strong          ONE 640x480 frame sharded over the ranks (contiguous ray slices, full-batch depth max,
+                  outputs all-gathered) -- the north star's "GPU g gets the contiguous ray slice"
+  train_allreduce one 5 000-ray Mapper iteration per step with the rays sharded over the ranks and ONE flat-bucket
+                  RCCL all-reduce of the loss gradients (48.6 MB at room0), and the frustum-masked bucket variant
+  sustained       the headline loop run for >= 2 s
+  torch_gpu_baseline  the reference's PyTorch ops (the oracle's functions) on the same GPU through PyTorch-ROCm
+  cpu_baseline    the oracle (CPU PyTorch restatement == reference) timed on this host's cores on a bounded ray
+                  sample of the same workload; parity_vs_oracle compares THE TIMED OUTPUT on those rays
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -41,23 +54,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA, spec
 F16X3_FLOP_COLOR = 90 * 32 * 32 * 16 * 2 / 32.0   # executed f16 MFMA FLOP per sample: 90 x 32x32x16 per 32-point tile
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
-
-
-def pmc_traffic(kernel_prefix, samples_per_launch):
-    """HBM bytes per launch of one kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE, separate runs, profiles/r01_pmc_hbm_traffic.csv holds bytes per sample): the counters
-    cannot be read from inside this process, so the figure is the profiled bytes/sample x this run's samples
-    per launch.  None when the file is absent."""
-    import csv
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.csv')
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        rows = [r for r in csv.reader(l for l in f if not l.startswith('#'))]
-    for r in rows[1:]:
-        if r[0].startswith(kernel_prefix):
-            return (float(r[3]) + float(r[4])) * samples_per_launch
-    return None
+CFG64 = {'rendering': {'lindisp': False, 'perturb': 0.0, 'N_samples': 48, 'N_surface': 16, 'N_importance': 0},
+         'scale': 1, 'occupancy': True, 'meshing': {'resolution': 256}}
 
 
 def parse():
@@ -68,30 +66,115 @@ def parse():
     ap.add_argument('--scene', default='room0')
     ap.add_argument('--cpu-rays', type=int, default=20000, help='ray sample of the CPU baseline leg (0 = skip)')
     ap.add_argument('--no-stage-timing', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='headline + roofline only (skip sustained / config5 / torch-gpu / dist legs)')
     return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# launcher: --gpus N without a torch.distributed environment.  Nothing here may initialise the GPU.
+# ----------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_workers(args):
+    import torch
+    have = torch.cuda.device_count()                     # counting devices does not initialise HIP
+    if have < args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s)', file=sys.stderr)
+        sys.exit(2)
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=600))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(max(abs(rc) for rc in rcs))
+
+
+# ----------------------------------------------------------------------------------------------------------
+def source_hash():
+    """sha256 of the kernel sources + C header: stamps profile-derived numbers with the build they belong to."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'attentive_dfprior_amd', 'csrc')
+    for f in sorted(os.listdir(d)) + ['../../include/adfp.h']:
+        p = os.path.join(d, f)
+        if os.path.isfile(p) and p.endswith(('.h', '.hip')):
+            h.update(open(p, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel_prefix, samples_per_launch, fname='r02_pmc_hbm_traffic.csv'):
+    """HBM bytes per launch of one kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE,
+    separate runs; the csv holds bytes per sample): the counters cannot be read from inside this process, so the figure
+    is the PROFILED bytes/sample x this run's samples per launch.  Returns (bytes or None, provenance dict); the csv's
+    header carries the source hash of the build it was taken from and `stale` says whether that is this build."""
+    import csv
+    for name in (fname, fname.replace('r02_', 'r01_')):
+        path = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(path):
+            break
+    else:
+        return None, {'file': None}
+    head = open(path).readline()
+    stamp = head.split('source_hash=')[1].split()[0].strip() if 'source_hash=' in head else None
+    prov = {'file': 'profiles/' + os.path.basename(path), 'profiled_source_hash': stamp, 'this_source_hash': source_hash(),
+            'stale': stamp != source_hash()}
+    with open(path) as f:
+        rows = [r for r in csv.reader(l for l in f if not l.startswith('#'))]
+    for r in rows[1:]:
+        if r[0].startswith(kernel_prefix):
+            return (float(r[3]) + float(r[4])) * samples_per_launch, prov
+    return None, prov
+
+
+def build_scene(A, synthetic, name, dev, H=480, W=640):
+    scene = synthetic.Scene(name, H=H, W=W, device=dev, grid_std_scale=20.0)
+    scene.c['grid_high'] = scene.c['grid_high'] * 100
+    sd = synthetic.seeded_state_dict(0)
+    dec = A.DF()
+    dec.load_state_dict(sd)
+    dec.bound = scene.bound
+    dec = dec.to(dev)
+    return scene, sd, dec
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        launch_workers(args)                                         # never returns
+    import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 or os.environ.get('ADFP_BENCH_FORCE_DIST') == '1':     # the env knob exercises the RCCL path on one GPU
+    dev = torch.device(f'cuda:{local_rank}')
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        os.environ.setdefault('RANK', '0')
-        os.environ.setdefault('WORLD_SIZE', '1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
-    else:
-        dist = None
-    n_gpus = world
-    if args.gpus != world and rank == 0:
-        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run '
-              f'--nproc-per-node {args.gpus} for a {args.gpus}-GPU run (reporting n_gpus={world})', file=sys.stderr)
-    dev = torch.device(f'cuda:{local_rank}')
-    torch.cuda.set_device(dev)
+        dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(minutes=30))
+    n_gpus = dist.get_world_size() if dist is not None else 1
+    if args.gpus != n_gpus and rank == 0:
+        print(f'bench.py: --gpus {args.gpus} but the process group has {n_gpus} rank(s); reporting n_gpus={n_gpus}', file=sys.stderr)
 
     import attentive_dfprior_amd as A
     from attentive_dfprior_amd import synthetic, _lib
@@ -99,16 +182,8 @@ def main():
 
     H, W, NS, NF = 480, 640, 48, 16
     S = NS + NF
-    scene = synthetic.Scene(args.scene, H=H, W=W, device=dev, grid_std_scale=20.0)
-    scene.c['grid_high'] = scene.c['grid_high'] * 100
-    sd = synthetic.seeded_state_dict(0)
-    dec = A.DF()
-    dec.load_state_dict(sd)
-    dec.bound = scene.bound
-    dec = dec.to(dev)
-    cfg = {'rendering': {'lindisp': False, 'perturb': 0.0, 'N_samples': NS, 'N_surface': NF, 'N_importance': 0},
-           'scale': 1, 'occupancy': True, 'meshing': {'resolution': 256}}
-    rend = A.Renderer(cfg, None, scene)
+    scene, sd, dec = build_scene(A, synthetic, args.scene, dev)
+    rend = A.Renderer(CFG64, None, scene)
     tsdf_bnds = scene.tsdf_bnds.to(dev)
     # one pose per rank (weak scaling: every rank renders a full frame)
     c2w = scene.default_c2w(offset=(0.3 * rank, 0.1 * rank, 0.0), yaw=0.3 + 0.4 * rank, pitch=-0.1)
@@ -126,20 +201,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_loop(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
+
+    elapsed, out = timed_loop(step, args.steps, args.warmup)
     depth_img, unc_img, color_img = out
     assert torch.isfinite(depth_img).all() and torch.isfinite(color_img).all()
+    rend.check_overflow(dev)
 
     ms_per_step = elapsed / args.steps * 1e3
     value = n_gpus * n_rays * args.steps / elapsed
@@ -155,10 +235,49 @@ def main():
                    'rays_per_step_per_gpu': n_rays, 'samples_per_ray': S,
                    'tsdf_voxels': list(scene.tsdf_volume.shape[2:]),
                    'grid_high': list(scene.c['grid_high'].shape[2:])},
+        'source_hash': source_hash(),
     }
 
+    # ---- legs every rank takes part in ---------------------------------------------------------------------
+    if not args.no_extra:
+        own_group = False
+        # RCCL prints its version banner on C-level stdout when the first communicator comes up: keep stdout = the ONE
+        # JSON line by pointing fd 1 at stderr for the duration of these legs (and flushing libc's buffer before it returns)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if dist is None:                       # single process: a world of one rank, so that the RCCL path runs here too
+                import torch.distributed as dist1
+                os.environ['MASTER_ADDR'] = '127.0.0.1'
+                os.environ['MASTER_PORT'] = str(free_port())
+                dist1.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+                own_group = True
+                dd = dist1
+            else:
+                dd = dist
+            legs = dist_legs(dd, A, synthetic, rend, dec, scene, tsdf_bnds, dev, args)
+        except Exception as e:                      # extra information, never the reason a bench fails
+            legs = {'dist_legs_error': repr(e)[:300]}
+        finally:
+            if own_group:
+                try:
+                    dist1.destroy_process_group()
+                except Exception:
+                    pass
+            try:
+                C.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
+        if rank == 0:
+            result.update(legs)
+
+    # ---- rank-0 legs -----------------------------------------------------------------------------------------
     if rank == 0 and not args.no_stage_timing:
         result.update(stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF))
+    if rank == 0 and n_gpus == 1 and not args.no_extra:
         if os.environ.get('ADFP_MATH', 'f16x3') == 'f16x3':
             # the same frame with every product on the exact f32-input MFMA (ADFP_MATH=f32), for reference:
             # the f16x3 split reproduces f32 products to 2^-22, this is the bit-exact mode
@@ -177,20 +296,147 @@ def main():
                 'value': n_rays / dt, 'unit': 'rays/s', 'ms_per_step': dt * 1e3, 'n_gpus': 1,
                 'max_abs_diff_color_vs_default_mode': float((out32[2] - color_img).abs().max()),
                 'max_rel_diff_depth_vs_default_mode': float(((out32[0] - depth_img).abs() / depth_img.abs().clamp_min(1e-3)).max())}
-    if rank == 0 and args.cpu_rays > 0:
-        result.update(cpu_leg(rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF, args.cpu_rays))
+        # sustained: the same loop for >= 2 s (the contract's 10-20 steps are ~0.1 s of GPU time)
+        n_sus = max(50, int(2.2 / (ms_per_step * 1e-3)))
+        el, _ = timed_loop(step, n_sus, 0)
+        result['sustained'] = {'value': n_rays * n_sus / el, 'unit': 'rays/s', 'steps': n_sus, 'seconds': el,
+                               'ms_per_step': el / n_sus * 1e3}
+        for name, leg in (('torch_gpu_baseline', lambda: torch_gpu_leg(rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF)),
+                          ('config5', lambda: config5_leg(A, synthetic, _lib, L, dev))):
+            try:
+                result[name] = leg()
+            except Exception as e:
+                result[name] = {'error': repr(e)[:300]}
+    if rank == 0 and n_gpus == 1 and args.cpu_rays > 0:
+        result.update(cpu_leg(rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, depth_img, color_img, dev, NS, NF, args.cpu_rays))
     if rank == 0:
         print(json.dumps(result))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
+# ----------------------------------------------------------------------------------------------------------
+def dist_legs(dist, A, synthetic, rend, dec, scene, tsdf_bnds, dev, args):
+    """`strong` and `train_allreduce` (module docstring).  Every rank runs this; timing = barrier + synchronize on
+    both sides, max over ranks."""
+    import torch
+    from attentive_dfprior_amd import dist as adist, mapping
+    from attentive_dfprior_amd.common import get_rays
+    world, rank = dist.get_world_size(), dist.get_rank()
+    out = {}
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = fn()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / steps, r
+
+    one = torch.ones(1, device=dev)
+    dist.all_reduce(one)
+    out['rccl'] = {'backend': dist.get_backend(), 'world_size': world, 'allreduce_of_ones': float(one.item())}
+
+    # ---- strong: ONE frame, contiguous ray slices, full-batch depth max, outputs all-gathered (28 B/ray)
+    c2w = scene.default_c2w(yaw=0.3, pitch=-0.1)
+    gd = scene.depth_image(c2w).reshape(-1)
+    ro, rd = get_rays(scene.H, scene.W, scene.fx, scene.fy, scene.cx, scene.cy, c2w, dev)
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    n = ro.shape[0]
+
+    def render_fn(o, d, z, m):
+        return rend.render_batch_ray(scene.c, dec, d, o, dev, scene.tsdf_volume, tsdf_bnds, 'color', z, depth_max=m)[:3]
+
+    def strong_step():
+        with torch.no_grad():
+            return adist.render_rays_sharded(render_fn, ro, rd, gd, gather=True)
+    t_strong, frame = timed(strong_step, max(5, args.steps), 2)
+    assert frame[0].shape[0] == n and torch.isfinite(frame[0]).all()
+    out['strong'] = {'value': n / t_strong, 'unit': 'rays/s', 'n_gpus': world, 'scaling': 'strong', 'ms_per_frame': t_strong * 1e3,
+                     'workload': 'ONE 640x480 x 64-sample frame as a single ray batch, rank r renders the contiguous slice '
+                                 '[r N/world, (r+1) N/world) with the full-batch depth max, depth/uncertainty/colour all-gathered '
+                                 '(28 B/ray) inside the timed region',
+                     'allgather_bytes': n * 28}
+
+    # ---- train_allreduce: one 5 000-ray Mapper iteration (stage color), rays sharded, ONE flat gradient all-reduce
+    n_train = 5000
+    g = torch.Generator().manual_seed(1)
+    pick = torch.randint(n, (n_train,), generator=g).to(dev)
+    lo, hi = adist.shard_range(n_train, rank, world)
+    tro, trd, tgd = ro[pick][lo:hi].contiguous(), rd[pick][lo:hi].contiguous(), gd[pick][lo:hi].contiguous()
+    tgc = torch.rand(n_train, 3, generator=g).to(dev)[lo:hi]
+    dmax = gd[pick].max().reshape(1)
+    frozen = list(dec.low_decoder.parameters()) + list(dec.high_decoder.parameters())
+    for p in frozen:
+        p.requires_grad_(False)                          # low is never optimised, fix_high: True (src/Mapper.py:364-371)
+    params = list(dec.color_decoder.parameters()) + list(dec.mlp.parameters())
+    params_before = [p.detach().clone() for p in params]           # the later legs compare against the seeded weights
+    grids = {k: v.detach().clone().requires_grad_(True) for k, v in scene.c.items()}
+    masks = {k: mapping.frustum_mask(c2w, tuple(v.shape[2:]), gd.reshape(scene.H, scene.W), scene.bound, scene.H, scene.W,
+                                     scene.fx, scene.fy, scene.cx, scene.cy) for k, v in grids.items()}
+    opt = torch.optim.Adam(params, lr=0.005)
+    buckets = {'dense': None, 'frustum_masked': adist.MaskedGradBucket(grids, masks, extra=params)}
+    res = {}
+    try:
+        for mode in ('dense', 'frustum_masked'):
+            opt_g = mapping.MaskedGridAdam(grids, masks if mode == 'frustum_masked' else None)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+            def it():
+                opt.zero_grad()
+                opt_g.zero_grad()
+                d, u, col, w = rend.render_batch_ray(grids, dec, trd, tro, dev, scene.tsdf_volume, tsdf_bnds, 'color', tgd, depth_max=dmax)
+                m = tgd > 0
+                (torch.abs(tgd[m] - d[m]).sum() + 0.2 * torch.abs(tgc - col).sum()).backward()
+                ev[0].record()
+                if mode == 'dense':
+                    nbytes = adist.allreduce_grads(list(grids.values()) + params, skip_single=False)
+                else:
+                    buckets[mode].allreduce(skip_single=False)
+                    nbytes = buckets[mode].numel() * 4
+                ev[1].record()
+                opt.step()
+                opt_g.step({'grid_low': 0.005, 'grid_high': 0.005, 'grid_color': 0.005})
+                return nbytes
+            t_it, nbytes = timed(it, 20, 3)
+            torch.cuda.synchronize(dev)
+            # the collective alone (pack + all-reduce + unpack), HIP events on the launch stream, last iteration
+            res[mode] = {'ms_per_iteration': t_it * 1e3, 'rays_per_s': n_train / t_it, 'bucket_bytes': int(nbytes),
+                         'allreduce_ms_incl_pack_unpack': ev[0].elapsed_time(ev[1])}
+    finally:
+        with torch.no_grad():
+            for p, p0 in zip(params, params_before):
+                p.copy_(p0)                                          # bumps _version: the packed images are rebuilt
+        for p in dec.parameters():
+            p.grad = None
+        for p in frozen:
+            p.requires_grad_(True)
+    out['train_allreduce'] = {'rays_per_iteration': n_train, 'rays_per_rank': hi - lo, 'n_gpus': world, 'stage': 'color',
+                              'samples_per_ray': 64, **res,
+                              'note': 'render forward + Mapper loss + backward on the rank\'s ray shard, ONE flat-bucket all-reduce (SUM, '
+                                      'fp32) of the three grids\' dense gradients + the trainable decoder parameters, then Adam on every '
+                                      'rank; frustum_masked = the bucket restricted to the frustum-selected voxels (SURVEY.md section 8e)'}
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------
 def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF, reps=5):
     """HIP-event time of the individual kernels, each launched alone on torch's current stream
     (the stream the library launches on), over EXACTLY the launch mix of one frame: the
     reference's ray batches (3 x 100 000 + 1 x 7 200 rays at 640x480), so that the average launch
     duration equals what `rocprofv3 --kernel-trace --stats` reports for the same command."""
+    import torch
     from attentive_dfprior_amd.common import get_rays
     eng = rend._engine
     S = NS + NF
@@ -253,32 +499,33 @@ def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, N
     if math_mode() == 'f32':
         roof = {'kernel': 'k_decode<32,4,COLOR> (colour decoder, exact f32-input MFMA)', 'bound': 'mfma',
                 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
-                'traffic': None}
+                'frac_algorithmic': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None}
     else:
         ex = F16X3_FLOP_COLOR * pts_per_launch / t_color / 1e12
         roof = {'kernel': 'k_decode_h<32,4,COLOR> (colour decoder, f16 MFMA with 3-product f32 operand split)',
                 'bound': 'mfma', 'achieved': ex, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ex / PEAK_F16_MFMA_TFLOPS, 'traffic': None,
-                'note': 'executed f16 MFMA FLOP (3 products per f32 product) against the 2.4 GHz spec peak; the chip '
-                        'clocks this kernel at ~1.8 GHz and PMC shows the matrix pipe busy 41 % of the time '
-                        '(profiles/r01_pmc_sq_forward.csv); the rest of the issue slots go to the gather / Fourier / split '
-                        'VALU work, which barely overlaps MFMA on a CDNA4 SIMD (tools/micro, DESIGN.md sections 4.1, 5)',
+                'frac': ex / PEAK_F16_MFMA_TFLOPS, 'frac_algorithmic': ach / PEAK_F16_MFMA_TFLOPS, 'traffic': None,
+                'note': 'achieved / frac = EXECUTED f16 MFMA FLOP (3 products per f32 product + K padding = 2.96 x algorithmic) '
+                        'against the 2.4 GHz dense-f16 spec peak; frac_algorithmic = algorithmic FLOP (2 x 15 575 per sample, '
+                        'SURVEY.md section 8d) against the same peak; algorithmic_f32_tflops / frac_of_f32_mfma_peak = the same '
+                        'algorithmic FLOP against the f32-input MFMA peak the exact mode is bound by',
                 'algorithmic_f32_tflops': ach, 'f32_mfma_peak_tflops': PEAK_F32_MFMA_TFLOPS,
                 'frac_of_f32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS}
     kname = 'void k_decode<32, 4, 2' if math_mode() == 'f32' else 'void k_decode_h<32, 4, 2'
-    roof['traffic'] = pmc_traffic(kname, pts_per_launch)
-    roof['traffic_note'] = ('HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) per sample of profiles/r01_pmc_hbm_traffic.csv '
-                            '(separate --pmc passes) x samples per launch; stores are 16-B/lane streams (exact), '
-                            'gather fetches are uncalibrated on gfx950 (MI355X_MICROARCH.md, HBM)')
+    roof['traffic'], prov = pmc_traffic(kname, pts_per_launch)
+    roof['traffic_source'] = dict(prov, note='PROFILED bytes/sample (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes) x this run\'s '
+                                             'samples per launch; stale = the csv was taken from a different build of the kernels')
     roof.update({'algorithmic_flop_per_launch': fl_color, 'avg_launch_ms': t_color * 1e3, 'launches_per_frame': nl,
                  'points_per_launch': pts_per_launch})
+    tsdf_traffic, _ = pmc_traffic('k_tsdf', pts_per_launch)
     return {
         'roofline': roof,
-        'roofline_tsdf': {'kernel': 'k_tsdf (TSDF trilerp + band mask + compaction)', 'bound': 'hbm',
-                          'achieved': by / t_tsdf / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
-                          'frac': by / t_tsdf / 1e9 / PEAK_HBM_GBPS, 'traffic': pmc_traffic('k_tsdf', pts_per_launch),
-                          'bytes_per_launch': by,
-                          'avg_launch_ms': t_tsdf * 1e3},
+        'roofline_tsdf': {'kernel': 'k_tsdf (TSDF trilerp + band mask + compaction), room0: the 785 MB volume is mostly cache-resident '
+                                    'along the frame\'s frustum; config5.roofline_tsdf is the streaming case',
+                          'bound': 'hbm', 'achieved': by / t_tsdf / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                          'frac': by / t_tsdf / 1e9 / PEAK_HBM_GBPS, 'traffic': tsdf_traffic,
+                          'real_hbm_gbps': (tsdf_traffic / t_tsdf / 1e9) if tsdf_traffic else None,
+                          'bytes_per_launch': by, 'avg_launch_ms': t_tsdf * 1e3},
         'stage_avg_launch_ms': {'color_decoder': t_color * 1e3, 'low_decoder': t_low * 1e3, 'tsdf': t_tsdf * 1e3,
                                 'whole_render_batch_ray': t_all * 1e3},
         'in_band_fraction': band_frac,
@@ -286,31 +533,177 @@ def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, N
     }
 
 
-def cpu_leg(rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF, n_cpu):
-    """The oracle on this host's cores on a bounded ray sample of the SAME workload, and the
-    GPU result on exactly those rays for PSNR / max-rel."""
+def config5_leg(A, synthetic, _lib, L, dev, n_rays=131072, NS=96, NF=32):
+    """BASELINE.json configs[4] at one GPU's share: 16 m cube, 1024^3 TSDF (4.3 GB: beyond L2 and the Infinity Cache),
+    128 samples/ray, rays of 8 poses.  Whole render_batch_ray rays/s and the trilerp stage alone."""
+    import torch
+    from attentive_dfprior_amd.common import get_rays
+    sc = synthetic.Scene('cube16', device=dev, grid_std_scale=20.0, voxel=16.0 / 1024, inset=2.0)
+    sc.c['grid_high'] = sc.c['grid_high'] * 100
+    dec = A.DF()
+    dec.load_state_dict(synthetic.seeded_state_dict(0))
+    dec.bound = sc.bound
+    dec = dec.to(dev)
+    cfg = {'rendering': {'lindisp': False, 'perturb': 0.0, 'N_samples': NS, 'N_surface': NF, 'N_importance': 0},
+           'scale': 1, 'occupancy': True, 'meshing': {'resolution': 256}}
+    rend = A.Renderer(cfg, None, sc, ray_batch_size=n_rays)
+    tb = sc.tsdf_bnds.to(dev)
+    S = NS + NF
+    eng = rend._engine
+    P = n_rays * S
+    flags = torch.empty((P,), dtype=torch.uint8, device=dev)
+    lst = torch.empty((P,), dtype=torch.int32, device=dev)
+    attu = torch.empty((P,), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((4,), dtype=torch.int32, device=dev)
+    st = _lib.current_stream(dev)
+
+    def ev_time(fn, reps):
+        fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    def measure(order):
+        """order 'pixel': every pose contributes a contiguous run of pixels (what render_img feeds: neighbouring rays are
+        neighbouring pixels); 'random': a random subset of each image (no coherence between consecutive rays)."""
+        g = torch.Generator().manual_seed(0)
+        ros, rds, gds = [], [], []
+        per = n_rays // 8
+        for k in range(8):
+            c2w = sc.default_c2w(offset=(0.5 * k - 2, 0.3 * k - 1, 0.2 * k), yaw=0.7 * k, pitch=-0.2 + 0.05 * k)
+            gd = sc.depth_image(c2w)
+            ro, rd = get_rays(sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2w, dev)
+            if order == 'random':
+                pick = torch.randperm(sc.H * sc.W, generator=g)[:per].to(dev)
+            else:
+                start = (sc.H * sc.W - per) // 2
+                pick = torch.arange(start, start + per, device=dev)
+            ros.append(ro.reshape(-1, 3)[pick]); rds.append(rd.reshape(-1, 3)[pick]); gds.append(gd.reshape(-1)[pick])
+        ro, rd, gd = torch.cat(ros).contiguous(), torch.cat(rds).contiguous(), torch.cat(gds).contiguous()
+
+        def whole():
+            with torch.no_grad():
+                return eng.render_forward(dec, sc.c, ro, rd, gd, sc.tsdf_volume, tb, sc.bound, 'color', NS, NF, want_aux=True)
+        d, u, c, w, aux = whole()
+        assert torch.isfinite(d).all() and torch.isfinite(c).all()
+        scn, keep = eng.scene(dec, sc.c, sc.tsdf_volume, tb, sc.bound, 'color')
+        ap = _lib.AdfpPoints()
+        ap.mode, ap.n_points = _lib.PTS_RAYS, P
+        ap.rays_o, ap.rays_d, ap.z_vals, ap.S = ro.data_ptr(), rd.data_ptr(), aux['z_vals'].data_ptr(), S
+        t_all = ev_time(whole, 5)
+        t_tsdf = ev_time(lambda: _lib.check(L.adfp_tsdf_stage(C.byref(scn), C.byref(ap), _lib.ptr(flags), _lib.ptr(lst), _lib.ptr(attu),
+                                                              None, _lib.ptr(cnt), st), 'tsdf'), 10)
+        return t_all, t_tsdf, float((w != 1).float().mean())
+    t_all, t_tsdf, band = measure('pixel')
+    t_all_r, t_tsdf_r, band_r = measure('random')
+    by = float(TSDF_BYTES_PER_SAMPLE) * P
+    traffic, prov = pmc_traffic('k_tsdf', P, 'r02_pmc_hbm_config5.csv')
+    return {'workload': '16 m cube, 1024^3 TSDF (4.29 GB), 128 samples/ray (96 + 32), 131 072 rays = 8 poses x 16 384 consecutive pixels '
+                        '(render_img order) = one GPU\'s share of BASELINE.json configs[4]', 'value': n_rays / t_all, 'unit': 'rays/s',
+            'ms_per_batch': t_all * 1e3, 'in_band_fraction': band,
+            'roofline_tsdf': {'kernel': 'k_tsdf', 'bound': 'hbm', 'achieved': by / t_tsdf / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                              'frac': by / t_tsdf / 1e9 / PEAK_HBM_GBPS, 'traffic': traffic,
+                              'real_hbm_gbps': (traffic / t_tsdf / 1e9) if traffic else None,
+                              'traffic_source': prov, 'bytes_per_launch': by, 'avg_launch_ms': t_tsdf * 1e3},
+            'random_ray_order': {'value': n_rays / t_all_r, 'unit': 'rays/s', 'ms_per_batch': t_all_r * 1e3, 'in_band_fraction': band_r,
+                                 'tsdf_algorithmic_gbps': by / t_tsdf_r / 1e9, 'tsdf_avg_launch_ms': t_tsdf_r * 1e3,
+                                 'note': 'the same volume and sample count with each pose\'s rays drawn at random from its image: consecutive '
+                                         'rays share no cache lines, every 8-corner lookup costs 4 HBM sectors'}}
+
+
+def torch_gpu_leg(rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF, n=100000):
+    """"the same restatement on 1 GPU via PyTorch-ROCm as the reference single-GPU PyTorch
+    denominator": the oracle's functions (== the reference's torch ops) on GPU tensors, with Renderer.eval_points'
+    500 000-point chunk loop (src/utils/Renderer.py:38), one reference ray batch (100 000 rays x 64 samples)."""
+    import torch
+    from oracle import adfp_oracle as O
+    from attentive_dfprior_amd.common import get_rays
+    ro, rd = get_rays(scene.H, scene.W, scene.fx, scene.fy, scene.cx, scene.cy, c2w, dev)
+    pick = torch.arange(0, scene.H * scene.W, 3, device=dev)[:n]
+    ro, rd, gd = ro.reshape(-1, 3)[pick].contiguous(), rd.reshape(-1, 3)[pick].contiguous(), gt_depth.reshape(-1)[pick].contiguous()
+    sd_g = {k: v.to(dev) for k, v in sd.items()}
+    bound_g = scene.bound.to(dev)
+
+    def torch_gpu():
+        with torch.no_grad():
+            z = O.sample_z(ro, rd, gd, bound_g, NS, NF, False, 0.0, None, None)
+            N, S = z.shape
+            pts = (ro[..., None, :] + rd[..., None, :] * z[..., :, None]).reshape(-1, 3)
+            raws = [O.eval_points(sd_g, pts[i:i + 500000], scene.c, scene.tsdf_volume, tsdf_bnds, bound_g, 'color')[0]
+                    for i in range(0, pts.shape[0], 500000)]
+            return O.raw2outputs(torch.cat(raws).reshape(N, S, 4), z)
+
+    def product():
+        with torch.no_grad():
+            return rend.render_batch_ray(scene.c, dec, rd, ro, dev, scene.tsdf_volume, tsdf_bnds, 'color', gt_depth=gd)
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            o = fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / reps, o
+    t_p, (d, u, c, w) = timed(product, 10)
+    t_t, (od, ov, oc, _) = timed(torch_gpu, 3)
+    return {'value': n / t_t, 'unit': 'rays/s', 'ms_per_100k_ray_batch': t_t * 1e3, 'product_ms_per_100k_ray_batch': t_p * 1e3,
+            'product_rays_per_s': n / t_p, 'speedup': t_t / t_p, 'kind': 'port (oracle functions on cuda tensors through PyTorch-ROCm)',
+            'max_rel_depth_product_vs_torch_gpu': float(((d - od).abs() / od.abs().clamp_min(1e-3)).max()),
+            'max_rel_color_product_vs_torch_gpu': float((c - oc).abs().max() / oc.abs().max())}
+
+
+def cpu_leg(rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, depth_img, color_img, dev, NS, NF, n_cpu):
+    """The oracle on this host's cores on a bounded ray sample of the SAME workload; parity of THE TIMED OUTPUT (the
+    images the last timed step produced) on exactly those rays.  render_img clamps `far` with each 100 000-ray batch's
+    own max depth (src/utils/Renderer.py:294-313), so the oracle gets every picked ray's batch max."""
+    import torch
     from oracle import adfp_oracle as O
     from attentive_dfprior_amd.common import get_rays
     ro, rd = get_rays(scene.H, scene.W, scene.fx, scene.fy, scene.cx, scene.cy, c2w, dev)
     tot = scene.H * scene.W
     pick = torch.arange(0, tot, max(1, tot // n_cpu), device=dev)[:n_cpu]
     ro, rd, gd = ro.reshape(-1, 3)[pick].contiguous(), rd.reshape(-1, 3)[pick].contiguous(), gt_depth.reshape(-1)[pick].contiguous()
-    with torch.no_grad():
-        d, u, c, w = rend.render_batch_ray(scene.c, dec, rd, ro, dev, scene.tsdf_volume, tsdf_bnds, 'color', gt_depth=gd)
+    d = depth_img.reshape(-1)[pick]
+    c = color_img.reshape(-1, 3)[pick]
+    bsz = rend.ray_batch_size
+    batch_of = (pick // bsz).cpu()
+    batch_max = [gt_depth.reshape(-1)[b * bsz:(b + 1) * bsz].max().cpu() for b in range((tot + bsz - 1) // bsz)]
     ncpu = os.cpu_count() or 1
     c_cpu = {k: v.cpu() for k, v in scene.c.items()}
     tsdf_cpu = scene.tsdf_volume.cpu()
     ro_c, rd_c, gd_c = ro.cpu(), rd.cpu(), gd.cpu()
+
+    def oracle(sl_idx, dmax):
+        return O.render_batch_ray(sd, c_cpu, rd_c[sl_idx], ro_c[sl_idx], tsdf_cpu, scene.tsdf_bnds, scene.bound, 'color',
+                                  gd_c[sl_idx], NS, NF, depth_max=dmax)
+
+    def oracle_all():
+        outs = []
+        for b in range(len(batch_max)):
+            idx = torch.nonzero(batch_of == b).reshape(-1)
+            if idx.numel():
+                outs.append((idx, oracle(idx, batch_max[b])))
+        od = torch.empty(len(pick), dtype=torch.float64)
+        oc = torch.empty(len(pick), 3)
+        for idx, (a, _, b_, _) in outs:
+            od[idx] = a
+            oc[idx] = b_
+        return od, oc
     # thread count: big hosts oversubscribe badly with all cores, so pick the faster of {all cores, 32}
     # on a 2 000-ray probe, then time the whole sample with it
-    probe = slice(0, min(2000, ro_c.shape[0]))
+    probe = torch.arange(0, min(2000, ro_c.shape[0]))
     cores, tprobe = ncpu, None
     for threads in sorted({ncpu, min(32, ncpu)}):
         torch.set_num_threads(threads)
         with torch.no_grad():
             t0 = time.perf_counter()
-            O.render_batch_ray(sd, c_cpu, rd_c[probe], ro_c[probe], tsdf_cpu, scene.tsdf_bnds, scene.bound, 'color',
-                               gd_c[probe], NS, NF)
+            oracle(probe, batch_max[0])
             dt = time.perf_counter() - t0
         if tprobe is None or dt < tprobe:
             tprobe, cores = dt, threads
@@ -319,8 +712,7 @@ def cpu_leg(rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF, n_cpu):
     with torch.no_grad():
         for it in range(3):          # 1 warm-up + best of 2
             t0 = time.perf_counter()
-            od, ou, oc, ow = O.render_batch_ray(sd, c_cpu, rd_c, ro_c, tsdf_cpu, scene.tsdf_bnds, scene.bound,
-                                                'color', gd_c, NS, NF)
+            od, oc = oracle_all()
             dt = time.perf_counter() - t0
             if it > 0 and (best is None or dt < best):
                 best = dt
@@ -368,6 +760,7 @@ def cpu_leg(rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF, n_cpu):
                                                                               / c_req['grid_color'].grad.abs().max())}}
         for p_ in dec.parameters():
             p_.grad = None
+            p_.requires_grad_(True)
     except Exception as e:                      # the training leg is extra information, never the reason a bench fails
         train = {'train_fwd_bwd': {'error': repr(e)[:200]}}
     mse = float(((c.cpu().double() - oc.double()) ** 2).mean())
@@ -383,7 +776,7 @@ def cpu_leg(rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF, n_cpu):
         'parity_vs_oracle': {'psnr_color_db': psnr, 'psnr_depth_db': 10.0 * torch.log10(torch.tensor(dpeak * dpeak / max(dmse, 1e-300))).item(),
                              'max_rel_depth': float(((d.cpu() - od).abs().max() / od.abs().max())),
                              'max_rel_color': float(((c.cpu() - oc).abs().max() / oc.abs().max())),
-                             'rays': len(pick)},
+                             'rays': len(pick), 'of': 'the images produced by the last TIMED step, indexed at the sampled rays'},
         **train,
     }
 

@@ -67,6 +67,8 @@ int main(int argc, char** argv) {
         sc.tsdf.Z = Z; sc.tsdf.Y = Y; sc.tsdf.X = X;
         sc.tsdf.sZ = 1; sc.tsdf.sY = Z; sc.tsdf.sX = (long long)Y * Z;
     }
+    HIP_OK(hipMalloc(&sc.status, 4));                                          // sticky status word (f16-range guard)
+    HIP_OK(hipMemsetAsync(sc.status, 0, 4, st));
     const char* nets[3] = {"low", "high", "color"};
     const float** w[3] = {&sc.w_low, &sc.w_high, &sc.w_color};
     const void** hw[3] = {&sc.h_low, &sc.h_high, &sc.h_color};
@@ -76,7 +78,7 @@ int main(int argc, char** argv) {
         HIP_OK(hipMalloc(&packed, adfp_decoder_packed_floats(k) * 4));
         HIP_OK(hipMalloc(&packed_h, adfp_decoder_packed_h_words(k) * 4));
         ADFP_OK(adfp_pack_decoder(k, flat, packed, st));
-        ADFP_OK(adfp_pack_decoder_h(k, flat, packed_h, st));
+        ADFP_OK(adfp_pack_decoder_h(k, flat, packed_h, sc.status, st));
         *w[k] = packed; *hw[k] = packed_h;
     }
     {
@@ -85,7 +87,7 @@ int main(int argc, char** argv) {
         HIP_OK(hipMalloc(&packed, adfp_attention_packed_floats() * 4));
         HIP_OK(hipMalloc(&packed_h, adfp_attention_packed_h_words() * 4));
         ADFP_OK(adfp_pack_attention(flat, packed, st));
-        ADFP_OK(adfp_pack_attention_h(flat, packed_h, st));
+        ADFP_OK(adfp_pack_attention_h(flat, packed_h, sc.status, st));
         sc.w_att = packed; sc.h_att = packed_h;
     }
 
@@ -103,6 +105,9 @@ int main(int argc, char** argv) {
     HIP_OK(hipMalloc(&a.workspace, a.workspace_bytes));
     ADFP_OK(adfp_render_forward(&sc, &a, st));
     HIP_OK(hipStreamSynchronize(st));
+    int status = 0;
+    HIP_OK(hipMemcpy(&status, sc.status, 4, hipMemcpyDeviceToHost));
+    if (status & ADFP_STATUS_F16_RANGE) { fprintf(stderr, "operand beyond the f16 range: use the exact images (h_* = NULL)\n"); return 3; }
     dump(d + "out_depth.f64", a.depth, N);
     dump(d + "out_uncertainty.f64", a.uncertainty, N);
     dump(d + "out_color.f32", a.color, (size_t)N * 3);

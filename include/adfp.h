@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 100
+#define ADFP_VERSION 110
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -84,7 +84,13 @@ typedef struct adfp_scene {
     const void* h_high;
     const void* h_color;
     const void* h_att;        /* adfp_pack_attention_h */
+    /* Sticky status word the kernels OR into (system-scope atomic): device memory or device-visible pinned
+     * host memory, NULL = none.  ADFP_STATUS_F16_RANGE: an operand of the f16-split decoders (a weight, a grid
+     * feature or a hidden activation) reached |x| >= 65504, which the split cannot represent -- the outputs
+     * of that call are invalid; re-run with the exact images (h_* = NULL).  The caller clears the word. */
+    int* status;
 } adfp_scene;
+#define ADFP_STATUS_F16_RANGE 1
 
 typedef struct adfp_points {
     int mode;                 /* ADFP_PTS_* */
@@ -112,11 +118,12 @@ int adfp_relayout_grid(const float* src_cm, float* dst_cl, int C, int Z, int Y, 
 int adfp_relayout_grid_back(const float* src_cl, float* dst_cm, int C, int Z, int Y, int X, void* stream);
 /* flat state_dict-order parameters -> packed MFMA image (MLP: decoder.py:91-203) */
 int adfp_pack_decoder(int kind, const float* flat, float* packed, void* stream);
-/* same parameters -> "H" image (f16 hi/lo halves of every weight), adfp_decoder_packed_h_words(kind) 32-bit words */
+/* same parameters -> "H" image (f16 hi/lo halves of every weight), adfp_decoder_packed_h_words(kind) 32-bit words.
+ * status (may be NULL): as adfp_scene.status -- ADFP_STATUS_F16_RANGE is raised for a weight with |w| >= 65504. */
 long long adfp_decoder_packed_h_words(int kind);
-int adfp_pack_decoder_h(int kind, const float* flat, void* packed, void* stream);
+int adfp_pack_decoder_h(int kind, const float* flat, void* packed, int* status, void* stream);
 long long adfp_attention_packed_h_words(void);
-int adfp_pack_attention_h(const float* flat, void* packed, void* stream);
+int adfp_pack_attention_h(const float* flat, void* packed, int* status, void* stream);
 /* mlp_tsdf parameters (decoder.py:206-258) */
 int adfp_pack_attention(const float* flat, float* packed, void* stream);
 

@@ -14,10 +14,14 @@ imported read-only in the build container by ``oracle/validate_against_reference
 fixtures under ``tests/golden/`` that ``tests/golden/make_golden.py`` generated from
 the reference's own modules.
 
-PARITY UNPINNED for three small restatements whose reference modules cannot be imported in the build
-container (they need pycuda / numba / skimage or cv2 / colorama) and for which the reference ships no
-vectors: ``tsdf_integrate_np`` (src/fusion.py:69-142), ``prefilter_mask`` (src/Mapper.py:440-445) and
-``frustum_mask_np`` / ``remap_linear_np`` (src/Mapper.py:90-158 with cv2.remap).  Each says so at its
+Mapper-side restatements (src.Mapper needs cv2 / colorama and cannot be imported in the build container):
+``prefilter_mask`` (src/Mapper.py:440-445) and ``frustum_mask_np`` (src/Mapper.py:90-158) are pinned by vectors that
+``tests/golden/make_mapper_golden.py`` produced by EXECUTING the reference's own source lines (the ten inline lines
+of optimize_map; get_mask_from_c2w as a method of a stub object) -- ``tests/test_oracle_golden.py`` checks both
+exactly.  In get_mask_from_c2w one name is substituted: ``cv2.remap`` (opencv-python==4.5.5.64,
+environment.yaml:194, absent here) resolves to ``remap_linear_np`` below, a restatement of OpenCV's documented
+bilinear remap; that one function stays PARITY UNPINNED, as does ``tsdf_integrate_np`` (the CUDA kernel string of
+src/fusion.py:69-142: pycuda / numba / skimage are absent and the reference ships no vectors).  Each says so at its
 definition; everything on the render path proper (rows a1-a15) is pinned as above.
 
 Every function cites the reference file:line it follows (paths relative to the
@@ -126,6 +130,7 @@ def sample_z(rays_o, rays_d, gt_depth, bound, N_samples, N_surface, lindisp=Fals
 
 # ----------------------------------------------------------------------------------
 # a3: the Mapper's bounding-box pre-filter  (src/Mapper.py:438-449)
+# pinned by tests/golden/mapper_prefilter.npz = the output of those very lines, executed from the reference's source
 # ----------------------------------------------------------------------------------
 def prefilter_mask(rays_o, rays_d, gt_depth, bound):
     """inside_mask of src/Mapper.py:440-445 (bound f64 [3,2], rays f32)."""
@@ -478,10 +483,10 @@ def tsdf_integrate_np(tsdf, weight, color, origin, voxel, cam_intr, cam_pose, co
 
 # ----------------------------------------------------------------------------------
 # frustum feature selection  (src/Mapper.py:90-158)
-# PARITY UNPINNED: src.Mapper needs cv2 / colorama, which the build container lacks, so the reference's
-# function cannot be executed here; cv2.remap is restated from OpenCV's documented algorithm
-# (imgproc remap, INTER_LINEAR: map rounded to 1/32 pixel with cvRound, weights from the 32x32 bilinear
-# table, BORDER_CONSTANT value 0 for taps outside the image).
+# frustum_mask_np is pinned by tests/golden/mapper_frustum.npz (the reference's get_mask_from_c2w executed from its
+# source, tests/golden/make_mapper_golden.py).  PARITY UNPINNED: remap_linear_np only -- cv2 is absent, so
+# cv2.remap is restated from OpenCV 4.5.5's documented algorithm (imgproc remap, INTER_LINEAR: map rounded to 1/32
+# pixel with cvRound, weights from the 32x32 bilinear table, BORDER_CONSTANT value 0 for taps outside the image).
 # ----------------------------------------------------------------------------------
 def remap_linear_np(img, u, v):
     import numpy as np

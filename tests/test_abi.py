@@ -36,7 +36,7 @@ def test_exports_every_declared_symbol():
 
 def test_version_and_sizes():
     L = _lib.lib()
-    assert L.adfp_version() == 100
+    assert L.adfp_version() == _lib.ABI_VERSION
     # parameter counts of the reference's modules (decoder.py:110-166, :212-228)
     assert [L.adfp_decoder_flat_floats(k) for k in range(3)] == [15800, 20920, 15899]
     assert L.adfp_attention_flat_floats() == 33410
@@ -67,8 +67,8 @@ def test_ctypes_struct_layout_matches_c(tmp_path):
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(adfp_grid), sizeof(adfp_tsdf), sizeof(adfp_scene), sizeof(adfp_points),
          sizeof(adfp_render_args), sizeof(adfp_train_state), sizeof(adfp_backward_args));
-  printf("%zu %zu %zu %zu\\n", offsetof(adfp_scene, low), offsetof(adfp_scene, tsdf), offsetof(adfp_scene, w_low),
-         offsetof(adfp_scene, w_att));
+  printf("%zu %zu %zu %zu %zu\\n", offsetof(adfp_scene, low), offsetof(adfp_scene, tsdf), offsetof(adfp_scene, w_low),
+         offsetof(adfp_scene, w_att), offsetof(adfp_scene, status));
   printf("%zu %zu %zu\\n", offsetof(adfp_points, pts), offsetof(adfp_points, z_vals), offsetof(adfp_points, S));
   printf("%zu %zu %zu %zu %zu\\n", offsetof(adfp_render_args, perturb), offsetof(adfp_render_args, rays_o),
          offsetof(adfp_render_args, workspace), offsetof(adfp_render_args, workspace_bytes), offsetof(adfp_render_args, state));
@@ -84,7 +84,7 @@ int main(void) {
                   ctypes.sizeof(_lib.AdfpPoints), ctypes.sizeof(_lib.AdfpRenderArgs),
                   ctypes.sizeof(_lib.AdfpTrainState), ctypes.sizeof(_lib.AdfpBackwardArgs)]
     S = _lib.AdfpScene
-    assert list(map(int, out[1].split())) == [S.low.offset, S.tsdf.offset, S.w_low.offset, S.w_att.offset]
+    assert list(map(int, out[1].split())) == [S.low.offset, S.tsdf.offset, S.w_low.offset, S.w_att.offset, S.status.offset]
     P = _lib.AdfpPoints
     assert list(map(int, out[2].split())) == [P.pts.offset, P.z_vals.offset, P.S.offset]
     R = _lib.AdfpRenderArgs

@@ -1,0 +1,116 @@
+"""GPU: BASELINE.json configs[2] -- Replica office0-sized scene (configs/Replica/office0.yaml:3), the mapping loop of
+src/Mapper.py:374-473 with the reference's 60 iterations per frame (configs/df_prior.yaml:63), 5 000 rays per
+iteration, on the product's entry points (render_batch_ray + autograd, pre-filter, frustum mask, masked Adam).
+
+  * stability: 20 frames x 60 iterations (+ a longer first frame): every loss finite, the depth error of a FIXED
+    held-out ray set (poses between the training poses) falls by at least 20 %;
+  * trajectory: three Adam iterations on the same scene against the oracle's autograd + torch.optim.Adam on the
+    host -- gradients within 2e-4, parameters after three steps within 2e-4 wherever the gradient is above the
+    float-atomics noise floor (Adam normalises a noise-sized gradient to a full +-lr step)."""
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT, assert_close
+from oracle import adfp_oracle as O
+
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import mapping_loop as ML                                            # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def test_office0_mapping_loop_is_stable_and_learns():
+    run = ML.MappingRun('office0', rays=5000, total_frames=200)
+    assert tuple(run.sc.tsdf_volume.shape[2:]) == (738, 779, 656)             # 1.51 GB
+    held = run.heldout_rays(20)
+    e0 = run.heldout_error(held)
+    hist = []
+    for f in range(20):
+        hist.append(run.map_frame(f, 300 if f == 0 else 60, ML.LR_FIRST_FACTOR if f == 0 else 1.0))
+    e1 = run.heldout_error(held)
+    assert run.n_iter == 300 + 19 * 60
+    assert all(torch.isfinite(v).all() for v in run.c.values())
+    assert all(torch.isfinite(p).all() for p in run.dec.parameters())
+    print(f'held-out depth L1 per ray {e0:.4f} -> {e1:.4f}; first/last frame loss per ray {hist[0]} {hist[-1]}')
+    assert e1 <= 0.8 * e0, (e0, e1)
+    run.rend.check_overflow()
+
+
+def test_three_iterations_follow_the_oracle_trajectory():
+    n = 1500
+    run = ML.MappingRun('office0', rays=n, total_frames=200)
+    sc, dev, dec = run.sc, run.dev, run.dec
+    # a grid scale at which all three stages have signal
+    c0 = {k: (v * (100.0 if k == 'grid_high' else 20.0)) for k, v in sc.c.items()}
+    c2w = ML.circle_pose(sc, 3, 200)
+    depth = sc.depth_image(c2w)
+    from attentive_dfprior_amd import common
+    torch.manual_seed(5)
+    ro, rd, gd, gc = common.get_samples(0, sc.H, 0, sc.W, n, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2w, depth,
+                                        run.target_color, dev)
+    ro, rd, gd, gc = common.filter_rays_in_bound(ro.float(), rd.float(), gd.float(), gc.float(), run.bound)
+    lr = ML.STAGE_LR['color']
+    sd0 = {k: v.detach().cpu().clone() for k, v in dec.state_dict().items()}
+
+    # ---- product path
+    from attentive_dfprior_amd import mapping
+    grids = {k: v.clone().requires_grad_(True) for k, v in c0.items()}
+    opt_g = mapping.MaskedGridAdam(grids, None)
+    trainable = list(dec.color_decoder.parameters()) + list(dec.mlp.parameters())
+    opt = torch.optim.Adam([{'params': list(dec.color_decoder.parameters()), 'lr': lr['dec']},
+                            {'params': list(dec.mlp.parameters()), 'lr': lr['mlp']}])
+    g_first = None
+    for it in range(3):
+        opt.zero_grad(); opt_g.zero_grad()
+        d, u, col, w = run.rend.render_batch_ray(grids, dec, rd, ro, dev, sc.tsdf_volume, run.tsdf_bnds, 'color', gd)
+        m = gd > 0
+        (torch.abs(gd[m] - d[m]).sum() + ML.W_COLOR_LOSS * torch.abs(gc - col).sum()).backward()
+        if it == 0:
+            g_first = {k: v.grad.detach().cpu().clone() for k, v in grids.items()}
+            g_first.update({n_: p.grad.detach().cpu().clone() for n_, p in dec.named_parameters() if p.grad is not None})
+        opt.step()
+        opt_g.step({'grid_low': lr['low'], 'grid_high': lr['high'], 'grid_color': lr['color']})
+    got = {k: v.detach().cpu() for k, v in grids.items()}
+    got.update({n_: p.detach().cpu() for n_, p in dec.named_parameters()})
+
+    # ---- oracle path on the host: same rays, same start, torch autograd + torch.optim.Adam
+    cg = {k: v.cpu().clone().requires_grad_(True) for k, v in c0.items()}
+    sdr = {k: (v.clone().requires_grad_(True) if k.startswith(('color_decoder', 'mlp')) else v.clone()) for k, v in sd0.items()}
+    groups = [{'params': [v for k, v in sdr.items() if k.startswith('color_decoder')], 'lr': lr['dec']},
+              {'params': [v for k, v in sdr.items() if k.startswith('mlp')], 'lr': lr['mlp']},
+              {'params': [cg['grid_low']], 'lr': lr['low']}, {'params': [cg['grid_high']], 'lr': lr['high']},
+              {'params': [cg['grid_color']], 'lr': lr['color']}]
+    ropt = torch.optim.Adam(groups)
+    tsdf_cpu = sc.tsdf_volume.cpu()
+    ro_c, rd_c, gd_c, gc_c = ro.cpu(), rd.cpu(), gd.cpu(), gc.cpu()
+    r_first = None
+    for it in range(3):
+        ropt.zero_grad()
+        od, ou, oc, ow = O.render_batch_ray(sdr, cg, rd_c, ro_c, tsdf_cpu, sc.tsdf_bnds, sc.bound, 'color', gd_c, 48, 16)
+        O.mapper_loss(od, oc, ow, gd_c, gc_c, 'color').backward()
+        if it == 0:
+            r_first = {k: v.grad.detach().clone() for k, v in cg.items()}
+            r_first.update({k: v.grad.detach().clone() for k, v in sdr.items() if v.requires_grad})
+        ropt.step()
+    ref = {k: v.detach() for k, v in cg.items()}
+    ref.update({k: v.detach() for k, v in sdr.items()})
+
+    for k, gr in r_first.items():
+        assert_close(g_first[k], gr, 2e-4, f'gradient of {k} at iteration 0')
+    worst = 0.0
+    for k, gr in r_first.items():
+        live = gr.abs() > 1e-4 * gr.abs().max()                     # above the accumulation-order noise
+        a, b = got[k][live], ref[k][live]
+        scale = ref[k].abs().max()
+        bad = (a - b).abs() > 2e-4 * (b.abs() + 0.1 * scale)
+        frac = float(bad.float().mean()) if bad.numel() else 0.0
+        worst = max(worst, frac)
+        assert frac <= 1e-3, f'{k}: {frac:.2e} of the live elements left the oracle trajectory after 3 Adam steps'
+        dead = ~live
+        if dead.any():                                               # untouched / noise-level elements moved at most 3 steps
+            step = {'grid_low': lr['low'], 'grid_high': lr['high'], 'grid_color': lr['color']}.get(k, lr['dec'])
+            assert float((got[k][dead] - ref[k][dead]).abs().max()) <= 6.0 * step + 1e-6
+    print(f'worst off-trajectory fraction {worst:.2e}')

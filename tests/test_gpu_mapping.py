@@ -122,3 +122,24 @@ def test_mapping_iterations_equal_reference_style_loop():
         assert bool(full[k].any()) and not bool(full[k].all())
         assert torch.equal(a[~full[k]], b[~full[k]])
         assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()), k      # a few ulp of the lr-sized steps
+
+
+def test_frustum_mask_vs_reference_lines():
+    """HIP frustum mask against the masks the reference's own get_mask_from_c2w lines produced
+    (tests/golden/mapper_frustum.npz; only cv2.remap substituted)."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, 'mapper_frustum.npz'))
+    H, W, fx, fy, cx, cy = g['intrinsics'].tolist()
+    bound = torch.from_numpy(g['bound'])
+    total = diff = 0
+    for k in range(3):
+        c2w = torch.from_numpy(g[f'pose{k}.c2w'])
+        depth = torch.from_numpy(g[f'pose{k}.depth']).to(DEV)
+        for key in ('grid_low', 'grid_high', 'grid_color'):
+            ref = g[f'pose{k}.{key}'].transpose(2, 1, 0)                      # [X,Y,Z] -> the grid tensor's [Z,Y,X]
+            got = mapping.frustum_mask(c2w, ref.shape, depth, bound, int(H), int(W), fx, fy, cx, cy)
+            diff += int((got.cpu().numpy() != ref).sum())
+            total += ref.size
+    assert diff <= 2, f'{diff} of {total} grid points differ from the reference-executed masks'

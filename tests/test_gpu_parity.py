@@ -42,7 +42,7 @@ def gm(mini):
 
 def test_native_library_is_loaded(gm):
     from attentive_dfprior_amd import _lib
-    assert _lib.lib().adfp_version() == 100
+    assert _lib.lib().adfp_version() == _lib.ABI_VERSION
     assert 'libadfp.so' in open('/proc/self/maps').read()
 
 
@@ -362,3 +362,20 @@ def test_prefilter_rays_vs_oracle(mini, n):
     if n:
         o.sum().backward()
         assert torch.equal(ro_g.grad.cpu(), mask.float().unsqueeze(-1).expand(-1, 3))
+
+
+def test_prefilter_rays_vs_reference_lines():
+    """a3 against the vectors the reference's own lines (src/Mapper.py:438-449) produced, executed by
+    tests/golden/make_mapper_golden.py: kept set, order, and the kept rows themselves, bit for bit."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, 'mapper_prefilter.npz'))
+    names = sorted({k.split('.')[0] for k in g.files if '.' in k})
+    for n in names:
+        ro, rd, gd, gc = (torch.from_numpy(g[f'{n}.{k}']).to(DEV) for k in ('rays_o', 'rays_d', 'gt_depth', 'gt_color'))
+        o, d, z, c = common.filter_rays_in_bound(ro, rd, gd, gc, torch.from_numpy(g[f'{n}.bound']))
+        mask = torch.from_numpy(g[f'{n}.inside_mask'])
+        assert o.shape[0] == int(mask.sum()), n
+        assert np.array_equal(o.cpu().numpy(), g[f'{n}.kept_rays_o'], equal_nan=True), n
+        assert np.array_equal(z.cpu().numpy(), g[f'{n}.kept_gt_depth'], equal_nan=True), n
+        assert torch.equal(c.cpu(), torch.from_numpy(g[f'{n}.gt_color'])[mask]), n

@@ -141,3 +141,45 @@ def test_prefilter_mask_properties(mini):
     assert bool(O.prefilter_mask(ro, rd, (0.95 * t_exit).float(), scene.bound).all())
     assert not bool(O.prefilter_mask(ro, rd, (1.05 * t_exit).float(), scene.bound).any())
     assert bool(O.prefilter_mask(ro, rd, torch.zeros(300), scene.bound).all())
+
+
+# --------------------------------------------------------------------------- Mapper-side rows (a3, f4)
+def _mapper_golden(name):
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, name))
+    return {k: z[k] for k in z.files}
+
+
+def test_prefilter_mask_vs_reference_lines():
+    """a3: tests/golden/mapper_prefilter.npz holds what the reference's OWN lines src/Mapper.py:438-449 computed
+    (tests/golden/make_mapper_golden.py executes them); the oracle restatement must give the same mask, including
+    the +-inf, NaN (0/0), non-finite-ray and depth == t cases."""
+    g = _mapper_golden('mapper_prefilter.npz')
+    names = sorted({k.split('.')[0] for k in g if '.' in k})
+    assert 'exact' in names and len(names) >= 6
+    for n in names:
+        ro, rd, gd = (torch.from_numpy(g[f'{n}.{k}']) for k in ('rays_o', 'rays_d', 'gt_depth'))
+        mask = O.prefilter_mask(ro, rd, gd, torch.from_numpy(g[f'{n}.bound']))
+        assert torch.equal(mask, torch.from_numpy(g[f'{n}.inside_mask'])), n
+    ex = torch.from_numpy(g['exact.inside_mask'])
+    assert not ex[1] and not ex[2] and not ex[3]          # 0/0 on a bound plane: NaN compares false, ray dropped
+
+
+def test_frustum_mask_vs_reference_lines():
+    """f4: Mapper.get_mask_from_c2w (src/Mapper.py:90-158) executed from the reference's source with only
+    cv2.remap substituted (OpenCV absent): the oracle's restatement of everything around the remap must reproduce
+    those masks exactly (same remap on both sides)."""
+    g = _mapper_golden('mapper_frustum.npz')
+    H, W, fx, fy, cx, cy = g['intrinsics'].tolist()
+    bound = torch.from_numpy(g['bound'])
+    for k in range(3):
+        c2w = torch.from_numpy(g[f'pose{k}.c2w'])
+        depth = g[f'pose{k}.depth']
+        for key in ('grid_low', 'grid_high', 'grid_color'):
+            ref_xyz = g[f'pose{k}.{key}']                                     # [X, Y, Z] as the reference returns it
+            X, Y, Z = ref_xyz.shape
+            got = O.frustum_mask_np(c2w, (Z, Y, X), depth, bound, int(H), int(W), fx, fy, cx, cy)   # [Z, Y, X]
+            assert (got == ref_xyz.transpose(2, 1, 0)).all(), (k, key)
+            assert 0 < ref_xyz.sum() < ref_xyz.size

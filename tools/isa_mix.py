@@ -1,0 +1,47 @@
+"""Instruction mix of one kernel of libadfp (compile with `hipcc -S --cuda-device-only`, then count per class).
+
+  python tools/isa_mix.py /tmp/isa/adfp.s k_decode_h 'ILi32ELi4ELi2E'
+"""
+import collections
+import re
+import sys
+
+
+def kernels(path):
+    out, name, body = {}, None, []
+    for line in open(path):
+        m = re.match(r'^(_Z\w+):', line)
+        if m:
+            name, body = m.group(1), []
+            out[name] = body
+        elif name and line.strip().startswith('.end_amdhsa_kernel'):
+            name = None
+        elif name:
+            body.append(line)
+    return out
+
+
+def main():
+    path, *pats = sys.argv[1:]
+    for name, body in kernels(path).items():
+        if not all(p in name for p in pats):
+            continue
+        c = collections.Counter()
+        for l in body:
+            t = l.strip().split()
+            if not t or t[0].startswith(('.', ';', '/')) or t[0].endswith(':'):
+                continue
+            c[t[0]] += 1
+        tot = sum(c.values())
+        valu = sum(v for k, v in c.items() if k.startswith('v_') and not k.startswith('v_mfma') and not k.startswith('v_accvgpr'))
+        mfma = sum(v for k, v in c.items() if k.startswith('v_mfma'))
+        pk = sum(v for k, v in c.items() if k.startswith('v_pk_'))
+        print(f'{name}: {tot} instr, VALU {valu} (packed {pk}), MFMA {mfma}, '
+              f'LDS {sum(v for k, v in c.items() if k.startswith("ds_"))}, '
+              f'VMEM {sum(v for k, v in c.items() if k.startswith(("global_", "buffer_", "flat_", "scratch_")))}, '
+              f'SALU {sum(v for k, v in c.items() if k.startswith("s_"))}')
+        for k, v in c.most_common(40):
+            print(f'   {v:5d} {k}')
+
+
+main()
