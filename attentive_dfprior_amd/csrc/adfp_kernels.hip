@@ -696,6 +696,7 @@ struct AttArgs {
 #endif
 #define ADFP_DECH_WG (ADFP_DECH_NT == 256 ? 2 : 1)
 #include "adfp_decode_h.h"
+#include "adfp_decode_p.h"
 
 // =====================================================================================
 // attention fusion mlp_tsdf (a11) on the in-band list
@@ -1076,6 +1077,15 @@ extern "C" int adfp_debug_phases(unsigned long long* host_out, int reset) {
 }
 #endif
 
+// ADFP_DECODE=p (default) the software-pipelined f16-split decoder (adfp_decode_p.h); =h the phase-separated one
+static int decode_pipelined() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ADFP_DECODE"); v = (e && e[0] == 'h') ? 0 : 1; }
+    return v;
+}
+#ifndef ADFP_DECP_NT
+#define ADFP_DECP_NT 512
+#endif
 static int decode_grid(int ntiles, int waves_per_wg, int wg_per_cu) {
     int g = (ntiles + waves_per_wg - 1) / waves_per_wg;
     const int cap = num_cu() * wg_per_cu;
@@ -1113,7 +1123,8 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
     a.g0 = make_grid(sc->low); a.g1 = a.g0;
     if (sc->h_low) {
         a.packed = (const float*)sc->h_low;
-        hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
+        if (decode_pipelined()) hipLaunchKernelGGL((k_decode_p<32, 1, ROLE_LOW, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
+        else hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
     } else {
         a.packed = sc->w_low;
         hipLaunchKernelGGL((k_decode<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
@@ -1123,7 +1134,8 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         a.g0 = make_grid(sc->color); a.g1 = a.g0;
         if (sc->h_color) {
             a.packed = (const float*)sc->h_color;
-            hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
+            if (decode_pipelined()) hipLaunchKernelGGL((k_decode_p<32, 4, ROLE_COLOR, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
+            else hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
         } else {
             a.packed = sc->w_color;
             hipLaunchKernelGGL((k_decode<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
@@ -1173,7 +1185,8 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
         a.g0 = make_grid(sc->low); a.g1 = a.g0;
         if (sc->h_low) {
             a.packed = (const float*)sc->h_low;
-            hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
+            if (decode_pipelined()) hipLaunchKernelGGL((k_decode_p<32, 1, ROLE_LOW, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
+        else hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
         } else {
             a.packed = sc->w_low;
             hipLaunchKernelGGL((k_decode<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
@@ -1183,7 +1196,8 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
         a.g0 = make_grid(sc->color); a.g1 = a.g0;
         if (sc->h_color) {
             a.packed = (const float*)sc->h_color;
-            hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
+            if (decode_pipelined()) hipLaunchKernelGGL((k_decode_p<32, 4, ROLE_COLOR, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
+            else hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
         } else {
             a.packed = sc->w_color;
             hipLaunchKernelGGL((k_decode<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);

@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 
 def test_office0_mapping_loop_is_stable_and_learns():
     run = ML.MappingRun('office0', rays=5000, total_frames=200)
-    assert tuple(run.sc.tsdf_volume.shape[2:]) == (738, 779, 656)             # 1.51 GB
+    assert tuple(run.sc.tsdf_volume.shape[2:]) == (656, 779, 738)             # [Z, Y, X]; SURVEY.md section 8: 1.51 GB
     held = run.heldout_rays(20)
     e0 = run.heldout_error(held)
     hist = []
