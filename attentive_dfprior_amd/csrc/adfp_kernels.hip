@@ -1077,10 +1077,13 @@ extern "C" int adfp_debug_phases(unsigned long long* host_out, int reset) {
 }
 #endif
 
-// ADFP_DECODE=p (default) the software-pipelined f16-split decoder (adfp_decode_p.h); =h the phase-separated one
+// ADFP_DECODE=p selects the software-pipelined f16-split decoder (adfp_decode_p.h) for the two dense decoders in ray mode:
+// an experiment that measured SLOWER than the phase-separated k_decode_h (0.90 vs 0.89 ms per 100 000-ray batch with only
+// the Fourier features in the MFMA gaps, 1.06-1.42 ms with the gather pipelined as well), so the
+// default stays k_decode_h.
 static int decode_pipelined() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("ADFP_DECODE"); v = (e && e[0] == 'h') ? 0 : 1; }
+    if (v < 0) { const char* e = getenv("ADFP_DECODE"); v = (e && e[0] == 'p') ? 1 : 0; }
     return v;
 }
 #ifndef ADFP_DECP_NT
@@ -1123,7 +1126,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
     a.g0 = make_grid(sc->low); a.g1 = a.g0;
     if (sc->h_low) {
         a.packed = (const float*)sc->h_low;
-        if (decode_pipelined()) hipLaunchKernelGGL((k_decode_p<32, 1, ROLE_LOW, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
+        if (decode_pipelined() && a.P.mode == ADFP_PTS_RAYS) hipLaunchKernelGGL((k_decode_p<32, 1, ROLE_LOW, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
         else hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
     } else {
         a.packed = sc->w_low;
@@ -1134,7 +1137,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         a.g0 = make_grid(sc->color); a.g1 = a.g0;
         if (sc->h_color) {
             a.packed = (const float*)sc->h_color;
-            if (decode_pipelined()) hipLaunchKernelGGL((k_decode_p<32, 4, ROLE_COLOR, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
+            if (decode_pipelined() && a.P.mode == ADFP_PTS_RAYS) hipLaunchKernelGGL((k_decode_p<32, 4, ROLE_COLOR, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
             else hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
         } else {
             a.packed = sc->w_color;
@@ -1185,7 +1188,7 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
         a.g0 = make_grid(sc->low); a.g1 = a.g0;
         if (sc->h_low) {
             a.packed = (const float*)sc->h_low;
-            if (decode_pipelined()) hipLaunchKernelGGL((k_decode_p<32, 1, ROLE_LOW, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
+            if (decode_pipelined() && a.P.mode == ADFP_PTS_RAYS) hipLaunchKernelGGL((k_decode_p<32, 1, ROLE_LOW, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
         else hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
         } else {
             a.packed = sc->w_low;
@@ -1196,7 +1199,7 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
         a.g0 = make_grid(sc->color); a.g1 = a.g0;
         if (sc->h_color) {
             a.packed = (const float*)sc->h_color;
-            if (decode_pipelined()) hipLaunchKernelGGL((k_decode_p<32, 4, ROLE_COLOR, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
+            if (decode_pipelined() && a.P.mode == ADFP_PTS_RAYS) hipLaunchKernelGGL((k_decode_p<32, 4, ROLE_COLOR, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
             else hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
         } else {
             a.packed = sc->w_color;
