@@ -65,7 +65,14 @@ class AdfpBackwardArgs(C.Structure):
                 ('g_grid_low', C.c_void_p), ('g_grid_high', C.c_void_p), ('g_grid_color', C.c_void_p),
                 ('g_flat_low', C.c_void_p), ('g_flat_high', C.c_void_p), ('g_flat_color', C.c_void_p),
                 ('g_flat_att', C.c_void_p), ('g_rays_o', C.c_void_p), ('g_rays_d', C.c_void_p),
-                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('ray_keep', C.c_void_p)]
+
+
+class AdfpLossArgs(C.Structure):
+    _fields_ = [('n_rays', C.c_int), ('S', C.c_int), ('stage', C.c_int), ('warmup', C.c_int), ('w_color_loss', C.c_float),
+                ('depth', C.c_void_p), ('color', C.c_void_p), ('weight', C.c_void_p), ('gt_depth', C.c_void_p),
+                ('gt_color', C.c_void_p), ('keep', C.c_void_p), ('loss', C.c_void_p), ('g_depth', C.c_void_p),
+                ('g_color', C.c_void_p), ('g_weight', C.c_void_p)]
 
 
 Bound = (C.c_double * 2) * 3
@@ -88,6 +95,10 @@ SYMBOLS = [
     ('adfp_pack_attention_h', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_get_rays', C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_rays_from_uv', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_rays_from_uv_backward', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_prefilter_rays', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
     ('adfp_sample_rays', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Bound),
@@ -108,6 +119,11 @@ SYMBOLS = [
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_masked_adam', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int,
                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    ('adfp_prefilter_mask', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_mapper_loss', C.c_int, [C.POINTER(AdfpLossArgs), C.c_void_p]),
+    ('adfp_adam_prep', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_void_p]),
+    ('adfp_masked_adam_dev', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int,
+                                       C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     ('adfp_tsdf_stage', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_backward_workspace_bytes', C.c_size_t, [C.c_longlong]),

@@ -44,10 +44,46 @@ def get_rays(H, W, fx, fy, cx, cy, c2w, device):
     return rays_o, rays_d
 
 
+class _RaysFromUV(torch.autograd.Function):
+    """adfp_rays_from_uv / adfp_rays_from_uv_backward: rays through given pixels, differentiable in the camera pose."""
+
+    @staticmethod
+    def forward(ctx, c2w, i, j, fx, fy, cx, cy):
+        dev = i.device
+        n = i.numel()
+        pi, pj = i.detach().reshape(-1).float().contiguous(), j.detach().reshape(-1).float().contiguous()
+        m = c2w.detach().to(dev, torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            ro = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            rd = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            check(lib().adfp_rays_from_uv(ptr(pi), ptr(pj), n, fx, fy, cx, cy, ptr(m), ptr(ro), ptr(rd), _lib.current_stream(dev)),
+                  'adfp_rays_from_uv')
+        ctx.pix = (pi, pj, fx, fy, cx, cy)
+        ctx.c2w_meta = (tuple(c2w.shape), c2w.dtype)
+        return ro, rd
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        pi, pj, fx, fy, cx, cy = ctx.pix
+        dev = pi.device
+        with torch.cuda.device(dev):
+            g = torch.empty((4, 4), dtype=torch.float32, device=dev)
+            go = None if g_o is None else g_o.float().contiguous()
+            gd = None if g_d is None else g_d.float().contiguous()
+            check(lib().adfp_rays_from_uv_backward(ptr(pi), ptr(pj), pi.numel(), fx, fy, cx, cy, ptr(go), ptr(gd), ptr(g),
+                                                   _lib.current_stream(dev)), 'adfp_rays_from_uv_backward')
+        shape, dtype = ctx.c2w_meta
+        g = g[:shape[0], :shape[1]].to(dtype)
+        return g, None, None, None, None, None, None
+
+
 def get_rays_from_uv(i, j, c2w, H, W, fx, fy, cx, cy, device):
-    """Rays through the given pixel coordinates (reference src/common.py:76-91)."""
+    """Rays through the given pixel coordinates (reference src/common.py:76-91).  On a GPU device the rays come from
+    libadfp.so and are differentiable in ``c2w`` (camera tracking / bundle adjustment)."""
     if isinstance(c2w, np.ndarray):
         c2w = torch.from_numpy(c2w).to(device)
+    if torch.device(device).type == 'cuda' and i.is_cuda:
+        return _RaysFromUV.apply(c2w, i, j, float(fx), float(fy), float(cx), float(cy))
     dirs = _pixel_dirs(i, j, fx, fy, cx, cy).to(device).reshape(-1, 1, 3)
     rays_d = (dirs * c2w[:3, :3]).sum(-1)
     rays_o = c2w[:3, -1].expand(rays_d.shape)

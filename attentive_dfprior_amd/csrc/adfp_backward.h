@@ -21,10 +21,15 @@
 #define CB_MAXC 4
 __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__ raw, const double* __restrict__ z, int n_rays, int S,
                                                        const double* __restrict__ g_depth, const double* __restrict__ g_var,
-                                                       const float* __restrict__ g_color, float* __restrict__ g_raw) {
+                                                       const float* __restrict__ g_color, float* __restrict__ g_raw,
+                                                       const unsigned char* __restrict__ keep) {
     const int lane = threadIdx.x & 63;
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
+    if (keep && !keep[ray]) {                        // a ray the pre-filter dropped: no gradient, whatever its samples hold (NaN * 0)
+        for (int s = lane; s < S; s += 64) *(f32x4*)(g_raw + ((long long)ray * S + s) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
     const int nc = (S + 63) >> 6;
     float alpha[CB_MAXC], T[CB_MAXC], w[CB_MAXC], f[CB_MAXC];
     f32x4 r[CB_MAXC];
@@ -231,6 +236,10 @@ __global__ __launch_bounds__(NT) void k_decode_bwd(DecodeBwdArgs a) {
         load_point(a.P, q, pt);
         normalize3(a.nb, pt, pn);
         pf[0] = (float)pt[0]; pf[1] = (float)pt[1]; pf[2] = (float)pt[2];
+        // a NaN position belongs to a ray the Mapper's pre-filter drops (0/0 in its slab test): its cotangent is zero, and the
+        // recomputed activations must not turn 0 * NaN into NaN in the staged rows of the weight gradients
+        const bool pnan = (pt[0] != pt[0]) | (pt[1] != pt[1]) | (pt[2] != pt[2]);
+        if (pnan) { pf[0] = 0.f; pf[1] = 0.f; pf[2] = 0.f; }
 
         // ---------------- forward recompute (ReLU masks; stage inputs when WGRAD) ----------------
         float c[L::KSC];

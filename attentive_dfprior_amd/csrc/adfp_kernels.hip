@@ -210,6 +210,50 @@ __global__ void k_get_rays(int H, int W, float fx, float fy, float cx, float cy,
 }
 
 // =====================================================================================
+// a2: get_rays_from_uv (common.py:76-91): the rays through n given pixels, and the gradient w.r.t. the camera pose that
+// the Tracker and the Mapper's bundle adjustment take through them (src/Tracker.py:97, src/Mapper.py:425)
+// =====================================================================================
+__global__ void k_rays_from_uv(const float* __restrict__ pi, const float* __restrict__ pj, int n, float fx, float fy, float cx, float cy,
+                               const float* __restrict__ c2w, float* __restrict__ ro, float* __restrict__ rd) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float dx = (pi[idx] - cx) / fx, dy = -(pj[idx] - cy) / fy, dz = -1.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // torch.sum(dirs * c2w[:3,:3], -1): products then left-to-right adds
+        rd[3 * idx + k] = __fadd_rn(__fadd_rn(__fmul_rn(dx, c2w[4 * k + 0]), __fmul_rn(dy, c2w[4 * k + 1])), __fmul_rn(dz, c2w[4 * k + 2]));
+        ro[3 * idx + k] = c2w[4 * k + 3];
+    }
+}
+// g_c2w[k][m] = sum_n g_d[n][k] * dirs[n][m] (m < 3), g_c2w[k][3] = sum_n g_o[n][k]; rows 3 of the 4x4 get zero.
+// One workgroup: pixel batches are a few hundred to a few thousand rays.
+__global__ __launch_bounds__(256) void k_rays_from_uv_bwd(const float* __restrict__ pi, const float* __restrict__ pj, int n, float fx, float fy,
+                                                          float cx, float cy, const float* __restrict__ g_o, const float* __restrict__ g_d,
+                                                          float* __restrict__ g_c2w) {
+    __shared__ float s[4][12];
+    float acc[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) acc[t] = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float dir[3] = {(pi[i] - cx) / fx, -(pj[i] - cy) / fy, -1.f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float gd = g_d ? g_d[3 * i + k] : 0.f;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc[4 * k + m] = fmaf(gd, dir[m], acc[4 * k + m]);
+            acc[4 * k + 3] += g_o ? g_o[3 * i + k] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 12; ++t) acc[t] = wave_sum(acc[t]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int t = 0; t < 12; ++t) s[threadIdx.x >> 6][t] = acc[t];
+    __syncthreads();
+    if (threadIdx.x < 16) g_c2w[threadIdx.x] = threadIdx.x < 12 ? (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]) : 0.f;
+}
+
+// =====================================================================================
 // a3: the Mapper's bounding-box pre-filter (Mapper.py:438-449): keep ray i iff
 //   min_axis max_side((bound - o) / d) >= gt_depth          (f64, NaN compares false)
 // Order-preserving compaction of the kept ray ids by ONE workgroup: a ballot prefix inside each
@@ -823,6 +867,7 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
 #include "adfp_backward.h"
 #include "adfp_fusion.h"
 #include "adfp_mapping.h"
+#include "adfp_mapper_iter.h"
 
 // =====================================================================================
 // host side: C ABI
@@ -987,6 +1032,22 @@ int adfp_pack_attention(const float* flat, float* packed, void* stream) {
 int adfp_get_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w, float* rays_o, float* rays_d, void* stream) {
     if (!c2w || !rays_o || !rays_d || H <= 0 || W <= 0) return ADFP_E_ARG;
     hipLaunchKernelGGL(k_get_rays, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, H, W, fx, fy, cx, cy, c2w, rays_o, rays_d);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
+int adfp_rays_from_uv(const float* pix_i, const float* pix_j, int n, float fx, float fy, float cx, float cy, const float* c2w,
+                      float* rays_o, float* rays_d, void* stream) {
+    if (n < 0 || !c2w || (n && (!pix_i || !pix_j || !rays_o || !rays_d))) return ADFP_E_ARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_rays_from_uv, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pix_i, pix_j, n, fx, fy, cx, cy, c2w, rays_o, rays_d);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+int adfp_rays_from_uv_backward(const float* pix_i, const float* pix_j, int n, float fx, float fy, float cx, float cy, const float* g_rays_o,
+                               const float* g_rays_d, float* g_c2w, void* stream) {
+    if (n < 0 || !g_c2w || (n && (!pix_i || !pix_j))) return ADFP_E_ARG;
+    hipLaunchKernelGGL(k_rays_from_uv_bwd, dim3(1), dim3(256), 0, (hipStream_t)stream, pix_i, pix_j, n, fx, fy, cx, cy, g_rays_o, g_rays_d, g_c2w);
     ADFP_CHECK_LAUNCH();
     return 0;
 }
@@ -1276,13 +1337,56 @@ int adfp_masked_adam(float* param, const float* grad, float* exp_avg, float* exp
     if (nvox == 0) return 0;
     AdamArgs a;
     a.param = param; a.grad = grad; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.mask = mask; a.nvox = nvox; a.C = channels;
-    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.derived = nullptr;
     // bias corrections in double like torch.optim (python floats), then one rounding to f32
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     a.step_size = (float)((double)lr / bc1);
     a.sqrt_bc2 = (float)sqrt(bc2);
     const long long threads = ((nvox + 3) >> 2) * channels;
     hipLaunchKernelGGL(k_masked_adam, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
+int adfp_adam_prep(int* steps, float* derived, int n_groups, const float* lr, float beta1, float beta2, void* stream) {
+    if (!steps || !derived || !lr || n_groups <= 0 || n_groups > ADFP_ADAM_MAX_GROUPS) return ADFP_E_ARG;
+    AdamPrepArgs a;
+    a.steps = steps; a.derived = derived; a.n = n_groups; a.beta1 = beta1; a.beta2 = beta2;
+    for (int g = 0; g < ADFP_ADAM_MAX_GROUPS; ++g) a.lr[g] = g < n_groups ? lr[g] : -1.f;
+    hipLaunchKernelGGL(k_adam_prep, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+int adfp_masked_adam_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const unsigned char* mask, long long nvox,
+                         int channels, float beta1, float beta2, float eps, const float* derived, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !derived || nvox < 0 || channels <= 0) return ADFP_E_ARG;
+    if (nvox == 0) return 0;
+    AdamArgs a;
+    a.param = param; a.grad = grad; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.mask = mask; a.nvox = nvox; a.C = channels;
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.step_size = 0.f; a.sqrt_bc2 = 1.f; a.derived = derived;
+    const long long threads = ((nvox + 3) >> 2) * channels;
+    hipLaunchKernelGGL(k_masked_adam, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+int adfp_prefilter_mask(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double* bound_dev,
+                        unsigned char* keep, float* depth_max, void* stream) {
+    if (!rays_o || !rays_d || !gt_depth || !bound_dev || !keep || !depth_max || n_rays <= 0) return ADFP_E_ARG;
+    hipLaunchKernelGGL(k_prefilter_mask, dim3(1), dim3(1024), 0, (hipStream_t)stream, rays_o, rays_d, gt_depth, n_rays, bound_dev, keep, depth_max);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+int adfp_mapper_loss(const adfp_loss_args* l, void* stream) {
+    if (!l || !l->depth || !l->gt_depth || !l->g_depth || l->n_rays < 0 || l->S <= 0) return ADFP_E_ARG;
+    if (l->stage < ADFP_STAGE_LOW || l->stage > ADFP_STAGE_COLOR) return ADFP_E_ARG;
+    if (l->stage == ADFP_STAGE_COLOR && (!l->color || !l->gt_color || !l->g_color)) return ADFP_E_ARG;
+    if (l->warmup && (!l->weight || !l->g_weight)) return ADFP_E_ARG;
+    if (l->n_rays == 0) return 0;
+    LossArgs a;
+    a.n = l->n_rays; a.S = l->S; a.color_term = l->stage == ADFP_STAGE_COLOR; a.warmup = l->warmup; a.w_color = l->w_color_loss;
+    a.depth = l->depth; a.color = l->color; a.weight = l->weight; a.gt_depth = l->gt_depth; a.gt_color = l->gt_color; a.keep = l->keep;
+    a.loss = l->loss; a.g_depth = l->g_depth; a.g_color = l->g_color; a.g_weight = l->g_weight;
+    hipLaunchKernelGGL(k_mapper_loss, dim3((l->n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     ADFP_CHECK_LAUNCH();
     return 0;
 }
@@ -1499,7 +1603,7 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
     const int P = (int)Pn;
 
     hipLaunchKernelGGL(k_composite_bwd, dim3((r->n_rays + 3) / 4), dim3(256), 0, st, r->raw, r->z_vals, r->n_rays, r->S,
-                       r->g_depth, r->g_uncertainty, r->g_color, bw.g_raw);
+                       r->g_depth, r->g_uncertainty, r->g_color, bw.g_raw, r->ray_keep);
     ADFP_CHECK_LAUNCH();
 
     PtsDev Pd;

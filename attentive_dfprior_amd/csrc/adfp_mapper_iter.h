@@ -1,0 +1,115 @@
+// adfp_mapper_iter.h -- the Mapper's per-iteration glue on the device (reference src/Mapper.py:438-473), so that one
+// optimisation iteration is a fixed sequence of kernels with no host read-back and can be captured into a HIP graph:
+//
+//   k_prefilter_mask   the bounding-box pre-filter as a per-ray keep flag + the max sensor depth of the KEPT rays
+//                      (src/Mapper.py:438-449 compacts the batch with boolean indexing, which synchronises and makes the
+//                      batch size data dependent; a dropped ray that is rendered anyway and masked out of the loss gives
+//                      the kept rays the same outputs and the same gradients, because `far` only sees the batch
+//                      through max(gt_depth), Renderer.py:159, :195)
+//   k_mapper_loss      the three L1 terms of src/Mapper.py:457-469 and their cotangents (torch's abs backward = sign)
+//   k_adam_prep        step += 1 and the bias corrections of torch.optim.Adam for every parameter group, on the device
+//   k_masked_adam_dev  k_masked_adam with the step-dependent scalars read from device memory
+#pragma once
+#include "adfp_device.h"
+
+__global__ __launch_bounds__(1024) void k_prefilter_mask(const float* __restrict__ ro, const float* __restrict__ rd,
+                                                         const float* __restrict__ depth, int n, const double* __restrict__ bnd,
+                                                         unsigned char* __restrict__ keep, float* __restrict__ depth_max) {
+    __shared__ float s_m[16];
+    double b[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) b[k] = bnd[k];
+    float mx = -INFINITY;
+    bool any_nan = false;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        double t = INFINITY; bool nan = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double o = (double)ro[3 * i + k], d = (double)rd[3 * i + k];
+            const double t0 = (b[2 * k] - o) / d, t1 = (b[2 * k + 1] - o) / d;
+            nan |= (t0 != t0) | (t1 != t1);            // torch.max / torch.min propagate NaN
+            const double tm = t0 > t1 ? t0 : t1;
+            t = tm < t ? tm : t;
+        }
+        const float dep = depth[i];
+        const bool k_ = !nan && (t >= (double)dep);
+        keep[i] = k_ ? 1 : 0;
+        if (k_) { any_nan |= dep != dep; mx = dep > mx ? dep : mx; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float v = __shfl_xor(mx, o); mx = v > mx ? v : mx; }
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = s_m[0];
+        for (int w = 1; w < 16; ++w) m = s_m[w] > m ? s_m[w] : m;
+        (void)any_nan;
+        *depth_max = m;
+    }
+}
+
+struct LossArgs {
+    int n, S, color_term, warmup;
+    float w_color;
+    const double* depth; const float* color; const float* weight;
+    const float* gt_depth; const float* gt_color; const unsigned char* keep;
+    double* loss; double* g_depth; float* g_color; float* g_weight;
+};
+ADFP_DEV float sign_f(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }     // torch.sign: 0 at 0, NaN -> 0 here
+// one wave per ray: lane 0 the depth term, lanes 0-2 the colour term, all lanes stride over the ray's S attention weights
+__global__ __launch_bounds__(256) void k_mapper_loss(LossArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= a.n) return;
+    const bool kept = !a.keep || a.keep[ray];
+    double part = 0.0;
+    if (lane == 0) {
+        const float gd = a.gt_depth[ray];
+        double g = 0.0;
+        if (kept && gd > 0.f) {                                        // depth_mask = batch_gt_depth > 0, Mapper.py:457
+            const double diff = (double)gd - a.depth[ray];            // f32 - f64 -> f64
+            part += diff < 0 ? -diff : diff;
+            g = diff > 0 ? -1.0 : (diff < 0 ? 1.0 : 0.0);              // d|gt - d|/dd = -sign(gt - d)
+        }
+        a.g_depth[ray] = g;
+    }
+    if (lane < 3) {
+        float g = 0.f;
+        if (a.color_term && kept) {                                    // Mapper.py:466-469
+            const float diff = a.gt_color[3 * ray + lane] - a.color[3 * ray + lane];
+            part += (double)(a.w_color * fabsf(diff));
+            g = -a.w_color * sign_f(diff);
+        }
+        if (a.g_color) a.g_color[3 * ray + lane] = g;
+    }
+    if (a.g_weight) {
+        for (int s = lane; s < a.S; s += 64) {
+            float g = 0.f;
+            if (a.warmup && kept) {                                    // + |weight - 1|.sum(), Mapper.py:459-461
+                const float diff = a.weight[(long long)ray * a.S + s] - 1.f;
+                part += (double)fabsf(diff);
+                g = sign_f(diff);
+            }
+            a.g_weight[(long long)ray * a.S + s] = g;
+        }
+    }
+    if (a.loss) {
+        part = wave_sum(part);
+        if (lane == 0 && part != 0.0) atomicAdd(a.loss, part);
+    }
+}
+
+// Per parameter group g < n with lr[g] >= 0:  t = ++steps[g],  derived[g] = { lr[g] / (1 - beta1^t), sqrt(1 - beta2^t) } -- the
+// python-float (double) arithmetic of torch.optim.Adam, rounded to f32 once.  A negative lr marks a group that does not step
+// in this iteration (torch skips parameters without a gradient).  One launch for all groups.
+#define ADFP_ADAM_MAX_GROUPS 8
+struct AdamPrepArgs { int* steps; float* derived; int n; float beta1, beta2; float lr[ADFP_ADAM_MAX_GROUPS]; };
+__global__ void k_adam_prep(AdamPrepArgs a) {
+    const int g = threadIdx.x;
+    if (blockIdx.x != 0 || g >= a.n || a.lr[g] < 0.f) return;
+    const int t = a.steps[g] + 1;
+    a.steps[g] = t;
+    const double bc1 = 1.0 - pow((double)a.beta1, (double)t), bc2 = 1.0 - pow((double)a.beta2, (double)t);
+    a.derived[2 * g] = (float)((double)a.lr[g] / bc1);
+    a.derived[2 * g + 1] = (float)sqrt(bc2);
+}

@@ -126,14 +126,15 @@ struct AdamArgs {
     float beta1, beta2, eps;
     float step_size;             // lr / (1 - beta1^t)
     float sqrt_bc2;              // sqrt(1 - beta2^t)
+    const float* derived;        // device {step_size, sqrt_bc2} written by k_adam_prep (graph-capturable steps), or NULL
 };
-ADFP_DEV void adam_one(const AdamArgs& a, long long i) {
+ADFP_DEV void adam_one(const AdamArgs& a, long long i, float step_size, float sqrt_bc2) {
     const float g = a.grad[i];
     const float m = __fadd_rn(__fmul_rn(a.exp_avg[i], a.beta1), __fmul_rn(g, 1.f - a.beta1));               // mul_(b1).add_(g, alpha=1-b1)
     const float v = __fadd_rn(__fmul_rn(a.exp_avg_sq[i], a.beta2), __fmul_rn(__fmul_rn(1.f - a.beta2, g), g)); // mul_(b2).addcmul_(g, g, value=1-b2)
     a.exp_avg[i] = m; a.exp_avg_sq[i] = v;
-    const float denom = __fadd_rn(__fdiv_rn(sqrtf(v), a.sqrt_bc2), a.eps);
-    a.param[i] = __fadd_rn(a.param[i], __fdiv_rn(__fmul_rn(-a.step_size, m), denom));                      // addcdiv_(m, denom, value=-step_size)
+    const float denom = __fadd_rn(__fdiv_rn(sqrtf(v), sqrt_bc2), a.eps);
+    a.param[i] = __fadd_rn(a.param[i], __fdiv_rn(__fmul_rn(-step_size, m), denom));                      // addcdiv_(m, denom, value=-step_size)
 }
 __global__ __launch_bounds__(256) void k_masked_adam(AdamArgs a) {
     const long long quads = (a.nvox + 3) >> 2;
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(256) void k_masked_adam(AdamArgs a) {
         else { mk = 0; for (int k = 0; k < 4 && v0 + k < a.nvox; ++k) mk |= (unsigned)(a.mask[v0 + k] != 0) << (8 * k); }
     } else if (!full) { mk = 0; for (int k = 0; k < 4 && v0 + k < a.nvox; ++k) mk |= 1u << (8 * k); }
     if (mk == 0) return;
+    const float step_size = a.derived ? a.derived[0] : a.step_size, sqrt_bc2 = a.derived ? a.derived[1] : a.sqrt_bc2;
     const long long base = c * a.nvox + v0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if ((mk >> (8 * k)) & 0xffu) adam_one(a, base + k);
+    for (int k = 0; k < 4; ++k) if ((mk >> (8 * k)) & 0xffu) adam_one(a, base + k, step_size, sqrt_bc2);
 }

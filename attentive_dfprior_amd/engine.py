@@ -249,7 +249,7 @@ class Engine(object):
                 P = N * S
                 aux.update(flags=torch.empty((P,), dtype=torch.uint8, device=dev),
                            list=torch.empty((P,), dtype=torch.int32, device=dev),
-                           counter=torch.zeros((4,), dtype=torch.int32, device=dev),
+                           counter=torch.empty((4,), dtype=torch.int32, device=dev),     # zeroed by the library (a kernel)
                            att_occ=torch.empty((P,), dtype=torch.float32, device=dev),
                            att_u=torch.empty((P,), dtype=torch.float32, device=dev),
                            rays_o=ro, rays_d=rd, S=S)
@@ -266,7 +266,7 @@ class Engine(object):
 
     # ---- a15 -------------------------------------------------------------------------------
     def render_backward(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, saved, g_depth, g_unc, g_color,
-                        g_weight, need_grid, need_flat, need_rays=False):
+                        g_weight, need_grid, need_flat, need_rays=False, ray_keep=None):
         """saved: the aux dict of render_forward(train=True).  need_grid / need_flat: dicts of bools.
         Returns (grid grads dict in the reference's [1,32,Z,Y,X] layout, flat parameter grads dict)."""
         ro = saved['rays_o']
@@ -290,6 +290,8 @@ class Engine(object):
                 prep(g_weight, torch.float32)
             a.g_depth, a.g_uncertainty = _lib.ptr(gd), _lib.ptr(gu)
             a.g_color, a.g_weight = _lib.ptr(gc), _lib.ptr(gw)
+            if ray_keep is not None:
+                a.ray_keep = ray_keep.data_ptr()
             grids_cl, flats = {}, {}
             for name, key in (('low', 'grid_low'), ('high', 'grid_high'), ('color', 'grid_color')):
                 if need_grid.get(name):

@@ -102,3 +102,174 @@ class MaskedGridAdam:
                                          float(lrs[k]), self.betas[0], self.betas[1], self.eps, st[2],
                                          _lib.current_stream(g.device)), 'adfp_masked_adam')
             torch.autograd.graph.increment_version(g)     # updated through a raw pointer: invalidate the layout caches
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# One optimisation iteration of Mapper.optimize_map (reference src/Mapper.py:380-482) as ONE call: pre-filter (as a keep
+# mask), render forward, the Mapper loss and its cotangents, render backward, Adam on the frustum-masked grid voxels and on
+# the trainable decoder parameters -- a fixed kernel sequence with no host read-back, replayed from a HIP graph.
+#
+# What the reference does per iteration on the host, and what replaces it:
+#   boolean-mask compaction of the ray batch (a sync, a data-dependent batch size)  -> adfp_prefilter_mask: keep flags +
+#       the max sensor depth of the kept rays; dropped rays are rendered too and masked out of loss and gradients
+#   loss assembled from ~10 torch ops with another boolean index                    -> adfp_mapper_loss (one kernel)
+#   torch.autograd graph walk                                                        -> a direct adfp_render_backward call
+#   torch.optim.Adam over 5 parameter groups (~10 multi-tensor launches)             -> adfp_adam_prep + adfp_masked_adam_dev on
+#       the dense grids (in place, masked) and on ONE flat buffer per trainable network (the nn.Parameters become views
+#       of it, so state_dict / deepcopy / .parameters() are unchanged)
+# ---------------------------------------------------------------------------------------------------------------------
+def flatten_parameters(module):
+    """Re-home the parameters of `module` in ONE contiguous float32 buffer (state_dict order); every nn.Parameter keeps its
+    identity and becomes a view of the buffer.  Returns the buffer."""
+    params = list(module.parameters())
+    flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.data = flat[off:off + n].view(p.shape)
+        off += n
+    return flat
+
+
+class MapperIteration(object):
+    """
+    it = MapperIteration(renderer, decoders, c, masks, tsdf_volume, tsdf_bnds, stage_lr)
+    for joint_iter in range(num_joint_iters):
+        ... rays_o, rays_d, gt_depth, gt_color = cat(get_samples(...))        # NOT pre-filtered: the iteration does it
+        loss = it.step(rays_o, rays_d, gt_depth, gt_color, stage, warmup)      # device double, no sync
+
+    c           dict of the three feature grids, float32 leaf tensors on the GPU, updated IN PLACE
+    masks       dict name -> bool [Z,Y,X] (frustum_mask) or None
+    stage_lr    {'low': {'low': lr, 'high': lr, 'color': lr, 'decoders': lr, 'mlp': lr}, 'high': {...}, 'color': {...}}
+                (configs/df_prior.yaml:65-83 times lr_factor)
+    train       which networks Adam updates: ('color', 'att') = fix_high: True, fix_color: False (src/Mapper.py:364-371)
+    """
+
+    def __init__(self, renderer, decoders, c, masks, tsdf_volume, tsdf_bnds, stage_lr, w_color_loss=0.2,
+                 train=('color', 'att'), betas=(0.9, 0.999), eps=1e-8, use_graph=True):
+        self.rend, self.dec, self.c = renderer, decoders, c
+        self.tsdf, self.tsdf_bnds = tsdf_volume, tsdf_bnds
+        self.stage_lr, self.w_color, self.betas, self.eps = stage_lr, float(w_color_loss), betas, eps
+        self.use_graph = use_graph
+        self.dev = next(iter(c.values())).device
+        dev = self.dev
+        for k, g in c.items():
+            _lib.require_cuda(g, k)
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                raise ValueError(f'{k}: expected a contiguous float32 grid')
+        self.masks = {k: (None if masks is None or masks.get(k) is None else masks[k].to(dev, torch.uint8).contiguous()) for k in c}
+        self.gstate = {k: (torch.zeros_like(g), torch.zeros_like(g)) for k, g in c.items()}
+        self.nets = tuple(train)
+        attr = {'low': 'low_decoder', 'high': 'high_decoder', 'color': 'color_decoder', 'att': 'mlp'}
+        self.flat = {n: flatten_parameters(getattr(decoders, attr[n])) for n in self.nets}
+        decoders._plists = {}                                        # the cached parameter tuples are still the same objects
+        self.fstate = {n: (torch.zeros_like(f), torch.zeros_like(f)) for n, f in self.flat.items()}
+        # torch.optim.Adam keeps one step counter PER PARAMETER and advances it only when the parameter has a gradient (the high
+        # and colour grids join in later stages): one device counter + derived scalars per group
+        self.groups = list(c.keys()) + list(self.nets)
+        self.step_count = torch.zeros(len(self.groups), dtype=torch.int32, device=dev)
+        self.derived = torch.empty((len(self.groups), 2), dtype=torch.float32, device=dev)
+        self._pool = None
+        self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.bound_dev = torch.as_tensor(renderer.bound).to(dev, torch.float64).contiguous()
+        self._graphs = {}
+        self._static = {}
+        self._versioned = list(c.values()) + [p for n in self.nets for p in getattr(decoders, attr[n]).parameters()]
+
+    # ---- the kernel sequence ------------------------------------------------------------------------------------------
+    def _sequence(self, ro, rd, gd, gc, stage, warmup, adam=True):
+        L = lib()
+        dev, eng, dec, rend = self.dev, self.rend._engine, self.dec, self.rend
+        st = _lib.current_stream(dev)
+        N = ro.shape[0]
+        keep = torch.empty((N,), dtype=torch.uint8, device=dev)
+        dmax = torch.empty((1,), dtype=torch.float32, device=dev)
+        check(L.adfp_prefilter_mask(ptr(ro), ptr(rd), ptr(gd), N, ptr(self.bound_dev), ptr(keep), ptr(dmax), st), 'adfp_prefilter_mask')
+        depth, unc, color, weight, aux = eng.render_forward(dec, self.c, ro, rd, gd, self.tsdf, self.tsdf_bnds, rend.bound, stage,
+                                                            rend.N_samples, rend.N_surface, rend.lindisp, rend.perturb, None, dmax,
+                                                            train=True)
+        S = aux['S']
+        la = _lib.AdfpLossArgs()
+        la.n_rays, la.S, la.stage, la.warmup, la.w_color_loss = N, S, _lib.STAGE[stage], 1 if warmup else 0, self.w_color
+        la.depth, la.color, la.weight = depth.data_ptr(), color.data_ptr(), weight.data_ptr()
+        la.gt_depth, la.gt_color, la.keep = gd.data_ptr(), gc.data_ptr(), keep.data_ptr()
+        g_depth = torch.empty((N,), dtype=torch.float64, device=dev)
+        g_color = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        g_weight = torch.empty((N, S), dtype=torch.float32, device=dev) if warmup else None
+        self.loss.zero_()
+        la.loss, la.g_depth, la.g_color = self.loss.data_ptr(), g_depth.data_ptr(), g_color.data_ptr()
+        la.g_weight = g_weight.data_ptr() if warmup else None
+        check(L.adfp_mapper_loss(C.byref(la), st), 'adfp_mapper_loss')
+        used = {'low': ('low',), 'high': ('low', 'high', 'att'), 'color': ('low', 'high', 'color', 'att')}[stage]
+        need_grid = {k: (k in used) for k in ('low', 'high', 'color')}
+        need_flat = {n: (n in used and n in self.nets) for n in ('low', 'high', 'color', 'att')}
+        grids, flats, _ = eng.render_backward(dec, self.c, self.tsdf, self.tsdf_bnds, rend.bound, stage, aux, g_depth, None,
+                                              g_color if stage == 'color' else None, g_weight, need_grid, need_flat, ray_keep=keep)
+        if not adam:
+            return grids, flats
+        lr = self.stage_lr[stage]
+        b1, b2 = self.betas
+        # Adam (src/Mapper.py:374-378, :472): a group whose parameters received no gradient in this stage is skipped by torch
+        # (grad is None) and is skipped here; a group with lr 0 still advances its moments
+        groups = []
+        for name, key in (('low', 'grid_low'), ('high', 'grid_high'), ('color', 'grid_color')):
+            if name in grids:
+                g = self.c[key]
+                groups.append((key, g, grids[name], self.gstate[key], self.masks[key], g.shape[2] * g.shape[3] * g.shape[4], g.shape[1], lr[name]))
+        for n in self.nets:
+            if n in flats:
+                f = self.flat[n]
+                groups.append((n, f, flats[n], self.fstate[n], None, f.numel(), 1, lr['decoders' if n in ('high', 'color') else 'mlp']))
+        lrs = (C.c_float * len(self.groups))(*([-1.0] * len(self.groups)))
+        for (gname, *_rest, lrv) in groups:
+            lrs[self.groups.index(gname)] = float(lrv)
+        check(L.adfp_adam_prep(ptr(self.step_count), ptr(self.derived), len(self.groups), lrs, b1, b2, st), 'adfp_adam_prep')
+        for (gname, p, g, (m, v), mask, nvox, ch, lrv) in groups:
+            d = self.derived[self.groups.index(gname)]
+            check(L.adfp_masked_adam_dev(ptr(p), ptr(g), ptr(m), ptr(v), ptr(mask) if mask is not None else None, int(nvox), int(ch),
+                                         b1, b2, self.eps, ptr(d), st), 'adfp_masked_adam_dev')
+        return grids, flats
+
+    def _bump_versions(self):
+        for t in self._versioned:
+            torch.autograd.graph.increment_version(t)        # updated through raw pointers: invalidate (data_ptr, _version) caches
+
+    @torch.no_grad()
+    def step(self, rays_o, rays_d, gt_depth, gt_color, stage, warmup=False):
+        """One iteration; returns the loss as a device float64 tensor (reading it synchronises -- do so sparingly)."""
+        dev = self.dev
+        with torch.cuda.device(dev):
+            N = rays_o.shape[0]
+            if not self.use_graph:
+                self._sequence(rays_o.float().contiguous(), rays_d.float().contiguous(), gt_depth.float().contiguous(),
+                               gt_color.float().contiguous(), stage, warmup)
+                self._bump_versions()
+                return self.loss
+            key = (N, stage, bool(warmup))
+            st = self._static.get(N)
+            if st is None:
+                st = self._static[N] = (torch.empty((N, 3), device=dev), torch.empty((N, 3), device=dev), torch.empty((N,), device=dev),
+                                        torch.empty((N, 3), device=dev))
+            for dst, src in zip(st, (rays_o, rays_d, gt_depth, gt_color)):
+                dst.copy_(src)
+            g = self._graphs.get(key)
+            if g is None:
+                # warm the host-side caches (bounds, workspace) without touching any optimiser state, then capture with the
+                # layout / packing caches cold so that their kernels are part of the graph
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    self._sequence(*st, stage, warmup, adam=False)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.synchronize(dev)
+                self.rend._engine._grid_cache.clear()
+                self.dec._packed.clear()
+                g = torch.cuda.CUDAGraph()
+                if self._pool is None:
+                    self._pool = torch.cuda.graph_pool_handle()      # the graphs replay one at a time: one pool for all
+                with torch.cuda.graph(g, pool=self._pool):
+                    self._sequence(*st, stage, warmup)
+                self._graphs[key] = g                 # capturing does not execute: fall through to the first replay
+            g.replay()
+            self._bump_versions()
+            return self.loss

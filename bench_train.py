@@ -71,9 +71,28 @@ def main():
                     rend.render_batch_ray(c, dec, rd, ro, dev, scene.tsdf_volume, tsdf_bnds, 'color', gt_depth=gd)
             torch.cuda.synchronize()
             df = (time.perf_counter() - t0) / args.iters
+            # the same iteration as one fused, graph-replayed call (mapping.MapperIteration): pre-filter mask, render, loss,
+            # backward and Adam with no host read-back
+            from attentive_dfprior_amd import mapping
+            import copy
+            dec_f = copy.deepcopy(dec)
+            cf = {k: v.detach().clone() for k, v in scene.c.items()}
+            lr = {'color': dict(low=0.005, high=0.005, color=0.005, decoders=0.005, mlp=0.005)}
+            res = {}
+            for mode, use_graph in (('fused_eager', False), ('fused_graph', True)):
+                itf = mapping.MapperIteration(A.Renderer(cfg, None, scene), dec_f, cf, None, scene.tsdf_volume, tsdf_bnds, lr, use_graph=use_graph)
+                for _ in range(3):
+                    itf.step(ro, rd, gd, gc, 'color')
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.iters):
+                    itf.step(ro, rd, gd, gc, 'color')
+                torch.cuda.synchronize()
+                res[mode] = (time.perf_counter() - t0) / args.iters * 1e3
             print(json.dumps({'metric': 'mapper iteration (render fwd + loss + bwd + Adam), stage color', 'rays': n_rays,
                               'samples_per_ray': ns + nf, 'ms_per_iter': dt * 1e3, 'rays_per_s_fwd_bwd': n_rays / dt,
-                              'ms_forward_only': df * 1e3, 'loss': float(loss)}))
+                              'ms_forward_only': df * 1e3, 'loss': float(loss),
+                              'ms_per_iter_fused_eager': res['fused_eager'], 'ms_per_iter_fused_graph': res['fused_graph']}))
 
 
 if __name__ == '__main__':

@@ -132,6 +132,16 @@ int adfp_pack_attention(const float* flat, float* packed, void* stream);
 int adfp_get_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w,
                   float* rays_o /*[H*W,3]*/, float* rays_d /*[H*W,3]*/, void* stream);
 
+/* ---- a2: get_rays_from_uv (src/common.py:76-91) ----------------------------------------- */
+/* Rays through n pixels (pix_i = column, pix_j = row coordinates as float, as get_sample_uv hands them on); c2w [4,4]
+ * row-major fp32 on the device.  The backward gives d/d c2w [4,4] (bottom row zero) from the cotangents of the rays:
+ * the camera pose of the Tracker and of the Mapper's bundle adjustment reaches the renderer only through this function
+ * (src/Tracker.py:97, src/Mapper.py:425).  Either cotangent may be NULL. */
+int adfp_rays_from_uv(const float* pix_i, const float* pix_j, int n, float fx, float fy, float cx, float cy, const float* c2w,
+                      float* rays_o /*[n,3]*/, float* rays_d /*[n,3]*/, void* stream);
+int adfp_rays_from_uv_backward(const float* pix_i, const float* pix_j, int n, float fx, float fy, float cx, float cy,
+                               const float* g_rays_o, const float* g_rays_d, float* g_c2w /*[4,4]*/, void* stream);
+
 /* ---- a3: the Mapper's bounding-box pre-filter (src/Mapper.py:438-449) ------------------ */
 /* Keeps ray i iff min over axes of max over the two bound planes of (bound - o) / d >= gt_depth
  * (f64 arithmetic on f32 rays, as the reference's f64 `self.bound` promotes it; NaN compares false).
@@ -237,6 +247,7 @@ typedef struct adfp_backward_args {
     float* g_rays_d;             /* [N,3] or NULL */
     void* workspace;
     size_t workspace_bytes;
+    const unsigned char* ray_keep;  /* [N] or NULL: rays flagged 0 (adfp_prefilter_mask) receive no gradient at all */
 } adfp_backward_args;
 size_t adfp_backward_workspace_bytes(long long n_points);
 int adfp_render_backward(const adfp_scene* scene /*host*/, const adfp_backward_args* args /*host*/, void* stream);
@@ -268,6 +279,46 @@ int adfp_frustum_mask(int X, int Y, int Z, const double bound[3][2], const float
  * outside the mask (mask == NULL: none) are not touched.  step counts from 1. */
 int adfp_masked_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const unsigned char* mask,
                      long long nvox, int channels, float lr, float beta1, float beta2, float eps, int step, void* stream);
+
+/* ---- One Mapper iteration as a fixed, sync-free kernel sequence (src/Mapper.py:438-473) ------------------------------- */
+/* The bounding-box pre-filter of adfp_prefilter_rays as a per-ray keep flag (1 = kept) plus *depth_max = the max sensor
+ * depth of the KEPT rays (device float, feeds adfp_render_args.depth_max).  The reference compacts the batch with boolean
+ * indexing (a device sync, a data-dependent batch size); rendering the dropped rays too and masking them out of the loss
+ * (adfp_loss_args.keep, adfp_backward_args.ray_keep) gives the kept rays identical outputs and gradients, because a ray
+ * sees the rest of its batch only through max(gt_depth) (src/utils/Renderer.py:159, :195). */
+int adfp_prefilter_mask(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double* bound_dev,
+                        unsigned char* keep /*[N]*/, float* depth_max /*device float*/, void* stream);
+/* The Mapper's loss (src/Mapper.py:457-469) and its cotangents w.r.t. the renderer's outputs:
+ *   sum_{gt_depth > 0} |gt_depth - depth|  [+ sum |weight - 1| when `warmup`]  [+ w_color_loss * sum |gt_color - color| in stage color]
+ * g_* = d loss / d output (sign functions, 0 at 0 like torch.abs's backward), zero for rays with keep == 0.
+ * loss (device double, may be NULL) is ACCUMULATED: zero it first. */
+typedef struct adfp_loss_args {
+    int n_rays, S;
+    int stage;                   /* ADFP_STAGE_*; the colour term exists in stage color only */
+    int warmup;                  /* src/Mapper.py:459: idx <= 1 and the 5 iterations after the low stage */
+    float w_color_loss;          /* configs/df_prior.yaml:56 */
+    const double* depth;         /* [N]   */
+    const float* color;          /* [N,3] (stage color) */
+    const float* weight;         /* [N,S] attention weight (warm-up) */
+    const float* gt_depth;       /* [N]   */
+    const float* gt_color;       /* [N,3] (stage color) */
+    const unsigned char* keep;   /* [N] or NULL */
+    double* loss;                /* device double or NULL */
+    double* g_depth;             /* [N]   out */
+    float* g_color;              /* [N,3] out (stage color; may be NULL otherwise) */
+    float* g_weight;             /* [N,S] out (warm-up; may be NULL otherwise) */
+} adfp_loss_args;
+int adfp_mapper_loss(const adfp_loss_args* args /*host*/, void* stream);
+/* torch.optim.Adam's step counters and bias corrections on the device, for n_groups <= 8 parameter groups in ONE launch:
+ * for every group g with lr[g] >= 0:  steps[g] += 1,  derived[2g] = lr[g] / (1 - beta1^steps[g]),  derived[2g+1] =
+ * sqrt(1 - beta2^steps[g])  (double arithmetic, one rounding, like the python floats of torch.optim); a negative lr[g]
+ * = the group has no gradient in this iteration and does not step.  lr is a HOST array. */
+int adfp_adam_prep(int* steps /*device int[n]*/, float* derived /*device float[n][2]*/, int n_groups, const float* lr /*host*/,
+                   float beta1, float beta2, void* stream);
+/* adfp_masked_adam with the step-dependent scalars read from `derived`: no host value changes from step to step, so
+ * the call can be replayed from a HIP graph. */
+int adfp_masked_adam_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const unsigned char* mask,
+                         long long nvox, int channels, float beta1, float beta2, float eps, const float* derived, void* stream);
 
 /* Per-stage timing hook for bench.py: runs ONLY the TSDF trilerp + band-mask kernel (a10).
  * w may be NULL (that is the render path's launch: there the LOW decoder writes w = 1). */

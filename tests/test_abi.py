@@ -65,8 +65,8 @@ def test_ctypes_struct_layout_matches_c(tmp_path):
 #include <stddef.h>
 #include "adfp.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(adfp_grid), sizeof(adfp_tsdf), sizeof(adfp_scene), sizeof(adfp_points),
-         sizeof(adfp_render_args), sizeof(adfp_train_state), sizeof(adfp_backward_args));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(adfp_grid), sizeof(adfp_tsdf), sizeof(adfp_scene), sizeof(adfp_points),
+         sizeof(adfp_render_args), sizeof(adfp_train_state), sizeof(adfp_backward_args), sizeof(adfp_loss_args));
   printf("%zu %zu %zu %zu %zu\\n", offsetof(adfp_scene, low), offsetof(adfp_scene, tsdf), offsetof(adfp_scene, w_low),
          offsetof(adfp_scene, w_att), offsetof(adfp_scene, status));
   printf("%zu %zu %zu\\n", offsetof(adfp_points, pts), offsetof(adfp_points, z_vals), offsetof(adfp_points, S));
@@ -74,6 +74,8 @@ int main(void) {
          offsetof(adfp_render_args, workspace), offsetof(adfp_render_args, workspace_bytes), offsetof(adfp_render_args, state));
   printf("%zu %zu %zu %zu %zu\\n", offsetof(adfp_backward_args, rays_o), offsetof(adfp_backward_args, state),
          offsetof(adfp_backward_args, g_depth), offsetof(adfp_backward_args, g_rays_d), offsetof(adfp_backward_args, workspace_bytes));
+  printf("%zu %zu %zu %zu\\n", offsetof(adfp_backward_args, ray_keep), offsetof(adfp_loss_args, w_color_loss), offsetof(adfp_loss_args, depth),
+         offsetof(adfp_loss_args, g_weight));
   return 0;
 }''')
     exe = tmp_path / 'layout'
@@ -82,7 +84,7 @@ int main(void) {
     sz = list(map(int, out[0].split()))
     assert sz == [ctypes.sizeof(_lib.AdfpGrid), ctypes.sizeof(_lib.AdfpTsdf), ctypes.sizeof(_lib.AdfpScene),
                   ctypes.sizeof(_lib.AdfpPoints), ctypes.sizeof(_lib.AdfpRenderArgs),
-                  ctypes.sizeof(_lib.AdfpTrainState), ctypes.sizeof(_lib.AdfpBackwardArgs)]
+                  ctypes.sizeof(_lib.AdfpTrainState), ctypes.sizeof(_lib.AdfpBackwardArgs), ctypes.sizeof(_lib.AdfpLossArgs)]
     S = _lib.AdfpScene
     assert list(map(int, out[1].split())) == [S.low.offset, S.tsdf.offset, S.w_low.offset, S.w_att.offset, S.status.offset]
     P = _lib.AdfpPoints
@@ -93,3 +95,5 @@ int main(void) {
     B = _lib.AdfpBackwardArgs
     assert list(map(int, out[4].split())) == [B.rays_o.offset, B.state.offset, B.g_depth.offset, B.g_rays_d.offset,
                                               B.workspace_bytes.offset]
+    Lo = _lib.AdfpLossArgs
+    assert list(map(int, out[5].split())) == [B.ray_keep.offset, Lo.w_color_loss.offset, Lo.depth.offset, Lo.g_weight.offset]

@@ -1,0 +1,116 @@
+"""GPU: mapping.MapperIteration -- one Mapper iteration (pre-filter, render, loss, backward, Adam) as a fixed kernel
+sequence replayed from a HIP graph -- against the reference-shaped path it replaces: common.filter_rays_in_bound
+(boolean compaction), Renderer.render_batch_ray under autograd, the loss written with torch ops (src/Mapper.py:457-469),
+loss.backward(), torch.optim.Adam on the decoder parameters and MaskedGridAdam on the grids.  Same rays, same start,
+several iterations through the low -> high -> color stages with the warm-up term: the parameters must agree."""
+import copy
+
+import pytest
+import torch
+
+import attentive_dfprior_amd as A
+from attentive_dfprior_amd import common, mapping, synthetic
+from oracle import adfp_oracle as O
+from conftest import make_cfg, to_dev, assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+STAGE_LR = {'low': dict(low=0.1, high=0.0, color=0.0, decoders=0.0, mlp=0.0),
+            'high': dict(low=0.005, high=0.005, color=0.0, decoders=0.0, mlp=0.005),
+            'color': dict(low=0.005, high=0.005, color=0.005, decoders=0.005, mlp=0.005)}
+SCHEDULE = [('low', False), ('low', False), ('high', True), ('high', False), ('color', False), ('color', False)]
+
+
+def setup():
+    sc = synthetic.mini_scene()
+    sd = O.random_state_dict(seed=3)
+    dec = A.DF()
+    dec.load_state_dict(sd)
+    dec.bound = sc.bound
+    dec = dec.to(DEV)
+    for p in list(dec.low_decoder.parameters()) + list(dec.high_decoder.parameters()):
+        p.requires_grad_(False)
+    rend = A.Renderer(make_cfg(32, 16), None, sc)
+    ro, rd, gd, gc = synthetic.make_ray_batch(sc, 700, seed=9, zero_frac=0.1)
+    gd = gd * (0.6 + 1.2 * torch.rand(gd.shape, generator=torch.Generator().manual_seed(1)))     # some beyond the box: dropped
+    rd[5, 0] = 0.0
+    c2w = sc.default_c2w(yaw=0.7, pitch=0.1)
+    masks = {k: mapping.frustum_mask(c2w, tuple(v.shape[2:]), sc.depth_image(c2w).to(DEV), sc.bound, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy)
+             for k, v in sc.c.items()}
+    return sc, dec, rend, [t.to(DEV) for t in (ro, rd, gd, gc)], masks
+
+
+def reference_path(sc, dec, rend, rays, masks):
+    ro, rd, gd, gc = rays
+    grids = {k: v.clone().to(DEV).requires_grad_(True) for k, v in sc.c.items()}
+    opt_g = mapping.MaskedGridAdam(grids, masks)
+    opt = torch.optim.Adam([{'params': list(dec.color_decoder.parameters()), 'lr': 0}, {'params': list(dec.mlp.parameters()), 'lr': 0}])
+    tsdf, tb, bound = sc.tsdf_volume.to(DEV), sc.tsdf_bnds.to(DEV), sc.bound.to(DEV)
+    losses = []
+    for stage, warm in SCHEDULE:
+        lr = STAGE_LR[stage]
+        opt.param_groups[0]['lr'], opt.param_groups[1]['lr'] = lr['decoders'], lr['mlp']
+        opt.zero_grad(); opt_g.zero_grad()
+        o, d, z, c = common.filter_rays_in_bound(ro, rd, gd, gc, bound)
+        depth, unc, col, w = rend.render_batch_ray(grids, dec, d, o, DEV, tsdf, tb, stage, z)
+        m = z > 0
+        loss = torch.abs(z[m] - depth[m]).sum()
+        if warm:
+            loss = loss + torch.abs(w - 1.0).sum()
+        if stage == 'color':
+            loss = loss + 0.2 * torch.abs(c - col).sum()
+        loss.backward()
+        opt.step()
+        opt_g.step({'grid_low': lr['low'], 'grid_high': lr['high'], 'grid_color': lr['color']})
+        losses.append(float(loss))
+    return {k: v.detach().clone() for k, v in grids.items()}, {n: p.detach().clone() for n, p in dec.named_parameters()}, losses
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_fused_iteration_follows_the_reference_shaped_path(use_graph):
+    sc, dec, rend, rays, masks = setup()
+    dec2 = copy.deepcopy(dec)
+    g_ref, p_ref, l_ref = reference_path(sc, dec, rend, rays, masks)
+
+    grids = {k: v.clone().to(DEV) for k, v in sc.c.items()}
+    rend2 = A.Renderer(make_cfg(32, 16), None, sc)
+    it = mapping.MapperIteration(rend2, dec2, grids, masks, sc.tsdf_volume.to(DEV), sc.tsdf_bnds.to(DEV), STAGE_LR, use_graph=use_graph)
+    sd_keys = list(dec2.state_dict().keys())
+    losses = [float(it.step(*rays, stage, warm)) for stage, warm in SCHEDULE]     # graph mode: a stage's second visit replays
+    assert list(dec2.state_dict().keys()) == sd_keys          # flattening the parameters left the module's interface alone
+    for a, b in zip(losses, l_ref):
+        assert abs(a - b) <= 1e-5 * abs(b), (losses, l_ref)
+    for k in g_ref:
+        assert_close(grids[k], g_ref[k], 2e-4, f'{k} after {len(SCHEDULE)} iterations')
+        outside = ~masks[k].to(DEV)
+        assert torch.equal(grids[k][0, :, outside], sc.c[k].to(DEV)[0, :, outside])     # untouched outside the frustum mask
+    for n, p in dec2.named_parameters():
+        assert_close(p, p_ref[n], 2e-4, n)
+    # the drop-in objects keep working after the fused iterations (version bumps invalidate the layout caches)
+    with torch.no_grad():
+        d1 = rend2.render_batch_ray(grids, dec2, rays[1], rays[0], DEV, sc.tsdf_volume.to(DEV), sc.tsdf_bnds.to(DEV), 'color', rays[2])[0]
+        d2 = rend.render_batch_ray({k: v for k, v in g_ref.items()}, dec, rays[1], rays[0], DEV, sc.tsdf_volume.to(DEV), sc.tsdf_bnds.to(DEV),
+                                   'color', rays[2])[0]
+    ok = torch.isfinite(d2)
+    assert_close(d1[ok], d2[ok], 1e-3, 'render after training, fused vs reference-shaped path')
+
+
+def test_graph_replays_with_new_rays():
+    """The captured sequence reads its rays from static buffers: a replay with different rays must equal the unfused
+    iteration on those rays."""
+    sc, dec, rend, rays, masks = setup()
+    dec_b = copy.deepcopy(dec)
+    tsdf, tb = sc.tsdf_volume.to(DEV), sc.tsdf_bnds.to(DEV)
+    ga = {k: v.clone().to(DEV) for k, v in sc.c.items()}
+    gb = {k: v.clone().to(DEV) for k, v in sc.c.items()}
+    it_a = mapping.MapperIteration(A.Renderer(make_cfg(32, 16), None, sc), dec, ga, masks, tsdf, tb, STAGE_LR, use_graph=True)
+    it_b = mapping.MapperIteration(A.Renderer(make_cfg(32, 16), None, sc), dec_b, gb, masks, tsdf, tb, STAGE_LR, use_graph=False)
+    for seed in (1, 2, 3):
+        ro, rd, gd, gc = [t.to(DEV) for t in synthetic.make_ray_batch(sc, 700, seed=seed)]
+        la = float(it_a.step(ro, rd, gd, gc, 'color'))
+        lb = float(it_b.step(ro, rd, gd, gc, 'color'))
+        assert abs(la - lb) <= 1e-6 * abs(lb)
+    for k in ga:
+        assert_close(ga[k], gb[k], 5e-5, k)
+    for (n, p), (_, q) in zip(dec.named_parameters(), dec_b.named_parameters()):
+        assert_close(p, q, 5e-5, n)

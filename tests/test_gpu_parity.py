@@ -379,3 +379,44 @@ def test_prefilter_rays_vs_reference_lines():
         assert np.array_equal(o.cpu().numpy(), g[f'{n}.kept_rays_o'], equal_nan=True), n
         assert np.array_equal(z.cpu().numpy(), g[f'{n}.kept_gt_depth'], equal_nan=True), n
         assert torch.equal(c.cpu(), torch.from_numpy(g[f'{n}.gt_color'])[mask]), n
+
+
+# --------------------------------------------------------------------------- a2: rays through given pixels
+def test_get_rays_from_uv_vs_golden_and_pose_gradient(mini):
+    """a2 (src/common.py:76-91) on the device: the reference's own vectors, then a larger seeded batch against the oracle
+    (values) and against torch autograd of the oracle's formula (gradient w.r.t. the camera pose)."""
+    g = mini.golden('rays')
+    i, j = torch.from_numpy(g['uv_i']).to(DEV), torch.from_numpy(g['uv_j']).to(DEV)
+    ro, rd = common.get_rays_from_uv(i, j, mini.c2w.to(DEV), mini.H, mini.W, mini.fx, mini.fy, mini.cx, mini.cy, DEV)
+    assert np.array_equal(ro.cpu().numpy(), g['uv_rays_o'])
+    assert np.abs(rd.cpu().numpy() - g['uv_rays_d']).max() <= 1.2e-7 * np.abs(g['uv_rays_d']).max()
+    gen = torch.Generator().manual_seed(4)
+    n = 1537
+    i = torch.rand(n, generator=gen) * (mini.W - 1)
+    j = torch.rand(n, generator=gen) * (mini.H - 1)
+    c2w = mini.c2w.clone().requires_grad_(True)
+    oro, ord_ = O.get_rays_from_uv(i, j, c2w, mini.fx, mini.fy, mini.cx, mini.cy)
+    wo, wd = torch.randn(n, 3, generator=gen), torch.randn(n, 3, generator=gen)
+    ((oro * wo).sum() + (ord_ * wd).sum()).backward()
+    c2w_g = mini.c2w.clone().to(DEV).requires_grad_(True)
+    ro, rd = common.get_rays_from_uv(i.to(DEV), j.to(DEV), c2w_g, mini.H, mini.W, mini.fx, mini.fy, mini.cx, mini.cy, DEV)
+    assert torch.equal(ro.detach().cpu(), oro.detach()) and (rd.detach().cpu() - ord_.detach()).abs().max() <= 2e-7 * ord_.abs().max()
+    ((ro * wo.to(DEV)).sum() + (rd * wd.to(DEV)).sum()).backward()
+    assert_close(c2w_g.grad, c2w.grad, 1e-5, 'd/d c2w')
+    assert 'libadfp.so' in open('/proc/self/maps').read()
+
+
+def test_get_samples_rng_stream_is_torch_randint(mini):
+    """a2: pixel selection keeps the reference's RNG -- ONE torch.randint(H*W, (n,)) draw on the device per call
+    (src/common.py:101) -- so a seeded run selects the reference's pixels; depth / colour follow the same indices."""
+    H, W = mini.H, mini.W
+    depth = mini.depth_img.to(DEV)
+    color = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(2)).to(DEV)
+    torch.manual_seed(123)
+    ro, rd, d, c = common.get_samples(0, H, 0, W, 77, H, W, mini.fx, mini.fy, mini.cx, mini.cy, mini.c2w.to(DEV), depth, color, DEV)
+    torch.manual_seed(123)
+    idx = torch.randint(H * W, (77,), device=DEV)
+    assert torch.equal(d, depth.reshape(-1)[idx]) and torch.equal(c, color.reshape(-1, 3)[idx])
+    jj, ii = idx // W, idx % W
+    oro, ord_ = O.get_rays_from_uv(ii.float().cpu(), jj.float().cpu(), mini.c2w, mini.fx, mini.fy, mini.cx, mini.cy)
+    assert (rd.cpu() - ord_).abs().max() <= 2e-7 * ord_.abs().max() and torch.equal(ro.cpu(), oro)
