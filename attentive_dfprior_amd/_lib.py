@@ -68,6 +68,13 @@ class AdfpBackwardArgs(C.Structure):
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('ray_keep', C.c_void_p)]
 
 
+class AdfpPointsBackwardArgs(C.Structure):
+    _fields_ = [('stage', C.c_int), ('flags', C.c_int), ('state', AdfpTrainState), ('g_raw', C.c_void_p), ('g_w', C.c_void_p),
+                ('g_grid_low', C.c_void_p), ('g_grid_high', C.c_void_p), ('g_grid_color', C.c_void_p),
+                ('g_flat_low', C.c_void_p), ('g_flat_high', C.c_void_p), ('g_flat_color', C.c_void_p), ('g_flat_att', C.c_void_p),
+                ('g_pts', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+
+
 class AdfpLossArgs(C.Structure):
     _fields_ = [('n_rays', C.c_int), ('S', C.c_int), ('stage', C.c_int), ('warmup', C.c_int), ('w_color_loss', C.c_float),
                 ('depth', C.c_void_p), ('color', C.c_void_p), ('weight', C.c_void_p), ('gt_depth', C.c_void_p),
@@ -106,6 +113,9 @@ SYMBOLS = [
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_eval_points', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ('adfp_eval_points_train', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(AdfpTrainState), C.c_void_p]),
+    ('adfp_eval_points_backward', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.POINTER(AdfpPointsBackwardArgs), C.c_void_p]),
     ('adfp_sample_tsdf', C.c_int, [C.POINTER(AdfpTsdf), C.POINTER(Bound), C.POINTER(AdfpPoints),
                                    C.c_void_p, C.c_void_p]),
     ('adfp_tsdf_integrate', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float * 3),

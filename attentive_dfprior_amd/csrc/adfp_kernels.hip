@@ -505,13 +505,17 @@ __global__ __launch_bounds__(256, TSDF_MINW) void k_tsdf(TsdfArgs a) {
     __shared__ int s_q[TSDF_CHUNK];
     __shared__ float s_u[TSDF_CHUNK];
     __shared__ double s_z[TSDF_CHUNK + 64];
-    __shared__ unsigned char s_f[TSDF_CHUNK];
-    __shared__ float s_ray[64 * 6];
+    // flags are written by lanes that hold the SAME sample of consecutive rays: with rows S bytes apart the 64 byte-stores of a
+    // wave fell into 4 banks (S = 64: 16 dwords per row; PMC: LDS bank-conflict fraction 0.58 of this kernel).  Rows are padded
+    // to SF bytes with SF / 4 odd, so that consecutive rows start in different banks; the ray block (6 floats per ray) to 7.
+    __shared__ unsigned char s_f[TSDF_CHUNK + 64 * 8];
+    __shared__ float s_ray[64 * 7];
     __shared__ int s_cnt, s_base;
     if (threadIdx.x == 0) s_cnt = 0;
     const int lane = threadIdx.x & 63;
     const bool rays = a.P.mode == ADFP_PTS_RAYS;
     const int S = a.P.S;
+    const int SF = rays ? 4 * (((S + 3) >> 2) | 1) : 0;          // flag row stride in LDS (ray mode)
     int RB = 1, q0, npts, rb = 1;
     if (rays) {
         while (RB * 2 * S <= TSDF_CHUNK && RB < 64) RB *= 2;
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(256, TSDF_MINW) void k_tsdf(TsdfArgs a) {
             if (i < npts) { const int row = (int)((unsigned)i / (unsigned)S), col = i - row * S; s_z[row * (S + 1) + col] = zr[k]; }
         }
 #pragma unroll
-        for (int k = 0; k < 2; ++k) { const int i = threadIdx.x + 256 * k; if (i < rb * 6) s_ray[i] = rr[k]; }
+        for (int k = 0; k < 2; ++k) { const int i = threadIdx.x + 256 * k; if (i < rb * 6) { const int row = i / 6; s_ray[row * 7 + (i - row * 6)] = rr[k]; } }
     } else {
         q0 = blockIdx.x * TSDF_CHUNK;
         npts = a.P.n - q0 < TSDF_CHUNK ? a.P.n - q0 : TSDF_CHUNK;
@@ -542,19 +546,19 @@ __global__ __launch_bounds__(256, TSDF_MINW) void k_tsdf(TsdfArgs a) {
     __syncthreads();
     const bool paired = a.t.sZ == 1 && a.t.Z >= 2;   // the reference's layout: z fastest
     for (int i0 = 0; i0 < npts; i0 += 256 * UB) {    // block-uniform trip count (ballots below)
-        double p[UB][3]; float pn[UB][3]; int loc[UB]; bool ok[UB]; float tv[UB];
+        double p[UB][3]; float pn[UB][3]; int loc[UB], floc[UB]; bool ok[UB]; float tv[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int i = i0 + 256 * u + threadIdx.x;
             ok[u] = i < npts;
             const int ic = ok[u] ? i : npts - 1;     // clamped: every lane does valid loads, results masked
-            loc[u] = ic;
+            loc[u] = ic; floc[u] = ic;
             if (rays) {
                 const int col = (int)((unsigned)ic / (unsigned)rb), row = ic - col * rb;   // transposed walk: lane <-> ray
-                loc[u] = row * S + col;
+                loc[u] = row * S + col; floc[u] = row * SF + col;
                 const double z = s_z[row * (S + 1) + col];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) p[u][k] = __dadd_rn((double)s_ray[row * 6 + k], __dmul_rn((double)s_ray[row * 6 + 3 + k], z));
+                for (int k = 0; k < 3; ++k) p[u][k] = __dadd_rn((double)s_ray[row * 7 + k], __dmul_rn((double)s_ray[row * 7 + 3 + k], z));
             } else load_point(a.P, q0 + ic, p[u]);
             normalize3(a.nt, p[u], pn[u]);
         }
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(256, TSDF_MINW) void k_tsdf(TsdfArgs a) {
             const bool band = ok[u] & !pnan & (t > (float)(-1.0 + 1e-4)) & (t < (float)(1.0 - 1e-4));
             if (ok[u]) {
                 if (a.tsdf_out) a.tsdf_out[q] = t;
-                s_f[loc[u]] = (unsigned char)((in_bound(p[u], a.b) ? ADFP_F_INBOUND : 0u) | (band ? ADFP_F_BAND : 0u));
+                s_f[floc[u]] = (unsigned char)((in_bound(p[u], a.b) ? ADFP_F_INBOUND : 0u) | (band ? ADFP_F_BAND : 0u));
             }
             if (a.list) {
                 const unsigned long long m = __ballot(band);
@@ -598,10 +602,19 @@ __global__ __launch_bounds__(256, TSDF_MINW) void k_tsdf(TsdfArgs a) {
     }
     __syncthreads();
     if (a.flags) {
-        if (((q0 | npts) & 3) == 0) {                // whole block 4-byte aligned: 4 flags per store
-            for (int i = threadIdx.x; i < (npts >> 2); i += 256) ((unsigned*)(a.flags + q0))[i] = ((const unsigned*)s_f)[i];
+        if (!rays) {
+            if (((q0 | npts) & 3) == 0) {            // whole block 4-byte aligned: 4 flags per store
+                for (int i = threadIdx.x; i < (npts >> 2); i += 256) ((unsigned*)(a.flags + q0))[i] = ((const unsigned*)s_f)[i];
+            } else {
+                for (int i = threadIdx.x; i < npts; i += 256) a.flags[q0 + i] = s_f[i];
+            }
+        } else if ((S & 3) == 0) {                   // rows are whole words: 4 flags per store, un-padding on the way out
+            for (int i = threadIdx.x; i < (npts >> 2); i += 256) {
+                const int e = 4 * i, row = (int)((unsigned)e / (unsigned)S), col = e - row * S;
+                ((unsigned*)(a.flags + q0))[i] = *(const unsigned*)(s_f + row * SF + col);
+            }
         } else {
-            for (int i = threadIdx.x; i < npts; i += 256) a.flags[q0 + i] = s_f[i];
+            for (int i = threadIdx.x; i < npts; i += 256) { const int row = (int)((unsigned)i / (unsigned)S); a.flags[q0 + i] = s_f[row * SF + (i - row * S)]; }
         }
     }
     if (a.w) for (int i = threadIdx.x; i < npts; i += 256) a.w[q0 + i] = 1.f;
@@ -1280,14 +1293,19 @@ static int check_scene(const adfp_scene* sc, int stage) {
     return 0;
 }
 
-int adfp_eval_points(const adfp_scene* scene, const adfp_points* pts, int stage, int flags, float* raw, float* w,
-                     void* workspace, size_t workspace_bytes, void* stream) {
+int adfp_eval_points_train(const adfp_scene* scene, const adfp_points* pts, int stage, int flags, float* raw, float* w,
+                           void* workspace, size_t workspace_bytes, const adfp_train_state* state, void* stream) {
     int rc = check_scene(scene, stage); if (rc) return rc;
     if (!raw || !w || !workspace) return ADFP_E_ARG;
+    if (state && stage != ADFP_STAGE_LOW && (!state->flags || !state->list || !state->counter || !state->att_occ || !state->att_u)) return ADFP_E_ARG;
     PtsDev P; rc = make_pts(pts, &P); if (rc) return rc;
     Workspace ws = carve(workspace, P.n);
     if (workspace_bytes < ws.bytes) return ADFP_E_WORKSPACE;
-    return eval_points_impl(scene, P, stage, (flags & ADFP_EVAL_APPLY_BOUND) ? 1 : 0, raw, w, ws, (hipStream_t)stream);
+    return eval_points_impl(scene, P, stage, (flags & ADFP_EVAL_APPLY_BOUND) ? 1 : 0, raw, w, ws, (hipStream_t)stream, state);
+}
+int adfp_eval_points(const adfp_scene* scene, const adfp_points* pts, int stage, int flags, float* raw, float* w,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    return adfp_eval_points_train(scene, pts, stage, flags, raw, w, workspace, workspace_bytes, nullptr, stream);
 }
 
 int adfp_tsdf_integrate(float* tsdf, float* weight, float* color, int dim_x, int dim_y, int dim_z, const float origin[3], float voxel_size,
@@ -1576,10 +1594,90 @@ static int run_decode_bwd(DecodeBwdArgs a, int total, const int* count_ptr, floa
                    : run_decode_bwd_p<CDIM, NOUT, ROLE, false>(a, total, count_ptr, flat, bw, st);
 }
 
+// gradient outputs shared by the two backward entries
+struct GradOut { float* grid_low; float* grid_high; float* grid_color; float* flat_low; float* flat_high; float* flat_color; float* flat_att; };
+
+static int zero_grad_outputs(const adfp_scene* sc, const GradOut& g, hipStream_t st) {
+    struct { float* p; size_t n; } zs[7] = {
+        {g.grid_low, (size_t)sc->low.Z * sc->low.Y * sc->low.X * 32},
+        {g.grid_high, (size_t)sc->high.Z * sc->high.Y * sc->high.X * 32},
+        {g.grid_color, (size_t)sc->color.Z * sc->color.Y * sc->color.X * 32},
+        {g.flat_low, (size_t)DecLayout<32, 1>::F_TOTAL}, {g.flat_high, (size_t)DecLayout<64, 1>::F_TOTAL},
+        {g.flat_color, (size_t)DecLayout<32, 4>::F_TOTAL}, {g.flat_att, (size_t)AttLayout::F_TOTAL}};
+    for (int k = 0; k < 7; ++k)
+        if (zs[k].p) { hipError_t e = zero_async(zs[k].p, zs[k].n * 4, st); if (e != hipSuccess) return (int)e; }
+    return 0;
+}
+
+// DF.forward backward over P points: bw.g_raw holds the cotangent of raw [P,4] (the attention pass reads .w and rewrites it
+// with d/d(high+low)); g_pts (bw.g_pts, zeroed here) receives d/d position when pgrad.
+static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, int P, const adfp_train_state& state, const float* g_weight,
+                           const GradOut& go, bool pgrad, BwdWorkspace& bw, hipStream_t st) {
+    int rc;
+    hipError_t e;
+    const bool fuse = stage != ADFP_STAGE_LOW;
+    DecodeBwdArgs a;
+    a.P = Pd; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
+    a.list = nullptr; a.count_ptr = nullptr; a.g_raw = bw.g_raw; a.att_g = nullptr; a.stage = nullptr;
+    a.g_pts = pgrad ? bw.g_pts : nullptr;
+    if (pgrad) { e = zero_async(bw.g_pts, (size_t)P * 12, st); if (e != hipSuccess) return (int)e; }
+
+    if (fuse) {
+        AttBwdArgs t;
+        t.packed = sc->w_att; t.list = state.list; t.count_ptr = state.counter; t.att_occ = state.att_occ;
+        t.att_u = state.att_u; t.g_weight = g_weight; t.g_raw = bw.g_raw; t.att_g = bw.att_g; t.stage = bw.stage;
+        t.P = Pd; t.nt = make_norm(sc->tsdf_bnds); t.t = make_tsdf(sc->tsdf); t.g_pts = a.g_pts;
+        OuterArgs oa; attention_jobs(oa);
+        if (go.flat_att) { rc = outer_begin(bw, AttLayout::F_TOTAL, st); if (rc) return rc; }
+        for (int lo = 0; lo < P; lo += bw.stage_rows) {
+            const int hi = lo + bw.stage_rows < P ? lo + bw.stage_rows : P;
+            t.chunk_lo = lo; t.chunk_hi = hi;
+            const int ntiles = (hi - lo + 31) / 32;
+            if (go.flat_att) {
+                if (pgrad) hipLaunchKernelGGL((k_attention_bwd<true, true>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
+                else hipLaunchKernelGGL((k_attention_bwd<true, false>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
+                ADFP_CHECK_LAUNCH();
+                rc = launch_outer(oa, bw, state.counter, lo, hi, go.flat_att, st);
+                if (rc) return rc;
+            } else {
+                if (pgrad) hipLaunchKernelGGL((k_attention_bwd<false, true>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
+                else hipLaunchKernelGGL((k_attention_bwd<false, false>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
+                ADFP_CHECK_LAUNCH();
+            }
+        }
+        if (go.flat_att) { rc = outer_end(bw, AttLayout::F_TOTAL, go.flat_att, st); if (rc) return rc; }
+        if (go.grid_high || go.flat_high || pgrad) {
+            DecodeBwdArgs hgh = a;
+            hgh.g0 = make_grid(sc->high); hgh.g1 = make_grid(sc->low); hgh.packed = sc->w_high;
+            hgh.list = state.list; hgh.count_ptr = state.counter; hgh.att_g = bw.att_g; hgh.g_grid = go.grid_high;
+            rc = run_decode_bwd<64, 1, ROLE_HIGH>(hgh, P, state.counter, go.flat_high, bw, st);
+            if (rc) return rc;
+        }
+    }
+    if (go.grid_low || go.flat_low || pgrad) {
+        DecodeBwdArgs lw = a;
+        lw.g0 = make_grid(sc->low); lw.g1 = lw.g0; lw.packed = sc->w_low; lw.g_grid = go.grid_low;
+        rc = run_decode_bwd<32, 1, ROLE_LOW>(lw, P, nullptr, go.flat_low, bw, st);
+        if (rc) return rc;
+    }
+    if (stage == ADFP_STAGE_COLOR && (go.grid_color || go.flat_color || pgrad)) {
+        DecodeBwdArgs cl = a;
+        cl.g0 = make_grid(sc->color); cl.g1 = cl.g0; cl.packed = sc->w_color; cl.g_grid = go.grid_color;
+        rc = run_decode_bwd<32, 4, ROLE_COLOR>(cl, P, nullptr, go.flat_color, bw, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+static int check_backward_scene(const adfp_scene* sc, int stage) {
+    int rc = check_scene(sc, stage); if (rc) return rc;
+    if (!sc->w_low || (stage >= ADFP_STAGE_HIGH && (!sc->w_high || !sc->w_att)) || (stage == ADFP_STAGE_COLOR && !sc->w_color)) return ADFP_E_ARG;   // exact-f32 images
+    return 0;
+}
+
 extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_args* r, void* stream) {
     if (!r) return ADFP_E_ARG;
-    int rc = check_scene(sc, r->stage); if (rc) return rc;
-    if (!sc->w_low || (r->stage >= ADFP_STAGE_HIGH && (!sc->w_high || !sc->w_att)) || (r->stage == ADFP_STAGE_COLOR && !sc->w_color)) return ADFP_E_ARG;   // exact-f32 images
+    int rc = check_backward_scene(sc, r->stage); if (rc) return rc;
     if (!r->rays_o || !r->rays_d || !r->z_vals || !r->raw || !r->workspace || r->n_rays < 0 || r->S <= 0) return ADFP_E_ARG;
     if (r->S > 64 * CB_MAXC) return ADFP_E_UNSUPPORTED;
     const long long Pn = (long long)r->n_rays * r->S;
@@ -1589,16 +1687,8 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
     const bool fuse = r->stage != ADFP_STAGE_LOW;
     if (fuse && (!r->state.flags || !r->state.list || !r->state.counter || !r->state.att_occ || !r->state.att_u)) return ADFP_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e;
-    // zero the outputs this call accumulates into
-    struct { float* p; size_t n; } zs[7] = {
-        {r->g_grid_low, (size_t)sc->low.Z * sc->low.Y * sc->low.X * 32},
-        {r->g_grid_high, (size_t)sc->high.Z * sc->high.Y * sc->high.X * 32},
-        {r->g_grid_color, (size_t)sc->color.Z * sc->color.Y * sc->color.X * 32},
-        {r->g_flat_low, (size_t)DecLayout<32, 1>::F_TOTAL}, {r->g_flat_high, (size_t)DecLayout<64, 1>::F_TOTAL},
-        {r->g_flat_color, (size_t)DecLayout<32, 4>::F_TOTAL}, {r->g_flat_att, (size_t)AttLayout::F_TOTAL}};
-    for (int k = 0; k < 7; ++k)
-        if (zs[k].p) { e = zero_async(zs[k].p, zs[k].n * 4, st); if (e != hipSuccess) return (int)e; }
+    const GradOut go = {r->g_grid_low, r->g_grid_high, r->g_grid_color, r->g_flat_low, r->g_flat_high, r->g_flat_color, r->g_flat_att};
+    rc = zero_grad_outputs(sc, go, st); if (rc) return rc;       // every non-NULL output is zeroed, then accumulated into
     if (r->n_rays == 0) return 0;
     const int P = (int)Pn;
 
@@ -1608,57 +1698,9 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
 
     PtsDev Pd;
     Pd.mode = ADFP_PTS_RAYS; Pd.S = r->S; Pd.n = P; Pd.pts = nullptr; Pd.ro = r->rays_o; Pd.rd = r->rays_d; Pd.z = r->z_vals;
-    DecodeBwdArgs a;
-    a.P = Pd; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
-    a.list = nullptr; a.count_ptr = nullptr; a.g_raw = bw.g_raw; a.att_g = nullptr; a.stage = nullptr;
     const bool pgrad = r->g_rays_o || r->g_rays_d;
-    a.g_pts = pgrad ? bw.g_pts : nullptr;
-    if (pgrad) { e = zero_async(bw.g_pts, (size_t)P * 12, st); if (e != hipSuccess) return (int)e; }
-
-    if (fuse) {
-        AttBwdArgs t;
-        t.packed = sc->w_att; t.list = r->state.list; t.count_ptr = r->state.counter; t.att_occ = r->state.att_occ;
-        t.att_u = r->state.att_u; t.g_weight = r->g_weight; t.g_raw = bw.g_raw; t.att_g = bw.att_g; t.stage = bw.stage;
-        t.P = Pd; t.nt = make_norm(sc->tsdf_bnds); t.t = make_tsdf(sc->tsdf); t.g_pts = a.g_pts;
-        OuterArgs oa; attention_jobs(oa);
-        if (r->g_flat_att) { rc = outer_begin(bw, AttLayout::F_TOTAL, st); if (rc) return rc; }
-        for (int lo = 0; lo < P; lo += bw.stage_rows) {
-            const int hi = lo + bw.stage_rows < P ? lo + bw.stage_rows : P;
-            t.chunk_lo = lo; t.chunk_hi = hi;
-            const int ntiles = (hi - lo + 31) / 32;
-            if (r->g_flat_att) {
-                if (pgrad) hipLaunchKernelGGL((k_attention_bwd<true, true>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
-                else hipLaunchKernelGGL((k_attention_bwd<true, false>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
-                ADFP_CHECK_LAUNCH();
-                rc = launch_outer(oa, bw, r->state.counter, lo, hi, r->g_flat_att, st);
-                if (rc) return rc;
-            } else {
-                if (pgrad) hipLaunchKernelGGL((k_attention_bwd<false, true>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
-                else hipLaunchKernelGGL((k_attention_bwd<false, false>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
-                ADFP_CHECK_LAUNCH();
-            }
-        }
-        if (r->g_flat_att) { rc = outer_end(bw, AttLayout::F_TOTAL, r->g_flat_att, st); if (rc) return rc; }
-        if (r->g_grid_high || r->g_flat_high || pgrad) {
-            DecodeBwdArgs hgh = a;
-            hgh.g0 = make_grid(sc->high); hgh.g1 = make_grid(sc->low); hgh.packed = sc->w_high;
-            hgh.list = r->state.list; hgh.count_ptr = r->state.counter; hgh.att_g = bw.att_g; hgh.g_grid = r->g_grid_high;
-            rc = run_decode_bwd<64, 1, ROLE_HIGH>(hgh, P, r->state.counter, r->g_flat_high, bw, st);
-            if (rc) return rc;
-        }
-    }
-    if (r->g_grid_low || r->g_flat_low || pgrad) {
-        DecodeBwdArgs lw = a;
-        lw.g0 = make_grid(sc->low); lw.g1 = lw.g0; lw.packed = sc->w_low; lw.g_grid = r->g_grid_low;
-        rc = run_decode_bwd<32, 1, ROLE_LOW>(lw, P, nullptr, r->g_flat_low, bw, st);
-        if (rc) return rc;
-    }
-    if (r->stage == ADFP_STAGE_COLOR && (r->g_grid_color || r->g_flat_color || pgrad)) {
-        DecodeBwdArgs cl = a;
-        cl.g0 = make_grid(sc->color); cl.g1 = cl.g0; cl.packed = sc->w_color; cl.g_grid = r->g_grid_color;
-        rc = run_decode_bwd<32, 4, ROLE_COLOR>(cl, P, nullptr, r->g_flat_color, bw, st);
-        if (rc) return rc;
-    }
+    rc = backward_points(sc, r->stage, Pd, P, r->state, r->g_weight, go, pgrad, bw, st);
+    if (rc) return rc;
     if (pgrad) {
         hipLaunchKernelGGL(k_rays_grad, dim3((r->n_rays + 3) / 4), dim3(256), 0, st, bw.g_pts, r->z_vals, r->n_rays, r->S,
                            r->g_rays_o, r->g_rays_d);
@@ -1667,3 +1709,42 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
     return 0;
 }
 
+// cotangent of Renderer.eval_points' raw -> the workspace copy the point backward consumes; where the forward replaced the
+// occupancy by 100 (point outside `bound`, Renderer.py:64) nothing flows back into the decoders
+__global__ __launch_bounds__(256) void k_evalpts_bwd_prep(PtsDev P, const float* __restrict__ g_raw_in, float* __restrict__ g_raw, double b0, double b1,
+                                                          double b2, double b3, double b4, double b5, int apply_bound) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= P.n) return;
+    f32x4 g = g_raw_in ? *(const f32x4*)(g_raw_in + 4ll * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (apply_bound) {
+        double pt[3]; load_point(P, q, pt);
+        const double b[6] = {b0, b1, b2, b3, b4, b5};
+        if (!in_bound(pt, b)) g.w = 0.f;
+    }
+    *(f32x4*)(g_raw + 4ll * q) = g;
+}
+
+extern "C" int adfp_eval_points_backward(const adfp_scene* sc, const adfp_points* pts, const adfp_points_backward_args* r, void* stream) {
+    if (!r || !pts) return ADFP_E_ARG;
+    int rc = check_backward_scene(sc, r->stage); if (rc) return rc;
+    if (!r->workspace) return ADFP_E_ARG;
+    PtsDev Pd; rc = make_pts(pts, &Pd); if (rc) return rc;
+    BwdWorkspace bw = carve_bwd(r->workspace, Pd.n);
+    if (r->workspace_bytes < bw.bytes) return ADFP_E_WORKSPACE;
+    const bool fuse = r->stage != ADFP_STAGE_LOW;
+    if (fuse && (!r->state.flags || !r->state.list || !r->state.counter || !r->state.att_occ || !r->state.att_u)) return ADFP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const GradOut go = {r->g_grid_low, r->g_grid_high, r->g_grid_color, r->g_flat_low, r->g_flat_high, r->g_flat_color, r->g_flat_att};
+    rc = zero_grad_outputs(sc, go, st); if (rc) return rc;
+    if (Pd.n == 0) return 0;
+    hipLaunchKernelGGL(k_evalpts_bwd_prep, dim3((Pd.n + 255) / 256), dim3(256), 0, st, Pd, r->g_raw, bw.g_raw, sc->bound[0][0], sc->bound[0][1],
+                       sc->bound[1][0], sc->bound[1][1], sc->bound[2][0], sc->bound[2][1], (r->flags & ADFP_EVAL_APPLY_BOUND) ? 1 : 0);
+    ADFP_CHECK_LAUNCH();
+    rc = backward_points(sc, r->stage, Pd, Pd.n, r->state, r->g_w, go, r->g_pts != nullptr, bw, st);
+    if (rc) return rc;
+    if (r->g_pts) {
+        hipError_t e = hipMemcpyAsync(r->g_pts, bw.g_pts, (size_t)Pd.n * 12, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}

@@ -20,7 +20,6 @@ __global__ __launch_bounds__(1024) void k_prefilter_mask(const float* __restrict
 #pragma unroll
     for (int k = 0; k < 6; ++k) b[k] = bnd[k];
     float mx = -INFINITY;
-    bool any_nan = false;
     for (int i = threadIdx.x; i < n; i += 1024) {
         double t = INFINITY; bool nan = false;
 #pragma unroll
@@ -34,7 +33,7 @@ __global__ __launch_bounds__(1024) void k_prefilter_mask(const float* __restrict
         const float dep = depth[i];
         const bool k_ = !nan && (t >= (double)dep);
         keep[i] = k_ ? 1 : 0;
-        if (k_) { any_nan |= dep != dep; mx = dep > mx ? dep : mx; }
+        if (k_) mx = dep > mx ? dep : mx;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const float v = __shfl_xor(mx, o); mx = v > mx ? v : mx; }
@@ -43,7 +42,6 @@ __global__ __launch_bounds__(1024) void k_prefilter_mask(const float* __restrict
     if (threadIdx.x == 0) {
         float m = s_m[0];
         for (int w = 1; w < 16; ++w) m = s_m[w] > m ? s_m[w] : m;
-        (void)any_nan;
         *depth_max = m;
     }
 }

@@ -137,17 +137,19 @@ class Engine(object):
 
     # ---- a5..a12 ---------------------------------------------------------------------------
     def eval_points(self, decoders, pts, c, tsdf_volume, tsdf_bnds, bound, stage, apply_bound_rule=True):
-        """pts [P,3] f64/f32 on the GPU -> raw [P,4] f32, w [P] f32."""
+        """pts [P,3] f64/f32 on the GPU -> raw [P,4] f32, w [P] f32.  Autograd-transparent like the reference's
+        Renderer.eval_points / DF.forward (src/utils/Renderer.py:27-71): with grad enabled and a point tensor, a grid or a
+        decoder parameter that requires grad, the call goes through adfp_eval_points_train / adfp_eval_points_backward."""
         _lib.require_cuda(pts, 'points')
-        # Point-wise queries are inference-only here (the reference's Mesher runs them under no_grad,
-        # src/utils/Mesher.py:437-447); training goes through Renderer.render_batch_ray.  The reference's
-        # eval_points is autograd-transparent, so a caller that expects gradients must hear about it: raise
-        # instead of returning detached tensors that silently yield zero gradients.
-        if torch.is_grad_enabled() and (pts.requires_grad or any(v.requires_grad for v in c.values())):
-            raise NotImplementedError(
-                'eval_points / DF.forward are not differentiable in libadfp: differentiate through '
-                'Renderer.render_batch_ray (grids, decoder parameters, rays), or call under torch.no_grad()')
+        if torch.is_grad_enabled() and (pts.requires_grad or any(v.requires_grad for v in c.values()) or decoders.any_requires_grad()):
+            from .autograd import eval_points_with_grad
+            return eval_points_with_grad(self, decoders, pts, c, tsdf_volume, tsdf_bnds, bound, stage, apply_bound_rule)
+        raw, w, _ = self.eval_points_forward(decoders, pts, c, tsdf_volume, tsdf_bnds, bound, stage, apply_bound_rule)
+        return raw, w
+
+    def eval_points_forward(self, decoders, pts, c, tsdf_volume, tsdf_bnds, bound, stage, apply_bound_rule=True, train=False):
         dev = pts.device
+        saved = None
         with torch.cuda.device(dev):
             if pts.dtype == torch.float64:
                 mode = _lib.PTS_F64
@@ -160,17 +162,69 @@ class Engine(object):
             raw = torch.empty((P, 4), dtype=torch.float32, device=dev)
             w = torch.empty((P,), dtype=torch.float32, device=dev)
             if P == 0:
-                return raw, w
+                return raw, w, saved
             sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage)
             ap = _lib.AdfpPoints()
             ap.mode = mode
             ap.n_points = P
             ap.pts = pts.data_ptr()
             ws = self.workspace(P, dev)
-            check(lib().adfp_eval_points(C.byref(sc), C.byref(ap), _lib.STAGE[stage], 1 if apply_bound_rule else 0,
-                                         ptr(raw), ptr(w), ptr(ws), ws.numel(), _lib.current_stream(dev)),
-                  'adfp_eval_points')
-        return raw, w
+            st = None
+            if train:
+                saved = dict(pts=pts, mode=mode, flags=torch.empty((P,), dtype=torch.uint8, device=dev),
+                             list=torch.empty((P,), dtype=torch.int32, device=dev), counter=torch.empty((4,), dtype=torch.int32, device=dev),
+                             att_occ=torch.empty((P,), dtype=torch.float32, device=dev), att_u=torch.empty((P,), dtype=torch.float32, device=dev))
+                st = _lib.AdfpTrainState()
+                st.flags, st.list, st.counter = saved['flags'].data_ptr(), saved['list'].data_ptr(), saved['counter'].data_ptr()
+                st.att_occ, st.att_u = saved['att_occ'].data_ptr(), saved['att_u'].data_ptr()
+                saved['_state'] = st
+            check(lib().adfp_eval_points_train(C.byref(sc), C.byref(ap), _lib.STAGE[stage], 1 if apply_bound_rule else 0,
+                                               ptr(raw), ptr(w), ptr(ws), ws.numel(), C.byref(st) if st is not None else None,
+                                               _lib.current_stream(dev)), 'adfp_eval_points')
+        return raw, w, saved
+
+    def eval_points_backward(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, apply_bound_rule, saved, g_raw, g_w,
+                             need_grid, need_flat, need_pts):
+        """Returns (grid grads dict in the reference's [1,32,Z,Y,X] layout, flat parameter grads dict, d/d pts [P,3] f32 or None)."""
+        pts = saved['pts']
+        dev = pts.device
+        L = lib()
+        with torch.cuda.device(dev):
+            P = pts.shape[0]
+            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=True)
+            ap = _lib.AdfpPoints()
+            ap.mode, ap.n_points, ap.pts = saved['mode'], P, pts.data_ptr()
+            a = _lib.AdfpPointsBackwardArgs()
+            a.stage, a.flags, a.state = _lib.STAGE[stage], 1 if apply_bound_rule else 0, saved['_state']
+            graw = None if g_raw is None else g_raw.detach().to(dev, torch.float32).contiguous()
+            gw = None if g_w is None else g_w.detach().to(dev, torch.float32).contiguous()
+            a.g_raw, a.g_w = _lib.ptr(graw), _lib.ptr(gw)
+            grids_cl, flats = {}, {}
+            for name, key in (('low', 'grid_low'), ('high', 'grid_high'), ('color', 'grid_color')):
+                if need_grid.get(name):
+                    Z, Y, X = c[key].shape[2:]
+                    grids_cl[name] = torch.empty((Z, Y, X, 32), dtype=torch.float32, device=dev)
+                    setattr(a, 'g_grid_' + name, grids_cl[name].data_ptr())
+            sizes = {'low': L.adfp_decoder_flat_floats(0), 'high': L.adfp_decoder_flat_floats(1),
+                     'color': L.adfp_decoder_flat_floats(2), 'att': L.adfp_attention_flat_floats()}
+            for name in ('low', 'high', 'color', 'att'):
+                if need_flat.get(name):
+                    flats[name] = torch.empty((sizes[name],), dtype=torch.float32, device=dev)
+                    setattr(a, 'g_flat_' + name, flats[name].data_ptr())
+            g_pts = torch.empty((P, 3), dtype=torch.float32, device=dev) if need_pts else None
+            a.g_pts = _lib.ptr(g_pts)
+            need = L.adfp_backward_workspace_bytes(P)
+            ws = torch.empty(int(need) + 1024, dtype=torch.uint8, device=dev)
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            stream = _lib.current_stream(dev)
+            check(L.adfp_eval_points_backward(C.byref(sc), C.byref(ap), C.byref(a), stream), 'adfp_eval_points_backward')
+            grids = {}
+            for name, g in grids_cl.items():
+                Z, Y, X = g.shape[:3]
+                out = torch.empty((1, 32, Z, Y, X), dtype=torch.float32, device=dev)
+                check(L.adfp_relayout_grid_back(ptr(g), ptr(out), 32, Z, Y, X, stream), 'adfp_relayout_grid_back')
+                grids[name] = out
+        return grids, flats, g_pts
 
     def sample_tsdf(self, pts, tsdf_volume, tsdf_bnds):
         _lib.require_cuda(pts, 'points')

@@ -176,6 +176,21 @@ class MapperIteration(object):
         self._static = {}
         self._versioned = list(c.values()) + [p for n in self.nets for p in getattr(decoders, attr[n]).parameters()]
 
+    def new_frame(self, masks=None):
+        """What the reference does at the top of every optimize_map call: a FRESH Adam (src/Mapper.py:374) and a new frustum
+        mask per grid (:330-361).  The moments and step counters are zeroed and the masks overwritten in place, so the
+        captured graphs stay valid."""
+        for m, v in list(self.gstate.values()) + list(self.fstate.values()):
+            m.zero_()
+            v.zero_()
+        self.step_count.zero_()
+        if masks is not None:
+            for k in self.c:
+                if (self.masks[k] is None) != (masks.get(k) is None):
+                    raise ValueError(f'{k}: a grid cannot switch between masked and unmasked across frames')
+                if self.masks[k] is not None:
+                    self.masks[k].copy_(masks[k].to(self.dev, torch.uint8))
+
     # ---- the kernel sequence ------------------------------------------------------------------------------------------
     def _sequence(self, ro, rd, gd, gc, stage, warmup, adam=True):
         L = lib()

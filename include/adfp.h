@@ -170,6 +170,12 @@ int adfp_sample_rays(const float* rays_o, const float* rays_d, const float* gt_d
 int adfp_eval_points(const adfp_scene* scene /*host*/, const adfp_points* pts /*host*/, int stage, int flags,
                      float* raw, float* w, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same with the state the point backward needs (autograd through Renderer.eval_points / DF.forward: the reference's
+ * eval_points is autograd-transparent, src/utils/Renderer.py:27-71).  state = NULL is adfp_eval_points. */
+struct adfp_train_state;
+int adfp_eval_points_train(const adfp_scene* scene, const adfp_points* pts, int stage, int flags, float* raw, float* w,
+                           void* workspace, size_t workspace_bytes, const struct adfp_train_state* state, void* stream);
+
 /* a10 alone: Renderer.sample_grid_tsdf / eval_points_tsdf (Renderer.py:73-107) */
 int adfp_sample_tsdf(const adfp_tsdf* tsdf /*host*/, const double tsdf_bnds[3][2],
                      const adfp_points* pts /*host*/, float* out /*[P]*/, void* stream);
@@ -251,6 +257,30 @@ typedef struct adfp_backward_args {
 } adfp_backward_args;
 size_t adfp_backward_workspace_bytes(long long n_points);
 int adfp_render_backward(const adfp_scene* scene /*host*/, const adfp_backward_args* args /*host*/, void* stream);
+
+/* Backward of adfp_eval_points_train: cotangents of raw [P,4] and of the attention weight [P] -> gradients of the grids and
+ * decoder parameters (as adfp_render_backward) and of the query points themselves (g_pts [P,3] fp32; through the trilinear
+ * coordinates of the feature grids and of the TSDF and through sin(p @ B)).  With ADFP_EVAL_APPLY_BOUND in `flags`, points outside
+ * scene->bound pass no occupancy gradient (the forward overwrote their occupancy with 100).  Any output may be NULL. */
+typedef struct adfp_points_backward_args {
+    int stage;
+    int flags;                   /* ADFP_EVAL_* of the forward call */
+    adfp_train_state state;      /* the one the forward call filled */
+    const float* g_raw;          /* [P,4] or NULL */
+    const float* g_w;            /* [P] or NULL */
+    float* g_grid_low;           /* [Z,Y,X,32] channels-last, or NULL */
+    float* g_grid_high;
+    float* g_grid_color;
+    float* g_flat_low;           /* adfp_decoder_flat_floats(kind) floats, or NULL */
+    float* g_flat_high;
+    float* g_flat_color;
+    float* g_flat_att;
+    float* g_pts;                /* [P,3] or NULL */
+    void* workspace;             /* adfp_backward_workspace_bytes(P) */
+    size_t workspace_bytes;
+} adfp_points_backward_args;
+int adfp_eval_points_backward(const adfp_scene* scene /*host*/, const adfp_points* pts /*host*/, const adfp_points_backward_args* args /*host*/,
+                              void* stream);
 
 /* ---- TSDF fusion of one RGB-D frame (src/fusion.py:69-142 CUDA kernel, launch :226-251) ---- */
 /* tsdf / weight / color: device volumes in the reference's physical order [X][Y][Z] (Z fastest), updated in

@@ -81,3 +81,28 @@ def assert_close(a, b, tol, what):
     bad = (a - b).abs() > tol * (b.abs() + 0.1 * scale)
     assert not bad.any(), (f'{what}: {int(bad.sum())}/{bad.numel()} elements beyond tol={tol}; '
                            f'max abs diff {(a - b).abs().max().item():.3e}, scale {scale.item():.3e}')
+
+
+def assert_close_scale(a, b, tol, what):
+    """|a-b| <= tol * max|b|: for sums over ~1e5 points (gradients), whose small elements carry the summation-order noise of the
+    large ones (float atomics, a different reduction tree than torch's)."""
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    assert a.shape == b.shape, f'{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}'
+    scale = b.abs().max().clamp_min(1e-30)
+    err = (a - b).abs().max()
+    assert err <= tol * scale, f'{what}: max abs diff {err.item():.3e} > {tol} x scale {scale.item():.3e}'
+
+
+def assert_adam_trajectory(a, b, lr, steps, what, tol=2e-4, max_outliers=2e-3):
+    """Parameters after a few Adam steps along two paths whose gradients agree to ~1e-5 of their scale: Adam normalises every
+    gradient element, so an element whose gradient is noise-sized moves by a full +-lr per step in a direction the noise
+    decides.  Almost every element must agree to `tol`; the few outliers may differ by at most the steps themselves."""
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    scale = b.abs().max().clamp_min(1e-30)
+    diff = (a - b).abs()
+    bad = diff > tol * (b.abs() + 0.1 * scale)
+    frac = float(bad.double().mean())
+    assert frac <= max_outliers, f'{what}: {frac:.2e} of the elements left the trajectory'
+    assert float(diff.max()) <= 2.0 * lr * steps + 1e-6, f'{what}: an element moved {float(diff.max()):.3e}, more than {steps} Adam steps of lr {lr} allow'

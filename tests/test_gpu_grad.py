@@ -232,3 +232,56 @@ def test_pose_gradient_through_get_rays_from_uv(mini):
                                           gd, mini.n_samples, mini.n_surface)
     O.tracker_loss(d2, u2, col2, gd, gcol).backward()
     grad_close(c2w.grad[:3], c2w_o.grad[:3], 'd/d c2w', tol=5e-4)
+
+
+# --------------------------------------------------------------------------- autograd through eval_points / DF.forward
+@pytest.mark.parametrize('stage', O.STAGES)
+@pytest.mark.parametrize('via', ['eval_points', 'df_forward'])
+def test_eval_points_is_autograd_transparent(mini, stage, via):
+    """The reference's Renderer.eval_points / DF.forward are plain torch ops (src/utils/Renderer.py:27-71,
+    src/conv_onet/models/decoder.py:307-353): gradients reach the query points, the grids and the decoder parameters.  Here they
+    run through adfp_eval_points_train / adfp_eval_points_backward and must match the oracle's autograd, including the
+    bound rule (occupancy 100 outside the bound: no gradient) that eval_points applies and DF.forward does not."""
+    g = torch.Generator().manual_seed(12)
+    lo, hi = mini.bound[:, 0], mini.bound[:, 1]
+    pts = lo + (hi - lo) * (torch.rand(600, 3, generator=g, dtype=torch.float64) * 1.1 - 0.05)     # some outside the bound
+    wr, ww = torch.randn(600, 4, generator=g), torch.randn(600, generator=g)
+    # oracle
+    c_o = {k: v.clone().requires_grad_(True) for k, v in mini.c.items()}
+    sd_o = {k: v.clone().requires_grad_(True) for k, v in mini.sd.items()}
+    p_o = pts.clone().requires_grad_(True)
+    if via == 'eval_points':
+        raw_o, w_o = O.eval_points(sd_o, p_o, c_o, mini.tsdf_volume, mini.tsdf_bnds, mini.bound, stage)
+    else:
+        raw_o, w_o = O.df_forward(sd_o, p_o, c_o, mini.tsdf_volume, mini.tsdf_bnds, mini.bound, stage)
+    ((raw_o * wr).sum() + (w_o * ww).sum()).backward()
+    # product
+    dec = A.DF()
+    dec.load_state_dict(mini.sd)
+    dec.bound = mini.bound
+    dec = dec.to(DEV)
+    rend = A.Renderer(make_cfg(mini.n_samples, mini.n_surface), None, mini)
+    c = {k: v.to(DEV).clone().requires_grad_(True) for k, v in mini.c.items()}
+    p = pts.to(DEV).requires_grad_(True)
+    tsdf, tb = mini.tsdf_volume.to(DEV), mini.tsdf_bnds.to(DEV)
+    if via == 'eval_points':
+        raw, w = rend.eval_points(p, dec, tsdf, tb, c, stage, DEV)
+    else:
+        raw, w = dec(p.unsqueeze(0), c_grid=c, tsdf_volume=tsdf, tsdf_bnds=tb, stage=stage)
+    assert raw.requires_grad
+    grad_close(raw, raw_o.detach(), 'raw', 1e-4)
+    ((raw * wr.to(DEV)).sum() + (w * ww.to(DEV)).sum()).backward()
+    assert p.grad.dtype == torch.float64
+    grad_close(p.grad, p_o.grad, 'd/d points', 5e-4)
+    used = {'low': ('grid_low',), 'high': ('grid_low', 'grid_high'), 'color': ('grid_low', 'grid_high', 'grid_color')}[stage]
+    for k in c:
+        if k in used:
+            grad_close(c[k].grad, c_o[k].grad, k)
+        else:
+            assert c[k].grad is None or float(c[k].grad.abs().max()) == 0.0
+    for name, prm in dec.named_parameters():
+        ref = sd_o[name].grad
+        if ref is None or float(ref.abs().max()) == 0.0:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, name
+        else:
+            grad_close(prm.grad, ref, name)

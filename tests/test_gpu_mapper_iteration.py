@@ -11,7 +11,7 @@ import torch
 import attentive_dfprior_amd as A
 from attentive_dfprior_amd import common, mapping, synthetic
 from oracle import adfp_oracle as O
-from conftest import make_cfg, to_dev, assert_close
+from conftest import make_cfg, to_dev, assert_close, assert_adam_trajectory
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda:0')
@@ -81,11 +81,11 @@ def test_fused_iteration_follows_the_reference_shaped_path(use_graph):
     for a, b in zip(losses, l_ref):
         assert abs(a - b) <= 1e-5 * abs(b), (losses, l_ref)
     for k in g_ref:
-        assert_close(grids[k], g_ref[k], 2e-4, f'{k} after {len(SCHEDULE)} iterations')
+        assert_adam_trajectory(grids[k], g_ref[k], 0.1 if k == 'grid_low' else 0.005, len(SCHEDULE), f'{k} after {len(SCHEDULE)} iterations')
         outside = ~masks[k].to(DEV)
         assert torch.equal(grids[k][0, :, outside], sc.c[k].to(DEV)[0, :, outside])     # untouched outside the frustum mask
     for n, p in dec2.named_parameters():
-        assert_close(p, p_ref[n], 2e-4, n)
+        assert_adam_trajectory(p, p_ref[n], 0.005, len(SCHEDULE), n)
     # the drop-in objects keep working after the fused iterations (version bumps invalidate the layout caches)
     with torch.no_grad():
         d1 = rend2.render_batch_ray(grids, dec2, rays[1], rays[0], DEV, sc.tsdf_volume.to(DEV), sc.tsdf_bnds.to(DEV), 'color', rays[2])[0]
@@ -111,6 +111,6 @@ def test_graph_replays_with_new_rays():
         lb = float(it_b.step(ro, rd, gd, gc, 'color'))
         assert abs(la - lb) <= 1e-6 * abs(lb)
     for k in ga:
-        assert_close(ga[k], gb[k], 5e-5, k)
+        assert_adam_trajectory(ga[k], gb[k], 0.005, 3, k)
     for (n, p), (_, q) in zip(dec.named_parameters(), dec_b.named_parameters()):
-        assert_close(p, q, 5e-5, n)
+        assert_adam_trajectory(p, q, 0.005, 3, n)

@@ -61,7 +61,8 @@ def mapper_loss(stage, it, n_iters, frame_idx, gd, gc, depth, color, weight):
 
 
 class MappingRun(object):
-    def __init__(self, scene='office0', rays=5000, total_frames=200, seed=0, device='cuda:0', window=5, keyframe_every=5):
+    def __init__(self, scene='office0', rays=5000, total_frames=200, seed=0, device='cuda:0', window=5, keyframe_every=5, fused=False):
+        self.fused, self.iteration = fused, None
         self.dev = torch.device(device)
         self.sc = synthetic.Scene(scene, device=self.dev)
         self.dec = A.DF()
@@ -111,6 +112,8 @@ class MappingRun(object):
         if f % self.keyframe_every == 0:
             self.keyframes.append((c2w, depth))
         frames = [(c2w, depth)] + self.keyframes[-(self.window - 1):]
+        if self.fused:
+            return self.map_frame_fused(f, n_iters, lr_factor, c2w, depth, frames)
         grids = {k: v.detach().requires_grad_(True) for k, v in self.c.items()}
         masks = {k: mapping.frustum_mask(c2w, tuple(v.shape[2:]), depth, sc.bound, H, W, fx, fy, cx, cy) for k, v in grids.items()}
         opt_grids = mapping.MaskedGridAdam(grids, masks)
@@ -147,6 +150,46 @@ class MappingRun(object):
         return first, last
 
 
+def _map_frame_fused(self, f, n_iters, lr_factor, c2w, depth, frames):
+    """The same frame through mapping.MapperIteration: pre-filter as a keep mask, loss, backward and Adam on the device, one
+    graph replay per iteration, no host read-back inside the loop."""
+    sc, dev = self.sc, self.dev
+    H, W, fx, fy, cx, cy = sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy
+    masks = {k: mapping.frustum_mask(c2w, tuple(v.shape[2:]), depth, sc.bound, H, W, fx, fy, cx, cy) for k, v in self.c.items()}
+    lrs = {st: {'low': v['low'] * lr_factor, 'high': v['high'] * lr_factor, 'color': v['color'] * lr_factor,
+                'decoders': v['dec'] * lr_factor, 'mlp': v['mlp'] * lr_factor} for st, v in STAGE_LR.items()}
+    key = float(lr_factor)
+    if self.iteration is None:
+        self.iteration = {}
+        self.c = {k: v.detach().clone().contiguous() for k, v in self.c.items()}
+    it = self.iteration.get(key)
+    if it is None:
+        it = self.iteration[key] = mapping.MapperIteration(self.rend, self.dec, self.c, masks, sc.tsdf_volume, self.tsdf_bnds, lrs,
+                                                         w_color_loss=W_COLOR_LOSS)
+    it.new_frame(masks)
+    low_end = int(n_iters * LOW_ITER_RATIO)
+    first = last = None
+    for i in range(n_iters):
+        stage = stage_of(i, n_iters)
+        ros, rds, gds, gcs = [], [], [], []
+        for kc2w, kdepth in frames:
+            ro, rd, gd, gc = common.get_samples(0, H, 0, W, self.rays // len(frames), H, W, fx, fy, cx, cy, kc2w, kdepth, self.target_color, dev)
+            ros.append(ro.float()); rds.append(rd.float()); gds.append(gd.float()); gcs.append(gc.float())
+        loss = it.step(torch.cat(ros), torch.cat(rds), torch.cat(gds), torch.cat(gcs), stage, warmup=(low_end < i <= low_end + 5 and f <= 1))
+        self.n_iter += 1
+        if i == 0 or i == n_iters - 1:
+            n_rays = sum(r.shape[0] for r in ros)
+            v = float(loss) / n_rays                       # total loss per ray (the loop's only read-backs: first and last iteration)
+            first = v if i == 0 else first
+            last = v
+    if not math.isfinite(last):
+        raise RuntimeError(f'non-finite loss at frame {f}')
+    return first, last
+
+
+MappingRun.map_frame_fused = _map_frame_fused
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--frames', type=int, default=200)
@@ -154,8 +197,9 @@ def main():
     ap.add_argument('--iters-first', type=int, default=300)       # the reference uses 1500 (:64)
     ap.add_argument('--rays', type=int, default=5000)
     ap.add_argument('--scene', default='office0')
+    ap.add_argument('--fused', action='store_true', help='mapping.MapperIteration (device-side iteration, graph replay)')
     args = ap.parse_args()
-    run = MappingRun(args.scene, args.rays, args.frames)
+    run = MappingRun(args.scene, args.rays, args.frames, fused=args.fused)
     held = run.heldout_rays(min(args.frames, 20))
     e0 = run.heldout_error(held)
     hist = []
@@ -169,7 +213,7 @@ def main():
     q = max(1, len(hist) // 4)
     mean = lambda xs: sum(xs) / len(xs)
     print(json.dumps({'config': f'{args.scene} mapping loop', 'frames': args.frames, 'iters_per_frame': args.iters,
-                      'iters_first': args.iters_first, 'rays_per_iter': args.rays, 'iterations': run.n_iter, 'seconds': dt,
+                      'iters_first': args.iters_first, 'rays_per_iter': args.rays, 'fused': args.fused, 'iterations': run.n_iter, 'seconds': dt,
                       'ms_per_iteration': dt / run.n_iter * 1e3,
                       'heldout_depth_l1_before': e0, 'heldout_depth_l1_after': e1,
                       'depth_loss_per_ray_first_quarter': mean([h[1] for h in hist[:q]]),

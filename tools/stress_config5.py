@@ -14,7 +14,7 @@ from attentive_dfprior_amd import synthetic            # noqa: E402
 from attentive_dfprior_amd.common import get_rays      # noqa: E402
 
 
-def main(n_rays=131072):
+def main(n_rays=131072, order='pixel'):
     dev = torch.device('cuda:0')
     sc = synthetic.Scene('cube16', device=dev, grid_std_scale=20.0, voxel=16.0 / 1024, inset=2.0)
     sc.c['grid_high'] = sc.c['grid_high'] * 100
@@ -30,7 +30,8 @@ def main(n_rays=131072):
         c2w = sc.default_c2w(offset=(0.5 * k - 2, 0.3 * k - 1, 0.2 * k), yaw=0.7 * k, pitch=-0.2 + 0.05 * k)
         gd = sc.depth_image(c2w)
         ro, rd = get_rays(sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2w, dev)
-        pick = torch.randperm(sc.H * sc.W, device=dev)[:n_rays // 8]
+        per = n_rays // 8
+        pick = torch.randperm(sc.H * sc.W, device=dev)[:per] if order == 'random' else torch.arange((sc.H * sc.W - per) // 2, (sc.H * sc.W - per) // 2 + per, device=dev)
         ros.append(ro.reshape(-1, 3)[pick]); rds.append(rd.reshape(-1, 3)[pick]); gds.append(gd.reshape(-1)[pick])
     ro, rd, gd = torch.cat(ros), torch.cat(rds), torch.cat(gds)
     with torch.no_grad():
@@ -43,10 +44,10 @@ def main(n_rays=131072):
         dt = (time.perf_counter() - t0) / 5
     d, u, c, w = out
     assert torch.isfinite(d).all() and torch.isfinite(c).all()
-    res = {'config': '1024^3 TSDF, 128 samples/ray', 'rays': ro.shape[0], 'ms': dt * 1e3, 'rays_per_s': ro.shape[0] / dt,
+    res = {'config': '1024^3 TSDF, 128 samples/ray', 'ray_order': order, 'rays': ro.shape[0], 'ms': dt * 1e3, 'rays_per_s': ro.shape[0] / dt,
            'tsdf_GB': sc.tsdf_volume.numel() * 4 / 1e9, 'in_band_fraction': float((w != 1).float().mean())}
     print(json.dumps(res))
 
 
 if __name__ == '__main__':
-    main()
+    main(order=sys.argv[1] if len(sys.argv) > 1 else 'pixel')
