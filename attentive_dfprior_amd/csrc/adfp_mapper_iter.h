@@ -54,41 +54,44 @@ struct LossArgs {
     double* loss; double* g_depth; float* g_color; float* g_weight;
 };
 ADFP_DEV float sign_f(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }     // torch.sign: 0 at 0, NaN -> 0 here
-// one wave per ray: lane 0 the depth term, lanes 0-2 the colour term, all lanes stride over the ray's S attention weights
+// A wave takes rays in a grid-stride loop: lane 0 the depth term, lanes 0-2 the colour term, all lanes stride over the ray's S
+// attention weights; the loss is summed in registers and leaves the wave through ONE f64 atomic (one atomic per ray
+// serialised 5 000 adders on one address: 63 us per call).
 __global__ __launch_bounds__(256) void k_mapper_loss(LossArgs a) {
     const int lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ray >= a.n) return;
-    const bool kept = !a.keep || a.keep[ray];
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     double part = 0.0;
-    if (lane == 0) {
-        const float gd = a.gt_depth[ray];
-        double g = 0.0;
-        if (kept && gd > 0.f) {                                        // depth_mask = batch_gt_depth > 0, Mapper.py:457
-            const double diff = (double)gd - a.depth[ray];            // f32 - f64 -> f64
-            part += diff < 0 ? -diff : diff;
-            g = diff > 0 ? -1.0 : (diff < 0 ? 1.0 : 0.0);              // d|gt - d|/dd = -sign(gt - d)
-        }
-        a.g_depth[ray] = g;
-    }
-    if (lane < 3) {
-        float g = 0.f;
-        if (a.color_term && kept) {                                    // Mapper.py:466-469
-            const float diff = a.gt_color[3 * ray + lane] - a.color[3 * ray + lane];
-            part += (double)(a.w_color * fabsf(diff));
-            g = -a.w_color * sign_f(diff);
-        }
-        if (a.g_color) a.g_color[3 * ray + lane] = g;
-    }
-    if (a.g_weight) {
-        for (int s = lane; s < a.S; s += 64) {
-            float g = 0.f;
-            if (a.warmup && kept) {                                    // + |weight - 1|.sum(), Mapper.py:459-461
-                const float diff = a.weight[(long long)ray * a.S + s] - 1.f;
-                part += (double)fabsf(diff);
-                g = sign_f(diff);
+    for (int ray = wave; ray < a.n; ray += nwaves) {
+        const bool kept = !a.keep || a.keep[ray];
+        if (lane == 0) {
+            const float gd = a.gt_depth[ray];
+            double g = 0.0;
+            if (kept && gd > 0.f) {                                        // depth_mask = batch_gt_depth > 0, Mapper.py:457
+                const double diff = (double)gd - a.depth[ray];            // f32 - f64 -> f64
+                part += diff < 0 ? -diff : diff;
+                g = diff > 0 ? -1.0 : (diff < 0 ? 1.0 : 0.0);              // d|gt - d|/dd = -sign(gt - d)
             }
-            a.g_weight[(long long)ray * a.S + s] = g;
+            a.g_depth[ray] = g;
+        }
+        if (lane < 3) {
+            float g = 0.f;
+            if (a.color_term && kept) {                                    // Mapper.py:466-469
+                const float diff = a.gt_color[3 * ray + lane] - a.color[3 * ray + lane];
+                part += (double)(a.w_color * fabsf(diff));
+                g = -a.w_color * sign_f(diff);
+            }
+            if (a.g_color) a.g_color[3 * ray + lane] = g;
+        }
+        if (a.g_weight) {
+            for (int s = lane; s < a.S; s += 64) {
+                float g = 0.f;
+                if (a.warmup && kept) {                                    // + |weight - 1|.sum(), Mapper.py:459-461
+                    const float diff = a.weight[(long long)ray * a.S + s] - 1.f;
+                    part += (double)fabsf(diff);
+                    g = sign_f(diff);
+                }
+                a.g_weight[(long long)ray * a.S + s] = g;
+            }
         }
     }
     if (a.loss) {

@@ -34,13 +34,33 @@ def global_depth_max(gt_depth, group=None):
 
 def _all_gather_rows(x, sizes, group):
     """all-gather tensors whose first dim differs per rank (sizes[r] rows on rank r)."""
-    world = len(sizes)
-    pad = max(sizes)
-    buf = torch.zeros((pad,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    buf[:x.shape[0]] = x
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf, group=group)
-    return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
+    return _all_gather_packed((x,), sizes, group)[0]
+
+
+def _all_gather_packed(outs, sizes, group):
+    """ONE collective for several per-ray outputs: every rank packs its rows (depth f64, uncertainty f64, colour 3 x f32 ... =
+    28 B per ray for a render) into one byte buffer padded to the largest shard, all_gather_into_tensor, unpack.  A frame's
+    outputs are ~1 MB per rank at 8 GPUs: the collective is latency bound, so one launch instead of one per output."""
+    world, pad = len(sizes), max(sizes)
+    rows = [o.contiguous().reshape(o.shape[0], -1) for o in outs]
+    widths = [r.shape[1] * r.element_size() for r in rows]
+    dev = outs[0].device
+    buf = torch.zeros((pad, sum(widths)), dtype=torch.uint8, device=dev)
+    off = 0
+    for r, wd in zip(rows, widths):
+        if r.shape[0]:
+            buf[:r.shape[0], off:off + wd] = r.view(torch.uint8)
+        off += wd
+    gathered = torch.empty((world * pad, sum(widths)), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(gathered, buf, group=group)
+    gathered = gathered.reshape(world, pad, -1)
+    res, off = [], 0
+    for o, wd in zip(outs, widths):
+        parts = [gathered[r, :sizes[r], off:off + wd] for r in range(world)]
+        flat = torch.cat(parts, dim=0).contiguous().view(o.dtype)
+        res.append(flat.reshape((flat.shape[0],) + tuple(o.shape[1:])))
+        off += wd
+    return tuple(res)
 
 
 def render_rays_sharded(render_fn, rays_o, rays_d, gt_depth, group=None, gather=True):
@@ -63,7 +83,7 @@ def render_rays_sharded(render_fn, rays_o, rays_d, gt_depth, group=None, gather=
     if not gather or world == 1:
         return outs
     sizes = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
-    return tuple(_all_gather_rows(o.contiguous(), sizes, group) for o in outs)
+    return _all_gather_packed(tuple(outs), sizes, group)
 
 
 def allreduce_grads(tensors, group=None, skip_single=True):

@@ -320,8 +320,10 @@ class Engine(object):
 
     # ---- a15 -------------------------------------------------------------------------------
     def render_backward(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, saved, g_depth, g_unc, g_color,
-                        g_weight, need_grid, need_flat, need_rays=False, ray_keep=None):
+                        g_weight, need_grid, need_flat, need_rays=False, ray_keep=None, out_grids=None, out_flats=None):
         """saved: the aux dict of render_forward(train=True).  need_grid / need_flat: dicts of bools.
+        out_grids / out_flats: optional caller-owned result tensors (name -> [1,32,Z,Y,X] / flat), e.g. slices of one
+        gradient bucket that is all-reduced as it stands.
         Returns (grid grads dict in the reference's [1,32,Z,Y,X] layout, flat parameter grads dict)."""
         ro = saved['rays_o']
         dev = ro.device
@@ -356,7 +358,8 @@ class Engine(object):
                      'color': L.adfp_decoder_flat_floats(2), 'att': L.adfp_attention_flat_floats()}
             for name in ('low', 'high', 'color', 'att'):
                 if need_flat.get(name):
-                    flats[name] = torch.empty((sizes[name],), dtype=torch.float32, device=dev)
+                    flats[name] = out_flats[name] if out_flats and name in out_flats else \
+                        torch.empty((sizes[name],), dtype=torch.float32, device=dev)
                     setattr(a, 'g_flat_' + name, flats[name].data_ptr())
             g_ro = g_rd = None
             if need_rays:
@@ -371,7 +374,7 @@ class Engine(object):
             grids = {}
             for name, g in grids_cl.items():
                 Z, Y, X = g.shape[:3]
-                out = torch.empty((1, 32, Z, Y, X), dtype=torch.float32, device=dev)
+                out = out_grids[name] if out_grids and name in out_grids else torch.empty((1, 32, Z, Y, X), dtype=torch.float32, device=dev)
                 check(L.adfp_relayout_grid_back(ptr(g), ptr(out), 32, Z, Y, X, stream), 'adfp_relayout_grid_back')
                 grids[name] = out
         return grids, flats, (g_ro, g_rd)

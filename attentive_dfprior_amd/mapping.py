@@ -146,7 +146,7 @@ class MapperIteration(object):
     """
 
     def __init__(self, renderer, decoders, c, masks, tsdf_volume, tsdf_bnds, stage_lr, w_color_loss=0.2,
-                 train=('color', 'att'), betas=(0.9, 0.999), eps=1e-8, use_graph=True):
+                 train=('color', 'att'), betas=(0.9, 0.999), eps=1e-8, use_graph=True, group=None, distributed=None):
         self.rend, self.dec, self.c = renderer, decoders, c
         self.tsdf, self.tsdf_bnds = tsdf_volume, tsdf_bnds
         self.stage_lr, self.w_color, self.betas, self.eps = stage_lr, float(w_color_loss), betas, eps
@@ -172,6 +172,28 @@ class MapperIteration(object):
         self._pool = None
         self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
         self.bound_dev = torch.as_tensor(renderer.bound).to(dev, torch.float64).contiguous()
+        # Ray-sharded iteration (new; the reference has no distributed code): every rank passes ITS rays to step(); the loss
+        # gradients are combined by ONE RCCL all-reduce (SUM) of a contiguous bucket -- the backward writes the grid and
+        # parameter gradients straight into slices of it, in the order low grid | attention net | high grid | colour net |
+        # colour grid, so that a stage reduces exactly the prefix it produced -- and the kept rays' max depth by a
+        # one-float all-reduce (MAX).  With frustum masks only the selected voxels' columns travel (_allreduce_gradients).
+        # The Mapper losses are plain sums, so no rescaling.
+        import torch.distributed as tdist
+        self.group = group
+        self.distributed = (tdist.is_available() and tdist.is_initialized()) if distributed is None else distributed
+        order = [('grid', 'low', 'grid_low'), ('flat', 'att', None), ('grid', 'high', 'grid_high'), ('flat', 'color', None),
+                 ('grid', 'color', 'grid_color')]
+        self._bucket_layout, off = [], 0
+        for kind, name, key in order:
+            if kind == 'flat' and name not in self.nets:
+                continue
+            n = c[key].numel() if kind == 'grid' else self.flat[name].numel()
+            self._bucket_layout.append((kind, name, key, off, n))
+            off += n
+        self.bucket = torch.empty(off, dtype=torch.float32, device=dev)
+        self._index = {}
+        if self.distributed:
+            self._build_index()
         self._graphs = {}
         self._static = {}
         self._versioned = list(c.values()) + [p for n in self.nets for p in getattr(decoders, attr[n]).parameters()]
@@ -190,6 +212,43 @@ class MapperIteration(object):
                     raise ValueError(f'{k}: a grid cannot switch between masked and unmasked across frames')
                 if self.masks[k] is not None:
                     self.masks[k].copy_(masks[k].to(self.dev, torch.uint8))
+            if self.distributed:
+                self._build_index()
+
+    def _build_index(self):
+        """Distributed mode with frustum masks: the selected voxels' flat indices, once per frame (one host sync, like the
+        reference's own boolean indexing at src/Mapper.py:345-361); identical on every rank, so the compact buckets line up."""
+        self._index = {k: (None if m is None else torch.nonzero(m.reshape(-1), as_tuple=False).reshape(-1)) for k, m in self.masks.items()}
+
+    def _allreduce_gradients(self, grids, flats, end):
+        """SUM over the ranks of what this stage's backward produced.  Without masks: the stage's prefix of the contiguous
+        bucket, in place.  With masks: outside the mask a grid is never updated, so only the selected voxels' gradient columns
+        travel -- gathered with the parameter gradients into one compact buffer, reduced, scattered back."""
+        import torch.distributed as tdist
+        key = {'low': 'grid_low', 'high': 'grid_high', 'color': 'grid_color'}
+        if all(self._index.get(key[n]) is None for n in grids):
+            tdist.all_reduce(self.bucket[:end], op=tdist.ReduceOp.SUM, group=self.group)
+            return end * 4
+        parts = [f for f in flats.values()]
+        for n, g in grids.items():
+            idx = self._index.get(key[n])
+            parts.append(g.reshape(-1) if idx is None else g.reshape(g.shape[1], -1).index_select(1, idx).reshape(-1))
+        buf = torch.cat(parts)
+        tdist.all_reduce(buf, op=tdist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for f in flats.values():
+            f.copy_(buf[off:off + f.numel()])
+            off += f.numel()
+        for n, g in grids.items():
+            idx = self._index.get(key[n])
+            if idx is None:
+                g.reshape(-1).copy_(buf[off:off + g.numel()])
+                off += g.numel()
+            else:
+                ch = g.shape[1]
+                g.reshape(ch, -1).index_copy_(1, idx, buf[off:off + ch * idx.numel()].reshape(ch, -1))
+                off += ch * idx.numel()
+        return buf.numel() * 4
 
     # ---- the kernel sequence ------------------------------------------------------------------------------------------
     def _sequence(self, ro, rd, gd, gc, stage, warmup, adam=True):
@@ -200,6 +259,9 @@ class MapperIteration(object):
         keep = torch.empty((N,), dtype=torch.uint8, device=dev)
         dmax = torch.empty((1,), dtype=torch.float32, device=dev)
         check(L.adfp_prefilter_mask(ptr(ro), ptr(rd), ptr(gd), N, ptr(self.bound_dev), ptr(keep), ptr(dmax), st), 'adfp_prefilter_mask')
+        if self.distributed:
+            import torch.distributed as tdist
+            tdist.all_reduce(dmax, op=tdist.ReduceOp.MAX, group=self.group)       # the far clamp sees the whole batch (Renderer.py:159)
         depth, unc, color, weight, aux = eng.render_forward(dec, self.c, ro, rd, gd, self.tsdf, self.tsdf_bnds, rend.bound, stage,
                                                             rend.N_samples, rend.N_surface, rend.lindisp, rend.perturb, None, dmax,
                                                             train=True)
@@ -218,8 +280,23 @@ class MapperIteration(object):
         used = {'low': ('low',), 'high': ('low', 'high', 'att'), 'color': ('low', 'high', 'color', 'att')}[stage]
         need_grid = {k: (k in used) for k in ('low', 'high', 'color')}
         need_flat = {n: (n in used and n in self.nets) for n in ('low', 'high', 'color', 'att')}
+        out_grids, out_flats, end = {}, {}, 0
+        for kind, name, key, off, n in self._bucket_layout:
+            view = self.bucket[off:off + n]
+            if kind == 'grid' and need_grid[name]:
+                out_grids[name] = view.view(self.c[key].shape)
+                end = off + n
+            elif kind == 'flat' and need_flat[name]:
+                out_flats[name] = view
+                end = off + n
         grids, flats, _ = eng.render_backward(dec, self.c, self.tsdf, self.tsdf_bnds, rend.bound, stage, aux, g_depth, None,
-                                              g_color if stage == 'color' else None, g_weight, need_grid, need_flat, ray_keep=keep)
+                                              g_color if stage == 'color' else None, g_weight, need_grid, need_flat, ray_keep=keep,
+                                              out_grids=out_grids, out_flats=out_flats)
+        self.bucket_bytes = end * 4
+        if self.distributed:
+            import torch.distributed as tdist
+            self.bucket_bytes = self._allreduce_gradients(grids, flats, end)
+            tdist.all_reduce(self.loss, op=tdist.ReduceOp.SUM, group=self.group)
         if not adam:
             return grids, flats
         lr = self.stage_lr[stage]
@@ -255,7 +332,7 @@ class MapperIteration(object):
         dev = self.dev
         with torch.cuda.device(dev):
             N = rays_o.shape[0]
-            if not self.use_graph:
+            if not self.use_graph or self.distributed:      # collectives stay out of the graph
                 self._sequence(rays_o.float().contiguous(), rays_d.float().contiguous(), gt_depth.float().contiguous(),
                                gt_color.float().contiguous(), stage, warmup)
                 self._bump_versions()

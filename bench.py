@@ -414,6 +414,19 @@ def dist_legs(dist, A, synthetic, rend, dec, scene, tsdf_bnds, dev, args):
             # the collective alone (pack + all-reduce + unpack), HIP events on the launch stream, last iteration
             res[mode] = {'ms_per_iteration': t_it * 1e3, 'rays_per_s': n_train / t_it, 'bucket_bytes': int(nbytes),
                          'allreduce_ms_incl_pack_unpack': ev[0].elapsed_time(ev[1])}
+        # the same iteration as ONE device-side call (mapping.MapperIteration, distributed mode): keep-mask pre-filter, loss and
+        # backward without autograd, the gradients written straight into one contiguous bucket that is all-reduced as it stands,
+        # Adam with device-side step state
+        import copy
+        dec_f = copy.deepcopy(dec)
+        cf = {k: v.detach().clone() for k, v in scene.c.items()}
+        lrs = {'color': dict(low=0.005, high=0.005, color=0.005, decoders=0.005, mlp=0.005)}
+        for mode in ('dense', 'frustum_masked'):
+            itf = mapping.MapperIteration(rend, dec_f, cf, masks if mode == 'frustum_masked' else None, scene.tsdf_volume, tsdf_bnds, lrs,
+                                          use_graph=False, distributed=True)
+            t_it, _ = timed(lambda: itf.step(tro, trd, tgd, tgc, 'color'), 20, 3)
+            res['fused_' + mode] = {'ms_per_iteration': t_it * 1e3, 'rays_per_s': n_train / t_it, 'bucket_bytes': int(itf.bucket_bytes),
+                                    'note': 'the bucket is dense either way (zero-copy: the backward writes into it); the mask only restricts Adam'}
     finally:
         with torch.no_grad():
             for p, p0 in zip(params, params_before):

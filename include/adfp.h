@@ -225,8 +225,9 @@ int adfp_render_forward(const adfp_scene* scene /*host*/, const adfp_render_args
 /* Cotangents of (depth, uncertainty, color, weight) -> gradients of the three feature grids
  * (channels-last, converted back by adfp_relayout_grid_back) and of the decoder parameters (flat
  * state_dict order).  Any output pointer may be NULL (= not needed: frozen decoder, lr 0 grid).
- * z_vals, raw and `state` are the ones the forward call wrote.  Every non-NULL output is zeroed
- * and then accumulated with float atomics (results are not bitwise reproducible run to run).
+ * z_vals, raw and `state` are the ones the forward call wrote.  Every non-NULL output is zeroed and then accumulated:
+ * the grid gradients with float atomics (not bitwise reproducible run to run), the parameter gradients atomic-free through
+ * per-workgroup partial sums (reproducible).
  * g_rays_o / g_rays_d: gradients w.r.t. the rays (p = o + d z; through the trilinear coordinates of the
  * feature grids and the TSDF and through sin(p @ B)) for the Tracker, src/Tracker.py:112-133. */
 typedef struct adfp_backward_args {

@@ -13,7 +13,7 @@ import torch.distributed as dist
 
 import attentive_dfprior_amd as A
 from attentive_dfprior_amd import dist as adist
-from conftest import make_cfg, to_dev
+from conftest import make_cfg, to_dev, assert_adam_trajectory
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300, method='thread')]
 DEV = torch.device('cuda:0')
@@ -91,3 +91,43 @@ def test_sharded_render_gathers_through_rccl(rccl, mini):
     assert torch.equal(rows, whole[2])
     gmax = adist.global_depth_max(gd)
     assert float(gmax) == float(gd.max())
+
+
+@pytest.mark.parametrize('masked', [False, True])
+def test_fused_mapper_iteration_reduces_its_bucket_through_rccl(rccl, mini, masked):
+    """mapping.MapperIteration in distributed mode: the backward writes into slices of one contiguous bucket, the stage's
+    prefix of it goes through ONE all-reduce (plus a one-float MAX for the far clamp).  In a world of one rank the result
+    must equal the non-distributed iteration.  With frustum masks only the selected voxels' gradient columns travel."""
+    import copy
+    from attentive_dfprior_amd import mapping, synthetic
+    sc = synthetic.mini_scene()
+    lr = {s: dict(low=0.01, high=0.005, color=0.005, decoders=0.005, mlp=0.005) for s in ('low', 'high', 'color')}
+    tsdf, tb = sc.tsdf_volume.to(DEV), sc.tsdf_bnds.to(DEV)
+    rays = [t.to(DEV) for t in synthetic.make_ray_batch(sc, 500, seed=3)]
+    masks = None
+    if masked:
+        c2w = sc.default_c2w(yaw=0.7, pitch=0.1)
+        masks = {k: mapping.frustum_mask(c2w, tuple(v.shape[2:]), sc.depth_image(c2w).to(DEV), sc.bound, sc.H, sc.W, sc.fx, sc.fy,
+                                         sc.cx, sc.cy) for k, v in sc.c.items()}
+    res = []
+    for distributed in (True, False):
+        dec = A.DF()
+        dec.load_state_dict(mini.sd)
+        dec.bound = sc.bound
+        dec = dec.to(DEV)
+        grids = {k: v.clone().to(DEV) for k, v in sc.c.items()}
+        it = mapping.MapperIteration(A.Renderer(make_cfg(32, 16), None, sc), dec, grids, masks, tsdf, tb, lr, use_graph=False,
+                                     distributed=distributed)
+        losses = [float(it.step(*rays, stage)) for stage in ('low', 'high', 'color', 'color')]
+        if distributed and not masked:
+            assert it.bucket_bytes == 4 * it.bucket.numel()                # stage color reduces the whole bucket
+        if distributed and masked:
+            sel = sum(int(m.sum()) * sc.c[k].shape[1] for k, m in masks.items())
+            assert it.bucket_bytes == 4 * (sel + sum(f.numel() for f in it.flat.values())) < 4 * it.bucket.numel()
+        res.append((grids, dec, losses))
+    (ga, da, la), (gb, db, lb) = res
+    assert all(abs(x - y) <= 1e-5 * abs(y) for x, y in zip(la, lb)), (la, lb)       # later losses inherit the Adam noise below
+    for k in ga:                                   # float atomics: the two runs differ in the last bits, Adam amplifies noise-sized gradients
+        assert_adam_trajectory(ga[k], gb[k], 0.01, 4, k)
+    for (n, p), (_, q) in zip(da.named_parameters(), db.named_parameters()):
+        assert_adam_trajectory(p, q, 0.005, 4, n)

@@ -44,4 +44,5 @@ def main():
             print(f'   {v:5d} {k}')
 
 
-main()
+if __name__ == "__main__":
+    main()
