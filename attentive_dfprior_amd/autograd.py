@@ -20,7 +20,7 @@ class _RenderFn(torch.autograd.Function):
         c = {'grid_low': grid_low, 'grid_high': grid_high, 'grid_color': grid_color}
         depth, unc, color, weight, saved = engine.render_forward(
             decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage, n_samples, n_surface,
-            lindisp, perturb, t_rand, depth_max, train=True)
+            lindisp, perturb, t_rand, depth_max, train=True, need_flat=None if need_param_grad else {})
         ctx.bundle = bundle
         ctx.saved = saved
         ctx.c = c

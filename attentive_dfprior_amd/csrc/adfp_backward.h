@@ -96,47 +96,6 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// staging rows (point-major, one row per point of the current chunk) for the weight gradients
-// ------------------------------------------------------------------------------------------
-template <int CDIM>
-struct DecStage {
-    static constexpr int SX = 0;                       // [x, y, z, 1, 0 ...]
-    static constexpr int SE = 32;                      // Fourier features (96)
-    static constexpr int SC = 128;                     // grid features (CDIM)
-    __host__ __device__ static constexpr int SH(int i) { return 128 + CDIM + 32 * i; }     // h_0..h_4
-    __host__ __device__ static constexpr int SGP(int i) { return SH(5) + 32 * i; }          // d/d pre_i
-    __host__ __device__ static constexpr int SGH(int i) { return SGP(5) + 32 * i; }         // d/d h_i
-    static constexpr int SGA = SGH(5);                 // d/d (p @ B) (96)
-    static constexpr int SGO = SGA + 96;               // d/d out (32, first NOUT used)
-    static constexpr int NCOLS = SGO + 32;
-};
-struct AttStage {
-    static constexpr int AX = 0;                       // [occ_in, u, 1, 0 ...]
-    static constexpr int AH0 = 32, AH1 = 96, AH2 = 224, AH3 = 352;
-    static constexpr int AG0 = 416, AG1 = 480, AG2 = 608, AG3 = 736;
-    static constexpr int AGL = 800;                    // d/d logits (2 used)
-    static constexpr int NCOLS = 832;
-};
-
-// 16 registers of a D-layout block -> columns col + kmapH(r,h) of the point's staging row
-template <typename VT>
-ADFP_DEV void stage_block(float* __restrict__ row, int col, int h, const VT& v, const int voff = 0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 t = {v[voff + 4 * q + 0], v[voff + 4 * q + 1], v[voff + 4 * q + 2], v[voff + 4 * q + 3]};
-        *(f32x4*)(row + col + 8 * q + 4 * h) = t;
-    }
-}
-// a block whose only non-zero entries are columns 0..3 (x, y, z, 1 / g_out / occ, u, 1)
-ADFP_DEV void stage_head(float* __restrict__ row, int col, int h, f32x4 head) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 t = (q == 0 && h == 0) ? head : f32x4{0.f, 0.f, 0.f, 0.f};
-        *(f32x4*)(row + col + 8 * q + 4 * h) = t;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // derivatives w.r.t. the sample position (camera tracking, src/Tracker.py:112-133): the trilinear
 // lookup is differentiable in its coordinates (grid_sample backward, 'border' padding zeroes the
 // gradient of clipped coordinates) and so is sin(p @ B).
@@ -167,6 +126,106 @@ ADFP_DEV float trilerp_scalar_grad(const TsdfDev& t, const float pn[3], const fl
     // a corner clamped onto its neighbour (i1 == i0 at the far face) has weight 0 and a clipped coordinate
     g[0] = gx * dx; g[1] = gy * dy; g[2] = gz * dz;
     return o;
+}
+
+// ------------------------------------------------------------------------------------------
+// scatter of d/d c (a tile's 32 points x 32 channels, D layout) into the channels-last grid gradient; shared by the exact
+// and the f16-split decoder backward.  Per-wave LDS: tr [32][33] (the tile transposed to [point][channel]), vox / cw
+// [32][8] corner voxel (| cache slot << 27) and weight, and with CACHE the write-combining cache described in k_decode_bwd:
+// cacc [2][32 slots][32 ch], ctag [2][32].
+// ------------------------------------------------------------------------------------------
+struct ScatterSmem { float* tr; int* vox; float* cw; float* cacc; int* ctag; };
+template <bool CACHE>
+ADFP_DEV void scatter_tile(float* __restrict__ g_grid, const GridDev& g0, const float pn[3], bool valid, const f32x16& gc, int lane, const ScatterSmem& sm) {
+    const int p = lane & 31, h = lane >> 5;
+    // corner voxels / weights of every point of the tile -> LDS (written by the h == 0 lanes)
+    if (h == 0) {
+        int xi[2], yi[2], zi[2]; float wx[2], wy[2], wz[2];
+        tri_axis(pn[0], g0.X, xi[0], xi[1], wx[0], wx[1]);
+        tri_axis(pn[1], g0.Y, yi[0], yi[1], wy[0], wy[1]);
+        tri_axis(pn[2], g0.Z, zi[0], zi[1], wz[0], wz[1]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+            const int x = xi[dx], y = yi[dy], z = zi[dz];
+            int vox = (z * g0.Y + y) * g0.X + x;
+            if constexpr (CACHE) vox |= ((x & 1) | ((y & 1) << 1) | ((z & 1) << 2) | ((((x >> 1) ^ (y >> 1) ^ (z >> 1)) & 3) << 3)) << 27;
+            sm.vox[p * 8 + k] = vox;
+            sm.cw[p * 8 + k] = valid ? (wx[dx] * wy[dy]) * wz[dz] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sm.tr[p * 33 + kmapH(r, h)] = gc[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int ch = lane & 31;
+    if constexpr (CACHE) {
+        float* cacc = sm.cacc + h * 1024;
+        int* ctag = sm.ctag + h * 32;
+        for (int i = 0; i < 16; ++i) {            // half h sweeps points 16 h .. 16 h + 15 in ray order
+            const int pi = 16 * h + i;
+            const float g = sm.tr[pi * 33 + ch];
+            const unsigned long long nz = __ballot(g != 0.f);
+            if ((unsigned)(nz >> (32 * h)) == 0u) continue;                // nothing to add from my half (the branch is per half)
+            // The 8 corners of a cell sit in 8 different slots (the slot carries the coordinate parities), so their
+            // read-modify-writes are independent: all tags and cells are fetched first, then updated, with ONE
+            // wave-level fence per point instead of one per corner.  A corner of weight 0 (a far-face corner clamped onto
+            // its neighbour: the same voxel, hence the same slot, as that neighbour) is skipped -- it is the only way two
+            // corners of a point can meet in a slot.
+            int pv[8], tag[8]; float w[8], old[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { pv[k] = sm.vox[pi * 8 + k]; w[k] = sm.cw[pi * 8 + k]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int slot = (unsigned)pv[k] >> 27;
+                tag[k] = ctag[slot];
+                old[k] = cacc[slot * 32 + ch];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (w[k] == 0.f) continue;
+                const int vox = pv[k] & 0x7ffffff, slot = (unsigned)pv[k] >> 27;
+                const float v = g * w[k];
+                float* cell = cacc + slot * 32 + ch;
+                if (tag[k] == vox) *cell = old[k] + v;
+                else {
+                    if (tag[k] >= 0 && old[k] != 0.f) atomicAdd(g_grid + (long long)tag[k] * 32 + ch, old[k]);
+                    *cell = v;
+                    if (ch == 0) ctag[slot] = vox;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    } else {
+        for (int pp = 0; pp < 32; pp += 2) {
+            const int pi = pp + (lane >> 5);
+            const float g = sm.tr[pi * 33 + ch];
+            if (__ballot(g != 0.f) == 0ull) continue;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float wgt = sm.cw[pi * 8 + k];
+                const float v = g * wgt;
+                if (v != 0.f) atomicAdd(g_grid + (long long)sm.vox[pi * 8 + k] * 32 + ch, v);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <bool CACHE>
+ADFP_DEV void scatter_flush(float* __restrict__ g_grid, int lane, const ScatterSmem& sm) {
+    if constexpr (CACHE) {
+        const int ch = lane & 31, h = lane >> 5;
+        for (int slot = 0; slot < 32; ++slot) {               // write the cached lines back
+            const int tag = sm.ctag[h * 32 + slot];
+            const float v = sm.cacc[h * 1024 + slot * 32 + ch];
+            if (tag >= 0 && v != 0.f) atomicAdd(g_grid + (long long)tag * 32 + ch, v);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -216,6 +275,7 @@ __global__ __launch_bounds__(NT) void k_decode_bwd(DecodeBwdArgs a) {
     __syncthreads();
 
     const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+    const ScatterSmem sm = {s_tr[wv], s_vox[wv], s_cw[wv], &s_cacc[CACHE ? wv : 0][0][0], &s_ctag[CACHE ? wv : 0][0][0]};
     const int lane_off = h * ADFP_RG + p * 4;
     const int loT = lane_off_T(p);
     const int wave = blockIdx.x * NW + wv;
@@ -381,84 +441,9 @@ __global__ __launch_bounds__(NT) void k_decode_bwd(DecodeBwdArgs a) {
             }
         }
         // ---------------- scatter d/d c into the channels-last grid gradient ----------------
-        if (a.g_grid) {
-            // corner voxels / weights of every point of the tile -> LDS (written by the h == 0 lanes)
-            if (h == 0) {
-                int xi[2], yi[2], zi[2]; float wx[2], wy[2], wz[2];
-                tri_axis(pn[0], a.g0.X, xi[0], xi[1], wx[0], wx[1]);
-                tri_axis(pn[1], a.g0.Y, yi[0], yi[1], wy[0], wy[1]);
-                tri_axis(pn[2], a.g0.Z, zi[0], zi[1], wz[0], wz[1]);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
-                    const int x = xi[dx], y = yi[dy], z = zi[dz];
-                    int vox = (z * a.g0.Y + y) * a.g0.X + x;
-                    if constexpr (CACHE) vox |= ((x & 1) | ((y & 1) << 1) | ((z & 1) << 2) | ((((x >> 1) ^ (y >> 1) ^ (z >> 1)) & 3) << 3)) << 27;
-                    s_vox[wv][p * 8 + k] = vox;
-                    s_cw[wv][p * 8 + k] = valid ? (wx[dx] * wy[dy]) * wz[dz] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s_tr[wv][p * 33 + kmapH(r, h)] = gc[r];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int ch = lane & 31;
-            if constexpr (CACHE) {
-                float* cacc = s_cacc[wv][h];
-                int* ctag = s_ctag[wv][h];
-                for (int i = 0; i < 16; ++i) {            // half h sweeps points 16 h .. 16 h + 15 in ray order
-                    const int pi = 16 * h + i;
-                    const float g = s_tr[wv][pi * 33 + ch];
-                    for (int k = 0; k < 8; ++k) {
-                        const float v = g * s_cw[wv][pi * 8 + k];
-                        const unsigned long long nz = __ballot(v != 0.f);
-                        if ((unsigned)(nz >> (32 * h)) != 0u) {               // something to add from my half
-                            const int pv = s_vox[wv][pi * 8 + k];
-                            const int vox = pv & 0x7ffffff, slot = (unsigned)pv >> 27;
-                            const int tag = ctag[slot];
-                            float* cell = cacc + slot * 32 + ch;
-                            if (tag == vox) *cell += v;
-                            else {
-                                const float old = *cell;
-                                if (tag >= 0 && old != 0.f) atomicAdd(a.g_grid + (long long)tag * 32 + ch, old);
-                                *cell = v;
-                                if (ch == 0) ctag[slot] = vox;
-                            }
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    }
-                }
-            } else {
-                for (int pp = 0; pp < 32; pp += 2) {
-                    const int pi = pp + (lane >> 5);
-                    const float g = s_tr[wv][pi * 33 + ch];
-                    if (__ballot(g != 0.f) == 0ull) continue;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const float wgt = s_cw[wv][pi * 8 + k];
-                        const float v = g * wgt;
-                        if (v != 0.f) atomicAdd(a.g_grid + (long long)s_vox[wv][pi * 8 + k] * 32 + ch, v);
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
+        if (a.g_grid) scatter_tile<CACHE>(a.g_grid, a.g0, pn, valid, gc, lane, sm);
     }
-    if constexpr (CACHE) {
-        if (a.g_grid) {                                   // write the cached lines back
-            const int ch = lane & 31;
-            for (int slot = 0; slot < 32; ++slot) {
-                const int tag = s_ctag[wv][h][slot];
-                const float v = s_cacc[wv][h][slot * 32 + ch];
-                if (tag >= 0 && v != 0.f) atomicAdd(a.g_grid + (long long)tag * 32 + ch, v);
-            }
-        }
-    }
+    if (a.g_grid) scatter_flush<CACHE>(a.g_grid, lane, sm);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -190,9 +190,32 @@ __device__ unsigned long long g_phase[8];             // debug build only: wave-
 #define ADFP_PHASE(k) do {} while (0)
 #endif
 
-template <int CDIM, int NOUT, int ROLE, int NT>
+// relu + the fc_c bias, recording which units are active: bit (15 - r) of the low half of `m` = (relu(acc[r]) > 0), the
+// predicate of torch's relu backward.  Two instructions per unit (0 - bits has its sign bit set exactly for bits > 0;
+// v_alignbit shifts it in).
+ADFP_DEV void relu_bias_mask(f32x16& acc, const float* __restrict__ bias, int h, unsigned& m) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 t = *(const f32x4*)(bias + 8 * q + 4 * h);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float v = relu_f(acc[4 * q + k]);
+            m = __builtin_amdgcn_alignbit(m, 0u - __float_as_uint(v), 31);
+            acc[4 * q + k] = v + t[k];
+        }
+    }
+}
+
+// TRAIN = 1: the training forward.  Besides its outputs the kernel leaves what the f16-split backward (adfp_backward_h.h)
+// needs, so that nothing is recomputed there: the ReLU masks of the five layers (a.masks: 3 words per lane half, always) and,
+// when the network's weight gradients are wanted (a.act != NULL), the inputs of every layer -- position, Fourier features,
+// grid features, h_0..h_4 -- as the X part of the point's staging row (DecStage: NX floats per point).  A NaN position
+// (a ray the Mapper's pre-filter drops) is decoded at the origin instead, so that the staged activations stay finite; its
+// outputs are NaN as before.
+template <int CDIM, int NOUT, int ROLE, int NT, int TRAIN = 0>
 __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 : 2))) void k_decode_h(DecodeArgs a) {
     using L = DecLayoutH<CDIM, NOUT>;
+    using ST = DecStage<CDIM>;
 #ifdef ADFP_STAMPS
     const unsigned long long stamp0 = wall_clock64();
 #endif
@@ -223,6 +246,15 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
         load_point(a.P, q, pt);
         normalize3(a.nb, pt, pn);
         pf[0] = (float)pt[0]; pf[1] = (float)pt[1]; pf[2] = (float)pt[2];   // p.float() decoder.py:189
+        float* srow = nullptr;                          // TRAIN: the X part of this point's staging row
+        if constexpr (TRAIN) {
+            const bool pnan = (pt[0] != pt[0]) | (pt[1] != pt[1]) | (pt[2] != pt[2]);
+            if (pnan) { pf[0] = 0.f; pf[1] = 0.f; pf[2] = 0.f; }
+            if (a.act && valid) {
+                srow = a.act + (long long)(ROLE == ROLE_HIGH ? idx : q) * ST::NX;
+                stage_head(srow, ST::SX, h, f32x4{pf[0], pf[1], pf[2], 1.f});
+            }
+        }
 
         // grid features -> split halves (k-steps of fc_c)
         f16x8 ch[L::KS_C], cl[L::KS_C];
@@ -230,6 +262,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
             float c[CDIM / 2];
             gather16(a.g0, pn, h, c);
             if (CDIM == 64) gather16(a.g1, pn, h, c + 16);
+            if constexpr (TRAIN) if (srow) {
+                stage_block(srow, ST::SC, h, c, 0);
+                if (CDIM == 64) stage_block(srow, ST::SC + 32, h, c, 16);
+            }
 #pragma unroll
             for (int ks = 0; ks < L::KS_C; ++ks) split8(c + 8 * ks, ch[ks], cl[ks], amax);
         }
@@ -249,6 +285,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
                 const float arg = fmaf(pf[2], bm.z, fmaf(pf[1], bm.y, pf[0] * bm.x));
                 e[j] = adfp_sinf(arg);
             }
+            if constexpr (TRAIN) if (srow) {              // registers 8 (ks & 1) + j of Fourier block ks >> 1
+                *(f32x4*)(srow + ST::SE + 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h) = f32x4{e[0], e[1], e[2], e[3]};
+                *(f32x4*)(srow + ST::SE + 32 * (ks >> 1) + 16 * (ks & 1) + 8 + 4 * h) = f32x4{e[4], e[5], e[6], e[7]};
+            }
             split8<false>(e, eh[ks], el[ks], amax);     // |sin| <= 1
         }
         ADFP_PHASE(2);                                  // Fourier features
@@ -257,6 +297,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
         // h = relu(W_i h + b_i) + (Wc_i c + bc_i); skip-concat [emb, h] feeds layer 3 (decoder.py:192-199)
         f32x16 acc;
         f16x8 hh[2], hl[2];
+        unsigned mk[5] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
     #ifdef ADFP_EXP_NOBIAS     // timing experiment only: no bias reads from LDS
@@ -272,9 +313,11 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
 #ifdef ADFP_EXP_NOBIAS
             for (int r = 0; r < 16; ++r) acc[r] = relu_f(acc[r]);
 #else
-            relu_bias(acc, lds + L::P_BC(i), h);
+            if constexpr (TRAIN) relu_bias_mask(acc, lds + L::P_BC(i), h, mk[i]);
+            else relu_bias(acc, lds + L::P_BC(i), h);
 #endif
             mfma_chain_h<L::KS_C>(acc, ldsu + L::P_WC(i), lane_off, ch, cl);
+            if constexpr (TRAIN) if (srow) stage_block(srow, ST::SH(i), h, acc);
             if (i < 4) {
                 float t[16];
 #pragma unroll
@@ -298,6 +341,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
         }
 
         nan_point_outputs<NOUT>(pt, out);
+        if constexpr (TRAIN) if (valid) {
+            unsigned* mrow = a.masks + ((long long)(ROLE == ROLE_HIGH ? idx : q) * 2 + h) * 3;
+            mrow[0] = (mk[0] & 0xFFFFu) | (mk[1] << 16); mrow[1] = (mk[2] & 0xFFFFu) | (mk[3] << 16); mrow[2] = mk[4] & 0xFFFFu;
+        }
         if (valid && h == 0) {
             if constexpr (ROLE == ROLE_LOW) {
                 const bool inb = in_bound(pt, a.b);

@@ -401,6 +401,53 @@ struct AttLayout {
 };
 
 
+// ------------------------------------------------------------------------------------------
+// staging rows (point-major, one row per point of the current chunk) for the weight gradients
+// ------------------------------------------------------------------------------------------
+template <int CDIM>
+struct DecStage {
+    static constexpr int SX = 0;                       // [x, y, z, 1, 0 ...]
+    static constexpr int SE = 32;                      // Fourier features (96)
+    static constexpr int SC = 128;                     // grid features (CDIM)
+    __host__ __device__ static constexpr int SH(int i) { return 128 + CDIM + 32 * i; }     // h_0..h_4
+    __host__ __device__ static constexpr int SGP(int i) { return SH(5) + 32 * i; }          // d/d pre_i
+    __host__ __device__ static constexpr int SGH(int i) { return SGP(5) + 32 * i; }         // d/d h_i
+    static constexpr int SGA = SGH(5);                 // d/d (p @ B) (96)
+    static constexpr int SGO = SGA + 96;               // d/d out (32, first NOUT used)
+    static constexpr int NCOLS = SGO + 32;
+    // The f16-split backward keeps a row in two pieces: the decoder's INPUTS, columns [0, NX), are written by the training
+    // forward (k_decode_h<..., TRAIN>) into caller-owned rows for all points; the GRADIENT blocks, columns [NX, NCOLS), by
+    // k_decode_bwd_h into the chunked staging buffer.  k_outer_lds2 puts the two pieces side by side in its LDS tile.
+    static constexpr int NX = 128 + CDIM + 160;
+    static constexpr int NG = NCOLS - NX;
+};
+struct AttStage {
+    static constexpr int AX = 0;                       // [occ_in, u, 1, 0 ...]
+    static constexpr int AH0 = 32, AH1 = 96, AH2 = 224, AH3 = 352;
+    static constexpr int AG0 = 416, AG1 = 480, AG2 = 608, AG3 = 736;
+    static constexpr int AGL = 800;                    // d/d logits (2 used)
+    static constexpr int NCOLS = 832;
+};
+
+// 16 registers of a D-layout block -> columns col + kmapH(r,h) of the point's staging row
+template <typename VT>
+ADFP_DEV void stage_block(float* __restrict__ row, int col, int h, const VT& v, const int voff = 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 t = {v[voff + 4 * q + 0], v[voff + 4 * q + 1], v[voff + 4 * q + 2], v[voff + 4 * q + 3]};
+        *(f32x4*)(row + col + 8 * q + 4 * h) = t;
+    }
+}
+// a block whose only non-zero entries are columns 0..3 (x, y, z, 1 / g_out / occ, u, 1)
+ADFP_DEV void stage_head(float* __restrict__ row, int col, int h, f32x4 head) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 t = (q == 0 && h == 0) ? head : f32x4{0.f, 0.f, 0.f, 0.f};
+        *(f32x4*)(row + col + 8 * q + 4 * h) = t;
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // Wave-wide sums and an inclusive product scan on DPP (data-parallel primitives inside the VALU: no trip
 // through the LDS crossbar that __shfl / ds_bpermute takes, ~8 cycles per step instead of ~100).

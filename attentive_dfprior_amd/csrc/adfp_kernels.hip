@@ -648,6 +648,8 @@ struct DecodeArgs {
     int write_w;
     int apply_bound;           // Renderer.eval_points' ret[~mask,3] = 100 (Renderer.py:64)
     int* status;               // adfp_scene.status (f16x3 kernels: operand range guard) or NULL
+    unsigned* masks;           // training forward (k_decode_h<..., 1>): ReLU masks, [rows][2][3] words
+    float* act;                // training forward: X part of the staging rows, [rows][DecStage::NX], or NULL
 };
 
 template <int CDIM, int NOUT, int ROLE, int NT>
@@ -878,6 +880,7 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
 }
 
 #include "adfp_backward.h"
+#include "adfp_backward_h.h"
 #include "adfp_fusion.h"
 #include "adfp_mapping.h"
 #include "adfp_mapper_iter.h"
@@ -1027,6 +1030,40 @@ int adfp_pack_decoder_h(int kind, const float* flat, void* packed, int* status, 
     }
     ADFP_CHECK_LAUNCH();
     return 0;
+}
+long long adfp_decoder_packed_ht_words(int kind) {
+    switch (kind) {
+        case ADFP_DEC_LOW: return DecLayoutHT<32, 1>::P_TOTAL;
+        case ADFP_DEC_HIGH: return DecLayoutHT<64, 1>::P_TOTAL;
+        case ADFP_DEC_COLOR: return DecLayoutHT<32, 4>::P_TOTAL;
+    }
+    return ADFP_E_ARG;
+}
+int adfp_pack_decoder_ht(int kind, const float* flat, void* packed, int* status, void* stream) {
+    if (!flat || !packed) return ADFP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* out = (unsigned*)packed;
+    switch (kind) {
+        case ADFP_DEC_LOW:
+            hipLaunchKernelGGL((k_pack_decoder_ht<32, 1>), dim3((DecLayoutHT<32, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status);
+            break;
+        case ADFP_DEC_HIGH:
+            hipLaunchKernelGGL((k_pack_decoder_ht<64, 1>), dim3((DecLayoutHT<64, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status);
+            break;
+        case ADFP_DEC_COLOR:
+            hipLaunchKernelGGL((k_pack_decoder_ht<32, 4>), dim3((DecLayoutHT<32, 4>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status);
+            break;
+        default: return ADFP_E_ARG;
+    }
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+long long adfp_train_act_floats(int kind) {
+    switch (kind) {
+        case ADFP_DEC_LOW: case ADFP_DEC_COLOR: return DecStage<32>::NX;
+        case ADFP_DEC_HIGH: return DecStage<64>::NX;
+    }
+    return ADFP_E_ARG;
 }
 long long adfp_attention_packed_h_words(void) { return AttLayoutH::P_TOTAL; }
 int adfp_pack_attention_h(const float* flat, void* packed, int* status, void* stream) {
@@ -1194,11 +1231,15 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
     a.P = P; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
     a.list = nullptr; a.count_ptr = nullptr; a.flags = fuse ? ws.flags : nullptr;
     a.raw = raw; a.w = w; a.att_occ = nullptr; a.write_w = 1; a.apply_bound = apply_bound;   // attention overwrites w on the band
-    a.status = sc->status;
+    a.status = sc->status; a.masks = nullptr; a.act = nullptr;
     const int ntiles = (P.n + 31) / 32;
     // LOW on every point
     a.g0 = make_grid(sc->low); a.g1 = a.g0;
-    if (sc->h_low) {
+    if (sc->h_low && state && state->masks_low) {              // training forward: leaves the ReLU masks (+ layer inputs)
+        a.packed = (const float*)sc->h_low; a.masks = state->masks_low; a.act = state->act_low;
+        hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, 512, 1>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
+        a.masks = nullptr; a.act = nullptr;
+    } else if (sc->h_low) {
         a.packed = (const float*)sc->h_low;
         if (decode_pipelined() && a.P.mode == ADFP_PTS_RAYS) hipLaunchKernelGGL((k_decode_p<32, 1, ROLE_LOW, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
         else hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
@@ -1209,7 +1250,11 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
     ADFP_CHECK_LAUNCH();
     if (stage == ADFP_STAGE_COLOR) {
         a.g0 = make_grid(sc->color); a.g1 = a.g0;
-        if (sc->h_color) {
+        if (sc->h_color && state && state->masks_color) {
+            a.packed = (const float*)sc->h_color; a.masks = state->masks_color; a.act = state->act_color;
+            hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, 512, 1>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
+            a.masks = nullptr; a.act = nullptr;
+        } else if (sc->h_color) {
             a.packed = (const float*)sc->h_color;
             if (decode_pipelined() && a.P.mode == ADFP_PTS_RAYS) hipLaunchKernelGGL((k_decode_p<32, 4, ROLE_COLOR, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
             else hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
@@ -1222,7 +1267,11 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
     if (fuse) {
         a.g0 = make_grid(sc->high); a.g1 = make_grid(sc->low);
         a.list = ws.list; a.count_ptr = ws.counter; a.att_occ = ws.att_occ;
-        if (sc->h_high) {
+        if (sc->h_high && state && state->masks_high) {
+            a.packed = (const float*)sc->h_high; a.masks = state->masks_high; a.act = state->act_high;
+            hipLaunchKernelGGL((k_decode_h<64, 1, ROLE_HIGH, 512, 1>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
+            a.masks = nullptr; a.act = nullptr;
+        } else if (sc->h_high) {
             a.packed = (const float*)sc->h_high;
             hipLaunchKernelGGL((k_decode_h<64, 1, ROLE_HIGH, 512>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
         } else {
@@ -1255,6 +1304,7 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
     a.P = P; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
     a.list = nullptr; a.count_ptr = nullptr; a.flags = nullptr;
     a.raw = raw; a.w = w; a.att_occ = nullptr; a.write_w = 1; a.apply_bound = 1; a.status = sc->status;
+    a.masks = nullptr; a.act = nullptr;
     const int ntiles = (P.n + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if (kind == ADFP_DEC_LOW) {
@@ -1589,6 +1639,49 @@ static int run_decode_bwd_p(DecodeBwdArgs a, int total, const int* count_ptr, fl
     }
     return outer_end(bw, DecLayout<CDIM, NOUT>::F_TOTAL, flat, st);
 }
+// The f16-split backward of one decoder (adfp_backward_h.h): `t` = its T image, `masks` / `act` = what the training forward
+// left.  Weight gradients: the G part of the staging rows is chunked like the exact path's rows (so that a chunk is still in
+// the Infinity Cache when k_outer_lds2 reads it back); the X part lies in `act` for all rows.
+#define ADFP_BWDH_NT 384
+template <int CDIM, int NOUT, int ROLE>
+static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigned* masks, const float* act, int* status, int total,
+                            const int* count_ptr, float* flat, BwdWorkspace& bw, hipStream_t st) {
+    if (total == 0) return 0;
+    if (o.g_grid && (long long)o.g0.X * o.g0.Y * o.g0.Z >= (1ll << 27)) return ADFP_E_UNSUPPORTED;     // scatter cache slot bits
+    DecodeBwdHArgs a;
+    a.P = o.P; a.nb = o.nb; a.g0 = o.g0; a.packed_t = (const unsigned*)t; a.list = o.list; a.count_ptr = o.count_ptr;
+    a.g_raw = o.g_raw; a.att_g = o.att_g; a.masks = masks; a.g_grid = o.g_grid; a.stage = nullptr; a.status = status;
+    constexpr int NW = ADFP_BWDH_NT / 64;
+    if (!flat) {
+        a.chunk_lo = 0; a.chunk_hi = total;
+        hipLaunchKernelGGL((k_decode_bwd_h<CDIM, NOUT, ROLE, false, ADFP_BWDH_NT>), dim3(decode_grid((total + 31) / 32, NW, 1)), dim3(ADFP_BWDH_NT), 0, st, a);
+        ADFP_CHECK_LAUNCH();
+        return 0;
+    }
+    using ST = DecStage<CDIM>;
+    Outer2Args oa; decoder_jobs<CDIM, NOUT>(oa.o);
+    oa.act = act; oa.nx = ST::NX;
+    a.stage = bw.stage;
+    const int rows_cap = (int)((size_t)bw.stage_rows * AttStage::NCOLS / ST::NG);
+    int rc = outer_begin(bw, DecLayout<CDIM, NOUT>::F_TOTAL, st);
+    if (rc) return rc;
+    for (int lo = 0; lo < total; lo += rows_cap) {
+        const int hi = lo + rows_cap < total ? lo + rows_cap : total;
+        a.chunk_lo = lo; a.chunk_hi = hi;
+        hipLaunchKernelGGL((k_decode_bwd_h<CDIM, NOUT, ROLE, true, ADFP_BWDH_NT>), dim3(decode_grid((hi - lo + 31) / 32, NW, 1)), dim3(ADFP_BWDH_NT), 0, st, a);
+        ADFP_CHECK_LAUNCH();
+        oa.o.stage = bw.stage; oa.o.count_ptr = count_ptr; oa.o.chunk_lo = lo; oa.o.chunk_hi = hi; oa.o.flat = flat;
+        oa.o.partial = bw.partial; oa.o.part_stride = bw.part_stride;
+        const int rows = hi - lo;
+        int per = (rows + OUTER_NSLOT - 1) / OUTER_NSLOT;
+        per = ((per < 64 ? 64 : per) + OUTER_RT - 1) / OUTER_RT * OUTER_RT;
+        oa.o.rows_per_wave = per;
+        hipLaunchKernelGGL(k_outer_lds2, dim3((rows + per - 1) / per), dim3(512), 0, st, oa);
+        ADFP_CHECK_LAUNCH();
+    }
+    return outer_end(bw, DecLayout<CDIM, NOUT>::F_TOTAL, flat, st);
+}
+
 template <int CDIM, int NOUT, int ROLE>
 static int run_decode_bwd(DecodeBwdArgs a, int total, const int* count_ptr, float* flat, BwdWorkspace& bw, hipStream_t st) {
     return a.g_pts ? run_decode_bwd_p<CDIM, NOUT, ROLE, true>(a, total, count_ptr, flat, bw, st)
@@ -1622,6 +1715,11 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
     a.list = nullptr; a.count_ptr = nullptr; a.g_raw = bw.g_raw; a.att_g = nullptr; a.stage = nullptr;
     a.g_pts = pgrad ? bw.g_pts : nullptr;
     if (pgrad) { e = zero_async(bw.g_pts, (size_t)P * 12, st); if (e != hipSuccess) return (int)e; }
+    // a decoder takes the f16-split backward when its T image and the forward's masks are there, no position gradient is
+    // wanted, and -- if its weight gradients are -- the forward also left the layer inputs
+    auto use_h = [&](const void* t, const unsigned* masks, const float* act, const float* flat) {
+        return t && masks && !pgrad && (!flat || act);
+    };
 
     if (fuse) {
         AttBwdArgs t;
@@ -1651,28 +1749,38 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
             DecodeBwdArgs hgh = a;
             hgh.g0 = make_grid(sc->high); hgh.g1 = make_grid(sc->low); hgh.packed = sc->w_high;
             hgh.list = state.list; hgh.count_ptr = state.counter; hgh.att_g = bw.att_g; hgh.g_grid = go.grid_high;
-            rc = run_decode_bwd<64, 1, ROLE_HIGH>(hgh, P, state.counter, go.flat_high, bw, st);
+            if (use_h(sc->ht_high, state.masks_high, state.act_high, go.flat_high))
+                rc = run_decode_bwd_h<64, 1, ROLE_HIGH>(hgh, sc->ht_high, state.masks_high, state.act_high, sc->status, P, state.counter, go.flat_high, bw, st);
+            else rc = sc->w_high ? run_decode_bwd<64, 1, ROLE_HIGH>(hgh, P, state.counter, go.flat_high, bw, st) : ADFP_E_ARG;
             if (rc) return rc;
         }
     }
     if (go.grid_low || go.flat_low || pgrad) {
         DecodeBwdArgs lw = a;
         lw.g0 = make_grid(sc->low); lw.g1 = lw.g0; lw.packed = sc->w_low; lw.g_grid = go.grid_low;
-        rc = run_decode_bwd<32, 1, ROLE_LOW>(lw, P, nullptr, go.flat_low, bw, st);
+        if (use_h(sc->ht_low, state.masks_low, state.act_low, go.flat_low))
+            rc = run_decode_bwd_h<32, 1, ROLE_LOW>(lw, sc->ht_low, state.masks_low, state.act_low, sc->status, P, nullptr, go.flat_low, bw, st);
+        else rc = sc->w_low ? run_decode_bwd<32, 1, ROLE_LOW>(lw, P, nullptr, go.flat_low, bw, st) : ADFP_E_ARG;
         if (rc) return rc;
     }
     if (stage == ADFP_STAGE_COLOR && (go.grid_color || go.flat_color || pgrad)) {
         DecodeBwdArgs cl = a;
         cl.g0 = make_grid(sc->color); cl.g1 = cl.g0; cl.packed = sc->w_color; cl.g_grid = go.grid_color;
-        rc = run_decode_bwd<32, 4, ROLE_COLOR>(cl, P, nullptr, go.flat_color, bw, st);
+        if (use_h(sc->ht_color, state.masks_color, state.act_color, go.flat_color))
+            rc = run_decode_bwd_h<32, 4, ROLE_COLOR>(cl, sc->ht_color, state.masks_color, state.act_color, sc->status, P, nullptr, go.flat_color, bw, st);
+        else rc = sc->w_color ? run_decode_bwd<32, 4, ROLE_COLOR>(cl, P, nullptr, go.flat_color, bw, st) : ADFP_E_ARG;
         if (rc) return rc;
     }
     return 0;
 }
 
 static int check_backward_scene(const adfp_scene* sc, int stage) {
-    int rc = check_scene(sc, stage); if (rc) return rc;
-    if (!sc->w_low || (stage >= ADFP_STAGE_HIGH && (!sc->w_high || !sc->w_att)) || (stage == ADFP_STAGE_COLOR && !sc->w_color)) return ADFP_E_ARG;   // exact-f32 images
+    if (!sc) return ADFP_E_ARG;
+    if (stage < ADFP_STAGE_LOW || stage > ADFP_STAGE_COLOR) return ADFP_E_ARG;
+    if (!sc->low.data || (stage >= ADFP_STAGE_HIGH && (!sc->high.data || !sc->tsdf.data)) || (stage == ADFP_STAGE_COLOR && !sc->color.data)) return ADFP_E_ARG;
+    // the attention backward is exact-f32 only; a decoder needs its exact image or its T image (backward_points picks)
+    if (!(sc->w_low || sc->ht_low) || (stage >= ADFP_STAGE_HIGH && (!(sc->w_high || sc->ht_high) || !sc->w_att)) ||
+        (stage == ADFP_STAGE_COLOR && !(sc->w_color || sc->ht_color))) return ADFP_E_ARG;
     return 0;
 }
 

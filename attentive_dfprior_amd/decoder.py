@@ -162,13 +162,26 @@ class DF(nn.Module):
     def packed_weights(self, name, fmt='f32'):
         """Packed (MFMA operand order) image of one sub-network, rebuilt only when a parameter
         changed (optimizer step bumps Parameter._version).  fmt 'f32' = exact f32-input MFMA image,
-        'h' = f16 hi/lo split image of the forward decoders (adfp_pack_decoder_h)."""
+        'h' = f16 hi/lo split image of the forward decoders (adfp_pack_decoder_h), 'ht' = the transposed split image of
+        the f16 backward (adfp_pack_decoder_ht; decoders only)."""
         module = self.net_params(name)
         key = _version_key(module)
-        slot = name if fmt == 'f32' else name + '.h'
+        slot = name if fmt == 'f32' else name + '.' + fmt
         hit = self._packed.get(slot)
         if hit is not None and hit[0] == key:
             return hit[1]
+        if fmt == 'ht':
+            flat = _flat_params(module)
+            _lib.require_cuda(flat, f'{name} decoder parameters')
+            L = lib()
+            dev = flat.device
+            with torch.cuda.device(dev):
+                kind = _lib.DEC_KIND[name]
+                packed = torch.empty(L.adfp_decoder_packed_ht_words(kind), dtype=torch.int32, device=dev)
+                _lib.check(L.adfp_pack_decoder_ht(kind, _lib.ptr(flat), _lib.ptr(packed), _lib.status_ptr(), _lib.current_stream(dev)),
+                           'adfp_pack_decoder_ht')
+            self._packed[slot] = (key, packed)
+            return packed
         if fmt == 'h':
             flat = _flat_params(module)
             _lib.require_cuda(flat, f'{name} decoder parameters')

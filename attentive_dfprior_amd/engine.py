@@ -82,9 +82,10 @@ class Engine(object):
         return dst
 
     # ---- descriptor ----------------------------------------------------------------------
-    def scene(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=False):
+    def scene(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=False, ht_nets=()):
         """Returns (AdfpScene, keepalive list).  The forward takes the f16-split decoder images unless
-        ADFP_MATH=f32; the backward always takes the exact f32 images."""
+        ADFP_MATH=f32.  The backward takes the exact f32 images, except for the decoders named in `ht_nets`: those get
+        their transposed f16-split image (the caller has checked that the forward left their ReLU masks)."""
         use_h = (not backward) and math_mode() == 'f16x3'
         _lib.check_status()                      # an f16-range violation of an EARLIER call surfaces here
         sc = _lib.AdfpScene()
@@ -104,6 +105,8 @@ class Engine(object):
             gd.Z, gd.Y, gd.X = g.shape[0], g.shape[1], g.shape[2]
         if use_h:
             sc.h_low = decoders.packed_weights('low', 'h').data_ptr()
+        elif 'low' in ht_nets:
+            sc.ht_low = decoders.packed_weights('low', 'ht').data_ptr()
         else:
             sc.w_low = decoders.packed_weights('low').data_ptr()
         if stage != 'low':
@@ -111,16 +114,54 @@ class Engine(object):
                 sc.h_high = decoders.packed_weights('high', 'h').data_ptr()
                 sc.h_att = decoders.packed_weights('att', 'h').data_ptr()
             else:
-                sc.w_high = decoders.packed_weights('high').data_ptr()
+                if 'high' in ht_nets:
+                    sc.ht_high = decoders.packed_weights('high', 'ht').data_ptr()
+                else:
+                    sc.w_high = decoders.packed_weights('high').data_ptr()
                 sc.w_att = decoders.packed_weights('att').data_ptr()
             _lib.fill_bound(sc.tsdf_bnds, self.host_bound(tsdf_bnds, 'tsdf_bnds'))
             self.fill_tsdf(sc.tsdf, tsdf_volume, keep)
         if stage == 'color':
             if use_h:
                 sc.h_color = decoders.packed_weights('color', 'h').data_ptr()
+            elif 'color' in ht_nets:
+                sc.ht_color = decoders.packed_weights('color', 'ht').data_ptr()
             else:
                 sc.w_color = decoders.packed_weights('color').data_ptr()
         return sc, keep
+
+    # ---- training state --------------------------------------------------------------------
+    @staticmethod
+    def train_state(P, stage, dev, decoders, need_flat=None):
+        """The caller-owned buffers a training forward leaves for the backward (adfp_train_state): always the TSDF stage's
+        flags / in-band list / attention inputs; in f16x3 mode also the ReLU masks of every decoder of the stage and, for a
+        decoder whose parameter gradient will be asked for (need_flat[name], default: any of its parameters requires
+        grad), its layer inputs -- with those the backward runs on f16 MFMA and recomputes nothing."""
+        bufs = dict(flags=torch.empty((P,), dtype=torch.uint8, device=dev), list=torch.empty((P,), dtype=torch.int32, device=dev),
+                    counter=torch.empty((4,), dtype=torch.int32, device=dev),          # zeroed by the library (a kernel)
+                    att_occ=torch.empty((P,), dtype=torch.float32, device=dev), att_u=torch.empty((P,), dtype=torch.float32, device=dev))
+        st = _lib.AdfpTrainState()
+        for k in ('flags', 'list', 'counter', 'att_occ', 'att_u'):
+            setattr(st, k, bufs[k].data_ptr())
+        if math_mode() == 'f16x3':
+            nets = ['low'] + (['high'] if stage != 'low' else []) + (['color'] if stage == 'color' else [])
+            for n in nets:
+                bufs['masks_' + n] = torch.empty((P, _lib.TRAIN_MASK_WORDS), dtype=torch.int32, device=dev)
+                setattr(st, 'masks_' + n, bufs['masks_' + n].data_ptr())
+                want = need_flat.get(n) if need_flat is not None else any(p.requires_grad for p in decoders.net_params(n))
+                if want:
+                    bufs['act_' + n] = torch.empty((P, lib().adfp_train_act_floats(_lib.DEC_KIND[n])), dtype=torch.float32, device=dev)
+                    setattr(st, 'act_' + n, bufs['act_' + n].data_ptr())
+        bufs['_state'] = st
+        return bufs
+
+    @staticmethod
+    def ht_nets(saved, need_flat, need_pos):
+        """Decoders whose backward can run f16-split: the forward left their masks, no position / ray gradient is wanted, and
+        their layer inputs are there if their parameter gradient is."""
+        if need_pos:
+            return ()
+        return tuple(n for n in ('low', 'high', 'color') if ('masks_' + n) in saved and (not need_flat.get(n) or ('act_' + n) in saved))
 
     @staticmethod
     def fill_tsdf(td, tsdf_volume, keep):
@@ -147,7 +188,8 @@ class Engine(object):
         raw, w, _ = self.eval_points_forward(decoders, pts, c, tsdf_volume, tsdf_bnds, bound, stage, apply_bound_rule)
         return raw, w
 
-    def eval_points_forward(self, decoders, pts, c, tsdf_volume, tsdf_bnds, bound, stage, apply_bound_rule=True, train=False):
+    def eval_points_forward(self, decoders, pts, c, tsdf_volume, tsdf_bnds, bound, stage, apply_bound_rule=True, train=False,
+                            need_flat=None):
         dev = pts.device
         saved = None
         with torch.cuda.device(dev):
@@ -171,13 +213,9 @@ class Engine(object):
             ws = self.workspace(P, dev)
             st = None
             if train:
-                saved = dict(pts=pts, mode=mode, flags=torch.empty((P,), dtype=torch.uint8, device=dev),
-                             list=torch.empty((P,), dtype=torch.int32, device=dev), counter=torch.empty((4,), dtype=torch.int32, device=dev),
-                             att_occ=torch.empty((P,), dtype=torch.float32, device=dev), att_u=torch.empty((P,), dtype=torch.float32, device=dev))
-                st = _lib.AdfpTrainState()
-                st.flags, st.list, st.counter = saved['flags'].data_ptr(), saved['list'].data_ptr(), saved['counter'].data_ptr()
-                st.att_occ, st.att_u = saved['att_occ'].data_ptr(), saved['att_u'].data_ptr()
-                saved['_state'] = st
+                saved = self.train_state(P, stage, dev, decoders, need_flat)
+                saved.update(pts=pts, mode=mode)
+                st = saved['_state']
             check(lib().adfp_eval_points_train(C.byref(sc), C.byref(ap), _lib.STAGE[stage], 1 if apply_bound_rule else 0,
                                                ptr(raw), ptr(w), ptr(ws), ws.numel(), C.byref(st) if st is not None else None,
                                                _lib.current_stream(dev)), 'adfp_eval_points')
@@ -191,7 +229,8 @@ class Engine(object):
         L = lib()
         with torch.cuda.device(dev):
             P = pts.shape[0]
-            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=True)
+            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=True,
+                                  ht_nets=self.ht_nets(saved, need_flat, need_pts))
             ap = _lib.AdfpPoints()
             ap.mode, ap.n_points, ap.pts = saved['mode'], P, pts.data_ptr()
             a = _lib.AdfpPointsBackwardArgs()
@@ -254,7 +293,7 @@ class Engine(object):
     # ---- a4..a13 ---------------------------------------------------------------------------
     def render_forward(self, decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage,
                        n_samples, n_surface, lindisp=False, perturb=0.0, t_rand=None, depth_max=None,
-                       want_aux=False, train=False):
+                       want_aux=False, train=False, need_flat=None):
         _lib.require_cuda(rays_o, 'rays_o')
         dev = rays_o.device
         with torch.cuda.device(dev):
@@ -300,18 +339,9 @@ class Engine(object):
                 a.raw = aux['raw'].data_ptr()
             if train:
                 # buffers the backward reads after this call returns (never the shared workspace)
-                P = N * S
-                aux.update(flags=torch.empty((P,), dtype=torch.uint8, device=dev),
-                           list=torch.empty((P,), dtype=torch.int32, device=dev),
-                           counter=torch.empty((4,), dtype=torch.int32, device=dev),     # zeroed by the library (a kernel)
-                           att_occ=torch.empty((P,), dtype=torch.float32, device=dev),
-                           att_u=torch.empty((P,), dtype=torch.float32, device=dev),
-                           rays_o=ro, rays_d=rd, S=S)
-                st = _lib.AdfpTrainState()
-                st.flags, st.list, st.counter = aux['flags'].data_ptr(), aux['list'].data_ptr(), aux['counter'].data_ptr()
-                st.att_occ, st.att_u = aux['att_occ'].data_ptr(), aux['att_u'].data_ptr()
-                aux['_state'] = st
-                a.state = C.pointer(st)
+                aux.update(self.train_state(N * S, stage, dev, decoders, need_flat))
+                aux.update(rays_o=ro, rays_d=rd, S=S)
+                a.state = C.pointer(aux['_state'])
             ws = self.workspace(N * S, dev)
             a.workspace = ws.data_ptr()
             a.workspace_bytes = ws.numel()
@@ -330,7 +360,8 @@ class Engine(object):
         L = lib()
         with torch.cuda.device(dev):
             N, S = ro.shape[0], saved['S']
-            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=True)
+            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=True,
+                                  ht_nets=self.ht_nets(saved, need_flat, need_rays))
             a = _lib.AdfpBackwardArgs()
             a.stage = _lib.STAGE[stage]
             a.n_rays, a.S = N, S

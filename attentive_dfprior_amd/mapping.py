@@ -262,9 +262,12 @@ class MapperIteration(object):
         if self.distributed:
             import torch.distributed as tdist
             tdist.all_reduce(dmax, op=tdist.ReduceOp.MAX, group=self.group)       # the far clamp sees the whole batch (Renderer.py:159)
+        used = {'low': ('low',), 'high': ('low', 'high', 'att'), 'color': ('low', 'high', 'color', 'att')}[stage]
+        need_grid = {k: (k in used) for k in ('low', 'high', 'color')}
+        need_flat = {n: (n in used and n in self.nets) for n in ('low', 'high', 'color', 'att')}
         depth, unc, color, weight, aux = eng.render_forward(dec, self.c, ro, rd, gd, self.tsdf, self.tsdf_bnds, rend.bound, stage,
                                                             rend.N_samples, rend.N_surface, rend.lindisp, rend.perturb, None, dmax,
-                                                            train=True)
+                                                            train=True, need_flat=need_flat)
         S = aux['S']
         la = _lib.AdfpLossArgs()
         la.n_rays, la.S, la.stage, la.warmup, la.w_color_loss = N, S, _lib.STAGE[stage], 1 if warmup else 0, self.w_color
@@ -277,9 +280,6 @@ class MapperIteration(object):
         la.loss, la.g_depth, la.g_color = self.loss.data_ptr(), g_depth.data_ptr(), g_color.data_ptr()
         la.g_weight = g_weight.data_ptr() if warmup else None
         check(L.adfp_mapper_loss(C.byref(la), st), 'adfp_mapper_loss')
-        used = {'low': ('low',), 'high': ('low', 'high', 'att'), 'color': ('low', 'high', 'color', 'att')}[stage]
-        need_grid = {k: (k in used) for k in ('low', 'high', 'color')}
-        need_flat = {n: (n in used and n in self.nets) for n in ('low', 'high', 'color', 'att')}
         out_grids, out_flats, end = {}, {}, 0
         for kind, name, key, off, n in self._bucket_layout:
             view = self.bucket[off:off + n]

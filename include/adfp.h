@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 110
+#define ADFP_VERSION 111
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -84,6 +84,13 @@ typedef struct adfp_scene {
     const void* h_high;
     const void* h_color;
     const void* h_att;        /* adfp_pack_attention_h */
+    /* optional "T" images (adfp_pack_decoder_ht: the transposed weights as f16 hi/lo halves).  With them, and with the ReLU
+     * masks the training forward left in adfp_train_state, the decoder BACKWARD runs on f16 MFMA with the same 3-product
+     * split and recomputes nothing; NULL (or no masks, or a ray / point gradient requested) = the exact f32 backward from
+     * w_*. */
+    const void* ht_low;
+    const void* ht_high;
+    const void* ht_color;
     /* Sticky status word the kernels OR into (system-scope atomic): device memory or device-visible pinned
      * host memory, NULL = none.  ADFP_STATUS_F16_RANGE: an operand of the f16-split decoders (a weight, a grid
      * feature or a hidden activation) reached |x| >= 65504, which the split cannot represent -- the outputs
@@ -122,6 +129,9 @@ int adfp_pack_decoder(int kind, const float* flat, float* packed, void* stream);
  * status (may be NULL): as adfp_scene.status -- ADFP_STATUS_F16_RANGE is raised for a weight with |w| >= 65504. */
 long long adfp_decoder_packed_h_words(int kind);
 int adfp_pack_decoder_h(int kind, const float* flat, void* packed, int* status, void* stream);
+/* -> "T" image for the f16-split backward, adfp_decoder_packed_ht_words(kind) 32-bit words */
+long long adfp_decoder_packed_ht_words(int kind);
+int adfp_pack_decoder_ht(int kind, const float* flat, void* packed, int* status, void* stream);
 long long adfp_attention_packed_h_words(void);
 int adfp_pack_attention_h(const float* flat, void* packed, int* status, void* stream);
 /* mlp_tsdf parameters (decoder.py:206-258) */
@@ -187,14 +197,26 @@ int adfp_composite(const float* raw /*[N,S,4]*/, const double* z_vals /*[N,S]*/,
                    float* weights /*[N,S] or NULL*/, void* stream);
 
 /* Buffers the backward needs from the forward (training only).  Caller-owned, sized for P points:
- * flags P bytes, list P ints, counter >= 4 bytes, att_occ / att_u P floats. */
+ * flags P bytes, list P ints, counter >= 4 bytes, att_occ / att_u P floats.
+ * Optional, for the f16-split backward (scene->h_* and ->ht_* set; any of them may be NULL = exact backward for that
+ * decoder): masks_* = ADFP_TRAIN_MASK_WORDS 32-bit words per point, the ReLU masks of the decoder's five layers;
+ * act_* = adfp_train_act_floats(kind) floats per point, the inputs of every layer (position, Fourier features, grid
+ * features, h_0..h_4) -- only needed when that decoder's parameter gradient (g_flat_*) will be requested. */
+#define ADFP_TRAIN_MASK_WORDS 6
 typedef struct adfp_train_state {
     unsigned char* flags;
     int* list;
     int* counter;
     float* att_occ;
     float* att_u;
+    unsigned* masks_low;
+    unsigned* masks_high;
+    unsigned* masks_color;
+    float* act_low;
+    float* act_high;
+    float* act_color;
 } adfp_train_state;
+long long adfp_train_act_floats(int kind);
 
 /* ---- a4..a13 in one call: Renderer.render_batch_ray (Renderer.py:110-255) ------------- */
 typedef struct adfp_render_args {

@@ -83,15 +83,25 @@ def assert_close(a, b, tol, what):
                            f'max abs diff {(a - b).abs().max().item():.3e}, scale {scale.item():.3e}')
 
 
-def assert_close_scale(a, b, tol, what):
+def assert_close_scale(a, b, tol, what, flip_frac=0.0, flip_tol=2e-3):
     """|a-b| <= tol * max|b|: for sums over ~1e5 points (gradients), whose small elements carry the summation-order noise of the
-    large ones (float atomics, a different reduction tree than torch's)."""
+    large ones (float atomics, a different reduction tree than torch's).
+
+    flip_frac > 0 (the f16-split backward, ADFP_MATH=f16x3): that backward takes its ReLU masks from the f16-split forward,
+    whose pre-activations differ from torch's by ~1e-6; a unit that lies that close to zero takes the other branch, and that
+    ONE sample's contribution appears in / vanishes from the unit's row of the weight gradient (measured against the exact
+    backward: every other row agrees to 3e-7, tools/diag_bwd.py) and, through W^T, nudges the earlier layers' rows.  Up to
+    `flip_frac` of a tensor's elements may then deviate by up to `flip_tol` x scale; a layout or indexing bug is off by
+    O(1) x scale and still fails.  The exact mode (ADFP_MATH=f32) is held to `tol` on every element."""
     a = torch.as_tensor(a).double().cpu()
     b = torch.as_tensor(b).double().cpu()
     assert a.shape == b.shape, f'{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}'
     scale = b.abs().max().clamp_min(1e-30)
-    err = (a - b).abs().max()
-    assert err <= tol * scale, f'{what}: max abs diff {err.item():.3e} > {tol} x scale {scale.item():.3e}'
+    err = (a - b).abs()
+    bad = err > tol * scale + 1e-9
+    frac = float(bad.double().mean())
+    assert frac <= flip_frac, f'{what}: {frac:.2e} of the elements differ by more than {tol} x scale {scale.item():.3e} (max {err.max().item():.3e})'
+    assert err.max() <= flip_tol * scale + 1e-9, f'{what}: max abs diff {err.max().item():.3e} > {flip_tol} x scale {scale.item():.3e}'
 
 
 def assert_adam_trajectory(a, b, lr, steps, what, tol=2e-4, max_outliers=2e-3):
@@ -104,5 +114,6 @@ def assert_adam_trajectory(a, b, lr, steps, what, tol=2e-4, max_outliers=2e-3):
     diff = (a - b).abs()
     bad = diff > tol * (b.abs() + 0.1 * scale)
     frac = float(bad.double().mean())
-    assert frac <= max_outliers, f'{what}: {frac:.2e} of the elements left the trajectory'
+    allowed = max(max_outliers, 4.0 / max(a.numel(), 1))          # a small tensor: a handful of elements, not a fraction
+    assert frac <= allowed, f'{what}: {frac:.2e} of the elements left the trajectory'
     assert float(diff.max()) <= 2.0 * lr * steps + 1e-6, f'{what}: an element moved {float(diff.max()):.3e}, more than {steps} Adam steps of lr {lr} allow'
