@@ -12,6 +12,31 @@
 #pragma once
 #include "adfp_device.h"
 
+// Global power-of-two scale of the staged gradient blocks.  k_outer_h multiplies staged gradients by staged activations on f16
+// MFMA; a cotangent is a small number and an f16 half below 6e-5 is subnormal, so the G part of the staging rows is written
+// multiplied by S = 2^k with k chosen from the largest |cotangent of raw| of the call (*gmax, an atomic max of float bits
+// filled by k_composite_bwd / k_evalpts_bwd_prep) such that this maximum lands in [64, 128): ten binades of headroom for what
+// the transposed chains add, and a row 2^-20 below the largest still splits into normal halves.  Undone exactly when the
+// per-workgroup partial sums are reduced (k_reduce_partials).
+ADFP_DEV float grad_scale(const float* gmax) {
+    if (!gmax) return 1.f;
+    const unsigned e = (__float_as_uint(*gmax) >> 23) & 0xFFu;
+    if (e == 0u) return 1.f;
+    int se = 127 + 6 + 127 - (int)e;
+    se = se < 1 ? 1 : (se > 253 ? 253 : se);
+    return __uint_as_float((unsigned)se << 23);
+}
+
+// a staged block multiplied by a (power-of-two) factor
+template <typename VT>
+ADFP_DEV void stage_block_mul(float* __restrict__ row, int col, int h, const VT& v, const int voff, float s) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 t = {v[voff + 4 * q + 0] * s, v[voff + 4 * q + 1] * s, v[voff + 4 * q + 2] * s, v[voff + 4 * q + 3] * s};
+        *(f32x4*)(row + col + 8 * q + 4 * h) = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // composite backward.  One wave per ray, lane = sample, up to 4 chunks of 64 samples.
 //   w_s = a_s T_s, T_s = prod_{j<s} f_j, f = 1 - a + 1e-10, a = sigmoid(10 occ)
@@ -22,12 +47,13 @@
 __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__ raw, const double* __restrict__ z, int n_rays, int S,
                                                        const double* __restrict__ g_depth, const double* __restrict__ g_var,
                                                        const float* __restrict__ g_color, float* __restrict__ g_raw,
-                                                       const unsigned char* __restrict__ keep) {
+                                                       const unsigned char* __restrict__ keep, float* __restrict__ gmax) {
     const int lane = threadIdx.x & 63;
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
     if (keep && !keep[ray]) {                        // a ray the pre-filter dropped: no gradient, whatever its samples hold (NaN * 0)
         for (int s = lane; s < S; s += 64) *(f32x4*)(g_raw + ((long long)ray * S + s) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (gmax && lane == 0) gmax[ray] = 0.f;
         return;
     }
     const int nc = (S + 63) >> 6;
@@ -68,6 +94,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
     float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f;
     if (g_color) { gc0 = g_color[3 * ray]; gc1 = g_color[3 * ray + 1]; gc2 = g_color[3 * ray + 2]; }
     float suffix = 0.f;          // sum of G_j w_j over later chunks
+    float mx = 0.f;              // largest |cotangent of raw| of this ray (the f16-split backward's gradient scale)
 #pragma unroll
     for (int c = CB_MAXC - 1; c >= 0; --c) {
         if (c < nc) {
@@ -90,8 +117,30 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
             if (ok) {
                 f32x4 o4 = {w[c] * gc0, w[c] * gc1, w[c] * gc2, gocc};
                 *(f32x4*)(g_raw + ((long long)ray * S + s) * 4) = o4;
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o4.x), fabsf(o4.y))), fmaxf(fabsf(o4.z), fabsf(o4.w)));
             }
         }
+    }
+    if (gmax) {                  // per-ray maximum; k_max_reduce folds them (5 000 atomics on one address cost 60 us)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (lane == 0) gmax[ray] = mx;
+    }
+}
+
+// out[0] = max(parts[0 .. n)): one workgroup
+__global__ __launch_bounds__(1024) void k_max_reduce(const float* __restrict__ parts, int n, float* __restrict__ out) {
+    __shared__ float s_m[16];
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) mx = fmaxf(mx, parts[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = s_m[0];
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, s_m[w]);
+        *out = m;
     }
 }
 
@@ -460,6 +509,7 @@ struct AttBwdArgs {
     int chunk_lo, chunk_hi;
     // PGRAD: the fused occupancy depends on the sample position through u = inv_tsdf(tsdf(p)) (decoder.py:241-248)
     PtsDev P; NormDev nt; TsdfDev t; float* g_pts;
+    const float* gmax;         // non-NULL: the staged GRADIENT blocks are multiplied by grad_scale(gmax) (for k_outer_h)
 };
 
 template <bool WGRAD, bool PGRAD>
@@ -475,6 +525,7 @@ __global__ __launch_bounds__(256) void k_attention_bwd(AttBwdArgs a) {
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
     const int cnt = *a.count_ptr;
+    const float gS = WGRAD ? grad_scale(a.gmax) : 1.f;
     const int hi = a.chunk_hi < cnt ? a.chunk_hi : cnt;
     const int count = hi - a.chunk_lo;
     const int ntiles = count > 0 ? (count + 31) >> 5 : 0;
@@ -550,14 +601,14 @@ __global__ __launch_bounds__(256) void k_attention_bwd(AttBwdArgs a) {
         const float ga0 = g_out * occ, ga1 = g_out * u + g_w;
         const float dot = a0 * ga0 + a1 * ga1;
         const float gl0 = a0 * (ga0 - dot), gl1 = a1 * (ga1 - dot);
-        if (WGRAD && valid) stage_head(srow, ST::AGL, h, f32x4{gl0, gl1, 0.f, 0.f});
+        if (WGRAD && valid) stage_head(srow, ST::AGL, h, f32x4{gl0 * gS, gl1 * gS, 0.f, 0.f});
         float gp3[32];
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             const float g = fmaf(lds[A::P_WO + (h * 2 + 0) * 32 + j], gl0, lds[A::P_WO + (h * 2 + 1) * 32 + j] * gl1);
             gp3[j] = (m3[j >> 4] >> (j & 15)) & 1u ? g : 0.f;
         }
-        if (WGRAD && valid) { stage_block(srow, ST::AG3, h, gp3, 0); stage_block(srow, ST::AG3 + 32, h, gp3, 16); }
+        if (WGRAD && valid) { stage_block_mul(srow, ST::AG3, h, gp3, 0, gS); stage_block_mul(srow, ST::AG3 + 32, h, gp3, 16, gS); }
         float gp2[64];
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) {
@@ -569,7 +620,7 @@ __global__ __launch_bounds__(256) void k_attention_bwd(AttBwdArgs a) {
                 mfma_chain_T(acc, lds + A::P_W3 + ob * A::BLK2 + ib * 4 * ADFP_SG, loT, h, gp3, 16 * ob);
 #pragma unroll
             for (int r = 0; r < 16; ++r) gp2[16 * ib + r] = (m2[ib] >> r) & 1u ? acc[r] : 0.f;
-            if (WGRAD && valid) stage_block(srow, ST::AG2 + 32 * ib, h, gp2, 16 * ib);
+            if (WGRAD && valid) stage_block_mul(srow, ST::AG2 + 32 * ib, h, gp2, 16 * ib, gS);
         }
         float gp1[64];
 #pragma unroll
@@ -582,7 +633,7 @@ __global__ __launch_bounds__(256) void k_attention_bwd(AttBwdArgs a) {
                 mfma_chain_T(acc, lds + A::P_W2 + ob * A::BLK2 + ib * 4 * ADFP_SG, loT, h, gp2, 16 * ob);
 #pragma unroll
             for (int r = 0; r < 16; ++r) gp1[16 * ib + r] = (m1[ib] >> r) & 1u ? acc[r] : 0.f;
-            if (WGRAD && valid) stage_block(srow, ST::AG1 + 32 * ib, h, gp1, 16 * ib);
+            if (WGRAD && valid) stage_block_mul(srow, ST::AG1 + 32 * ib, h, gp1, 16 * ib, gS);
         }
         float gx = 0.f, gxu = 0.f;
 #pragma unroll
@@ -600,7 +651,7 @@ __global__ __launch_bounds__(256) void k_attention_bwd(AttBwdArgs a) {
                 gx = fmaf(lds[A::P_A0 + (32 * ib + kmapH(r, h)) * 4], g0[r], gx);     // d/d occ_in through layer 0
                 if (PGRAD) gxu = fmaf(lds[A::P_A0 + (32 * ib + kmapH(r, h)) * 4 + 1], g0[r], gxu);   // d/d u
             }
-            if (WGRAD && valid) stage_block(srow, ST::AG0 + 32 * ib, h, g0);
+            if (WGRAD && valid) stage_block_mul(srow, ST::AG0 + 32 * ib, h, g0, 0, gS);
         }
         gx += __shfl_xor(gx, 32);
         const float g_in = a0 * g_out + gx;

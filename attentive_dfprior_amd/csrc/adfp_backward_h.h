@@ -12,7 +12,8 @@
 //   k_decode_bwd_h    cotangent chains  gh -> Wc_i^T gh (d/d c),  gp = mask . gh,  Wp_i^T gp (d/d h_{i-1}, d/d e)  out of
 //                     the "T" image, scatter of d/d c into the grid gradient (the shared write-combining scatter), and the
 //                     gradient blocks of the staging row (G part) for the weight gradients
-//   k_outer_lds2      k_outer_lds with its LDS tile assembled from the two row pieces (X from the forward, G from here)
+//   k_scatter_sorted  adds the d/d c rows to the grid gradient in spatial order (run-length sums in registers)
+//   k_outer_h         weight gradients on f16 MFMA from the two row pieces (X from the forward, G from here)
 //
 // d/d position (the Tracker's pose gradient) stays on the exact kernel.
 #pragma once
@@ -105,6 +106,8 @@ struct DecodeBwdHArgs {
     float* stage;              // G part of this chunk's staging rows (WGRAD) or NULL
     int chunk_lo, chunk_hi;
     int* status;
+    const float* gmax;         // see grad_scale (WGRAD)
+    float* gc_out;             // SCAT = false: [P][32] d/d c rows (row = point) for k_scatter_bins, or NULL
 };
 
 // 16 D-layout registers -> the two k-steps of a B operand
@@ -124,26 +127,33 @@ ADFP_DEV void stage_block_scaled(float* __restrict__ row, int col, int h, const 
     }
 }
 
-template <int CDIM, int NOUT, int ROLE, bool WGRAD, int NT>
+// SCAT = true: d/d c goes into the grid gradient from inside the kernel (the write-combining scatter of adfp_backward.h; the
+// scatter structures limit the workgroup to 6 waves).  SCAT = false: the kernel only writes d/d c, one 128-B row per point
+// (a.gc_out), and k_scatter_bins adds the rows to the grid gradient in spatial order -- the path the host takes whenever the
+// grid fits the binning (run_decode_bwd_h).
+template <int CDIM, int NOUT, int ROLE, bool WGRAD, bool SCAT, int NT>
 __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
     using LT = DecLayoutHT<CDIM, NOUT>;
     using ST = DecStage<CDIM>;
     constexpr int NW = NT / 64;
+    constexpr int NS = SCAT ? NW : 1;
     constexpr bool CACHE = true;
     __shared__ __attribute__((aligned(16))) unsigned ldsu[LT::P_TOTAL];
-    __shared__ float s_tr[NW][32 * 33];
-    __shared__ int s_vox[NW][32 * 8];
-    __shared__ float s_cw[NW][32 * 8];
-    __shared__ float s_cacc[NW][2][32 * 32];
-    __shared__ int s_ctag[NW][2][32];
+    __shared__ float s_tr[NS][SCAT ? 32 * 33 : 1];
+    __shared__ int s_vox[NS][SCAT ? 32 * 8 : 1];
+    __shared__ float s_cw[NS][SCAT ? 32 * 8 : 1];
+    __shared__ float s_cacc[NS][2][SCAT ? 32 * 32 : 1];
+    __shared__ int s_ctag[NS][2][SCAT ? 32 : 1];
     for (int i = threadIdx.x; i < LT::P_TOTAL / 4; i += NT) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed_t)[i];
-    for (int i = threadIdx.x; i < NW * 2 * 32 * 32; i += NT) (&s_cacc[0][0][0])[i] = 0.f;
-    for (int i = threadIdx.x; i < NW * 2 * 32; i += NT) (&s_ctag[0][0][0])[i] = -1;
+    if constexpr (SCAT) {
+        for (int i = threadIdx.x; i < NW * 2 * 32 * 32; i += NT) (&s_cacc[0][0][0])[i] = 0.f;
+        for (int i = threadIdx.x; i < NW * 2 * 32; i += NT) (&s_ctag[0][0][0])[i] = -1;
+    }
     __syncthreads();
     const float* lds = (const float*)ldsu;
 
     const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-    const ScatterSmem sm = {s_tr[wv], s_vox[wv], s_cw[wv], &s_cacc[wv][0][0], &s_ctag[wv][0][0]};
+    const ScatterSmem sm = {s_tr[SCAT ? wv : 0], s_vox[SCAT ? wv : 0], s_cw[SCAT ? wv : 0], &s_cacc[SCAT ? wv : 0][0][0], &s_ctag[SCAT ? wv : 0][0][0]};
     const int lane_off = h * 128 + p * 4;
     const int wave = blockIdx.x * NW + wv;
     const int nwaves = gridDim.x * NW;
@@ -152,6 +162,7 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
     const int count = hi - a.chunk_lo;
     const int ntiles = count > 0 ? (count + 31) >> 5 : 0;
     float amax = 0.f;
+    const float gS = WGRAD ? grad_scale(a.gmax) : 1.f;
 
     for (int tile = wave; tile < ntiles; tile += nwaves) {
         const int loc = tile * 32 + p;
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
             else if (ROLE == ROLE_COLOR) { go[0] = a.g_raw[4ll * q]; go[1] = a.g_raw[4ll * q + 1]; go[2] = a.g_raw[4ll * q + 2]; }
             else go[0] = a.att_g[idx];
         }
-        if (WGRAD && valid) stage_head(srow, ST::SGO, h, f32x4{go[0], go[1], go[2], go[3]});
+        if (WGRAD && valid) stage_head(srow, ST::SGO, h, f32x4{go[0] * gS, go[1] * gS, go[2] * gS, go[3] * gS});
 
         // d/d h_4 = Wo^T g_out (VALU, f32)
         f32x16 gh;
@@ -207,13 +218,14 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) gh[r] *= sc;
         }
+        const float ssc = WGRAD ? isc * gS : 1.f;            // staged gradient blocks carry the global scale S
         f32x16 gc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) gc[r] = 0.f;
 
 #pragma unroll
         for (int i = 4; i >= 0; --i) {
-            if (WGRAD && valid) stage_block_scaled(srow, ST::SGH(i), h, gh, isc);
+            if (WGRAD && valid) stage_block_scaled(srow, ST::SGH(i), h, gh, ssc);
             f16x8 xh[2], xl[2];
             // through fc_c[i]: d/d c += Wc_i^T gh
             split16(gh, xh, xl, amax);
@@ -225,7 +237,7 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
                 const int keep = ((int)(mk[i] << (16 + r))) >> 31;                   // v_bfe_i32: -1 where unit r was active
                 gp[r] = __uint_as_float(__float_as_uint(gh[r]) & (unsigned)keep);
             }
-            if (WGRAD && valid) stage_block_scaled(srow, ST::SGP(i), h, gp, isc);
+            if (WGRAD && valid) stage_block_scaled(srow, ST::SGP(i), h, gp, ssc);
             if (i == 0 && !WGRAD) break;                                              // layer 0 only feeds d/d e
             split16(gp, xh, xl, amax);                                                // |gp| <= |gh|: already range-checked
             if constexpr (WGRAD) {
@@ -259,7 +271,7 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
                         for (int r = 0; r < 16; ++r) {
                             const f32x4 bm = *(const f32x4*)(lds + LT::P_BM + (32 * b + kmapH(r, h)) * 4);
                             const float arg = fmaf(pf[2], bm.z, fmaf(pf[1], bm.y, pf[0] * bm.x));
-                            ge[r] = (ge[r] * isc) * __builtin_amdgcn_cosf(adfp_turns(arg));
+                            ge[r] = (ge[r] * ssc) * __builtin_amdgcn_cosf(adfp_turns(arg));
                         }
                         if (valid) stage_block(srow, ST::SGA + 32 * b, h, ge);
                     }
@@ -273,30 +285,156 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
                 gh = gn;
             }
         }
-#ifdef ADFP_EXP_NOSCATTER      // timing experiment only (wrong grid gradients): the kernel without its scatter
-        if (a.g_grid && gc[0] == 12345.f) a.g_grid[lane] = gc[1];
-#else
-        if (a.g_grid) {
+        if constexpr (SCAT) {
+            if (a.g_grid) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gc[r] *= isc;
-            scatter_tile<CACHE>(a.g_grid, a.g0, pn, valid, gc, lane, sm);
+                for (int r = 0; r < 16; ++r) gc[r] *= isc;
+                scatter_tile<CACHE>(a.g_grid, a.g0, pn, valid, gc, lane, sm);
+            }
+        } else {
+            if (a.gc_out && valid) stage_block_scaled(a.gc_out + 32ll * q, 0, h, gc, isc);
         }
-#endif
     }
-    if (a.g_grid) scatter_flush<CACHE>(a.g_grid, lane, sm);
+    if constexpr (SCAT) { if (a.g_grid) scatter_flush<CACHE>(a.g_grid, lane, sm); }
     report_range(a.status, amax);
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_outer_lds with the rows in two pieces: X part (columns [0, nx), row pitch nx, indexed by ABSOLUTE row = chunk_lo + m,
-// written by the training forward) and G part (columns [nx, ncols), row pitch ncols - nx, indexed by the row inside the
-// chunk).  Each of the 8 waves brings in two of the tile's 16 rows; the job table and everything after the tile is in LDS
-// are k_outer_lds's.
+// Grid-gradient scatter in spatial order.  Float atomics to the memory-side L2 run at ~325 G lane-adds/s chip-wide, and the
+// in-kernel write-combining cache (32 lines per half wave, points in ray order) still sends 40-60 % of the 8 corner lines per
+// point there: 150-190 us per grid for a 5 000-ray x 64-sample iteration, five times what the cotangent chains cost.  A camera
+// frustum is a small part of the scene -- 320 000 sample points fall into ~8 000 cells of the finest grid -- so:
+//
+//   k_bin_keys + radix sort     the points ordered by the Morton code of the reference (finest) grid's cell they fall in
+//   k_scatter_sorted            every half wave walks 64 consecutive sorted points, lane = channel, and sums the 8 corner
+//                               contributions in REGISTERS for as long as the cell (of the grid being scattered) stays the
+//                               same; a run ends in 8 line-atomics.  ~40 points share a cell on average: a few per cent of
+//                               the atomics, and nothing goes through LDS atomics (ds_add_f32 measured at ~170 cycles per
+//                               64-lane instruction here, which made an LDS-accumulator variant slower than the cache).
 // ---------------------------------------------------------------------------------------------
-struct Outer2Args { OuterArgs o; const float* act; int nx; };
-__global__ __launch_bounds__(512) void k_outer_lds2(Outer2Args b) {
+#define ADFP_BIN_MAXBITS 8            // cells per axis <= 256: 24-bit keys
+__host__ __device__ inline unsigned morton_spread(unsigned v) {       // 8 bits -> every third bit
+    v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+struct BinArgs {
+    PtsDev P; NormDev nb;
+    int RX, RY, RZ;            // dims of the reference (finest) grid
+    int* key; int* val;        // out: Morton cell id and point id of every point (the radix sort's input)
+};
+ADFP_DEV int cell_axis(float pn, int size) {                 // i0 of tri_axis
+    float c = ((pn + 1.f) / 2.f) * (float)(size - 1);
+    c = fminf(fmaxf(c, 0.f), (float)(size - 1));
+    const int i0 = (int)floorf(c);
+    return i0 < 0 ? 0 : i0;
+}
+__global__ __launch_bounds__(256) void k_bin_keys(BinArgs a) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.P.n) return;
+    double pt[3]; float pn[3];
+    load_point(a.P, q, pt);
+    normalize3(a.nb, pt, pn);
+    a.key[q] = (int)(morton_spread(cell_axis(pn[0], a.RX)) | (morton_spread(cell_axis(pn[1], a.RY)) << 1) | (morton_spread(cell_axis(pn[2], a.RZ)) << 2));
+    a.val[q] = q;
+}
+
+struct ScatterSortedArgs {
+    PtsDev P; NormDev nb;
+    GridDev g;                 // the grid whose gradient is scattered (dims)
+    const float* gc;           // [P][32] d/d c rows
+    float* g_grid;
+    const int* perm; int n;    // the points in sorted order
+    const unsigned char* flags; unsigned flag_mask;      // HIGH: only points with (flags[q] & flag_mask) carry a row
+};
+#define ADFP_SCAT_PW 128              // sorted points per wave (64 per half)
+__global__ __launch_bounds__(256) void k_scatter_sorted(ScatterSortedArgs a) {
+    __shared__ int s_q[4][ADFP_SCAT_PW];
+    __shared__ int s_cell[4][ADFP_SCAT_PW];       // x0 | y0 << 10 | z0 << 20
+    __shared__ float s_w[4][ADFP_SCAT_PW][6];     // wx0, wx1, wy0, wy1, wz0, wz1 (tri_axis)
+    const int lane = threadIdx.x & 63, ch = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+    const int w0 = (blockIdx.x * 4 + wv) * ADFP_SCAT_PW;
+    if (w0 >= a.n) return;
+    // ---- phase A: one lane per point -> cell and weights
+#pragma unroll
+    for (int b = 0; b < ADFP_SCAT_PW / 64; ++b) {
+        const int i = w0 + 64 * b + lane;
+        int q = -1, cell = -1;
+        float w[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (i < a.n) {
+            q = a.perm[i];
+            if (a.flags && !(a.flags[q] & a.flag_mask)) q = -1;
+        }
+        if (q >= 0) {
+            double pt[3]; float pn[3];
+            load_point(a.P, q, pt);
+            normalize3(a.nb, pt, pn);
+            int x0, y0, z0, x1, y1, z1;
+            tri_axis(pn[0], a.g.X, x0, x1, w[0], w[1]);
+            tri_axis(pn[1], a.g.Y, y0, y1, w[2], w[3]);
+            tri_axis(pn[2], a.g.Z, z0, z1, w[4], w[5]);
+            cell = x0 | (y0 << 10) | (z0 << 20);
+        }
+        s_q[wv][64 * b + lane] = q; s_cell[wv][64 * b + lane] = cell;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_w[wv][64 * b + lane][k] = w[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- phase B: half h walks its 64 points; lane = channel; a run of points in one cell is summed in registers
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int cur = -1;
+    auto flush = [&]() {
+        if (cur < 0) return;
+        const int x0 = cur & 1023, y0 = (cur >> 10) & 1023, z0 = cur >> 20;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (acc[k] != 0.f) {                   // a far-face corner (clamped onto its neighbour) has weight 0: never set
+                const int x = x0 + (k & 1), y = y0 + ((k >> 1) & 1), z = z0 + (k >> 2);
+                atomicAdd(a.g_grid + ((long long)(z * a.g.Y + y) * a.g.X + x) * 32 + ch, acc[k]);
+            }
+            acc[k] = 0.f;
+        }
+    };
+    for (int j0 = 0; j0 < 64; j0 += 16) {
+        float gv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {             // the rows of the next 16 points, fetched together
+            const int q = s_q[wv][64 * h + j0 + j];
+            gv[j] = q >= 0 ? a.gc[32ll * q + ch] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int pi = 64 * h + j0 + j;
+            const float g = gv[j];
+            const unsigned long long nz = __ballot(g != 0.f);
+            if ((unsigned)(nz >> (32 * h)) == 0u) continue;       // no gradient from this point (a dropped ray, a point outside the band)
+            const int cell = s_cell[wv][pi];
+            if (cell != cur) { flush(); cur = cell; }
+            float w6[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) w6[k] = s_w[wv][pi][k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += g * ((w6[k & 1] * w6[2 + ((k >> 1) & 1)]) * w6[4 + (k >> 2)]);
+        }
+    }
+    flush();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradients on f16 MFMA: k_outer_lds's job table and per-workgroup partial sums, with the 16-row tile turned into
+// MFMA operands ONCE per tile instead of being read row by row as f32 operands (8 x v_mfma_f32_32x32x2_f32 = 512 cycles per
+// job and tile; here 3 x v_mfma_f32_32x32x16_f16 = 96).  An f16 operand is 8 consecutive k per lane and k = the tile's rows, so
+// after the coalesced f32 stash every thread takes whole COLUMNS of the tile (16 rows each), splits them into hi / lo halves
+// and writes them k-major -- [hi|lo][rows 0-7 | 8-15][column][8 halves], the k-step layout of the H image, so that an operand
+// is one conflict-free ds_read_b128.  The rows come in two pieces (X part from the training forward, indexed by the absolute
+// row; G part from k_decode_bwd_h, scaled by S = grad_scale) or, with act = NULL, as whole rows (the attention network).
+// ---------------------------------------------------------------------------------------------
+struct OuterHArgs { OuterArgs o; const float* act; int nx; int* status; };
+__global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
     const OuterArgs& a = b.o;
-    __shared__ __attribute__((aligned(16))) float sm[2 * OUTER_RT * OUTER_MAXCOLS];
+    __shared__ __attribute__((aligned(16))) float sf[OUTER_RT * OUTER_MAXCOLS];                 // the tile, f32, row-major
+    __shared__ __attribute__((aligned(16))) unsigned st[4 * OUTER_MAXCOLS * 4];                   // the tile as operands
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
     int hi = a.chunk_hi;
     if (a.count_ptr) { const int cnt = *a.count_ptr; hi = hi < cnt ? hi : cnt; }
@@ -304,7 +442,8 @@ __global__ __launch_bounds__(512) void k_outer_lds2(Outer2Args b) {
     const int m0 = blockIdx.x * a.rows_per_wave;          // rows per WORKGROUP
     if (m0 >= rows) return;
     const int m1 = (m0 + a.rows_per_wave < rows) ? m0 + a.rows_per_wave : rows;
-    const int nc = a.ncols, nx4 = b.nx / 4, ng4 = (nc - b.nx) / 4;
+    const int nc = a.ncols;
+    const int nx4 = b.act ? b.nx / 4 : 0, ng4 = (nc - (b.act ? b.nx : 0)) / 4;
     f32x16 acc[OUTER_JW];
 #pragma unroll
     for (int j = 0; j < OUTER_JW; ++j)
@@ -317,54 +456,66 @@ __global__ __launch_bounds__(512) void k_outer_lds2(Outer2Args b) {
         ca[j] = job < a.njobs ? a.jobs[job].colA + i : -1;
         cb[j] = job < a.njobs ? a.jobs[job].colB + i : -1;
     }
-    f32x4 ld[2][4];                                        // this wave's two rows: X pieces lane, lane + 64; G pieces likewise
+    f32x4 ld[2][6];                                        // this wave's two rows: X pieces lane, lane + 64; G pieces lane + 64 k
     auto fetch = [&](int row0) {
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int m = row0 + 2 * wv + rr;
             const bool ok = m < m1;
             const f32x4* sx = (const f32x4*)(b.act + (long long)(a.chunk_lo + m) * b.nx);
-            const f32x4* sg = (const f32x4*)(a.stage + (long long)m * (nc - b.nx));
+            const f32x4* sg = (const f32x4*)(a.stage + (long long)m * (ng4 * 4));
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int e = lane + 64 * k;
                 ld[rr][k] = (ok && e < nx4) ? sx[e] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = lane + 64 * k;
                 ld[rr][2 + k] = (ok && e < ng4) ? sg[e] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            f32x4* dst = (f32x4*)(sm + buf * OUTER_RT * OUTER_MAXCOLS + (2 * wv + rr) * nc);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int e = lane + 64 * k;
-                if (e < nx4) dst[e] = ld[rr][k];
-                if (e < ng4) dst[nx4 + e] = ld[rr][2 + k];
-            }
-        }
-    };
+    float amax = 0.f;
     fetch(m0);
-    stash(0);
-    int buf = 0;
-    for (int m = m0; m < m1; m += OUTER_RT, buf ^= 1) {
-        const bool more = m + OUTER_RT < m1;
-        if (more) fetch(m + OUTER_RT);
+    for (int m = m0; m < m1; m += OUTER_RT) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {                   // registers -> f32 tile
+            f32x4* dst = (f32x4*)(sf + (2 * wv + rr) * nc);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { const int e = lane + 64 * k; if (e < nx4) dst[e] = ld[rr][k]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int e = lane + 64 * k; if (e < ng4) dst[nx4 + e] = ld[rr][2 + k]; }
+        }
+        __syncthreads();                                   // tile complete; everyone is done with the previous operands
+        if (m + OUTER_RT < m1) fetch(m + OUTER_RT);        // in flight during the conversion and the MFMAs
+        for (int c = threadIdx.x; c < nc; c += 512) {      // columns -> k-major hi / lo halves
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = sf[r * nc + c];
+            f16x8 xh, xl;
+            split8(v, xh, xl, amax);
+            *(u32x4*)(st + ((0 * nc) + c) * 4) = __builtin_bit_cast(u32x4, xh);
+            *(u32x4*)(st + ((2 * nc) + c) * 4) = __builtin_bit_cast(u32x4, xl);
+            split8(v + 8, xh, xl, amax);
+            *(u32x4*)(st + ((1 * nc) + c) * 4) = __builtin_bit_cast(u32x4, xh);
+            *(u32x4*)(st + ((3 * nc) + c) * 4) = __builtin_bit_cast(u32x4, xl);
+        }
         __syncthreads();
-        const float* t = sm + buf * OUTER_RT * OUTER_MAXCOLS;
 #pragma unroll
         for (int j = 0; j < OUTER_JW; ++j) {
             if (ca[j] >= 0) {
-#pragma unroll
-                for (int s = 0; s < OUTER_RT / 2; ++s) {
-                    const float va = t[(2 * s + h) * nc + ca[j]], vb = t[(2 * s + h) * nc + cb[j]];
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, vb, acc[j], 0, 0, 0);
-                }
+                const f16x8 ah = __builtin_bit_cast(f16x8, *(const u32x4*)(st + ((0 + h) * nc + ca[j]) * 4));
+                const f16x8 al = __builtin_bit_cast(f16x8, *(const u32x4*)(st + ((2 + h) * nc + ca[j]) * 4));
+                const f16x8 bh = __builtin_bit_cast(f16x8, *(const u32x4*)(st + ((0 + h) * nc + cb[j]) * 4));
+                const f16x8 bl = __builtin_bit_cast(f16x8, *(const u32x4*)(st + ((2 + h) * nc + cb[j]) * 4));
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[j], 0, 0, 0);
             }
         }
-        if (more) stash(buf ^ 1);
     }
+    report_range(b.status, amax);
     float* part = a.partial + (long long)blockIdx.x * a.part_stride;
 #pragma unroll
     for (int j = 0; j < OUTER_JW; ++j) {
@@ -381,4 +532,21 @@ __global__ __launch_bounds__(512) void k_outer_lds2(Outer2Args b) {
             }
         }
     }
+}
+
+// flat[e] += 2^-k sum over the workgroup slots of partial[slot][e]   (k_reduce_partials with the gradient scale undone)
+__global__ __launch_bounds__(256) void k_reduce_partials_scaled(const float* __restrict__ partial, int nslots, int stride, int n,
+                                                                float* __restrict__ flat, const float* __restrict__ gmax) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= nslots; k += 4) {
+        s0 += partial[(long long)k * stride + e]; s1 += partial[(long long)(k + 1) * stride + e];
+        s2 += partial[(long long)(k + 2) * stride + e]; s3 += partial[(long long)(k + 3) * stride + e];
+    }
+    for (; k < nslots; ++k) s0 += partial[(long long)k * stride + e];
+    const float S = grad_scale(gmax);
+    const float inv = __uint_as_float((254u - (__float_as_uint(S) >> 23)) << 23);      // exact reciprocal of a power of two
+    flat[e] += ((s0 + s1) + (s2 + s3)) * inv;
 }

@@ -879,6 +879,7 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
     }
 }
 
+#include <hipcub/hipcub.hpp>          // DeviceRadixSort: the points by bin id, for k_scatter_bins
 #include "adfp_backward.h"
 #include "adfp_backward_h.h"
 #include "adfp_fusion.h"
@@ -1506,7 +1507,9 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
 #define STG_ROWS_MAX 65536
 
 #define OUTER_NSLOT 256         // workgroups per weight-gradient launch = private gradient copies (one per CU)
-struct BwdWorkspace { float* g_raw; float* att_g; float* g_pts; float* stage; int stage_rows; float* partial; int part_stride; size_t bytes; };
+struct BwdWorkspace { float* g_raw; float* att_g; float* g_pts; float* stage; int stage_rows; float* partial; int part_stride; float* gmax; float* gmax_parts;
+                      float* gc; int* bin_key; int* bin_val; int* bin_key_sorted; int* bin_perm; void* sort_temp; size_t sort_temp_bytes;
+                      size_t bytes; };
 static BwdWorkspace carve_bwd(void* base, long long P) {
     BwdWorkspace w; size_t o = 0; char* b = (char*)base;
     w.g_raw = (float*)(b + o); o += align256((size_t)P * 16);
@@ -1521,6 +1524,16 @@ static BwdWorkspace carve_bwd(void* base, long long P) {
     if (AttLayout::F_TOTAL > fmax) fmax = AttLayout::F_TOTAL;
     w.part_stride = (fmax + 63) / 64 * 64;
     w.partial = (float*)(b + o); o += align256((size_t)OUTER_NSLOT * w.part_stride * 4);
+    w.gmax = (float*)(b + o); o += 256;            // largest |cotangent of raw| of the call (grad_scale)
+    w.gmax_parts = (float*)(b + o); o += align256((size_t)P * 4);     // ... per ray / per workgroup, before k_max_reduce
+    // spatially ordered grid-gradient scatter of the f16-split backward (k_scatter_bins): d/d c rows, bin keys, sorted order
+    w.gc = (float*)(b + o); o += align256((size_t)P * 128);
+    w.bin_key = (int*)(b + o); o += align256((size_t)P * 4);
+    w.bin_val = (int*)(b + o); o += align256((size_t)P * 4);
+    w.bin_key_sorted = (int*)(b + o); o += align256((size_t)P * 4);
+    w.bin_perm = (int*)(b + o); o += align256((size_t)P * 4);
+    w.sort_temp_bytes = align256((size_t)P * 16 + (4u << 20));          // upper bound; checked against the sort's own figure
+    w.sort_temp = (void*)(b + o); o += w.sort_temp_bytes;
     w.bytes = o;
     return w;
 }
@@ -1591,6 +1604,11 @@ static int outer_end(const BwdWorkspace& bw, int n_floats, float* flat, hipStrea
 #endif
     return 0;
 }
+static int outer_end_scaled(const BwdWorkspace& bw, int n_floats, float* flat, hipStream_t st) {
+    hipLaunchKernelGGL(k_reduce_partials_scaled, dim3((n_floats + 255) / 256), dim3(256), 0, st, bw.partial, OUTER_NSLOT, bw.part_stride, n_floats, flat, bw.gmax);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
 static int launch_outer(OuterArgs& oa, const BwdWorkspace& bw, const int* count_ptr, int lo, int hi, float* flat, hipStream_t st) {
     const float* stage = bw.stage;
     oa.stage = stage; oa.count_ptr = count_ptr; oa.chunk_lo = lo; oa.chunk_hi = hi; oa.flat = flat;
@@ -1641,26 +1659,42 @@ static int run_decode_bwd_p(DecodeBwdArgs a, int total, const int* count_ptr, fl
 }
 // The f16-split backward of one decoder (adfp_backward_h.h): `t` = its T image, `masks` / `act` = what the training forward
 // left.  Weight gradients: the G part of the staging rows is chunked like the exact path's rows (so that a chunk is still in
-// the Infinity Cache when k_outer_lds2 reads it back); the X part lies in `act` for all rows.
+// the Infinity Cache when k_outer_h reads it back); the X part lies in `act` for all rows.
 #define ADFP_BWDH_NT 384
+// binning of the call's points for k_scatter_bins (set up once per backward call by backward_points)
+struct BinPlan { bool ok; BinArgs args; };
+static int scatter_bins(const BinPlan& bp, const DecodeBwdArgs& o, const BwdWorkspace& bw, const unsigned char* flags, hipStream_t st) {
+    (void)bp;
+    ScatterSortedArgs s;
+    s.P = o.P; s.nb = o.nb; s.g = o.g0; s.gc = bw.gc; s.g_grid = o.g_grid; s.perm = bw.bin_perm; s.n = o.P.n; s.flags = flags; s.flag_mask = ADFP_F_BAND;
+    if (o.g0.X > 1023 || o.g0.Y > 1023 || o.g0.Z > 1023) return ADFP_E_UNSUPPORTED;          // packed cell coordinates
+    const int wgs = (o.P.n + 4 * ADFP_SCAT_PW - 1) / (4 * ADFP_SCAT_PW);
+    hipLaunchKernelGGL(k_scatter_sorted, dim3(wgs), dim3(256), 0, st, s);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int CDIM, int NOUT, int ROLE>
 static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigned* masks, const float* act, int* status, int total,
-                            const int* count_ptr, float* flat, BwdWorkspace& bw, hipStream_t st) {
+                            const int* count_ptr, float* flat, BwdWorkspace& bw, const BinPlan& bp, const unsigned char* flags, hipStream_t st) {
     if (total == 0) return 0;
-    if (o.g_grid && (long long)o.g0.X * o.g0.Y * o.g0.Z >= (1ll << 27)) return ADFP_E_UNSUPPORTED;     // scatter cache slot bits
+    const bool binned = bp.ok && o.g_grid;            // d/d c rows + k_scatter_bins instead of the in-kernel scatter
+    if (!binned && o.g_grid && (long long)o.g0.X * o.g0.Y * o.g0.Z >= (1ll << 27)) return ADFP_E_UNSUPPORTED;     // scatter cache slot bits
     DecodeBwdHArgs a;
     a.P = o.P; a.nb = o.nb; a.g0 = o.g0; a.packed_t = (const unsigned*)t; a.list = o.list; a.count_ptr = o.count_ptr;
-    a.g_raw = o.g_raw; a.att_g = o.att_g; a.masks = masks; a.g_grid = o.g_grid; a.stage = nullptr; a.status = status;
+    a.g_raw = o.g_raw; a.att_g = o.att_g; a.masks = masks; a.g_grid = o.g_grid; a.stage = nullptr; a.status = status; a.gmax = bw.gmax;
+    a.gc_out = binned ? bw.gc : nullptr;
     constexpr int NW = ADFP_BWDH_NT / 64;
     if (!flat) {
         a.chunk_lo = 0; a.chunk_hi = total;
-        hipLaunchKernelGGL((k_decode_bwd_h<CDIM, NOUT, ROLE, false, ADFP_BWDH_NT>), dim3(decode_grid((total + 31) / 32, NW, 1)), dim3(ADFP_BWDH_NT), 0, st, a);
+        if (o.g_grid && !binned) hipLaunchKernelGGL((k_decode_bwd_h<CDIM, NOUT, ROLE, false, true, ADFP_BWDH_NT>), dim3(decode_grid((total + 31) / 32, NW, 1)), dim3(ADFP_BWDH_NT), 0, st, a);
+        else hipLaunchKernelGGL((k_decode_bwd_h<CDIM, NOUT, ROLE, false, false, 512>), dim3(decode_grid((total + 31) / 32, 8, 1)), dim3(512), 0, st, a);
         ADFP_CHECK_LAUNCH();
-        return 0;
+        return binned ? scatter_bins(bp, o, bw, flags, st) : 0;
     }
     using ST = DecStage<CDIM>;
-    Outer2Args oa; decoder_jobs<CDIM, NOUT>(oa.o);
-    oa.act = act; oa.nx = ST::NX;
+    OuterHArgs oa; decoder_jobs<CDIM, NOUT>(oa.o);
+    oa.act = act; oa.nx = ST::NX; oa.status = status;
     a.stage = bw.stage;
     const int rows_cap = (int)((size_t)bw.stage_rows * AttStage::NCOLS / ST::NG);
     int rc = outer_begin(bw, DecLayout<CDIM, NOUT>::F_TOTAL, st);
@@ -1668,7 +1702,8 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
     for (int lo = 0; lo < total; lo += rows_cap) {
         const int hi = lo + rows_cap < total ? lo + rows_cap : total;
         a.chunk_lo = lo; a.chunk_hi = hi;
-        hipLaunchKernelGGL((k_decode_bwd_h<CDIM, NOUT, ROLE, true, ADFP_BWDH_NT>), dim3(decode_grid((hi - lo + 31) / 32, NW, 1)), dim3(ADFP_BWDH_NT), 0, st, a);
+        if (o.g_grid && !binned) hipLaunchKernelGGL((k_decode_bwd_h<CDIM, NOUT, ROLE, true, true, ADFP_BWDH_NT>), dim3(decode_grid((hi - lo + 31) / 32, NW, 1)), dim3(ADFP_BWDH_NT), 0, st, a);
+        else hipLaunchKernelGGL((k_decode_bwd_h<CDIM, NOUT, ROLE, true, false, 512>), dim3(decode_grid((hi - lo + 31) / 32, 8, 1)), dim3(512), 0, st, a);
         ADFP_CHECK_LAUNCH();
         oa.o.stage = bw.stage; oa.o.count_ptr = count_ptr; oa.o.chunk_lo = lo; oa.o.chunk_hi = hi; oa.o.flat = flat;
         oa.o.partial = bw.partial; oa.o.part_stride = bw.part_stride;
@@ -1676,10 +1711,12 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
         int per = (rows + OUTER_NSLOT - 1) / OUTER_NSLOT;
         per = ((per < 64 ? 64 : per) + OUTER_RT - 1) / OUTER_RT * OUTER_RT;
         oa.o.rows_per_wave = per;
-        hipLaunchKernelGGL(k_outer_lds2, dim3((rows + per - 1) / per), dim3(512), 0, st, oa);
+        hipLaunchKernelGGL(k_outer_h, dim3((rows + per - 1) / per), dim3(512), 0, st, oa);
         ADFP_CHECK_LAUNCH();
     }
-    return outer_end(bw, DecLayout<CDIM, NOUT>::F_TOTAL, flat, st);
+    rc = outer_end_scaled(bw, DecLayout<CDIM, NOUT>::F_TOTAL, flat, st);
+    if (rc) return rc;
+    return binned ? scatter_bins(bp, o, bw, flags, st) : 0;
 }
 
 template <int CDIM, int NOUT, int ROLE>
@@ -1720,13 +1757,52 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
     auto use_h = [&](const void* t, const unsigned* masks, const float* act, const float* flat) {
         return t && masks && !pgrad && (!flat || act);
     };
+    // The grid gradients of the decoders that take the f16-split backward are scattered in spatial order (k_scatter_bins): one
+    // counting sort of the points by the 4-cell bins of the finest such grid, shared by all of them.
+    BinPlan bp; bp.ok = false;
+    {
+        const bool h_low = go.grid_low && use_h(sc->ht_low, state.masks_low, state.act_low, go.flat_low);
+        const bool h_high = fuse && go.grid_high && use_h(sc->ht_high, state.masks_high, state.act_high, go.flat_high);
+        const bool h_color = stage == ADFP_STAGE_COLOR && go.grid_color && use_h(sc->ht_color, state.masks_color, state.act_color, go.flat_color);
+        const adfp_grid* ref = nullptr;
+        auto vox = [](const adfp_grid& g) { return (long long)g.X * g.Y * g.Z; };
+        if (h_low) ref = &sc->low;
+        if (h_high && (!ref || vox(sc->high) > vox(*ref))) ref = &sc->high;
+        if (h_color && (!ref || vox(sc->color) > vox(*ref))) ref = &sc->color;
+        if (ref && ref->X >= 2 && ref->Y >= 2 && ref->Z >= 2 && P > 0) {
+            int bits = 0;
+            const int nbx = ref->X, nby = ref->Y, nbz = ref->Z;               // cell indices 0 .. dim - 1
+            while ((1 << bits) < nbx || (1 << bits) < nby || (1 << bits) < nbz) ++bits;
+            if (bits < 1) bits = 1;
+            if (bits <= ADFP_BIN_MAXBITS) {
+                BinArgs& b = bp.args;
+                b.P = Pd; b.nb = a.nb; b.RX = ref->X; b.RY = ref->Y; b.RZ = ref->Z;
+                b.key = bw.bin_key; b.val = bw.bin_val;
+                hipLaunchKernelGGL(k_bin_keys, dim3((P + 255) / 256), dim3(256), 0, st, b);
+                ADFP_CHECK_LAUNCH();
+                size_t need = 0;
+                e = hipcub::DeviceRadixSort::SortPairs(nullptr, need, bw.bin_key, bw.bin_key_sorted, bw.bin_val, bw.bin_perm, P, 0, 3 * bits, st);
+                if (e != hipSuccess) return (int)e;
+                if (need > bw.sort_temp_bytes) return ADFP_E_WORKSPACE;
+                need = bw.sort_temp_bytes;
+                e = hipcub::DeviceRadixSort::SortPairs(bw.sort_temp, need, bw.bin_key, bw.bin_key_sorted, bw.bin_val, bw.bin_perm, P, 0, 3 * bits, st);
+                if (e != hipSuccess) return (int)e;
+                bp.ok = true;
+            }
+        }
+    }
 
     if (fuse) {
         AttBwdArgs t;
         t.packed = sc->w_att; t.list = state.list; t.count_ptr = state.counter; t.att_occ = state.att_occ;
         t.att_u = state.att_u; t.g_weight = g_weight; t.g_raw = bw.g_raw; t.att_g = bw.att_g; t.stage = bw.stage;
         t.P = Pd; t.nt = make_norm(sc->tsdf_bnds); t.t = make_tsdf(sc->tsdf); t.g_pts = a.g_pts;
-        OuterArgs oa; attention_jobs(oa);
+        // weight gradients of the attention network: with the f16-split images in use (sc->ht_*: ADFP_MATH=f16x3) the outer
+        // products run on f16 MFMA (k_outer_h) and the staged gradient blocks carry the call's power-of-two scale
+        const bool att_h = sc->ht_low != nullptr;
+        t.gmax = att_h ? bw.gmax : nullptr;
+        OuterHArgs oh; attention_jobs(oh.o); oh.act = nullptr; oh.nx = 0; oh.status = sc->status;
+        OuterArgs& oa = oh.o;
         if (go.flat_att) { rc = outer_begin(bw, AttLayout::F_TOTAL, st); if (rc) return rc; }
         for (int lo = 0; lo < P; lo += bw.stage_rows) {
             const int hi = lo + bw.stage_rows < P ? lo + bw.stage_rows : P;
@@ -1736,21 +1812,32 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
                 if (pgrad) hipLaunchKernelGGL((k_attention_bwd<true, true>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
                 else hipLaunchKernelGGL((k_attention_bwd<true, false>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
                 ADFP_CHECK_LAUNCH();
-                rc = launch_outer(oa, bw, state.counter, lo, hi, go.flat_att, st);
-                if (rc) return rc;
+                if (att_h) {
+                    oa.stage = bw.stage; oa.count_ptr = state.counter; oa.chunk_lo = lo; oa.chunk_hi = hi; oa.flat = go.flat_att;
+                    oa.partial = bw.partial; oa.part_stride = bw.part_stride;
+                    const int rows = hi - lo;
+                    int per = (rows + OUTER_NSLOT - 1) / OUTER_NSLOT;
+                    per = ((per < 64 ? 64 : per) + OUTER_RT - 1) / OUTER_RT * OUTER_RT;
+                    oa.rows_per_wave = per;
+                    hipLaunchKernelGGL(k_outer_h, dim3((rows + per - 1) / per), dim3(512), 0, st, oh);
+                    ADFP_CHECK_LAUNCH();
+                } else {
+                    rc = launch_outer(oa, bw, state.counter, lo, hi, go.flat_att, st);
+                    if (rc) return rc;
+                }
             } else {
                 if (pgrad) hipLaunchKernelGGL((k_attention_bwd<false, true>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
                 else hipLaunchKernelGGL((k_attention_bwd<false, false>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
                 ADFP_CHECK_LAUNCH();
             }
         }
-        if (go.flat_att) { rc = outer_end(bw, AttLayout::F_TOTAL, go.flat_att, st); if (rc) return rc; }
+        if (go.flat_att) { rc = att_h ? outer_end_scaled(bw, AttLayout::F_TOTAL, go.flat_att, st) : outer_end(bw, AttLayout::F_TOTAL, go.flat_att, st); if (rc) return rc; }
         if (go.grid_high || go.flat_high || pgrad) {
             DecodeBwdArgs hgh = a;
             hgh.g0 = make_grid(sc->high); hgh.g1 = make_grid(sc->low); hgh.packed = sc->w_high;
             hgh.list = state.list; hgh.count_ptr = state.counter; hgh.att_g = bw.att_g; hgh.g_grid = go.grid_high;
             if (use_h(sc->ht_high, state.masks_high, state.act_high, go.flat_high))
-                rc = run_decode_bwd_h<64, 1, ROLE_HIGH>(hgh, sc->ht_high, state.masks_high, state.act_high, sc->status, P, state.counter, go.flat_high, bw, st);
+                rc = run_decode_bwd_h<64, 1, ROLE_HIGH>(hgh, sc->ht_high, state.masks_high, state.act_high, sc->status, P, state.counter, go.flat_high, bw, bp, state.flags, st);
             else rc = sc->w_high ? run_decode_bwd<64, 1, ROLE_HIGH>(hgh, P, state.counter, go.flat_high, bw, st) : ADFP_E_ARG;
             if (rc) return rc;
         }
@@ -1759,7 +1846,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         DecodeBwdArgs lw = a;
         lw.g0 = make_grid(sc->low); lw.g1 = lw.g0; lw.packed = sc->w_low; lw.g_grid = go.grid_low;
         if (use_h(sc->ht_low, state.masks_low, state.act_low, go.flat_low))
-            rc = run_decode_bwd_h<32, 1, ROLE_LOW>(lw, sc->ht_low, state.masks_low, state.act_low, sc->status, P, nullptr, go.flat_low, bw, st);
+            rc = run_decode_bwd_h<32, 1, ROLE_LOW>(lw, sc->ht_low, state.masks_low, state.act_low, sc->status, P, nullptr, go.flat_low, bw, bp, nullptr, st);
         else rc = sc->w_low ? run_decode_bwd<32, 1, ROLE_LOW>(lw, P, nullptr, go.flat_low, bw, st) : ADFP_E_ARG;
         if (rc) return rc;
     }
@@ -1767,7 +1854,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         DecodeBwdArgs cl = a;
         cl.g0 = make_grid(sc->color); cl.g1 = cl.g0; cl.packed = sc->w_color; cl.g_grid = go.grid_color;
         if (use_h(sc->ht_color, state.masks_color, state.act_color, go.flat_color))
-            rc = run_decode_bwd_h<32, 4, ROLE_COLOR>(cl, sc->ht_color, state.masks_color, state.act_color, sc->status, P, nullptr, go.flat_color, bw, st);
+            rc = run_decode_bwd_h<32, 4, ROLE_COLOR>(cl, sc->ht_color, state.masks_color, state.act_color, sc->status, P, nullptr, go.flat_color, bw, bp, nullptr, st);
         else rc = sc->w_color ? run_decode_bwd<32, 4, ROLE_COLOR>(cl, P, nullptr, go.flat_color, bw, st) : ADFP_E_ARG;
         if (rc) return rc;
     }
@@ -1802,7 +1889,9 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
     const int P = (int)Pn;
 
     hipLaunchKernelGGL(k_composite_bwd, dim3((r->n_rays + 3) / 4), dim3(256), 0, st, r->raw, r->z_vals, r->n_rays, r->S,
-                       r->g_depth, r->g_uncertainty, r->g_color, bw.g_raw, r->ray_keep);
+                       r->g_depth, r->g_uncertainty, r->g_color, bw.g_raw, r->ray_keep, bw.gmax_parts);
+    ADFP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_max_reduce, dim3(1), dim3(1024), 0, st, bw.gmax_parts, r->n_rays, bw.gmax);
     ADFP_CHECK_LAUNCH();
 
     PtsDev Pd;
@@ -1821,16 +1910,22 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
 // cotangent of Renderer.eval_points' raw -> the workspace copy the point backward consumes; where the forward replaced the
 // occupancy by 100 (point outside `bound`, Renderer.py:64) nothing flows back into the decoders
 __global__ __launch_bounds__(256) void k_evalpts_bwd_prep(PtsDev P, const float* __restrict__ g_raw_in, float* __restrict__ g_raw, double b0, double b1,
-                                                          double b2, double b3, double b4, double b5, int apply_bound) {
+                                                          double b2, double b3, double b4, double b5, int apply_bound, float* __restrict__ gmax) {
     const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= P.n) return;
-    f32x4 g = g_raw_in ? *(const f32x4*)(g_raw_in + 4ll * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-    if (apply_bound) {
-        double pt[3]; load_point(P, q, pt);
-        const double b[6] = {b0, b1, b2, b3, b4, b5};
-        if (!in_bound(pt, b)) g.w = 0.f;
+    float mx = 0.f;
+    if (q < P.n) {
+        f32x4 g = g_raw_in ? *(const f32x4*)(g_raw_in + 4ll * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (apply_bound) {
+            double pt[3]; load_point(P, q, pt);
+            const double b[6] = {b0, b1, b2, b3, b4, b5};
+            if (!in_bound(pt, b)) g.w = 0.f;
+        }
+        *(f32x4*)(g_raw + 4ll * q) = g;
+        mx = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
     }
-    *(f32x4*)(g_raw + 4ll * q) = g;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) gmax[blockIdx.x * 4 + (threadIdx.x >> 6)] = mx;          // per wave; k_max_reduce folds them (grad_scale)
 }
 
 extern "C" int adfp_eval_points_backward(const adfp_scene* sc, const adfp_points* pts, const adfp_points_backward_args* r, void* stream) {
@@ -1847,7 +1942,9 @@ extern "C" int adfp_eval_points_backward(const adfp_scene* sc, const adfp_points
     rc = zero_grad_outputs(sc, go, st); if (rc) return rc;
     if (Pd.n == 0) return 0;
     hipLaunchKernelGGL(k_evalpts_bwd_prep, dim3((Pd.n + 255) / 256), dim3(256), 0, st, Pd, r->g_raw, bw.g_raw, sc->bound[0][0], sc->bound[0][1],
-                       sc->bound[1][0], sc->bound[1][1], sc->bound[2][0], sc->bound[2][1], (r->flags & ADFP_EVAL_APPLY_BOUND) ? 1 : 0);
+                       sc->bound[1][0], sc->bound[1][1], sc->bound[2][0], sc->bound[2][1], (r->flags & ADFP_EVAL_APPLY_BOUND) ? 1 : 0, bw.gmax_parts);
+    ADFP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_max_reduce, dim3(1), dim3(1024), 0, st, bw.gmax_parts, ((Pd.n + 255) / 256) * 4, bw.gmax);
     ADFP_CHECK_LAUNCH();
     rc = backward_points(sc, r->stage, Pd, Pd.n, r->state, r->g_w, go, r->g_pts != nullptr, bw, st);
     if (rc) return rc;
