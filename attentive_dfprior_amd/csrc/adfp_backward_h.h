@@ -346,17 +346,21 @@ struct ScatterSortedArgs {
     const int* perm; int n;    // the points in sorted order
     const unsigned char* flags; unsigned flag_mask;      // HIGH: only points with (flags[q] & flag_mask) carry a row
 };
-#define ADFP_SCAT_PW 128              // sorted points per wave (64 per half)
-__global__ __launch_bounds__(256) void k_scatter_sorted(ScatterSortedArgs a) {
-    __shared__ int s_q[4][ADFP_SCAT_PW];
-    __shared__ int s_cell[4][ADFP_SCAT_PW];       // x0 | y0 << 10 | z0 << 20
-    __shared__ float s_w[4][ADFP_SCAT_PW][6];     // wx0, wx1, wy0, wy1, wz0, wz1 (tri_axis)
-    const int lane = threadIdx.x & 63, ch = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-    const int w0 = (blockIdx.x * 4 + wv) * ADFP_SCAT_PW;
-    if (w0 >= a.n) return;
-    // ---- phase A: one lane per point -> cell and weights
+// One wave per workgroup; half h of wave w owns the 64 consecutive sorted points [128 w + 64 h, + 64) (phase A: one lane per
+// point computes cell and weights of the wave's 128 points; phase B: lane = channel).  A run that the range boundary cuts is
+// added in pieces, which is harmless: atomics on ONE line cost ~17 ns each (tools/micro/atomic_rates.hip), and even the cells
+// around the camera, where every ray starts, are cut into a few hundred pieces.  (Longer ranges per wave only lengthen the
+// critical path: 128 points 1.90 ms per iteration, 1 024 points 2.15 ms.  Collecting the pieces in records and merging them in a
+// second kernel cost more than the atomics it saved.)
+__global__ __launch_bounds__(64) void k_scatter_sorted(ScatterSortedArgs a) {
+    __shared__ int s_q[128];
+    __shared__ int s_cell[128];                   // x0 | y0 << 10 | z0 << 20
+    __shared__ float s_w[128][6];                 // wx0, wx1, wy0, wy1, wz0, wz1 (tri_axis)
+    const int lane = threadIdx.x & 63, ch = lane & 31, h = lane >> 5;
+    const int w0 = blockIdx.x * 128;
+    // ---- phase A
 #pragma unroll
-    for (int b = 0; b < ADFP_SCAT_PW / 64; ++b) {
+    for (int b = 0; b < 2; ++b) {
         const int i = w0 + 64 * b + lane;
         int q = -1, cell = -1;
         float w[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -374,14 +378,14 @@ __global__ __launch_bounds__(256) void k_scatter_sorted(ScatterSortedArgs a) {
             tri_axis(pn[2], a.g.Z, z0, z1, w[4], w[5]);
             cell = x0 | (y0 << 10) | (z0 << 20);
         }
-        s_q[wv][64 * b + lane] = q; s_cell[wv][64 * b + lane] = cell;
+        s_q[64 * b + lane] = q; s_cell[64 * b + lane] = cell;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) s_w[wv][64 * b + lane][k] = w[k];
+        for (int k = 0; k < 6; ++k) s_w[64 * b + lane][k] = w[k];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- phase B: half h walks its 64 points; lane = channel; a run of points in one cell is summed in registers
+    // ---- phase B: a run of points in one cell is summed in registers
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int cur = -1;
     auto flush = [&]() {
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(256) void k_scatter_sorted(ScatterSortedArgs a) {
         float gv[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {             // the rows of the next 16 points, fetched together
-            const int q = s_q[wv][64 * h + j0 + j];
+            const int q = s_q[64 * h + j0 + j];
             gv[j] = q >= 0 ? a.gc[32ll * q + ch] : 0.f;
         }
 #pragma unroll
@@ -409,11 +413,11 @@ __global__ __launch_bounds__(256) void k_scatter_sorted(ScatterSortedArgs a) {
             const float g = gv[j];
             const unsigned long long nz = __ballot(g != 0.f);
             if ((unsigned)(nz >> (32 * h)) == 0u) continue;       // no gradient from this point (a dropped ray, a point outside the band)
-            const int cell = s_cell[wv][pi];
+            const int cell = s_cell[pi];
             if (cell != cur) { flush(); cur = cell; }
             float w6[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) w6[k] = s_w[wv][pi][k];
+            for (int k = 0; k < 6; ++k) w6[k] = s_w[pi][k];
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[k] += g * ((w6[k & 1] * w6[2 + ((k >> 1) & 1)]) * w6[4 + (k >> 2)]);
         }
