@@ -305,7 +305,7 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
 // point there: 150-190 us per grid for a 5 000-ray x 64-sample iteration, five times what the cotangent chains cost.  A camera
 // frustum is a small part of the scene -- 320 000 sample points fall into ~8 000 cells of the finest grid -- so:
 //
-//   k_bin_keys + radix sort     the points ordered by the Morton code of the reference (finest) grid's cell they fall in
+//   k_bin_keys + radix sort     the points ordered by the cell of the coarsest grid they fall in, then by the finest grid's
 //   k_scatter_sorted            every half wave walks 64 consecutive sorted points, lane = channel, and sums the 8 corner
 //                               contributions in REGISTERS for as long as the cell (of the grid being scattered) stays the
 //                               same; a run ends in 8 line-atomics.  ~40 points share a cell on average: a few per cent of
@@ -319,8 +319,9 @@ __host__ __device__ inline unsigned morton_spread(unsigned v) {       // 8 bits 
 }
 struct BinArgs {
     PtsDev P; NormDev nb;
-    int RX, RY, RZ;            // dims of the reference (finest) grid
-    int* key; int* val;        // out: Morton cell id and point id of every point (the radix sort's input)
+    int CX, CY, CZ;            // dims of the coarsest grid that is scattered
+    int RX, RY, RZ;            // dims of the finest one (may be the same grid)
+    int* key; int* val;        // out: sort key and point id of every point (the radix sort's input)
 };
 ADFP_DEV int cell_axis(float pn, int size) {                 // i0 of tri_axis
     float c = ((pn + 1.f) / 2.f) * (float)(size - 1);
@@ -334,7 +335,22 @@ __global__ __launch_bounds__(256) void k_bin_keys(BinArgs a) {
     double pt[3]; float pn[3];
     load_point(a.P, q, pt);
     normalize3(a.nb, pt, pn);
-    a.key[q] = (int)(morton_spread(cell_axis(pn[0], a.RX)) | (morton_spread(cell_axis(pn[1], a.RY)) << 1) | (morton_spread(cell_axis(pn[2], a.RZ)) << 2));
+    // The lattices of a 0.32 m and a 0.16 m grid are incommensurate (align_corners: cell = extent / (dim - 1)), so no order makes
+    // the runs of both exact.  Key = Morton code of the COARSE cell, then the fine cell's offset inside it (2 bits per axis): the
+    // coarse grid's runs are exact, and a fine cell is cut only where it straddles a coarse face.  (Sorted by the fine cell alone,
+    // the points inside a fine cell alternate between coarse cells: a flush per point, 374 us for the coarse grid.)
+    const int dims_c[3] = {a.CX, a.CY, a.CZ}, dims_f[3] = {a.RX, a.RY, a.RZ};
+    unsigned cc[3], off = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        cc[k] = (unsigned)cell_axis(pn[k], dims_c[k]);
+        const int fc = cell_axis(pn[k], dims_f[k]);
+        const int f0 = (int)floorf((float)cc[k] * ((float)(dims_f[k] - 1) / (float)(dims_c[k] - 1)) - 1e-3f);
+        int d = fc - (f0 < 0 ? 0 : f0);
+        d = d < 0 ? 0 : (d > 3 ? 3 : d);
+        off |= (unsigned)d << (2 * k);
+    }
+    a.key[q] = (int)(((morton_spread(cc[0]) | (morton_spread(cc[1]) << 1) | (morton_spread(cc[2]) << 2)) << 6) | off);
     a.val[q] = q;
 }
 

@@ -1677,9 +1677,10 @@ template <int CDIM, int NOUT, int ROLE>
 static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigned* masks, const float* act, int* status, int total,
                             const int* count_ptr, float* flat, BwdWorkspace& bw, const BinPlan& bp, const unsigned char* flags, hipStream_t st) {
     if (total == 0) return 0;
-    // d/d c rows + k_scatter_sorted instead of the in-kernel scatter: for a grid on the lattice the points were sorted by (its
-    // runs of equal cells are then exact; a coarser grid's cells do not nest in that order and measured 14x slower than this)
-    const bool binned = bp.ok && o.g_grid && o.g0.X == bp.args.RX && o.g0.Y == bp.args.RY && o.g0.Z == bp.args.RZ;
+    // d/d c rows + k_scatter_sorted instead of the in-kernel scatter: for a grid on one of the two lattices the points were
+    // sorted by (k_bin_keys); a third lattice keeps the in-kernel scatter
+    const bool binned = bp.ok && o.g_grid && ((o.g0.X == bp.args.RX && o.g0.Y == bp.args.RY && o.g0.Z == bp.args.RZ) ||
+                                              (o.g0.X == bp.args.CX && o.g0.Y == bp.args.CY && o.g0.Z == bp.args.CZ));
     if (!binned && o.g_grid && (long long)o.g0.X * o.g0.Y * o.g0.Z >= (1ll << 27)) return ADFP_E_UNSUPPORTED;     // scatter cache slot bits
     DecodeBwdHArgs a;
     a.P = o.P; a.nb = o.nb; a.g0 = o.g0; a.packed_t = (const unsigned*)t; a.list = o.list; a.count_ptr = o.count_ptr;
@@ -1765,28 +1766,29 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         const bool h_low = go.grid_low && use_h(sc->ht_low, state.masks_low, state.act_low, go.flat_low);
         const bool h_high = fuse && go.grid_high && use_h(sc->ht_high, state.masks_high, state.act_high, go.flat_high);
         const bool h_color = stage == ADFP_STAGE_COLOR && go.grid_color && use_h(sc->ht_color, state.masks_color, state.act_color, go.flat_color);
-        const adfp_grid* ref = nullptr;
+        const adfp_grid* fine = nullptr; const adfp_grid* coarse = nullptr;
         auto vox = [](const adfp_grid& g) { return (long long)g.X * g.Y * g.Z; };
-        if (h_low) ref = &sc->low;
-        if (h_high && (!ref || vox(sc->high) > vox(*ref))) ref = &sc->high;
-        if (h_color && (!ref || vox(sc->color) > vox(*ref))) ref = &sc->color;
-        if (ref && ref->X >= 2 && ref->Y >= 2 && ref->Z >= 2 && P > 0) {
+        const adfp_grid* cand[3] = {h_low ? &sc->low : nullptr, h_high ? &sc->high : nullptr, h_color ? &sc->color : nullptr};
+        for (int k = 0; k < 3; ++k) {
+            if (!cand[k]) continue;
+            if (!fine || vox(*cand[k]) > vox(*fine)) fine = cand[k];
+            if (!coarse || vox(*cand[k]) < vox(*coarse)) coarse = cand[k];
+        }
+        if (fine && coarse->X >= 2 && coarse->Y >= 2 && coarse->Z >= 2 && P > 0) {
             int bits = 0;
-            const int nbx = ref->X, nby = ref->Y, nbz = ref->Z;               // cell indices 0 .. dim - 1
-            while ((1 << bits) < nbx || (1 << bits) < nby || (1 << bits) < nbz) ++bits;
-            if (bits < 1) bits = 1;
+            while ((1 << bits) < coarse->X || (1 << bits) < coarse->Y || (1 << bits) < coarse->Z) ++bits;
             if (bits <= ADFP_BIN_MAXBITS) {
                 BinArgs& b = bp.args;
-                b.P = Pd; b.nb = a.nb; b.RX = ref->X; b.RY = ref->Y; b.RZ = ref->Z;
+                b.P = Pd; b.nb = a.nb; b.CX = coarse->X; b.CY = coarse->Y; b.CZ = coarse->Z; b.RX = fine->X; b.RY = fine->Y; b.RZ = fine->Z;
                 b.key = bw.bin_key; b.val = bw.bin_val;
                 hipLaunchKernelGGL(k_bin_keys, dim3((P + 255) / 256), dim3(256), 0, st, b);
                 ADFP_CHECK_LAUNCH();
                 size_t need = 0;
-                e = hipcub::DeviceRadixSort::SortPairs(nullptr, need, bw.bin_key, bw.bin_key_sorted, bw.bin_val, bw.bin_perm, P, 0, 3 * bits, st);
+                e = hipcub::DeviceRadixSort::SortPairs(nullptr, need, bw.bin_key, bw.bin_key_sorted, bw.bin_val, bw.bin_perm, P, 0, 3 * bits + 6, st);
                 if (e != hipSuccess) return (int)e;
                 if (need > bw.sort_temp_bytes) return ADFP_E_WORKSPACE;
                 need = bw.sort_temp_bytes;
-                e = hipcub::DeviceRadixSort::SortPairs(bw.sort_temp, need, bw.bin_key, bw.bin_key_sorted, bw.bin_val, bw.bin_perm, P, 0, 3 * bits, st);
+                e = hipcub::DeviceRadixSort::SortPairs(bw.sort_temp, need, bw.bin_key, bw.bin_key_sorted, bw.bin_val, bw.bin_perm, P, 0, 3 * bits + 6, st);
                 if (e != hipSuccess) return (int)e;
                 bp.ok = true;
             }
