@@ -169,8 +169,8 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
         const bool valid = loc < count;
         const int idx = a.chunk_lo + (valid ? loc : 0);
         const int q = (ROLE == ROLE_HIGH) ? a.list[idx] : idx;
-        // G part of the staging row, addressed with the full row's column numbers
-        float* srow = WGRAD ? a.stage + (long long)loc * ST::NG - ST::NX : nullptr;
+        // G piece of the staging row (d/d h_i, d/d (p @ B), d/d out), addressed with the full row's column numbers
+        float* srow = WGRAD ? a.stage + (long long)loc * ST::NGM - ST::SGH(0) : nullptr;
 
         double pt[3]; float pn[3];
         load_point(a.P, q, pt);
@@ -237,7 +237,6 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
                 const int keep = ((int)(mk[i] << (16 + r))) >> 31;                   // v_bfe_i32: -1 where unit r was active
                 gp[r] = __uint_as_float(__float_as_uint(gh[r]) & (unsigned)keep);
             }
-            if (WGRAD && valid) stage_block_scaled(srow, ST::SGP(i), h, gp, ssc);
             if (i == 0 && !WGRAD) break;                                              // layer 0 only feeds d/d e
             split16(gp, xh, xl, amax);                                                // |gp| <= |gh|: already range-checked
             if constexpr (WGRAD) {
@@ -447,14 +446,27 @@ __global__ __launch_bounds__(64) void k_scatter_sorted(ScatterSortedArgs a) {
 // job and tile; here 3 x v_mfma_f32_32x32x16_f16 = 96).  An f16 operand is 8 consecutive k per lane and k = the tile's rows, so
 // after the coalesced f32 stash every thread takes whole COLUMNS of the tile (16 rows each), splits them into hi / lo halves
 // and writes them k-major -- [hi|lo][rows 0-7 | 8-15][column][8 halves], the k-step layout of the H image, so that an operand
-// is one conflict-free ds_read_b128.  The rows come in two pieces (X part from the training forward, indexed by the absolute
-// row; G part from k_decode_bwd_h, scaled by S = grad_scale) or, with act = NULL, as whole rows (the attention network).
+// is one conflict-free ds_read_b128.  The rows come in two stored pieces (X from the training forward, indexed by the absolute
+// row; G from k_decode_bwd_h, scaled by S = grad_scale) -- the kernel is bound by reading them, so what can be rebuilt is not
+// stored: the conversion pass recomputes the 96 Fourier columns from x, y, z and forms d/d pre_i from d/d h_i and the forward's
+// ReLU mask words -- or, with act = NULL, as whole rows (the attention network).
 // ---------------------------------------------------------------------------------------------
-struct OuterHArgs { OuterArgs o; const float* act; int nx; int* status; };
+struct OuterHArgs {
+    OuterArgs o;
+    const float* act;          // X pieces (row pitch 4 nxm4 floats, absolute row index) or NULL = whole rows in o.stage
+    int nxm4, ngm4;            // f32x4 pieces per stored X / G piece
+    int g_dst4;                // f32x4 index in the tile row where the stored G piece starts
+    const unsigned* masks;     // decoders: the forward's ReLU mask words (absolute row index), NULL = no virtual columns
+    const float* bm;           // decoders: [96][4] Fourier matrix rows (the packed image's P_BM block)
+    int col_se, col_sgp;       // decoders: first column of the recomputed Fourier block / of the masked d/d pre block
+    int* status;
+};
 __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
     const OuterArgs& a = b.o;
     __shared__ __attribute__((aligned(16))) float sf[OUTER_RT * OUTER_MAXCOLS];                 // the tile, f32, row-major
     __shared__ __attribute__((aligned(16))) unsigned st[4 * OUTER_MAXCOLS * 4];                   // the tile as operands
+    __shared__ __attribute__((aligned(16))) float s_bm[96 * 4];
+    __shared__ unsigned s_mask[OUTER_RT][6];
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
     int hi = a.chunk_hi;
     if (a.count_ptr) { const int cnt = *a.count_ptr; hi = hi < cnt ? hi : cnt; }
@@ -463,7 +475,8 @@ __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
     if (m0 >= rows) return;
     const int m1 = (m0 + a.rows_per_wave < rows) ? m0 + a.rows_per_wave : rows;
     const int nc = a.ncols;
-    const int nx4 = b.act ? b.nx / 4 : 0, ng4 = (nc - (b.act ? b.nx : 0)) / 4;
+    const bool dec = b.masks != nullptr;
+    if (dec) for (int t = threadIdx.x; t < 96 * 4; t += 512) s_bm[t] = b.bm[t];
     f32x16 acc[OUTER_JW];
 #pragma unroll
     for (int j = 0; j < OUTER_JW; ++j)
@@ -473,46 +486,63 @@ __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
 #pragma unroll
     for (int j = 0; j < OUTER_JW; ++j) {
         const int job = wv + OUTER_NW * j;
-        ca[j] = job < a.njobs ? a.jobs[job].colA + i : -1;
-        cb[j] = job < a.njobs ? a.jobs[job].colB + i : -1;
+        ca[j] = job < a.njobs ? a.jobs[job].colA + i : i;      // a missing job multiplies columns 0..31 by themselves and is never
+        cb[j] = job < a.njobs ? a.jobs[job].colB + i : i;      // written out: no branch in the MFMA phase, its LDS reads overlap
     }
     f32x4 ld[2][6];                                        // this wave's two rows: X pieces lane, lane + 64; G pieces lane + 64 k
+    unsigned mreg = 0u;                                    // threads 0..95: one mask word of the tile
     auto fetch = [&](int row0) {
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int m = row0 + 2 * wv + rr;
             const bool ok = m < m1;
-            const f32x4* sx = (const f32x4*)(b.act + (long long)(a.chunk_lo + m) * b.nx);
-            const f32x4* sg = (const f32x4*)(a.stage + (long long)m * (ng4 * 4));
+            const f32x4* sx = (const f32x4*)(b.act + (long long)(a.chunk_lo + m) * (b.nxm4 * 4));
+            const f32x4* sg = (const f32x4*)(a.stage + (long long)m * (b.ngm4 * 4));
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int e = lane + 64 * k;
-                ld[rr][k] = (ok && e < nx4) ? sx[e] : f32x4{0.f, 0.f, 0.f, 0.f};
+                ld[rr][k] = (ok && e < b.nxm4) ? sx[e] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int e = lane + 64 * k;
-                ld[rr][2 + k] = (ok && e < ng4) ? sg[e] : f32x4{0.f, 0.f, 0.f, 0.f};
+                ld[rr][2 + k] = (ok && e < b.ngm4) ? sg[e] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+        }
+        if (dec && threadIdx.x < OUTER_RT * 6) {
+            const int m = row0 + (int)threadIdx.x / 6;
+            mreg = m < m1 ? b.masks[(long long)(a.chunk_lo + m) * 6 + threadIdx.x % 6] : 0u;
         }
     };
     float amax = 0.f;
     fetch(m0);
     for (int m = m0; m < m1; m += OUTER_RT) {
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {                   // registers -> f32 tile
+        for (int rr = 0; rr < 2; ++rr) {                   // registers -> f32 tile (the stored X piece lacks the 96 Fourier columns)
             f32x4* dst = (f32x4*)(sf + (2 * wv + rr) * nc);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) { const int e = lane + 64 * k; if (e < nx4) dst[e] = ld[rr][k]; }
+            for (int k = 0; k < 2; ++k) { const int e = lane + 64 * k; if (e < b.nxm4) dst[e < 8 ? e : e + 24] = ld[rr][k]; }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const int e = lane + 64 * k; if (e < ng4) dst[nx4 + e] = ld[rr][2 + k]; }
+            for (int k = 0; k < 4; ++k) { const int e = lane + 64 * k; if (e < b.ngm4) dst[b.g_dst4 + e] = ld[rr][2 + k]; }
         }
+        if (dec && threadIdx.x < OUTER_RT * 6) s_mask[threadIdx.x / 6][threadIdx.x % 6] = mreg;
         __syncthreads();                                   // tile complete; everyone is done with the previous operands
         if (m + OUTER_RT < m1) fetch(m + OUTER_RT);        // in flight during the conversion and the MFMAs
         for (int c = threadIdx.x; c < nc; c += 512) {      // columns -> k-major hi / lo halves
             float v[16];
+            if (dec && c >= b.col_se && c < b.col_se + 96) {                 // Fourier features of the rows, from x, y, z
+                const f32x4 bmr = *(const f32x4*)(s_bm + (c - b.col_se) * 4);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = sf[r * nc + c];
+                for (int r = 0; r < 16; ++r) v[r] = adfp_sinf(fmaf(sf[r * nc + 2], bmr.z, fmaf(sf[r * nc + 1], bmr.y, sf[r * nc] * bmr.x)));
+            } else if (dec && c >= b.col_sgp && c < b.col_sgp + 160) {       // d/d pre_i = mask . d/d h_i
+                const int u = (c - b.col_sgp) & 31, li = (c - b.col_sgp) >> 5;
+                const int word = ((u >> 2) & 1) * 3 + (li >> 1), bit = 15 - ((u & 3) | ((u >> 3) << 2)) + 16 * (li & 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = (s_mask[r][word] >> bit) & 1u ? sf[r * nc + c + 160] : 0.f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = sf[r * nc + c];
+            }
             f16x8 xh, xl;
             split8(v, xh, xl, amax);
             *(u32x4*)(st + ((0 * nc) + c) * 4) = __builtin_bit_cast(u32x4, xh);
@@ -524,15 +554,13 @@ __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < OUTER_JW; ++j) {
-            if (ca[j] >= 0) {
-                const f16x8 ah = __builtin_bit_cast(f16x8, *(const u32x4*)(st + ((0 + h) * nc + ca[j]) * 4));
-                const f16x8 al = __builtin_bit_cast(f16x8, *(const u32x4*)(st + ((2 + h) * nc + ca[j]) * 4));
-                const f16x8 bh = __builtin_bit_cast(f16x8, *(const u32x4*)(st + ((0 + h) * nc + cb[j]) * 4));
-                const f16x8 bl = __builtin_bit_cast(f16x8, *(const u32x4*)(st + ((2 + h) * nc + cb[j]) * 4));
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[j], 0, 0, 0);
-            }
+            const f16x8 ah = __builtin_bit_cast(f16x8, *(const u32x4*)(st + ((0 + h) * nc + ca[j]) * 4));
+            const f16x8 al = __builtin_bit_cast(f16x8, *(const u32x4*)(st + ((2 + h) * nc + ca[j]) * 4));
+            const f16x8 bh = __builtin_bit_cast(f16x8, *(const u32x4*)(st + ((0 + h) * nc + cb[j]) * 4));
+            const f16x8 bl = __builtin_bit_cast(f16x8, *(const u32x4*)(st + ((2 + h) * nc + cb[j]) * 4));
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[j], 0, 0, 0);
         }
     }
     report_range(b.status, amax);

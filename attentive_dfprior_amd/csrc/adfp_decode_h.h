@@ -208,8 +208,8 @@ ADFP_DEV void relu_bias_mask(f32x16& acc, const float* __restrict__ bias, int h,
 
 // TRAIN = 1: the training forward.  Besides its outputs the kernel leaves what the f16-split backward (adfp_backward_h.h)
 // needs, so that nothing is recomputed there: the ReLU masks of the five layers (a.masks: 3 words per lane half, always) and,
-// when the network's weight gradients are wanted (a.act != NULL), the inputs of every layer -- position, Fourier features,
-// grid features, h_0..h_4 -- as the X part of the point's staging row (DecStage: NX floats per point).  A NaN position
+// when the network's weight gradients are wanted (a.act != NULL), the inputs of every layer -- position (the Fourier features
+// are recomputed from it), grid features, h_0..h_4 -- as the X piece of the point's staging row (DecStage: NXM floats per point).  A NaN position
 // (a ray the Mapper's pre-filter drops) is decoded at the origin instead, so that the staged activations stay finite; its
 // outputs are NaN as before.
 template <int CDIM, int NOUT, int ROLE, int NT, int TRAIN = 0>
@@ -251,8 +251,8 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
             const bool pnan = (pt[0] != pt[0]) | (pt[1] != pt[1]) | (pt[2] != pt[2]);
             if (pnan) { pf[0] = 0.f; pf[1] = 0.f; pf[2] = 0.f; }
             if (a.act && valid) {
-                srow = a.act + (long long)(ROLE == ROLE_HIGH ? idx : q) * ST::NX;
-                stage_head(srow, ST::SX, h, f32x4{pf[0], pf[1], pf[2], 1.f});
+                srow = a.act + (long long)(ROLE == ROLE_HIGH ? idx : q) * ST::NXM;
+                stage_head(srow, ST::xm(ST::SX), h, f32x4{pf[0], pf[1], pf[2], 1.f});
             }
         }
 
@@ -263,8 +263,8 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
             gather16(a.g0, pn, h, c);
             if (CDIM == 64) gather16(a.g1, pn, h, c + 16);
             if constexpr (TRAIN) if (srow) {
-                stage_block(srow, ST::SC, h, c, 0);
-                if (CDIM == 64) stage_block(srow, ST::SC + 32, h, c, 16);
+                stage_block(srow, ST::xm(ST::SC), h, c, 0);
+                if (CDIM == 64) stage_block(srow, ST::xm(ST::SC + 32), h, c, 16);
             }
 #pragma unroll
             for (int ks = 0; ks < L::KS_C; ++ks) split8(c + 8 * ks, ch[ks], cl[ks], amax);
@@ -284,10 +284,6 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
 #endif
                 const float arg = fmaf(pf[2], bm.z, fmaf(pf[1], bm.y, pf[0] * bm.x));
                 e[j] = adfp_sinf(arg);
-            }
-            if constexpr (TRAIN) if (srow) {              // registers 8 (ks & 1) + j of Fourier block ks >> 1
-                *(f32x4*)(srow + ST::SE + 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h) = f32x4{e[0], e[1], e[2], e[3]};
-                *(f32x4*)(srow + ST::SE + 32 * (ks >> 1) + 16 * (ks & 1) + 8 + 4 * h) = f32x4{e[4], e[5], e[6], e[7]};
             }
             split8<false>(e, eh[ks], el[ks], amax);     // |sin| <= 1
         }
@@ -317,7 +313,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
             else relu_bias(acc, lds + L::P_BC(i), h);
 #endif
             mfma_chain_h<L::KS_C>(acc, ldsu + L::P_WC(i), lane_off, ch, cl);
-            if constexpr (TRAIN) if (srow) stage_block(srow, ST::SH(i), h, acc);
+            if constexpr (TRAIN) if (srow) stage_block(srow, ST::xm(ST::SH(i)), h, acc);
             if (i < 4) {
                 float t[16];
 #pragma unroll

@@ -1061,8 +1061,8 @@ int adfp_pack_decoder_ht(int kind, const float* flat, void* packed, int* status,
 }
 long long adfp_train_act_floats(int kind) {
     switch (kind) {
-        case ADFP_DEC_LOW: case ADFP_DEC_COLOR: return DecStage<32>::NX;
-        case ADFP_DEC_HIGH: return DecStage<64>::NX;
+        case ADFP_DEC_LOW: case ADFP_DEC_COLOR: return DecStage<32>::NXM;
+        case ADFP_DEC_HIGH: return DecStage<64>::NXM;
     }
     return ADFP_E_ARG;
 }
@@ -1696,9 +1696,10 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
     }
     using ST = DecStage<CDIM>;
     OuterHArgs oa; decoder_jobs<CDIM, NOUT>(oa.o);
-    oa.act = act; oa.nx = ST::NX; oa.status = status;
+    oa.act = act; oa.nxm4 = ST::NXM / 4; oa.ngm4 = ST::NGM / 4; oa.g_dst4 = ST::SGH(0) / 4; oa.masks = masks; oa.bm = (const float*)t;   // P_BM = word 0 of the T image
+    oa.col_se = ST::SE; oa.col_sgp = ST::SGP(0); oa.status = status;
     a.stage = bw.stage;
-    const int rows_cap = (int)((size_t)bw.stage_rows * AttStage::NCOLS / ST::NG);
+    const int rows_cap = (int)((size_t)bw.stage_rows * AttStage::NCOLS / ST::NGM);
     int rc = outer_begin(bw, DecLayout<CDIM, NOUT>::F_TOTAL, st);
     if (rc) return rc;
     for (int lo = 0; lo < total; lo += rows_cap) {
@@ -1774,7 +1775,10 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
             if (!fine || vox(*cand[k]) > vox(*fine)) fine = cand[k];
             if (!coarse || vox(*cand[k]) < vox(*coarse)) coarse = cand[k];
         }
-        if (fine && coarse->X >= 2 && coarse->Y >= 2 && coarse->Z >= 2 && P > 0) {
+        // ADFP_SCATTER=cache keeps every grid on the in-kernel write-combining scatter (A/B switch, and what tests compare against)
+        static int force_cache = -1;
+        if (force_cache < 0) { const char* ev = getenv("ADFP_SCATTER"); force_cache = (ev && ev[0] == 'c') ? 1 : 0; }
+        if (fine && !force_cache && coarse->X >= 2 && coarse->Y >= 2 && coarse->Z >= 2 && P > 0) {
             int bits = 0;
             while ((1 << bits) < coarse->X || (1 << bits) < coarse->Y || (1 << bits) < coarse->Z) ++bits;
             if (bits <= ADFP_BIN_MAXBITS) {
@@ -1804,7 +1808,8 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         // products run on f16 MFMA (k_outer_h) and the staged gradient blocks carry the call's power-of-two scale
         const bool att_h = sc->ht_low != nullptr;
         t.gmax = att_h ? bw.gmax : nullptr;
-        OuterHArgs oh; attention_jobs(oh.o); oh.act = nullptr; oh.nx = 0; oh.status = sc->status;
+        OuterHArgs oh; attention_jobs(oh.o); oh.act = nullptr; oh.nxm4 = 0; oh.ngm4 = AttStage::NCOLS / 4; oh.g_dst4 = 0; oh.masks = nullptr; oh.bm = nullptr;
+        oh.col_se = 0; oh.col_sgp = 0; oh.status = sc->status;
         OuterArgs& oa = oh.o;
         if (go.flat_att) { rc = outer_begin(bw, AttLayout::F_TOTAL, st); if (rc) return rc; }
         for (int lo = 0; lo < P; lo += bw.stage_rows) {

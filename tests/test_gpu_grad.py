@@ -293,3 +293,71 @@ def test_eval_points_is_autograd_transparent(mini, stage, via):
             assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, name
         else:
             grad_close(prm.grad, ref, name)
+
+
+def _grads_of_case(mini, monkeypatch, mode, no_masks=False):
+    """Gradients of the second-seed case (300 rays x 64 samples, all networks trainable) under ADFP_MATH=mode; no_masks: the
+    training forward leaves no ReLU masks, so the f16-split forward is followed by the EXACT backward."""
+    from attentive_dfprior_amd import engine
+    monkeypatch.setenv('ADFP_MATH', mode)
+    if no_masks:
+        orig = engine.Engine.train_state
+
+        def without_masks(P, stage, dev, decoders, need_flat=None):
+            monkeypatch.setenv('ADFP_MATH', 'f32')
+            try:
+                return orig(P, stage, dev, decoders, need_flat)
+            finally:
+                monkeypatch.setenv('ADFP_MATH', mode)
+        monkeypatch.setattr(engine.Engine, 'train_state', staticmethod(without_masks))
+    sd = O.random_state_dict(seed=17)
+    rays = synthetic.make_ray_batch(synthetic.mini_scene(), 300, seed=8, poses=3)
+    loss, c, dec = run(mini, 'color', True, sd=sd, n_samples=48, n_surface=16, rays=rays)
+    out = {k: v.grad.detach().clone() for k, v in c.items()}
+    out.update({n: p.grad.detach().clone() for n, p in dec.named_parameters() if p.grad is not None})
+    return out
+
+
+def test_f16_split_backward_against_the_exact_backward(mini, monkeypatch):
+    """Same f16-split forward, then the two backwards: k_decode_bwd_h / k_outer_h / k_scatter_sorted (masks and layer inputs from
+    the forward, f16 MFMA with operand split, sorted scatter) against k_decode_bwd / k_outer_lds (recompute, f32 MFMA, in-kernel
+    scatter).  Measured: every element agrees to ~3e-7 of its tensor's scale except the row of a unit whose ReLU the two
+    forwards decide differently (tools/diag_bwd.py)."""
+    exact = _grads_of_case(mini, monkeypatch, 'f16x3', no_masks=True)
+    monkeypatch.undo()
+    split = _grads_of_case(mini, monkeypatch, 'f16x3')
+    assert set(exact) == set(split)
+    tight = 0
+    for k in exact:
+        a, b = split[k].double().cpu(), exact[k].double().cpu()
+        scale = b.abs().max().clamp_min(1e-30)
+        err = (a - b).abs() / scale
+        tight += int((err <= 5e-6).all())
+        grad_close(split[k], exact[k], f'f16-split vs exact backward: {k}', tol=1e-4)
+    assert tight >= 0.7 * len(exact), f'only {tight} of {len(exact)} tensors agree to 5e-6'
+
+
+def test_sorted_scatter_equals_cached_scatter(mini):
+    """Grid gradients through k_scatter_sorted (radix sort by cell, run-length sums) and through the in-kernel write-combining
+    scatter (ADFP_SCATTER=cache is read once per process: the comparison runs in a child process)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = ('import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n'
+            'import test_gpu_grad as T, conftest\n'
+            'from attentive_dfprior_amd import synthetic\n'
+            'from oracle import adfp_oracle as O\n'
+            'mini = conftest.Mini()\n'
+            'rays = synthetic.make_ray_batch(synthetic.mini_scene(), 300, seed=8, poses=3)\n'
+            'loss, c, dec = T.run(mini, "color", True, sd=O.random_state_dict(seed=17), n_samples=48, n_surface=16, rays=rays)\n'
+            'torch.save({k: v.grad.cpu() for k, v in c.items()}, sys.argv[1])\n') % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                   os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    with tempfile.TemporaryDirectory() as d:
+        for name, env in (('sorted', {}), ('cache', {'ADFP_SCATTER': 'cache'})):
+            path = os.path.join(d, name + '.pt')
+            subprocess.run([sys.executable, '-c', code, path], check=True, env={**os.environ, **env}, timeout=300)
+            got[name] = torch.load(path)
+    for k in got['sorted']:
+        assert_close_scale(got['sorted'][k], got['cache'][k], 2e-6, f'{k}: sorted vs cached scatter')
