@@ -79,7 +79,7 @@ typedef struct adfp_scene {
     const float* w_att;
     /* optional "H" images (adfp_pack_decoder_h): when non-NULL the FORWARD decoders run their MLP on
      * f16 MFMA with a 3-product split of every f32 operand (fp32-grade accuracy);
-     * NULL = exact f32-input MFMA from w_*.  The backward always uses w_*. */
+     * NULL = exact f32-input MFMA from w_*. */
     const void* h_low;
     const void* h_high;
     const void* h_color;
@@ -250,6 +250,10 @@ int adfp_render_forward(const adfp_scene* scene /*host*/, const adfp_render_args
  * z_vals, raw and `state` are the ones the forward call wrote.  Every non-NULL output is zeroed and then accumulated:
  * the grid gradients with float atomics (not bitwise reproducible run to run), the parameter gradients atomic-free through
  * per-workgroup partial sums (reproducible).
+ * Two implementations per decoder, chosen by what the caller provides: with scene->ht_* and the forward's state->masks_* (and
+ * state->act_* when g_flat_* is wanted) the f16-split backward (f16 MFMA, nothing recomputed, grid gradients scattered in
+ * sorted order); otherwise -- and always when g_rays_* / g_pts is requested -- the exact f32 backward from scene->w_*.  The
+ * attention network's backward is exact f32 (w_att); with ht_* in use its weight gradients take the f16 outer-product kernel.
  * g_rays_o / g_rays_d: gradients w.r.t. the rays (p = o + d z; through the trilinear coordinates of the
  * feature grids and the TSDF and through sin(p @ B)) for the Tracker, src/Tracker.py:112-133. */
 typedef struct adfp_backward_args {
