@@ -206,7 +206,8 @@ ADFP_DEV void relu_bias_mask(f32x16& acc, const float* __restrict__ bias, int h,
     }
 }
 
-// TRAIN = 1: the training forward.  Besides its outputs the kernel leaves what the f16-split backward (adfp_backward_h.h)
+// TRAIN = 1 (masks only) / 2 (masks + layer inputs): the training forward, 2 waves per SIMD (at the 168 registers of 3 waves the
+// mask words alone spill 55).  Besides its outputs the kernel leaves what the f16-split backward (adfp_backward_h.h)
 // needs, so that nothing is recomputed there: the ReLU masks of the five layers (a.masks: 3 words per lane half, always) and,
 // when the network's weight gradients are wanted (a.act != NULL), the inputs of every layer -- position (the Fourier features
 // are recomputed from it), grid features, h_0..h_4 -- as the X piece of the point's staging row (DecStage: NXM floats per point).  A NaN position
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
         if constexpr (TRAIN) {
             const bool pnan = (pt[0] != pt[0]) | (pt[1] != pt[1]) | (pt[2] != pt[2]);
             if (pnan) { pf[0] = 0.f; pf[1] = 0.f; pf[2] = 0.f; }
-            if (a.act && valid) {
+            if (TRAIN == 2 && a.act && valid) {
                 srow = a.act + (long long)(ROLE == ROLE_HIGH ? idx : q) * ST::NXM;
                 stage_head(srow, ST::xm(ST::SX), h, f32x4{pf[0], pf[1], pf[2], 1.f});
             }

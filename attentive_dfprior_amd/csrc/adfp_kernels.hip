@@ -1238,7 +1238,8 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
     a.g0 = make_grid(sc->low); a.g1 = a.g0;
     if (sc->h_low && state && state->masks_low) {              // training forward: leaves the ReLU masks (+ layer inputs)
         a.packed = (const float*)sc->h_low; a.masks = state->masks_low; a.act = state->act_low;
-        hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, 512, 1>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
+        if (a.act) hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, 512, 2>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, 512, 1>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
         a.masks = nullptr; a.act = nullptr;
     } else if (sc->h_low) {
         a.packed = (const float*)sc->h_low;
@@ -1253,7 +1254,8 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         a.g0 = make_grid(sc->color); a.g1 = a.g0;
         if (sc->h_color && state && state->masks_color) {
             a.packed = (const float*)sc->h_color; a.masks = state->masks_color; a.act = state->act_color;
-            hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, 512, 1>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
+            if (a.act) hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, 512, 2>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, 512, 1>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
             a.masks = nullptr; a.act = nullptr;
         } else if (sc->h_color) {
             a.packed = (const float*)sc->h_color;
@@ -1270,7 +1272,8 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         a.list = ws.list; a.count_ptr = ws.counter; a.att_occ = ws.att_occ;
         if (sc->h_high && state && state->masks_high) {
             a.packed = (const float*)sc->h_high; a.masks = state->masks_high; a.act = state->act_high;
-            hipLaunchKernelGGL((k_decode_h<64, 1, ROLE_HIGH, 512, 1>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
+            if (a.act) hipLaunchKernelGGL((k_decode_h<64, 1, ROLE_HIGH, 512, 2>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((k_decode_h<64, 1, ROLE_HIGH, 512, 1>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
             a.masks = nullptr; a.act = nullptr;
         } else if (sc->h_high) {
             a.packed = (const float*)sc->h_high;
