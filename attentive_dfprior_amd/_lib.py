@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ADFP_LIB_PATH', os.path.join(_HERE, 'libadfp.so'))   # override: kernel A/B builds
 
-ABI_VERSION = 111                 # ADFP_VERSION of include/adfp.h this binding was written against
+ABI_VERSION = 112                 # ADFP_VERSION of include/adfp.h this binding was written against
 STATUS_F16_RANGE = 1
 STAGE = {'low': 0, 'high': 1, 'color': 2}
 DEC_KIND = {'low': 0, 'high': 1, 'color': 2}
@@ -51,6 +51,11 @@ class AdfpTrainState(C.Structure):
 
 
 TRAIN_MASK_WORDS = 6              # ADFP_TRAIN_MASK_WORDS
+
+
+class AdfpAdamGroup(C.Structure):
+    _fields_ = [('param', C.c_void_p), ('grad', C.c_void_p), ('exp_avg', C.c_void_p), ('exp_avg_sq', C.c_void_p),
+                ('mask', C.c_void_p), ('nvox', C.c_longlong), ('channels', C.c_int), ('derived', C.c_void_p)]
 
 
 class AdfpRenderArgs(C.Structure):
@@ -143,6 +148,7 @@ SYMBOLS = [
     ('adfp_adam_prep', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_void_p]),
     ('adfp_masked_adam_dev', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int,
                                        C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    ('adfp_masked_adam_multi', C.c_int, [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     ('adfp_tsdf_stage', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_backward_workspace_bytes', C.c_size_t, [C.c_longlong]),

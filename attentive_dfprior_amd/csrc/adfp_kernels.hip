@@ -38,6 +38,41 @@ __global__ __launch_bounds__(256) void k_zero(unsigned* __restrict__ p, long lon
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_words; i += stride) p[i] = 0u;
     }
 }
+// several buffers in ONE launch
+#define ZERO_MULTI 8
+struct ZeroJobs { unsigned* p[ZERO_MULTI]; long long words[ZERO_MULTI]; unsigned first_block[ZERO_MULTI + 1]; int n; };
+__global__ __launch_bounds__(256) void k_zero_multi(ZeroJobs z) {
+    int j = 0;
+    while (j + 1 < z.n && blockIdx.x >= z.first_block[j + 1]) ++j;
+    unsigned* p = z.p[j];
+    const long long n_words = z.words[j], n4 = n_words >> 2;
+    const long long b = blockIdx.x - z.first_block[j], stride = (long long)(z.first_block[j + 1] - z.first_block[j]) * 256;
+    if ((((unsigned long long)p) & 15ull) == 0) {
+        for (long long i = b * 256 + threadIdx.x; i < n4; i += stride) ((uint4*)p)[i] = uint4{0u, 0u, 0u, 0u};
+        for (long long i = (n4 << 2) + b * 256 + threadIdx.x; i < n_words; i += stride) p[i] = 0u;
+    } else {
+        for (long long i = b * 256 + threadIdx.x; i < n_words; i += stride) p[i] = 0u;
+    }
+}
+struct ZeroBatch {
+    ZeroJobs z; unsigned blocks;
+    ZeroBatch() : blocks(0) { z.n = 0; z.first_block[0] = 0; }
+    hipError_t flush(hipStream_t st) {
+        if (z.n == 0) return hipSuccess;
+        hipLaunchKernelGGL(k_zero_multi, dim3(blocks), dim3(256), 0, st, z);
+        z.n = 0; blocks = 0; z.first_block[0] = 0;
+        return hipGetLastError();
+    }
+    hipError_t add(void* p, size_t bytes, hipStream_t st) {
+        if (!p || bytes == 0) return hipSuccess;
+        if (z.n == ZERO_MULTI) { hipError_t e = flush(st); if (e != hipSuccess) return e; }
+        const long long words = (long long)(bytes / 4);
+        long long b = (words / 4 + 255) / 256;
+        b = b < 1 ? 1 : (b > 1024 ? 1024 : b);
+        z.p[z.n] = (unsigned*)p; z.words[z.n] = words; blocks += (unsigned)b; z.first_block[++z.n] = blocks;
+        return hipSuccess;
+    }
+};
 static hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
     if (bytes == 0) return hipSuccess;
     const long long words = (long long)(bytes / 4);
@@ -1441,6 +1476,25 @@ int adfp_masked_adam_dev(float* param, const float* grad, float* exp_avg, float*
     ADFP_CHECK_LAUNCH();
     return 0;
 }
+int adfp_masked_adam_multi(int n_groups, const adfp_adam_group* groups, float beta1, float beta2, float eps, void* stream) {
+    if (n_groups < 0 || n_groups > ADFP_ADAM_MULTI || (n_groups && !groups)) return ADFP_E_ARG;
+    AdamMultiArgs m; m.n = 0; m.first_block[0] = 0;
+    for (int k = 0; k < n_groups; ++k) {
+        const adfp_adam_group& g = groups[k];
+        if (!g.param || !g.grad || !g.exp_avg || !g.exp_avg_sq || !g.derived || g.nvox < 0 || g.channels <= 0) return ADFP_E_ARG;
+        if (g.nvox == 0) continue;
+        AdamArgs& a = m.g[m.n];
+        a.param = g.param; a.grad = g.grad; a.exp_avg = g.exp_avg; a.exp_avg_sq = g.exp_avg_sq; a.mask = g.mask; a.nvox = g.nvox; a.C = g.channels;
+        a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.step_size = 0.f; a.sqrt_bc2 = 1.f; a.derived = g.derived;
+        const long long threads = ((g.nvox + 3) >> 2) * g.channels;
+        m.first_block[m.n + 1] = m.first_block[m.n] + (unsigned)((threads + 255) / 256);
+        ++m.n;
+    }
+    if (m.n == 0) return 0;
+    hipLaunchKernelGGL(k_masked_adam_multi, dim3(m.first_block[m.n]), dim3(256), 0, (hipStream_t)stream, m);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
 int adfp_prefilter_mask(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double* bound_dev,
                         unsigned char* keep, float* depth_max, void* stream) {
     if (!rays_o || !rays_d || !gt_depth || !bound_dev || !keep || !depth_max || n_rays <= 0) return ADFP_E_ARG;
@@ -1741,9 +1795,10 @@ static int zero_grad_outputs(const adfp_scene* sc, const GradOut& g, hipStream_t
         {g.grid_color, (size_t)sc->color.Z * sc->color.Y * sc->color.X * 32},
         {g.flat_low, (size_t)DecLayout<32, 1>::F_TOTAL}, {g.flat_high, (size_t)DecLayout<64, 1>::F_TOTAL},
         {g.flat_color, (size_t)DecLayout<32, 4>::F_TOTAL}, {g.flat_att, (size_t)AttLayout::F_TOTAL}};
+    ZeroBatch zb;
     for (int k = 0; k < 7; ++k)
-        if (zs[k].p) { hipError_t e = zero_async(zs[k].p, zs[k].n * 4, st); if (e != hipSuccess) return (int)e; }
-    return 0;
+        if (zs[k].p) { hipError_t e = zb.add(zs[k].p, zs[k].n * 4, st); if (e != hipSuccess) return (int)e; }
+    return (int)zb.flush(st);
 }
 
 // DF.forward backward over P points: bw.g_raw holds the cotangent of raw [P,4] (the attention pass reads .w and rewrites it

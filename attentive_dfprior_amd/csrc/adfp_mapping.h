@@ -136,9 +136,19 @@ ADFP_DEV void adam_one(const AdamArgs& a, long long i, float step_size, float sq
     const float denom = __fadd_rn(__fdiv_rn(sqrtf(v), sqrt_bc2), a.eps);
     a.param[i] = __fadd_rn(a.param[i], __fdiv_rn(__fmul_rn(-step_size, m), denom));                      // addcdiv_(m, denom, value=-step_size)
 }
-__global__ __launch_bounds__(256) void k_masked_adam(AdamArgs a) {
+ADFP_DEV void masked_adam_block(const AdamArgs& a, long long block);
+__global__ __launch_bounds__(256) void k_masked_adam(AdamArgs a) { masked_adam_block(a, blockIdx.x); }
+// several parameter groups in ONE launch (a Mapper iteration steps five: three grids and two networks)
+#define ADFP_ADAM_MULTI 8
+struct AdamMultiArgs { AdamArgs g[ADFP_ADAM_MULTI]; unsigned first_block[ADFP_ADAM_MULTI + 1]; int n; };
+__global__ __launch_bounds__(256) void k_masked_adam_multi(AdamMultiArgs m) {
+    int j = 0;
+    while (j + 1 < m.n && blockIdx.x >= m.first_block[j + 1]) ++j;
+    masked_adam_block(m.g[j], (long long)blockIdx.x - m.first_block[j]);
+}
+ADFP_DEV void masked_adam_block(const AdamArgs& a, long long block) {
     const long long quads = (a.nvox + 3) >> 2;
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long t = block * 256 + threadIdx.x;
     if (t >= quads * a.C) return;
     const long long c = t / quads, v0 = (t - c * quads) << 2;
     const bool full = v0 + 4 <= a.nvox;

@@ -316,10 +316,14 @@ class MapperIteration(object):
         for (gname, *_rest, lrv) in groups:
             lrs[self.groups.index(gname)] = float(lrv)
         check(L.adfp_adam_prep(ptr(self.step_count), ptr(self.derived), len(self.groups), lrs, b1, b2, st), 'adfp_adam_prep')
-        for (gname, p, g, (m, v), mask, nvox, ch, lrv) in groups:
-            d = self.derived[self.groups.index(gname)]
-            check(L.adfp_masked_adam_dev(ptr(p), ptr(g), ptr(m), ptr(v), ptr(mask) if mask is not None else None, int(nvox), int(ch),
-                                         b1, b2, self.eps, ptr(d), st), 'adfp_masked_adam_dev')
+        arr = (_lib.AdfpAdamGroup * len(groups))()                   # one launch for all groups
+        for k, (gname, p, g, (m, v), mask, nvox, ch, lrv) in enumerate(groups):
+            a = arr[k]
+            a.param, a.grad, a.exp_avg, a.exp_avg_sq = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+            a.mask = mask.data_ptr() if mask is not None else None
+            a.nvox, a.channels = int(nvox), int(ch)
+            a.derived = self.derived[self.groups.index(gname)].data_ptr()
+        check(L.adfp_masked_adam_multi(len(groups), C.byref(arr), b1, b2, self.eps, st), 'adfp_masked_adam_multi')
         return grids, flats
 
     def _bump_versions(self):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 111
+#define ADFP_VERSION 112
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -376,6 +376,14 @@ int adfp_adam_prep(int* steps /*device int[n]*/, float* derived /*device float[n
  * the call can be replayed from a HIP graph. */
 int adfp_masked_adam_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const unsigned char* mask,
                          long long nvox, int channels, float beta1, float beta2, float eps, const float* derived, void* stream);
+/* The same for up to 8 parameter groups in ONE launch (a Mapper iteration steps three grids and two networks). */
+typedef struct adfp_adam_group {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    const unsigned char* mask;   /* [nvox] or NULL */
+    long long nvox; int channels;
+    const float* derived;        /* this group's {step size, sqrt(bias correction 2)} from adfp_adam_prep */
+} adfp_adam_group;
+int adfp_masked_adam_multi(int n_groups, const adfp_adam_group* groups /*host*/, float beta1, float beta2, float eps, void* stream);
 
 /* Per-stage timing hook for bench.py: runs ONLY the TSDF trilerp + band-mask kernel (a10).
  * w may be NULL (that is the render path's launch: there the LOW decoder writes w = 1). */

@@ -76,6 +76,9 @@ int main(void) {
          offsetof(adfp_backward_args, g_depth), offsetof(adfp_backward_args, g_rays_d), offsetof(adfp_backward_args, workspace_bytes));
   printf("%zu %zu %zu %zu\\n", offsetof(adfp_backward_args, ray_keep), offsetof(adfp_loss_args, w_color_loss), offsetof(adfp_loss_args, depth),
          offsetof(adfp_loss_args, g_weight));
+  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(adfp_adam_group), offsetof(adfp_adam_group, mask), offsetof(adfp_adam_group, channels),
+         offsetof(adfp_adam_group, derived), offsetof(adfp_scene, ht_low), offsetof(adfp_train_state, masks_low),
+         offsetof(adfp_train_state, act_color));
   return 0;
 }''')
     exe = tmp_path / 'layout'
@@ -97,3 +100,6 @@ int main(void) {
                                               B.workspace_bytes.offset]
     Lo = _lib.AdfpLossArgs
     assert list(map(int, out[5].split())) == [B.ray_keep.offset, Lo.w_color_loss.offset, Lo.depth.offset, Lo.g_weight.offset]
+    G, T = _lib.AdfpAdamGroup, _lib.AdfpTrainState
+    assert list(map(int, out[6].split())) == [ctypes.sizeof(G), G.mask.offset, G.channels.offset, G.derived.offset, S.ht_low.offset,
+                                              T.masks_low.offset, T.act_color.offset]
