@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ADFP_LIB_PATH', os.path.join(_HERE, 'libadfp.so'))   # override: kernel A/B builds
 
-ABI_VERSION = 112                 # ADFP_VERSION of include/adfp.h this binding was written against
+ABI_VERSION = 113                 # ADFP_VERSION of include/adfp.h this binding was written against
 STATUS_F16_RANGE = 1
 STAGE = {'low': 0, 'high': 1, 'color': 2}
 DEC_KIND = {'low': 0, 'high': 1, 'color': 2}
@@ -34,7 +34,7 @@ class AdfpScene(C.Structure):
                 ('low', AdfpGrid), ('high', AdfpGrid), ('color', AdfpGrid), ('tsdf', AdfpTsdf),
                 ('w_low', C.c_void_p), ('w_high', C.c_void_p), ('w_color', C.c_void_p), ('w_att', C.c_void_p),
                 ('h_low', C.c_void_p), ('h_high', C.c_void_p), ('h_color', C.c_void_p), ('h_att', C.c_void_p),
-                ('ht_low', C.c_void_p), ('ht_high', C.c_void_p), ('ht_color', C.c_void_p),
+                ('ht_low', C.c_void_p), ('ht_high', C.c_void_p), ('ht_color', C.c_void_p), ('ht_att', C.c_void_p),
                 ('status', C.c_void_p)]
 
 
@@ -47,10 +47,13 @@ class AdfpTrainState(C.Structure):
     _fields_ = [('flags', C.c_void_p), ('list', C.c_void_p), ('counter', C.c_void_p),
                 ('att_occ', C.c_void_p), ('att_u', C.c_void_p),
                 ('masks_low', C.c_void_p), ('masks_high', C.c_void_p), ('masks_color', C.c_void_p),
-                ('act_low', C.c_void_p), ('act_high', C.c_void_p), ('act_color', C.c_void_p)]
+                ('act_low', C.c_void_p), ('act_high', C.c_void_p), ('act_color', C.c_void_p),
+                ('masks_att', C.c_void_p), ('act_att', C.c_void_p)]
 
 
 TRAIN_MASK_WORDS = 6              # ADFP_TRAIN_MASK_WORDS
+TRAIN_ATT_MASK_WORDS = 14         # ADFP_TRAIN_ATT_MASK_WORDS
+TRAIN_ATT_ACT_FLOATS = 416        # ADFP_TRAIN_ATT_ACT_FLOATS
 
 
 class AdfpAdamGroup(C.Structure):
@@ -112,6 +115,8 @@ SYMBOLS = [
     ('adfp_decoder_packed_ht_words', C.c_longlong, [C.c_int]),
     ('adfp_pack_decoder_ht', C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_train_act_floats', C.c_longlong, [C.c_int]),
+    ('adfp_attention_packed_ht_words', C.c_longlong, []),
+    ('adfp_pack_attention_ht', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_attention_packed_h_words', C.c_longlong, []),
     ('adfp_pack_attention_h', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_get_rays', C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,

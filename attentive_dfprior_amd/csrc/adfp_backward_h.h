@@ -448,14 +448,15 @@ __global__ __launch_bounds__(64) void k_scatter_sorted(ScatterSortedArgs a) {
 // and writes them k-major -- [hi|lo][rows 0-7 | 8-15][column][8 halves], the k-step layout of the H image, so that an operand
 // is one conflict-free ds_read_b128.  The rows come in two stored pieces (X from the training forward, indexed by the absolute
 // row; G from k_decode_bwd_h, scaled by S = grad_scale) -- the kernel is bound by reading them, so what can be rebuilt is not
-// stored: the conversion pass recomputes the 96 Fourier columns from x, y, z and forms d/d pre_i from d/d h_i and the forward's
-// ReLU mask words -- or, with act = NULL, as whole rows (the attention network).
+// stored: the 96 Fourier columns are recomputed from x, y, z (3 sines per thread) and d/d pre_i is formed from d/d h_i and the
+// forward's ReLU mask words -- or, with act = NULL, as whole rows (the attention network).
 // ---------------------------------------------------------------------------------------------
 struct OuterHArgs {
     OuterArgs o;
     const float* act;          // X pieces (row pitch 4 nxm4 floats, absolute row index) or NULL = whole rows in o.stage
-    int nxm4, ngm4;            // f32x4 pieces per stored X / G piece
+    int nxm4, ngm4;            // f32x4 pieces per stored X / G piece (at most 128 each)
     int g_dst4;                // f32x4 index in the tile row where the stored G piece starts
+    int x_gap_at4, x_gap4;     // the stored X piece skips x_gap4 f32x4 of the tile row after its first x_gap_at4 (decoders: the Fourier block)
     const unsigned* masks;     // decoders: the forward's ReLU mask words (absolute row index), NULL = no virtual columns
     const float* bm;           // decoders: [96][4] Fourier matrix rows (the packed image's P_BM block)
     int col_se, col_sgp;       // decoders: first column of the recomputed Fourier block / of the masked d/d pre block
@@ -471,9 +472,14 @@ __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
     int hi = a.chunk_hi;
     if (a.count_ptr) { const int cnt = *a.count_ptr; hi = hi < cnt ? hi : cnt; }
     const int rows = hi - a.chunk_lo;
-    const int m0 = blockIdx.x * a.rows_per_wave;          // rows per WORKGROUP
-    if (m0 >= rows) return;
-    const int m1 = (m0 + a.rows_per_wave < rows) ? m0 + a.rows_per_wave : rows;
+    // Blocks of a.rows_per_wave rows (a multiple of 16) are dealt round-robin: workgroup b takes blocks b, b + G, ...  The host
+    // makes the block the workgroup's whole share when it knows the row count (contiguous ranges: measured 25 % faster per
+    // tile than interleaved tiles) and 64 rows when it does not (the in-band list: the count is only on the device, and a
+    // share computed from its upper bound left half the workgroups idle).
+    const int BR = a.rows_per_wave;
+    int blk = blockIdx.x, m = blk * BR;
+    if (m >= rows) return;
+    int m1 = m + BR < rows ? m + BR : rows;               // end of the current block = row limit of fetch()
     const int nc = a.ncols;
     const bool dec = b.masks != nullptr;
     if (dec) for (int t = threadIdx.x; t < 96 * 4; t += 512) s_bm[t] = b.bm[t];
@@ -489,7 +495,7 @@ __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
         ca[j] = job < a.njobs ? a.jobs[job].colA + i : i;      // a missing job multiplies columns 0..31 by themselves and is never
         cb[j] = job < a.njobs ? a.jobs[job].colB + i : i;      // written out: no branch in the MFMA phase, its LDS reads overlap
     }
-    f32x4 ld[2][6];                                        // this wave's two rows: X pieces lane, lane + 64; G pieces lane + 64 k
+    f32x4 ld[2][4];                                        // this wave's two rows: X pieces lane, lane + 64; G pieces likewise (a piece <= 2 KB)
     unsigned mreg = 0u;                                    // threads 0..95: one mask word of the tile
     auto fetch = [&](int row0) {
 #pragma unroll
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
                 ld[rr][k] = (ok && e < b.nxm4) ? sx[e] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 2; ++k) {
                 const int e = lane + 64 * k;
                 ld[rr][2 + k] = (ok && e < b.ngm4) ? sg[e] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -515,26 +521,34 @@ __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
         }
     };
     float amax = 0.f;
-    fetch(m0);
-    for (int m = m0; m < m1; m += OUTER_RT) {
+    fetch(m);
+    for (;;) {
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {                   // registers -> f32 tile (the stored X piece lacks the 96 Fourier columns)
             f32x4* dst = (f32x4*)(sf + (2 * wv + rr) * nc);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) { const int e = lane + 64 * k; if (e < b.nxm4) dst[e < 8 ? e : e + 24] = ld[rr][k]; }
+            for (int k = 0; k < 2; ++k) { const int e = lane + 64 * k; if (e < b.nxm4) dst[e < b.x_gap_at4 ? e : e + b.x_gap4] = ld[rr][k]; }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const int e = lane + 64 * k; if (e < b.ngm4) dst[b.g_dst4 + e] = ld[rr][2 + k]; }
+            for (int k = 0; k < 2; ++k) { const int e = lane + 64 * k; if (e < b.ngm4) dst[b.g_dst4 + e] = ld[rr][2 + k]; }
         }
         if (dec && threadIdx.x < OUTER_RT * 6) s_mask[threadIdx.x / 6][threadIdx.x % 6] = mreg;
         __syncthreads();                                   // tile complete; everyone is done with the previous operands
-        if (m + OUTER_RT < m1) fetch(m + OUTER_RT);        // in flight during the conversion and the MFMAs
+        int nm = m + OUTER_RT, nblk = blk, nm1 = m1;       // the tile after this one: same block, or the first of my next block
+        if (nm >= m1) { nblk = blk + gridDim.x; nm = nblk * BR; nm1 = nm + BR < rows ? nm + BR : rows; }
+        const bool more = nm < rows;
+        const int cur_m1 = m1;
+        if (more) { m1 = nm1; fetch(nm); m1 = cur_m1; }    // in flight during the conversion and the MFMAs
+        if (dec) {                                         // the 96 Fourier columns of the 16 rows from x, y, z: 3 sines per thread
+            for (int e = threadIdx.x; e < OUTER_RT * 96; e += 512) {
+                const int r = e / 96, jf = e - 96 * r;
+                const f32x4 bmr = *(const f32x4*)(s_bm + jf * 4);
+                sf[r * nc + b.col_se + jf] = adfp_sinf(fmaf(sf[r * nc + 2], bmr.z, fmaf(sf[r * nc + 1], bmr.y, sf[r * nc] * bmr.x)));
+            }
+            __syncthreads();
+        }
         for (int c = threadIdx.x; c < nc; c += 512) {      // columns -> k-major hi / lo halves
             float v[16];
-            if (dec && c >= b.col_se && c < b.col_se + 96) {                 // Fourier features of the rows, from x, y, z
-                const f32x4 bmr = *(const f32x4*)(s_bm + (c - b.col_se) * 4);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = adfp_sinf(fmaf(sf[r * nc + 2], bmr.z, fmaf(sf[r * nc + 1], bmr.y, sf[r * nc] * bmr.x)));
-            } else if (dec && c >= b.col_sgp && c < b.col_sgp + 160) {       // d/d pre_i = mask . d/d h_i
+            if (dec && c >= b.col_sgp && c < b.col_sgp + 160) {              // d/d pre_i = mask . d/d h_i
                 const int u = (c - b.col_sgp) & 31, li = (c - b.col_sgp) >> 5;
                 const int word = ((u >> 2) & 1) * 3 + (li >> 1), bit = 15 - ((u & 3) | ((u >> 3) << 2)) + 16 * (li & 1);
 #pragma unroll
@@ -562,6 +576,8 @@ __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[j], 0, 0, 0);
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[j], 0, 0, 0);
         }
+        if (!more) break;
+        m = nm; blk = nblk; m1 = nm1;
     }
     report_range(b.status, amax);
     float* part = a.partial + (long long)blockIdx.x * a.part_stride;
@@ -571,12 +587,12 @@ __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
         if (job < a.njobs) {
             const OuterJob jb = a.jobs[job];
             const int c = i - jb.j0;
-            if (c >= 0 && c < jb.nc) {
+            if (c >= 0 && c < jb.nc) {                     // read the 16 slots, then write them: a += per element serialises 16 round trips
+                float old[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = kmapH(r, h);
-                    if (row < jb.nr) part[jb.dst + row * jb.rs + c * jb.cs] += acc[j][r];
-                }
+                for (int r = 0; r < 16; ++r) { const int row = kmapH(r, h); old[r] = part[jb.dst + (row < jb.nr ? row : 0) * jb.rs + c * jb.cs]; }    // unconditional: 16 loads in flight
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const int row = kmapH(r, h); if (row < jb.nr) part[jb.dst + row * jb.rs + c * jb.cs] = old[r] + acc[j][r]; }
             }
         }
     }
@@ -597,4 +613,190 @@ __global__ __launch_bounds__(256) void k_reduce_partials_scaled(const float* __r
     const float S = grad_scale(gmax);
     const float inv = __uint_as_float((254u - (__float_as_uint(S) >> 23)) << 23);      // exact reciprocal of a power of two
     flat[e] += ((s0 + s1) + (s2 + s3)) * inv;
+}
+
+// =============================================================================================
+// attention network (mlp_tsdf) backward on f16 MFMA: the decoder scheme again.  The training forward (k_attention_h<1>) leaves
+// the ReLU masks, the softmax weights and -- for the weight gradients -- the layer inputs; the chains run out of a "T" image
+// (W3^T, W2^T, W1^T as [in-block][out-block] k-step pairs, 128 KB, the one thing in LDS); nothing is recomputed.  The exact
+// kernel (k_attention_bwd) stays for the position gradient.
+// =============================================================================================
+struct AttLayoutHT {
+    using F = AttLayout;
+    static constexpr int P_A0 = 0;                               // [64][4] f32 = (w0, w1, b, 0), unit order
+    static constexpr int T_W3 = 256;                             // 4 in-blocks x 2 out-blocks
+    static constexpr int T_W2 = T_W3 + 8 * 1024;                 // 4 x 4
+    static constexpr int T_W1 = T_W2 + 16 * 1024;                // 2 x 4
+    static constexpr int P_WO = T_W1 + 8 * 1024;                 // [2 h][2 o][32] f32
+    static constexpr int P_TOTAL = P_WO + 128;
+};
+__device__ HSrc att_ht_src(int t) {
+    using L = AttLayoutHT;
+    using F = AttLayout;
+    if (t < L::T_W3) {
+        const int k = t >> 2, c = t & 3;
+        return HSrc{0, c < 2 ? F::F_W0 + k * 2 + c : (c == 2 ? F::F_B0 + k : -1), -1};
+    }
+    auto chain = [](int u, int nob, int base, int ld) {          // block (ib, ob) of W^T: rows = in units of ib, k = out units of ob
+        const int blk = u >> 10, v = u & 1023;
+        const int ib = blk / nob, ob = blk % nob;
+        const int ks = v >> 9, part = (v >> 8) & 1, h = (v >> 7) & 1, row = (v >> 2) & 31, jp = (v & 3) * 2;
+        const int o0 = 32 * ob + kmapH(8 * ks + jp, h), o1 = 32 * ob + kmapH(8 * ks + jp + 1, h), in = 32 * ib + row;
+        return HSrc{1 + part, base + o0 * ld + in, base + o1 * ld + in};
+    };
+    if (t < L::T_W2) return chain(t - L::T_W3, 2, F::F_W3, 128);
+    if (t < L::T_W1) return chain(t - L::T_W2, 4, F::F_W2, 128);
+    if (t < L::P_WO) return chain(t - L::T_W1, 4, F::F_W1, 64);
+    const int u = t - L::P_WO, h = u >> 6, o = (u >> 5) & 1, j = u & 31;
+    return HSrc{0, F::F_WO + o * 64 + unit_of(j, h), -1};
+}
+__global__ void k_pack_attention_ht(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= AttLayoutHT::P_TOTAL) return;
+    const HSrc s = att_ht_src(t);
+    if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(flat[s.s0]); return; }
+    const float a = flat[s.s0], b = flat[s.s1];
+    if (status && !(fmaxf(fabsf(a), fabsf(b)) < 65504.0f))
+        __hip_atomic_fetch_or(status, ADFP_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const float ah = f16_hi_part(a), bh = f16_hi_part(b);
+    _Float16 x, y;
+    if (s.kind == 1) { x = (_Float16)ah; y = (_Float16)bh; }
+    else { x = (_Float16)(a - ah); y = (_Float16)(b - bh); }
+    packed[t] = (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+
+struct AttBwdHArgs {
+    const unsigned* packed_t; const int* list; const int* count_ptr;
+    const float* att_occ; const float* att_u;
+    const unsigned* masks;     // [rows][2][7] from k_attention_h<1>
+    const float* g_weight;     // [P] cotangent of the attention weight output (or NULL)
+    float* g_raw;              // [P,4]: .w read as cotangent of the fused occupancy, then overwritten with d/d(high+low)
+    float* att_g;              // per list entry: d/d(high+low) for the HIGH backward
+    float* stage;              // G piece of this chunk's staging rows (AttStage columns [416, 832)) or NULL
+    int chunk_lo, chunk_hi;
+    int* status; const float* gmax;
+};
+// 16 values of a float array -> the two k-steps of a B operand
+ADFP_DEV void split16a(const float* __restrict__ v, f16x8* __restrict__ xh, f16x8* __restrict__ xl, float& amax) {
+    split8(v, xh[0], xl[0], amax);
+    split8(v + 8, xh[1], xl[1], amax);
+}
+template <bool WGRAD>
+__global__ __launch_bounds__(512) void k_attention_bwd_h(AttBwdHArgs a) {
+    using T = AttLayoutHT;
+    using ST = AttStage;
+    __shared__ __attribute__((aligned(16))) unsigned ldsu[T::P_TOTAL];
+    for (int i = threadIdx.x; i < T::P_TOTAL / 4; i += 512) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed_t)[i];
+    __syncthreads();
+    const float* lds = (const float*)ldsu;
+    const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+    const int lane_off = h * 128 + p * 4;
+    const int wave = blockIdx.x * 8 + (threadIdx.x >> 6), nwaves = gridDim.x * 8;
+    const int cnt = *a.count_ptr;
+    const int hi = a.chunk_hi < cnt ? a.chunk_hi : cnt;
+    const int count = hi - a.chunk_lo;
+    const int ntiles = count > 0 ? (count + 31) >> 5 : 0;
+    const float gS = WGRAD ? grad_scale(a.gmax) : 1.f;
+    float amax = 0.f;
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int loc = tile * 32 + p;
+        const bool valid = loc < count;
+        const int idx = a.chunk_lo + (valid ? loc : 0);
+        const int q = a.list[idx];
+        float* srow = WGRAD ? a.stage + (long long)loc * 416 - ST::AG0 : nullptr;      // addressed with the full row's columns
+        const float occ = a.att_occ[idx], u = a.att_u[idx];
+        const unsigned* mrow = a.masks + (long long)idx * ADFP_ATT_MASK_WORDS;
+        unsigned mk[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) mk[k] = valid ? mrow[h * 7 + k] : 0u;
+        const float a0 = __uint_as_float(mrow[6]), a1 = __uint_as_float(mrow[13]);
+        // ---- softmax / blend backward: out = a0 occ + a1 u, w = a1
+        const float g_out = valid ? a.g_raw[4ll * q + 3] : 0.f;
+        const float g_w = (valid && a.g_weight) ? a.g_weight[q] : 0.f;
+        const float ga0 = g_out * occ, ga1 = g_out * u + g_w;
+        const float dot = a0 * ga0 + a1 * ga1;
+        const float gl0 = a0 * (ga0 - dot), gl1 = a1 * (ga1 - dot);
+        if (WGRAD && valid) stage_head(srow, ST::AGL, h, f32x4{gl0 * gS, gl1 * gS, 0.f, 0.f});
+        // per-point power-of-two scale of the cotangents (see k_decode_bwd_h)
+        float sc = 1.f, isc = 1.f;
+        {
+            const float m = fmaxf(fabsf(gl0), fabsf(gl1));
+            if (m > 0.f) {
+                int se = 127 + 4 + 127 - (int)((__float_as_uint(m) >> 23) & 0xFFu);
+                se = se < 1 ? 1 : (se > 253 ? 253 : se);
+                sc = __uint_as_float((unsigned)se << 23);
+                isc = __uint_as_float((unsigned)(254 - se) << 23);
+            }
+        }
+        const float ssc = isc * gS, s0 = gl0 * sc, s1 = gl1 * sc;
+        // ---- layer 3: d/d pre_3 = mask . (WO^T gl)
+        float gp3[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float g = fmaf(lds[T::P_WO + (h * 2 + 0) * 32 + j], s0, lds[T::P_WO + (h * 2 + 1) * 32 + j] * s1);
+            const int keep = ((int)(mk[5] << j)) >> 31;
+            gp3[j] = __uint_as_float(__float_as_uint(g) & (unsigned)keep);
+        }
+        if (WGRAD && valid) { stage_block_mul(srow, ST::AG3, h, gp3, 0, ssc); stage_block_mul(srow, ST::AG3 + 32, h, gp3, 16, ssc); }
+        f16x8 xh[8], xl[8];
+        split16a(gp3, xh, xl, amax); split16a(gp3 + 16, xh + 2, xl + 2, amax);
+        // ---- layer 2: d/d pre_2 = mask . (W3^T gp3)
+        float gp2[64];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) mfma_chain_h<2>(acc, ldsu + T::T_W3 + (ib * 2 + ob) * 1024, lane_off, xh + 2 * ob, xl + 2 * ob);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int keep = ((int)(mk[3 + (ib >> 1)] << (16 * (ib & 1) + r))) >> 31;
+                gp2[16 * ib + r] = __uint_as_float(__float_as_uint(acc[r]) & (unsigned)keep);
+            }
+            if (WGRAD && valid) stage_block_mul(srow, ST::AG2 + 32 * ib, h, gp2, 16 * ib, ssc);
+        }
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) split16a(gp2 + 16 * ob, xh + 2 * ob, xl + 2 * ob, amax);
+        // ---- layer 1: d/d pre_1 = mask . (W2^T gp2)
+        float gp1[64];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) mfma_chain_h<2>(acc, ldsu + T::T_W2 + (ib * 4 + ob) * 1024, lane_off, xh + 2 * ob, xl + 2 * ob);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int keep = ((int)(mk[1 + (ib >> 1)] << (16 * (ib & 1) + r))) >> 31;
+                gp1[16 * ib + r] = __uint_as_float(__float_as_uint(acc[r]) & (unsigned)keep);
+            }
+            if (WGRAD && valid) stage_block_mul(srow, ST::AG1 + 32 * ib, h, gp1, 16 * ib, ssc);
+        }
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) split16a(gp1 + 16 * ob, xh + 2 * ob, xl + 2 * ob, amax);
+        // ---- layer 0: d/d pre_0 = mask . (W1^T gp1); d/d occ_in through the 2 -> 64 layer
+        float gx = 0.f;
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) mfma_chain_h<2>(acc, ldsu + T::T_W1 + (ib * 4 + ob) * 1024, lane_off, xh + 2 * ob, xl + 2 * ob);
+            float g0[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int keep = ((int)(mk[0] << (16 * ib + r))) >> 31;
+                g0[r] = __uint_as_float(__float_as_uint(acc[r]) & (unsigned)keep);
+                gx = fmaf(lds[T::P_A0 + (32 * ib + kmapH(r, h)) * 4], g0[r], gx);
+            }
+            if (WGRAD && valid) stage_block_mul(srow, ST::AG0 + 32 * ib, h, g0, 0, ssc);
+        }
+        gx += __shfl_xor(gx, 32);
+        const float g_in = a0 * g_out + gx * isc;
+        if (valid && h == 0) { a.att_g[idx] = g_in; a.g_raw[4ll * q + 3] = g_in; }
+    }
+    report_range(a.status, amax);
 }

@@ -422,8 +422,21 @@ __global__ void k_pack_attention_h(const float* __restrict__ flat, unsigned* __r
     packed[t] = (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
 
+// relu(v) with its activity bit shifted into `m` (see relu_bias_mask)
+ADFP_DEV float relu_mask(float v, unsigned& m) {
+    const float t = relu_f(v);
+    m = __builtin_amdgcn_alignbit(m, 0u - __float_as_uint(t), 31);
+    return t;
+}
+// TRAIN: besides its outputs the kernel leaves what the f16-split attention backward needs (k_attention_bwd_h): per lane half
+// 7 words -- the ReLU masks of the four layers (word 0: layer 0, value 8 ks + j at bit 31 - (8 ks + j); words 1-2 / 3-4: layers
+// 1 / 2, out-block ob in word ob >> 1, its register r at bit 31 - 16 (ob & 1) - r; word 5: layer 3 likewise) and the softmax
+// weight (half 0: a0, half 1: a1) -- and, when a.act is set, the layer inputs (AttStage columns [0, 416)).
+#define ADFP_ATT_MASK_WORDS 14
+template <int TRAIN>
 __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
     using A = AttLayoutH;
+    using ST = AttStage;
     __shared__ __attribute__((aligned(16))) unsigned ldsu[A::P_TOTAL];
     __shared__ int s_next;
     for (int i = threadIdx.x; i < A::P_TOTAL / 4; i += 512) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed)[i];
@@ -440,6 +453,9 @@ __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
         const bool valid = idx < count;
         const int ii = valid ? idx : 0;
         const float occ = a.att_occ[ii], u = a.att_u[ii];
+        unsigned mk[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+        float* srow = (TRAIN && a.act && valid) ? a.act + (long long)idx * 416 : nullptr;
+        if constexpr (TRAIN) if (srow) stage_head(srow, ST::AX, h, f32x4{occ, u, 1.f, 0.f});
         // layer 0 (2 -> 64) on the VALU
         f16x8 xh[8], xl[8];
 #pragma unroll
@@ -448,7 +464,12 @@ __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const f32x4 t = *(const f32x4*)(lds + A::P_A0 + unit_of_h(ks, h, j) * 4);
-                t8[j] = relu_f(fmaf(u, t.y, fmaf(occ, t.x, t.z)));
+                const float v = fmaf(u, t.y, fmaf(occ, t.x, t.z));
+                t8[j] = TRAIN ? relu_mask(v, mk[0]) : relu_f(v);
+            }
+            if constexpr (TRAIN) if (srow) {
+                *(f32x4*)(srow + ST::AH0 + 32 * (ks >> 1) + 16 * (ks & 1) + 4 * h) = f32x4{t8[0], t8[1], t8[2], t8[3]};
+                *(f32x4*)(srow + ST::AH0 + 32 * (ks >> 1) + 16 * (ks & 1) + 8 + 4 * h) = f32x4{t8[4], t8[5], t8[6], t8[7]};
             }
             split8(t8, xh[ks], xl[ks], amax);
         }
@@ -462,7 +483,8 @@ __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
             mfma_chain_h<4>(acc, ldsu + A::P_W1 + ob * 4 * 512, lane_off, xh, xl);
             float t[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) t[r] = relu_f(acc[r]);
+            for (int r = 0; r < 16; ++r) t[r] = TRAIN ? relu_mask(acc[r], mk[1 + (ob >> 1)]) : relu_f(acc[r]);
+            if constexpr (TRAIN) if (srow) stage_block(srow, ST::AH1 + 32 * ob, h, t, 0);
             split8(t, yh[2 * ob], yl[2 * ob], amax);
             split8(t + 8, yh[2 * ob + 1], yl[2 * ob + 1], amax);
         }
@@ -474,7 +496,8 @@ __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
             mfma_chain_h<8>(acc, ldsu + A::P_W2 + ob * 8 * 512, lane_off, yh, yl);
             float t[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) t[r] = relu_f(acc[r]);
+            for (int r = 0; r < 16; ++r) t[r] = TRAIN ? relu_mask(acc[r], mk[3 + (ob >> 1)]) : relu_f(acc[r]);
+            if constexpr (TRAIN) if (srow) stage_block(srow, ST::AH2 + 32 * ob, h, t, 0);
             split8(t, xh[2 * ob], xl[2 * ob], amax);
             split8(t + 8, xh[2 * ob + 1], xl[2 * ob + 1], amax);
         }
@@ -487,12 +510,15 @@ __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
             mfma_chain_h<8>(acc, ldsu + A::P_W3 + ob * 8 * 512, lane_off, xh, xl);
             const float* w0 = lds + A::P_WO + (h * 2 + 0) * 32 + 16 * ob;
             const float* w1 = lds + A::P_WO + (h * 2 + 1) * 32 + 16 * ob;
+            float t[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = relu_f(acc[r]);
+                const float v = TRAIN ? relu_mask(acc[r], mk[5]) : relu_f(acc[r]);
+                t[r] = v;
                 l0 = fmaf(v, w0[r], l0);
                 l1 = fmaf(v, w1[r], l1);
             }
+            if constexpr (TRAIN) if (srow) stage_block(srow, ST::AH3 + 32 * ob, h, t, 0);
         }
         l0 += __shfl_xor(l0, 32); l1 += __shfl_xor(l1, 32);
         l0 += lds[A::P_BO]; l1 += lds[A::P_BO + 1];
@@ -502,6 +528,12 @@ __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
         const float den = e0 + e1;
         const float a0 = e0 / den, a1 = e1 / den;
         const float fused = a0 * occ + a1 * u;
+        if constexpr (TRAIN) if (valid) {
+            unsigned* mrow = a.masks + ((long long)idx * 2 + h) * (ADFP_ATT_MASK_WORDS / 2);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) mrow[k] = mk[k];
+            mrow[6] = __float_as_uint(h ? a1 : a0);
+        }
         if (valid && h == 0) {
             const int q = a.list[ii];
             const bool inb = (a.flags[q] & ADFP_F_INBOUND) != 0;

@@ -781,6 +781,8 @@ struct AttArgs {
     const float* att_occ; const float* att_u; const unsigned char* flags;
     float* raw; float* w; int apply_bound;
     int* status;
+    unsigned* masks;           // training forward (k_attention_h<1>): ReLU masks + softmax weights, [rows][2][ATT_MASK_WORDS / 2]
+    float* act;                // training forward: X piece of the staging rows ([rows][416]: inputs, h_0..h_3), or NULL
 };
 
 // workgroup shape of the dense f16x3 decoder kernels: 256 threads x 2 workgroups per CU, or one
@@ -1108,6 +1110,13 @@ int adfp_pack_attention_h(const float* flat, void* packed, int* status, void* st
     ADFP_CHECK_LAUNCH();
     return 0;
 }
+long long adfp_attention_packed_ht_words(void) { return AttLayoutHT::P_TOTAL; }
+int adfp_pack_attention_ht(const float* flat, void* packed, int* status, void* stream) {
+    if (!flat || !packed) return ADFP_E_ARG;
+    hipLaunchKernelGGL(k_pack_attention_ht, dim3((AttLayoutHT::P_TOTAL + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat, (unsigned*)packed, status);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
 int adfp_pack_attention(const float* flat, float* packed, void* stream) {
     if (!flat || !packed) return ADFP_E_ARG;
     hipLaunchKernelGGL(k_pack_attention, dim3((AttLayout::P_TOTAL + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat, packed);
@@ -1321,9 +1330,13 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         AttArgs t;
         t.list = ws.list; t.count_ptr = ws.counter; t.att_occ = ws.att_occ; t.att_u = ws.att_u;
         t.flags = ws.flags; t.raw = raw; t.w = w; t.apply_bound = apply_bound; t.status = sc->status;
-        if (sc->h_att) {
+        t.masks = nullptr; t.act = nullptr;
+        if (sc->h_att && state && state->masks_att) {
+            t.packed = (const float*)sc->h_att; t.masks = state->masks_att; t.act = state->act_att;
+            hipLaunchKernelGGL(k_attention_h<1>, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
+        } else if (sc->h_att) {
             t.packed = (const float*)sc->h_att;
-            hipLaunchKernelGGL(k_attention_h, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
+            hipLaunchKernelGGL(k_attention_h<0>, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
         } else {
             t.packed = sc->w_att;
             hipLaunchKernelGGL(k_attention, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
@@ -1753,7 +1766,7 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
     }
     using ST = DecStage<CDIM>;
     OuterHArgs oa; decoder_jobs<CDIM, NOUT>(oa.o);
-    oa.act = act; oa.nxm4 = ST::NXM / 4; oa.ngm4 = ST::NGM / 4; oa.g_dst4 = ST::SGH(0) / 4; oa.masks = masks; oa.bm = (const float*)t;   // P_BM = word 0 of the T image
+    oa.act = act; oa.nxm4 = ST::NXM / 4; oa.ngm4 = ST::NGM / 4; oa.g_dst4 = ST::SGH(0) / 4; oa.x_gap_at4 = 8; oa.x_gap4 = 24; oa.masks = masks; oa.bm = (const float*)t;   // P_BM = word 0 of the T image
     oa.col_se = ST::SE; oa.col_sgp = ST::SGP(0); oa.status = status;
     a.stage = bw.stage;
     const int rows_cap = (int)((size_t)bw.stage_rows * AttStage::NCOLS / ST::NGM);
@@ -1767,11 +1780,14 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
         ADFP_CHECK_LAUNCH();
         oa.o.stage = bw.stage; oa.o.count_ptr = count_ptr; oa.o.chunk_lo = lo; oa.o.chunk_hi = hi; oa.o.flat = flat;
         oa.o.partial = bw.partial; oa.o.part_stride = bw.part_stride;
-        const int rows = hi - lo;
-        int per = (rows + OUTER_NSLOT - 1) / OUTER_NSLOT;
-        per = ((per < 64 ? 64 : per) + OUTER_RT - 1) / OUTER_RT * OUTER_RT;
-        oa.o.rows_per_wave = per;
-        hipLaunchKernelGGL(k_outer_h, dim3((rows + per - 1) / per), dim3(512), 0, st, oa);
+        {   // block = a workgroup's whole share when the row count is known here, 64 rows for a list (count on the device)
+            const int rows = hi - lo;
+            int br = 64;
+            if (!count_ptr) { br = (rows + OUTER_NSLOT - 1) / OUTER_NSLOT; br = ((br < 64 ? 64 : br) + OUTER_RT - 1) / OUTER_RT * OUTER_RT; }
+            const int nblk = (rows + br - 1) / br;
+            oa.o.rows_per_wave = br;
+            hipLaunchKernelGGL(k_outer_h, dim3(nblk < OUTER_NSLOT ? nblk : OUTER_NSLOT), dim3(512), 0, st, oa);
+        }
         ADFP_CHECK_LAUNCH();
     }
     rc = outer_end_scaled(bw, DecLayout<CDIM, NOUT>::F_TOTAL, flat, st);
@@ -1858,17 +1874,44 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
     }
 
     if (fuse) {
+        const bool att_full_h = use_h(sc->ht_att, state.masks_att, state.act_att, go.flat_att);
+        if (att_full_h) {
+            // the attention backward on f16 MFMA (k_attention_bwd_h): masks, softmax weights and layer inputs from the forward
+            AttBwdHArgs t;
+            t.packed_t = (const unsigned*)sc->ht_att; t.list = state.list; t.count_ptr = state.counter; t.att_occ = state.att_occ; t.att_u = state.att_u;
+            t.masks = state.masks_att; t.g_weight = g_weight; t.g_raw = bw.g_raw; t.att_g = bw.att_g; t.stage = bw.stage;
+            t.status = sc->status; t.gmax = bw.gmax;
+            OuterHArgs oh; attention_jobs(oh.o);
+            oh.act = state.act_att; oh.nxm4 = 416 / 4; oh.ngm4 = 416 / 4; oh.g_dst4 = 416 / 4; oh.x_gap_at4 = 1 << 20; oh.x_gap4 = 0;
+            oh.masks = nullptr; oh.bm = nullptr; oh.col_se = 0; oh.col_sgp = 0; oh.status = sc->status;
+            OuterArgs& oa = oh.o;
+            const int rows_cap = bw.stage_rows * 2;               // the G piece is half a row
+            if (go.flat_att) { rc = outer_begin(bw, AttLayout::F_TOTAL, st); if (rc) return rc; }
+            for (int lo = 0; lo < P; lo += rows_cap) {
+                const int hi = lo + rows_cap < P ? lo + rows_cap : P;
+                t.chunk_lo = lo; t.chunk_hi = hi;
+                const int ntiles = (hi - lo + 31) / 32;
+                if (go.flat_att) hipLaunchKernelGGL(k_attention_bwd_h<true>, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
+                else hipLaunchKernelGGL(k_attention_bwd_h<false>, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
+                ADFP_CHECK_LAUNCH();
+                if (go.flat_att) {
+                    oa.stage = bw.stage; oa.count_ptr = state.counter; oa.chunk_lo = lo; oa.chunk_hi = hi; oa.flat = go.flat_att;
+                    oa.partial = bw.partial; oa.part_stride = bw.part_stride;
+                    const int nblk = (hi - lo + 63) / 64;          // list-based: blocks of 64 rows, round-robin
+                    oa.rows_per_wave = 64;
+                    hipLaunchKernelGGL(k_outer_h, dim3(nblk < OUTER_NSLOT ? nblk : OUTER_NSLOT), dim3(512), 0, st, oh);
+                    ADFP_CHECK_LAUNCH();
+                }
+            }
+            if (go.flat_att) { rc = outer_end_scaled(bw, AttLayout::F_TOTAL, go.flat_att, st); if (rc) return rc; }
+        } else {
+        if (!sc->w_att) return ADFP_E_ARG;
         AttBwdArgs t;
         t.packed = sc->w_att; t.list = state.list; t.count_ptr = state.counter; t.att_occ = state.att_occ;
         t.att_u = state.att_u; t.g_weight = g_weight; t.g_raw = bw.g_raw; t.att_g = bw.att_g; t.stage = bw.stage;
         t.P = Pd; t.nt = make_norm(sc->tsdf_bnds); t.t = make_tsdf(sc->tsdf); t.g_pts = a.g_pts;
-        // weight gradients of the attention network: with the f16-split images in use (sc->ht_*: ADFP_MATH=f16x3) the outer
-        // products run on f16 MFMA (k_outer_h) and the staged gradient blocks carry the call's power-of-two scale
-        const bool att_h = sc->ht_low != nullptr;
-        t.gmax = att_h ? bw.gmax : nullptr;
-        OuterHArgs oh; attention_jobs(oh.o); oh.act = nullptr; oh.nxm4 = 0; oh.ngm4 = AttStage::NCOLS / 4; oh.g_dst4 = 0; oh.masks = nullptr; oh.bm = nullptr;
-        oh.col_se = 0; oh.col_sgp = 0; oh.status = sc->status;
-        OuterArgs& oa = oh.o;
+        t.gmax = nullptr;
+        OuterArgs oa; attention_jobs(oa);
         if (go.flat_att) { rc = outer_begin(bw, AttLayout::F_TOTAL, st); if (rc) return rc; }
         for (int lo = 0; lo < P; lo += bw.stage_rows) {
             const int hi = lo + bw.stage_rows < P ? lo + bw.stage_rows : P;
@@ -1878,26 +1921,16 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
                 if (pgrad) hipLaunchKernelGGL((k_attention_bwd<true, true>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
                 else hipLaunchKernelGGL((k_attention_bwd<true, false>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
                 ADFP_CHECK_LAUNCH();
-                if (att_h) {
-                    oa.stage = bw.stage; oa.count_ptr = state.counter; oa.chunk_lo = lo; oa.chunk_hi = hi; oa.flat = go.flat_att;
-                    oa.partial = bw.partial; oa.part_stride = bw.part_stride;
-                    const int rows = hi - lo;
-                    int per = (rows + OUTER_NSLOT - 1) / OUTER_NSLOT;
-                    per = ((per < 64 ? 64 : per) + OUTER_RT - 1) / OUTER_RT * OUTER_RT;
-                    oa.rows_per_wave = per;
-                    hipLaunchKernelGGL(k_outer_h, dim3((rows + per - 1) / per), dim3(512), 0, st, oh);
-                    ADFP_CHECK_LAUNCH();
-                } else {
-                    rc = launch_outer(oa, bw, state.counter, lo, hi, go.flat_att, st);
-                    if (rc) return rc;
-                }
+                rc = launch_outer(oa, bw, state.counter, lo, hi, go.flat_att, st);
+                if (rc) return rc;
             } else {
                 if (pgrad) hipLaunchKernelGGL((k_attention_bwd<false, true>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
                 else hipLaunchKernelGGL((k_attention_bwd<false, false>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
                 ADFP_CHECK_LAUNCH();
             }
         }
-        if (go.flat_att) { rc = att_h ? outer_end_scaled(bw, AttLayout::F_TOTAL, go.flat_att, st) : outer_end(bw, AttLayout::F_TOTAL, go.flat_att, st); if (rc) return rc; }
+        if (go.flat_att) { rc = outer_end(bw, AttLayout::F_TOTAL, go.flat_att, st); if (rc) return rc; }
+        }
         if (go.grid_high || go.flat_high || pgrad) {
             DecodeBwdArgs hgh = a;
             hgh.g0 = make_grid(sc->high); hgh.g1 = make_grid(sc->low); hgh.packed = sc->w_high;
@@ -1931,8 +1964,8 @@ static int check_backward_scene(const adfp_scene* sc, int stage) {
     if (!sc) return ADFP_E_ARG;
     if (stage < ADFP_STAGE_LOW || stage > ADFP_STAGE_COLOR) return ADFP_E_ARG;
     if (!sc->low.data || (stage >= ADFP_STAGE_HIGH && (!sc->high.data || !sc->tsdf.data)) || (stage == ADFP_STAGE_COLOR && !sc->color.data)) return ADFP_E_ARG;
-    // the attention backward is exact-f32 only; a decoder needs its exact image or its T image (backward_points picks)
-    if (!(sc->w_low || sc->ht_low) || (stage >= ADFP_STAGE_HIGH && (!(sc->w_high || sc->ht_high) || !sc->w_att)) ||
+    // every network needs its exact image or its T image (backward_points picks)
+    if (!(sc->w_low || sc->ht_low) || (stage >= ADFP_STAGE_HIGH && (!(sc->w_high || sc->ht_high) || !(sc->w_att || sc->ht_att))) ||
         (stage == ADFP_STAGE_COLOR && !(sc->w_color || sc->ht_color))) return ADFP_E_ARG;
     return 0;
 }

@@ -163,7 +163,7 @@ class DF(nn.Module):
         """Packed (MFMA operand order) image of one sub-network, rebuilt only when a parameter
         changed (optimizer step bumps Parameter._version).  fmt 'f32' = exact f32-input MFMA image,
         'h' = f16 hi/lo split image of the forward decoders (adfp_pack_decoder_h), 'ht' = the transposed split image of
-        the f16 backward (adfp_pack_decoder_ht; decoders only)."""
+        the f16 backward (adfp_pack_decoder_ht / adfp_pack_attention_ht)."""
         module = self.net_params(name)
         key = _version_key(module)
         slot = name if fmt == 'f32' else name + '.' + fmt
@@ -176,10 +176,15 @@ class DF(nn.Module):
             L = lib()
             dev = flat.device
             with torch.cuda.device(dev):
-                kind = _lib.DEC_KIND[name]
-                packed = torch.empty(L.adfp_decoder_packed_ht_words(kind), dtype=torch.int32, device=dev)
-                _lib.check(L.adfp_pack_decoder_ht(kind, _lib.ptr(flat), _lib.ptr(packed), _lib.status_ptr(), _lib.current_stream(dev)),
-                           'adfp_pack_decoder_ht')
+                if name == 'att':
+                    packed = torch.empty(L.adfp_attention_packed_ht_words(), dtype=torch.int32, device=dev)
+                    _lib.check(L.adfp_pack_attention_ht(_lib.ptr(flat), _lib.ptr(packed), _lib.status_ptr(), _lib.current_stream(dev)),
+                               'adfp_pack_attention_ht')
+                else:
+                    kind = _lib.DEC_KIND[name]
+                    packed = torch.empty(L.adfp_decoder_packed_ht_words(kind), dtype=torch.int32, device=dev)
+                    _lib.check(L.adfp_pack_decoder_ht(kind, _lib.ptr(flat), _lib.ptr(packed), _lib.status_ptr(), _lib.current_stream(dev)),
+                               'adfp_pack_decoder_ht')
             self._packed[slot] = (key, packed)
             return packed
         if fmt == 'h':

@@ -118,7 +118,10 @@ class Engine(object):
                     sc.ht_high = decoders.packed_weights('high', 'ht').data_ptr()
                 else:
                     sc.w_high = decoders.packed_weights('high').data_ptr()
-                sc.w_att = decoders.packed_weights('att').data_ptr()
+                if 'att' in ht_nets:
+                    sc.ht_att = decoders.packed_weights('att', 'ht').data_ptr()
+                else:
+                    sc.w_att = decoders.packed_weights('att').data_ptr()
             _lib.fill_bound(sc.tsdf_bnds, self.host_bound(tsdf_bnds, 'tsdf_bnds'))
             self.fill_tsdf(sc.tsdf, tsdf_volume, keep)
         if stage == 'color':
@@ -152,6 +155,13 @@ class Engine(object):
                 if want:
                     bufs['act_' + n] = torch.empty((P, lib().adfp_train_act_floats(_lib.DEC_KIND[n])), dtype=torch.float32, device=dev)
                     setattr(st, 'act_' + n, bufs['act_' + n].data_ptr())
+            if stage != 'low':                       # the attention network, rows = in-band list entries (at most P)
+                bufs['masks_att'] = torch.empty((P, _lib.TRAIN_ATT_MASK_WORDS), dtype=torch.int32, device=dev)
+                st.masks_att = bufs['masks_att'].data_ptr()
+                want = need_flat.get('att') if need_flat is not None else any(p.requires_grad for p in decoders.net_params('att'))
+                if want:
+                    bufs['act_att'] = torch.empty((P, _lib.TRAIN_ATT_ACT_FLOATS), dtype=torch.float32, device=dev)
+                    st.act_att = bufs['act_att'].data_ptr()
         bufs['_state'] = st
         return bufs
 
@@ -161,7 +171,7 @@ class Engine(object):
         their layer inputs are there if their parameter gradient is."""
         if need_pos:
             return ()
-        return tuple(n for n in ('low', 'high', 'color') if ('masks_' + n) in saved and (not need_flat.get(n) or ('act_' + n) in saved))
+        return tuple(n for n in ('low', 'high', 'color', 'att') if ('masks_' + n) in saved and (not need_flat.get(n) or ('act_' + n) in saved))
 
     @staticmethod
     def fill_tsdf(td, tsdf_volume, keep):

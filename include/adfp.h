@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 112
+#define ADFP_VERSION 113
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -91,6 +91,7 @@ typedef struct adfp_scene {
     const void* ht_low;
     const void* ht_high;
     const void* ht_color;
+    const void* ht_att;       /* adfp_pack_attention_ht: the attention network's backward on f16 MFMA */
     /* Sticky status word the kernels OR into (system-scope atomic): device memory or device-visible pinned
      * host memory, NULL = none.  ADFP_STATUS_F16_RANGE: an operand of the f16-split decoders (a weight, a grid
      * feature or a hidden activation) reached |x| >= 65504, which the split cannot represent -- the outputs
@@ -133,6 +134,8 @@ int adfp_pack_decoder_h(int kind, const float* flat, void* packed, int* status, 
 long long adfp_decoder_packed_ht_words(int kind);
 int adfp_pack_decoder_ht(int kind, const float* flat, void* packed, int* status, void* stream);
 long long adfp_attention_packed_h_words(void);
+long long adfp_attention_packed_ht_words(void);
+int adfp_pack_attention_ht(const float* flat, void* packed, int* status, void* stream);
 int adfp_pack_attention_h(const float* flat, void* packed, int* status, void* stream);
 /* mlp_tsdf parameters (decoder.py:206-258) */
 int adfp_pack_attention(const float* flat, float* packed, void* stream);
@@ -215,7 +218,11 @@ typedef struct adfp_train_state {
     float* act_low;
     float* act_high;
     float* act_color;
+    unsigned* masks_att;      /* ADFP_TRAIN_ATT_MASK_WORDS words per point (in-band list entry): masks + softmax weights */
+    float* act_att;           /* ADFP_TRAIN_ATT_ACT_FLOATS floats per point, only when g_flat_att will be requested */
 } adfp_train_state;
+#define ADFP_TRAIN_ATT_MASK_WORDS 14
+#define ADFP_TRAIN_ATT_ACT_FLOATS 416
 long long adfp_train_act_floats(int kind);
 
 /* ---- a4..a13 in one call: Renderer.render_batch_ray (Renderer.py:110-255) ------------- */

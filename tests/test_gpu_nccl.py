@@ -128,6 +128,6 @@ def test_fused_mapper_iteration_reduces_its_bucket_through_rccl(rccl, mini, mask
     (ga, da, la), (gb, db, lb) = res
     assert all(abs(x - y) <= 1e-5 * abs(y) for x, y in zip(la, lb)), (la, lb)       # later losses inherit the Adam noise below
     for k in ga:                                   # float atomics: the two runs differ in the last bits, Adam amplifies noise-sized gradients
-        assert_adam_trajectory(ga[k], gb[k], 0.01, 4, k)
+        assert_adam_trajectory(ga[k], gb[k], 0.01, 4, k, max_outliers=1e-2)
     for (n, p), (_, q) in zip(da.named_parameters(), db.named_parameters()):
-        assert_adam_trajectory(p, q, 0.005, 4, n)
+        assert_adam_trajectory(p, q, 0.005, 4, n, max_outliers=1e-2)      # ReLU-boundary samples, Adam-amplified (conftest)
