@@ -260,7 +260,7 @@ int adfp_render_forward(const adfp_scene* scene /*host*/, const adfp_render_args
  * Two implementations per decoder, chosen by what the caller provides: with scene->ht_* and the forward's state->masks_* (and
  * state->act_* when g_flat_* is wanted) the f16-split backward (f16 MFMA, nothing recomputed, grid gradients scattered in
  * sorted order); otherwise -- and always when g_rays_* / g_pts is requested -- the exact f32 backward from scene->w_*.  The
- * attention network's backward is exact f32 (w_att); with ht_* in use its weight gradients take the f16 outer-product kernel.
+ * attention network likewise (ht_att + state->masks_att [+ act_att], else w_att).
  * g_rays_o / g_rays_d: gradients w.r.t. the rays (p = o + d z; through the trilinear coordinates of the
  * feature grids and the TSDF and through sin(p @ B)) for the Tracker, src/Tracker.py:112-133. */
 typedef struct adfp_backward_args {
