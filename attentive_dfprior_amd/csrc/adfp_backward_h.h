@@ -107,7 +107,7 @@ struct DecodeBwdHArgs {
     int chunk_lo, chunk_hi;
     int* status;
     const float* gmax;         // see grad_scale (WGRAD)
-    float* gc_out;             // SCAT = false: [P][32] d/d c rows (row = point) for k_scatter_bins, or NULL
+    float* gc_out;             // SCAT = false: [P][32] d/d c rows (row = point) for k_scatter_sorted, or NULL
 };
 
 // 16 D-layout registers -> the two k-steps of a B operand
@@ -129,7 +129,7 @@ ADFP_DEV void stage_block_scaled(float* __restrict__ row, int col, int h, const 
 
 // SCAT = true: d/d c goes into the grid gradient from inside the kernel (the write-combining scatter of adfp_backward.h; the
 // scatter structures limit the workgroup to 6 waves).  SCAT = false: the kernel only writes d/d c, one 128-B row per point
-// (a.gc_out), and k_scatter_bins adds the rows to the grid gradient in spatial order -- the path the host takes whenever the
+// (a.gc_out), and k_scatter_sorted adds the rows to the grid gradient in spatial order -- the path the host takes whenever the
 // grid fits the binning (run_decode_bwd_h).
 template <int CDIM, int NOUT, int ROLE, bool WGRAD, bool SCAT, int NT>
 __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {

@@ -417,7 +417,7 @@ struct DecStage {
     static constexpr int NCOLS = SGO + 32;
     // The f16-split backward keeps a row in two pieces: the decoder's INPUTS, columns [0, NX), are written by the training
     // forward (k_decode_h<..., TRAIN>) into caller-owned rows for all points; the GRADIENT blocks, columns [NX, NCOLS), by
-    // k_decode_bwd_h into the chunked staging buffer.  k_outer_lds2 puts the two pieces side by side in its LDS tile.
+    // k_decode_bwd_h into the chunked staging buffer.  k_outer_h puts the two pieces side by side in its LDS tile.
     static constexpr int NX = 128 + CDIM + 160;
     static constexpr int NG = NCOLS - NX;
     // What is actually stored of the two pieces (k_outer_h keeps the full column numbering in its LDS tile and fills in the

@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
     }
 }
 
-#include <hipcub/hipcub.hpp>          // DeviceRadixSort: the points by bin id, for k_scatter_bins
+#include <hipcub/hipcub.hpp>          // DeviceRadixSort: the points by cell, for k_scatter_sorted
 #include "adfp_backward.h"
 #include "adfp_backward_h.h"
 #include "adfp_fusion.h"
@@ -1596,7 +1596,7 @@ static BwdWorkspace carve_bwd(void* base, long long P) {
     w.partial = (float*)(b + o); o += align256((size_t)OUTER_NSLOT * w.part_stride * 4);
     w.gmax = (float*)(b + o); o += 256;            // largest |cotangent of raw| of the call (grad_scale)
     w.gmax_parts = (float*)(b + o); o += align256((size_t)P * 4);     // ... per ray / per workgroup, before k_max_reduce
-    // spatially ordered grid-gradient scatter of the f16-split backward (k_scatter_bins): d/d c rows, bin keys, sorted order
+    // spatially ordered grid-gradient scatter of the f16-split backward (k_scatter_sorted): d/d c rows, sort keys, sorted order
     w.gc = (float*)(b + o); o += align256((size_t)P * 128);
     w.bin_key = (int*)(b + o); o += align256((size_t)P * 4);
     w.bin_val = (int*)(b + o); o += align256((size_t)P * 4);
@@ -1731,7 +1731,7 @@ static int run_decode_bwd_p(DecodeBwdArgs a, int total, const int* count_ptr, fl
 // left.  Weight gradients: the G part of the staging rows is chunked like the exact path's rows (so that a chunk is still in
 // the Infinity Cache when k_outer_h reads it back); the X part lies in `act` for all rows.
 #define ADFP_BWDH_NT 384
-// binning of the call's points for k_scatter_bins (set up once per backward call by backward_points)
+// sort of the call's points for k_scatter_sorted (set up once per backward call by backward_points)
 struct BinPlan { bool ok; BinArgs args; };
 static int scatter_bins(const BinPlan& bp, const DecodeBwdArgs& o, const BwdWorkspace& bw, const unsigned char* flags, hipStream_t st) {
     (void)bp;
@@ -1834,8 +1834,8 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
     auto use_h = [&](const void* t, const unsigned* masks, const float* act, const float* flat) {
         return t && masks && !pgrad && (!flat || act);
     };
-    // The grid gradients of the decoders that take the f16-split backward are scattered in spatial order (k_scatter_bins): one
-    // counting sort of the points by the 4-cell bins of the finest such grid, shared by all of them.
+    // The grid gradients of the decoders that take the f16-split backward are scattered in spatial order (k_scatter_sorted): one
+    // radix sort of the points by (coarsest such grid's cell, finest grid's cell inside it), shared by all of them.
     BinPlan bp; bp.ok = false;
     {
         const bool h_low = go.grid_low && use_h(sc->ht_low, state.masks_low, state.act_low, go.flat_low);

@@ -1,5 +1,5 @@
 """Diagnostic: how the sample points of one Mapper iteration distribute over the 4-cell bins of the finest grid (the work
-distribution of k_scatter_bins)."""
+distribution of k_scatter_sorted: points per 4-cell bin of a grid)."""
 import os
 import sys
 
