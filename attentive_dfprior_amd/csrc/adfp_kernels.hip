@@ -1859,16 +1859,17 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
                 BinArgs& b = bp.args;
                 b.P = Pd; b.nb = a.nb; b.CX = coarse->X; b.CY = coarse->Y; b.CZ = coarse->Z; b.RX = fine->X; b.RY = fine->Y; b.RZ = fine->Z;
                 b.key = bw.bin_key; b.val = bw.bin_val;
-                hipLaunchKernelGGL(k_bin_keys, dim3((P + 255) / 256), dim3(256), 0, st, b);
-                ADFP_CHECK_LAUNCH();
-                size_t need = 0;
+                size_t need = 0;                   // the sort's own temporary-storage figure against the workspace's allowance
                 e = hipcub::DeviceRadixSort::SortPairs(nullptr, need, bw.bin_key, bw.bin_key_sorted, bw.bin_val, bw.bin_perm, P, 0, 3 * bits + 6, st);
                 if (e != hipSuccess) return (int)e;
-                if (need > bw.sort_temp_bytes) return ADFP_E_WORKSPACE;
+                if (need <= bw.sort_temp_bytes) {   // (otherwise: every grid keeps the in-kernel scatter)
+                hipLaunchKernelGGL(k_bin_keys, dim3((P + 255) / 256), dim3(256), 0, st, b);
+                ADFP_CHECK_LAUNCH();
                 need = bw.sort_temp_bytes;
                 e = hipcub::DeviceRadixSort::SortPairs(bw.sort_temp, need, bw.bin_key, bw.bin_key_sorted, bw.bin_val, bw.bin_perm, P, 0, 3 * bits + 6, st);
                 if (e != hipSuccess) return (int)e;
                 bp.ok = true;
+                }
             }
         }
     }
