@@ -1675,7 +1675,7 @@ static int outer_end(const BwdWorkspace& bw, int n_floats, float* flat, hipStrea
     return 0;
 }
 static int outer_end_scaled(const BwdWorkspace& bw, int n_floats, float* flat, hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_partials_scaled, dim3((n_floats + 255) / 256), dim3(256), 0, st, bw.partial, OUTER_NSLOT, bw.part_stride, n_floats, flat, bw.gmax);
+    hipLaunchKernelGGL(k_reduce_partials_scaled, dim3((n_floats + 31) / 32), dim3(256), 0, st, bw.partial, OUTER_NSLOT, bw.part_stride, n_floats, flat, bw.gmax);
     ADFP_CHECK_LAUNCH();
     return 0;
 }

@@ -103,6 +103,21 @@ class mlp_tsdf(nn.Module):
 
 
 def _flat_params(params):
+    """The parameters of one network as one flat float32 tensor in state_dict order.  When they already lie back to back in one
+    storage (mapping.flatten_parameters re-homes a trained network that way) this is a view of that storage, not a copy."""
+    first = params[0]
+    if first.dtype == torch.float32:
+        off, ok = first.storage_offset(), True
+        for p in params:
+            if p.dtype != torch.float32 or not p.is_contiguous() or p.storage_offset() != off or \
+                    p.untyped_storage().data_ptr() != first.untyped_storage().data_ptr():
+                ok = False
+                break
+            off += p.numel()
+        if ok:
+            flat = first.detach().new_empty(0)
+            flat.set_(first.untyped_storage(), first.storage_offset(), (off - first.storage_offset(),))
+            return flat
     return torch.cat([p.detach().reshape(-1).float() for p in params])
 
 
