@@ -1525,8 +1525,7 @@ int adfp_mapper_loss(const adfp_loss_args* l, void* stream) {
     a.n = l->n_rays; a.S = l->S; a.color_term = l->stage == ADFP_STAGE_COLOR; a.warmup = l->warmup; a.w_color = l->w_color_loss;
     a.depth = l->depth; a.color = l->color; a.weight = l->weight; a.gt_depth = l->gt_depth; a.gt_color = l->gt_color; a.keep = l->keep;
     a.loss = l->loss; a.g_depth = l->g_depth; a.g_color = l->g_color; a.g_weight = l->g_weight;
-    int blocks = (l->n_rays + 3) / 4; if (blocks > 128) blocks = 128;                  // 512 waves, a grid-stride loop over the rays
-    hipLaunchKernelGGL(k_mapper_loss, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_mapper_loss, dim3((l->n_rays + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);      // one thread per ray
     ADFP_CHECK_LAUNCH();
     return 0;
 }

@@ -54,44 +54,47 @@ struct LossArgs {
     double* loss; double* g_depth; float* g_color; float* g_weight;
 };
 ADFP_DEV float sign_f(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }     // torch.sign: 0 at 0, NaN -> 0 here
-// A wave takes rays in a grid-stride loop: lane 0 the depth term, lanes 0-2 the colour term, all lanes stride over the ray's S
-// attention weights; the loss is summed in registers and leaves the wave through ONE f64 atomic (one atomic per ray
-// serialised 5 000 adders on one address: 63 us per call).
+// One thread per ray for the depth and colour terms, then all threads stride over the N x S attention weights of the warm-up
+// term; the loss is summed in registers and leaves a wave through ONE f64 atomic (one atomic per ray serialised 5 000 adders on
+// one address: 63 us per call; a wave walking its rays one after the other was latency bound: 19 us).
 __global__ __launch_bounds__(256) void k_mapper_loss(LossArgs a) {
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int ray = blockIdx.x * 256 + threadIdx.x;
     double part = 0.0;
-    for (int ray = wave; ray < a.n; ray += nwaves) {
+    if (ray < a.n) {
         const bool kept = !a.keep || a.keep[ray];
-        if (lane == 0) {
-            const float gd = a.gt_depth[ray];
-            double g = 0.0;
-            if (kept && gd > 0.f) {                                        // depth_mask = batch_gt_depth > 0, Mapper.py:457
-                const double diff = (double)gd - a.depth[ray];            // f32 - f64 -> f64
-                part += diff < 0 ? -diff : diff;
-                g = diff > 0 ? -1.0 : (diff < 0 ? 1.0 : 0.0);              // d|gt - d|/dd = -sign(gt - d)
-            }
-            a.g_depth[ray] = g;
+        const float gd = a.gt_depth[ray];
+        double g = 0.0;
+        if (kept && gd > 0.f) {                                        // depth_mask = batch_gt_depth > 0, Mapper.py:457
+            const double diff = (double)gd - a.depth[ray];            // f32 - f64 -> f64
+            part += diff < 0 ? -diff : diff;
+            g = diff > 0 ? -1.0 : (diff < 0 ? 1.0 : 0.0);              // d|gt - d|/dd = -sign(gt - d)
         }
-        if (lane < 3) {
-            float g = 0.f;
-            if (a.color_term && kept) {                                    // Mapper.py:466-469
-                const float diff = a.gt_color[3 * ray + lane] - a.color[3 * ray + lane];
+        a.g_depth[ray] = g;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float gk = 0.f;
+            if (a.color_term && kept) {                                // Mapper.py:466-469
+                const float diff = a.gt_color[3 * ray + k] - a.color[3 * ray + k];
                 part += (double)(a.w_color * fabsf(diff));
-                g = -a.w_color * sign_f(diff);
+                gk = -a.w_color * sign_f(diff);
             }
-            if (a.g_color) a.g_color[3 * ray + lane] = g;
+            if (a.g_color) a.g_color[3 * ray + k] = gk;
         }
-        if (a.g_weight) {
-            for (int s = lane; s < a.S; s += 64) {
-                float g = 0.f;
-                if (a.warmup && kept) {                                    // + |weight - 1|.sum(), Mapper.py:459-461
-                    const float diff = a.weight[(long long)ray * a.S + s] - 1.f;
+    }
+    if (a.g_weight) {
+        const long long total = (long long)a.n * a.S, stride = (long long)gridDim.x * 256;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+            float g = 0.f;
+            if (a.warmup) {                                            // + |weight - 1|.sum(), Mapper.py:459-461
+                const int r = (int)(i / a.S);
+                if (!a.keep || a.keep[r]) {
+                    const float diff = a.weight[i] - 1.f;
                     part += (double)fabsf(diff);
                     g = sign_f(diff);
                 }
-                a.g_weight[(long long)ray * a.S + s] = g;
             }
+            a.g_weight[i] = g;
         }
     }
     if (a.loss) {
