@@ -84,6 +84,8 @@ def free_port():
 def launch_workers(args):
     import torch
     have = torch.cuda.device_count()                     # counting devices does not initialise HIP
+    if os.environ.get('ADFP_BENCH_TEST_SAME_DEVICE') == '1':       # test hook (tests/test_gpu_bench_world2.py): all ranks on cuda:0
+        have = max(have, args.gpus)
     if have < args.gpus:
         print(f'bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s)', file=sys.stderr)
         sys.exit(2)
@@ -163,6 +165,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # Test hooks (never set by the driver): ADFP_BENCH_TEST_SAME_DEVICE=1 puts every rank on cuda:0 and
+    # ADFP_BENCH_TEST_BACKEND=gloo replaces RCCL, so that the N > 1 control flow of this file -- self-launch, barriers, the
+    # max over ranks, the sharded legs -- can be exercised on a box with ONE GPU (RCCL refuses two ranks on one device).
+    backend = os.environ.get('ADFP_BENCH_TEST_BACKEND', 'nccl')
+    if os.environ.get('ADFP_BENCH_TEST_SAME_DEVICE') == '1':
+        local_rank = 0
     dev = torch.device(f'cuda:{local_rank}')
     torch.cuda.set_device(dev)
     dist = None
@@ -171,7 +179,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(minutes=30))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(minutes=30))
+        else:
+            dist.init_process_group(backend, timeout=datetime.timedelta(minutes=30))
     n_gpus = dist.get_world_size() if dist is not None else 1
     if args.gpus != n_gpus and rank == 0:
         print(f'bench.py: --gpus {args.gpus} but the process group has {n_gpus} rank(s); reporting n_gpus={n_gpus}', file=sys.stderr)
