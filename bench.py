@@ -97,14 +97,28 @@ def launch_workers(args):
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=600))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(-9)
+    # Rank 0's stdout (the ONE JSON line) is drained by a thread while the parent watches all ranks: a rank that dies would leave
+    # the others waiting in a collective until the 30-minute process-group timeout, so the first failure ends the whole job.
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + 3600
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+        if bad or time.time() > deadline:
+            failed = bad[0] if bad else -9
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                      # the exact children this parent started
+            break
+        time.sleep(0.2)
+    for p in procs:
+        p.wait()
+    reader.join(timeout=10)
+    out = b''.join(c for c in chunks if c)
+    rcs = [failed] if failed is not None else [p.returncode for p in procs]
     sys.stdout.write(out.decode())
     sys.stdout.flush()
     sys.exit(max(abs(rc) for rc in rcs))
