@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
     }
 }
 
-#include <hipcub/hipcub.hpp>          // DeviceRadixSort: the points by cell, for k_scatter_sorted
+#include "adfp_sort.h"
 #include "adfp_backward.h"
 #include "adfp_backward_h.h"
 #include "adfp_fusion.h"
@@ -1577,7 +1577,7 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
 
 #define OUTER_NSLOT 256         // workgroups per weight-gradient launch = private gradient copies (one per CU)
 struct BwdWorkspace { float* g_raw; float* att_g; float* g_pts; float* stage; int stage_rows; float* partial; int part_stride; float* gmax; float* gmax_parts;
-                      float* gc; int* bin_key; int* bin_val; int* bin_key_sorted; int* bin_perm; void* sort_temp; size_t sort_temp_bytes;
+                      float* gc; int* bin_key; int* bin_val; int* bin_key_sorted; int* bin_perm; int* sort_table;
                       size_t bytes; };
 static BwdWorkspace carve_bwd(void* base, long long P) {
     BwdWorkspace w; size_t o = 0; char* b = (char*)base;
@@ -1601,8 +1601,7 @@ static BwdWorkspace carve_bwd(void* base, long long P) {
     w.bin_val = (int*)(b + o); o += align256((size_t)P * 4);
     w.bin_key_sorted = (int*)(b + o); o += align256((size_t)P * 4);
     w.bin_perm = (int*)(b + o); o += align256((size_t)P * 4);
-    w.sort_temp_bytes = align256((size_t)P * 16 + (4u << 20));          // upper bound; checked against the sort's own figure
-    w.sort_temp = (void*)(b + o); o += w.sort_temp_bytes;
+    w.sort_table = (int*)(b + o); o += align256((((size_t)P + ADFP_RS_TILE - 1) / ADFP_RS_TILE) * 256 * 4 + 1024);     // [256 digits][tiles] + [256] totals
     w.bytes = o;
     return w;
 }
@@ -1731,11 +1730,10 @@ static int run_decode_bwd_p(DecodeBwdArgs a, int total, const int* count_ptr, fl
 // the Infinity Cache when k_outer_h reads it back); the X part lies in `act` for all rows.
 #define ADFP_BWDH_NT 384
 // sort of the call's points for k_scatter_sorted (set up once per backward call by backward_points)
-struct BinPlan { bool ok; BinArgs args; };
+struct BinPlan { bool ok; BinArgs args; const int* perm; };
 static int scatter_bins(const BinPlan& bp, const DecodeBwdArgs& o, const BwdWorkspace& bw, const unsigned char* flags, hipStream_t st) {
-    (void)bp;
     ScatterSortedArgs s;
-    s.P = o.P; s.nb = o.nb; s.g = o.g0; s.gc = bw.gc; s.g_grid = o.g_grid; s.perm = bw.bin_perm; s.n = o.P.n; s.flags = flags; s.flag_mask = ADFP_F_BAND;
+    s.P = o.P; s.nb = o.nb; s.g = o.g0; s.gc = bw.gc; s.g_grid = o.g_grid; s.perm = bp.perm; s.n = o.P.n; s.flags = flags; s.flag_mask = ADFP_F_BAND;
     if (o.g0.X > 1023 || o.g0.Y > 1023 || o.g0.Z > 1023) return ADFP_E_UNSUPPORTED;          // packed cell coordinates
     hipLaunchKernelGGL(k_scatter_sorted, dim3((o.P.n + 127) / 128), dim3(64), 0, st, s);
     ADFP_CHECK_LAUNCH();
@@ -1858,17 +1856,23 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
                 BinArgs& b = bp.args;
                 b.P = Pd; b.nb = a.nb; b.CX = coarse->X; b.CY = coarse->Y; b.CZ = coarse->Z; b.RX = fine->X; b.RY = fine->Y; b.RZ = fine->Z;
                 b.key = bw.bin_key; b.val = bw.bin_val;
-                size_t need = 0;                   // the sort's own temporary-storage figure against the workspace's allowance
-                e = hipcub::DeviceRadixSort::SortPairs(nullptr, need, bw.bin_key, bw.bin_key_sorted, bw.bin_val, bw.bin_perm, P, 0, 3 * bits + 6, st);
-                if (e != hipSuccess) return (int)e;
-                if (need <= bw.sort_temp_bytes) {   // (otherwise: every grid keeps the in-kernel scatter)
                 hipLaunchKernelGGL(k_bin_keys, dim3((P + 255) / 256), dim3(256), 0, st, b);
                 ADFP_CHECK_LAUNCH();
-                need = bw.sort_temp_bytes;
-                e = hipcub::DeviceRadixSort::SortPairs(bw.sort_temp, need, bw.bin_key, bw.bin_key_sorted, bw.bin_val, bw.bin_perm, P, 0, 3 * bits + 6, st);
-                if (e != hipSuccess) return (int)e;
-                bp.ok = true;
+                // stable LSD radix sort, 8 bits per pass (adfp_sort.h), ping-pong between the two buffer pairs
+                RadixArgs rs; rs.table = bw.sort_table; rs.n = P; rs.ntiles = (P + ADFP_RS_TILE - 1) / ADFP_RS_TILE;
+                rs.totals = bw.sort_table + (size_t)256 * rs.ntiles;
+                const int key_bits = 3 * bits + 6, passes = (key_bits + 7) / 8;
+                int* kin = bw.bin_key; int* vin = bw.bin_val; int* kout = bw.bin_key_sorted; int* vout = bw.bin_perm;
+                for (int ps = 0; ps < passes; ++ps) {
+                    rs.key_in = kin; rs.val_in = vin; rs.key_out = kout; rs.val_out = vout; rs.shift = 8 * ps;
+                    hipLaunchKernelGGL(k_rs_hist, dim3(rs.ntiles), dim3(256), 0, st, rs);
+                    hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, st, rs.table, rs.ntiles, rs.totals);
+                    hipLaunchKernelGGL(k_rs_scatter, dim3(rs.ntiles), dim3(256), 0, st, rs);
+                    ADFP_CHECK_LAUNCH();
+                    int* tk = kin; kin = kout; kout = tk; int* tv = vin; vin = vout; vout = tv;
                 }
+                bp.perm = vin;                      // the pair the last pass wrote
+                bp.ok = true;
             }
         }
     }
