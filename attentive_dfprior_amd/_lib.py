@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ADFP_LIB_PATH', os.path.join(_HERE, 'libadfp.so'))   # override: kernel A/B builds
 
-ABI_VERSION = 113                 # ADFP_VERSION of include/adfp.h this binding was written against
+ABI_VERSION = 114                 # ADFP_VERSION of include/adfp.h this binding was written against
 STATUS_F16_RANGE = 1
 STAGE = {'low': 0, 'high': 1, 'color': 2}
 DEC_KIND = {'low': 0, 'high': 1, 'color': 2}
@@ -154,6 +154,8 @@ SYMBOLS = [
     ('adfp_masked_adam_dev', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int,
                                        C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     ('adfp_masked_adam_multi', C.c_int, [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    ('adfp_sort_workspace_bytes', C.c_size_t, [C.c_longlong]),
+    ('adfp_sort_pairs', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     ('adfp_tsdf_stage', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_backward_workspace_bytes', C.c_size_t, [C.c_longlong]),

@@ -1730,6 +1730,43 @@ static int run_decode_bwd_p(DecodeBwdArgs a, int total, const int* count_ptr, fl
 // the Infinity Cache when k_outer_h reads it back); the X part lies in `act` for all rows.
 #define ADFP_BWDH_NT 384
 // sort of the call's points for k_scatter_sorted (set up once per backward call by backward_points)
+// Sorts n (key, value) pairs by the low key_bits bits of the key, stable.  The two buffer pairs are used in turn; *key_fin / *val_fin
+// = the pair the last pass wrote (a / b).  table: 256 * ceil(n / ADFP_RS_TILE) + 256 ints.
+static int radix_sort_pairs(int* key_a, int* val_a, int* key_b, int* val_b, int n, int key_bits, int* table, const int** key_fin,
+                            const int** val_fin, hipStream_t st) {
+    RadixArgs rs; rs.table = table; rs.n = n; rs.ntiles = (n + ADFP_RS_TILE - 1) / ADFP_RS_TILE;
+    rs.totals = table + (size_t)256 * rs.ntiles;
+    const int passes = (key_bits + 7) / 8;
+    int* kin = key_a; int* vin = val_a; int* kout = key_b; int* vout = val_b;
+    for (int ps = 0; ps < passes; ++ps) {
+        rs.key_in = kin; rs.val_in = vin; rs.key_out = kout; rs.val_out = vout; rs.shift = 8 * ps;
+        hipLaunchKernelGGL(k_rs_hist, dim3(rs.ntiles), dim3(256), 0, st, rs);
+        hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, st, rs.table, rs.ntiles, rs.totals);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(rs.ntiles), dim3(256), 0, st, rs);
+        ADFP_CHECK_LAUNCH();
+        int* tk = kin; kin = kout; kout = tk; int* tv = vin; vin = vout; vout = tv;
+    }
+    if (key_fin) *key_fin = kin;
+    if (val_fin) *val_fin = vin;
+    return 0;
+}
+extern "C" size_t adfp_sort_workspace_bytes(long long n) { return n < 0 ? 0 : ((size_t)((n + ADFP_RS_TILE - 1) / ADFP_RS_TILE) * 256 + 256) * 4; }
+extern "C" int adfp_sort_pairs(int* key, int* val, int* key_tmp, int* val_tmp, long long n, int key_bits, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    if (!key || !val || !key_tmp || !val_tmp || !workspace || n < 0 || n > 0x7fffffffll || key_bits < 1 || key_bits > 31) return ADFP_E_ARG;
+    if (workspace_bytes < adfp_sort_workspace_bytes(n)) return ADFP_E_WORKSPACE;
+    if (n == 0) return 0;
+    const int* kf; const int* vf;
+    int rc = radix_sort_pairs(key, val, key_tmp, val_tmp, (int)n, key_bits, (int*)workspace, &kf, &vf, (hipStream_t)stream);
+    if (rc) return rc;
+    if (kf != key) {                               // an odd number of passes: bring the result home
+        hipError_t e = hipMemcpyAsync(key, kf, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(val, vf, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
 struct BinPlan { bool ok; BinArgs args; const int* perm; };
 static int scatter_bins(const BinPlan& bp, const DecodeBwdArgs& o, const BwdWorkspace& bw, const unsigned char* flags, hipStream_t st) {
     ScatterSortedArgs s;
@@ -1859,18 +1896,10 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
                 hipLaunchKernelGGL(k_bin_keys, dim3((P + 255) / 256), dim3(256), 0, st, b);
                 ADFP_CHECK_LAUNCH();
                 // stable LSD radix sort, 8 bits per pass (adfp_sort.h), ping-pong between the two buffer pairs
-                RadixArgs rs; rs.table = bw.sort_table; rs.n = P; rs.ntiles = (P + ADFP_RS_TILE - 1) / ADFP_RS_TILE;
-                rs.totals = bw.sort_table + (size_t)256 * rs.ntiles;
-                const int key_bits = 3 * bits + 6, passes = (key_bits + 7) / 8;
-                int* kin = bw.bin_key; int* vin = bw.bin_val; int* kout = bw.bin_key_sorted; int* vout = bw.bin_perm;
-                for (int ps = 0; ps < passes; ++ps) {
-                    rs.key_in = kin; rs.val_in = vin; rs.key_out = kout; rs.val_out = vout; rs.shift = 8 * ps;
-                    hipLaunchKernelGGL(k_rs_hist, dim3(rs.ntiles), dim3(256), 0, st, rs);
-                    hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, st, rs.table, rs.ntiles, rs.totals);
-                    hipLaunchKernelGGL(k_rs_scatter, dim3(rs.ntiles), dim3(256), 0, st, rs);
-                    ADFP_CHECK_LAUNCH();
-                    int* tk = kin; kin = kout; kout = tk; int* tv = vin; vin = vout; vout = tv;
-                }
+                const int* vfin = nullptr;
+                rc = radix_sort_pairs(bw.bin_key, bw.bin_val, bw.bin_key_sorted, bw.bin_perm, P, 3 * bits + 6, bw.sort_table, nullptr, &vfin, st);
+                if (rc) return rc;
+                const int* vin = vfin;
                 bp.perm = vin;                      // the pair the last pass wrote
                 bp.ok = true;
             }

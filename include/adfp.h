@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 113
+#define ADFP_VERSION 114
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -391,6 +391,12 @@ typedef struct adfp_adam_group {
     const float* derived;        /* this group's {step size, sqrt(bias correction 2)} from adfp_adam_prep */
 } adfp_adam_group;
 int adfp_masked_adam_multi(int n_groups, const adfp_adam_group* groups /*host*/, float beta1, float beta2, float eps, void* stream);
+
+/* Stable radix sort of n (key, value) int pairs by the low key_bits bits of the (non-negative) keys, in place (key_tmp / val_tmp:
+ * n ints each).  What the f16-split backward orders the sample points with (by grid cell, adfp_sort.h); exported for testing. */
+size_t adfp_sort_workspace_bytes(long long n);
+int adfp_sort_pairs(int* key, int* val, int* key_tmp, int* val_tmp, long long n, int key_bits, void* workspace, size_t workspace_bytes,
+                    void* stream);
 
 /* Per-stage timing hook for bench.py: runs ONLY the TSDF trilerp + band-mask kernel (a10).
  * w may be NULL (that is the render path's launch: there the LOW decoder writes w = 1). */
