@@ -370,7 +370,7 @@ struct ScatterSortedArgs {
 __global__ __launch_bounds__(64) void k_scatter_sorted(ScatterSortedArgs a) {
     __shared__ int s_q[128];
     __shared__ int s_cell[128];                   // x0 | y0 << 10 | z0 << 20
-    __shared__ float s_w[128][6];                 // wx0, wx1, wy0, wy1, wz0, wz1 (tri_axis)
+    __shared__ __attribute__((aligned(16))) float s_w[128][8];     // the 8 corner weights (wx wy) wz, corner k = dx + 2 dy + 4 dz
     const int lane = threadIdx.x & 63, ch = lane & 31, h = lane >> 5;
     const int w0 = blockIdx.x * 128;
     // ---- phase A
@@ -394,8 +394,10 @@ __global__ __launch_bounds__(64) void k_scatter_sorted(ScatterSortedArgs a) {
             cell = x0 | (y0 << 10) | (z0 << 20);
         }
         s_q[64 * b + lane] = q; s_cell[64 * b + lane] = cell;
+        f32x4 lo4, hi4;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) s_w[64 * b + lane][k] = w[k];
+        for (int k = 0; k < 4; ++k) { lo4[k] = (w[k & 1] * w[2 + (k >> 1)]) * w[4]; hi4[k] = (w[k & 1] * w[2 + (k >> 1)]) * w[5]; }
+        *(f32x4*)&s_w[64 * b + lane][0] = lo4; *(f32x4*)&s_w[64 * b + lane][4] = hi4;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -430,11 +432,9 @@ __global__ __launch_bounds__(64) void k_scatter_sorted(ScatterSortedArgs a) {
             if ((unsigned)(nz >> (32 * h)) == 0u) continue;       // no gradient from this point (a dropped ray, a point outside the band)
             const int cell = s_cell[pi];
             if (cell != cur) { flush(); cur = cell; }
-            float w6[6];
+            const f32x4 wl = *(const f32x4*)&s_w[pi][0], wh = *(const f32x4*)&s_w[pi][4];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) w6[k] = s_w[pi][k];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc[k] += g * ((w6[k & 1] * w6[2 + ((k >> 1) & 1)]) * w6[4 + (k >> 2)]);
+            for (int k = 0; k < 4; ++k) { acc[k] += g * wl[k]; acc[4 + k] += g * wh[k]; }
         }
     }
     flush();
