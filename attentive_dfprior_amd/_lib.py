@@ -9,8 +9,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ADFP_LIB_PATH', os.path.join(_HERE, 'libadfp.so'))   # override: kernel A/B builds
 
-ABI_VERSION = 114                 # ADFP_VERSION of include/adfp.h this binding was written against
+ABI_VERSION = 115                 # ADFP_VERSION of include/adfp.h this binding was written against
 STATUS_F16_RANGE = 1
+BWD_SCATTER_IN_KERNEL = 1        # ADFP_BWD_SCATTER_IN_KERNEL
 STAGE = {'low': 0, 'high': 1, 'color': 2}
 DEC_KIND = {'low': 0, 'high': 1, 'color': 2}
 PTS_RAYS, PTS_F64, PTS_F32 = 0, 1, 2
@@ -79,14 +80,14 @@ class AdfpBackwardArgs(C.Structure):
                 ('g_grid_low', C.c_void_p), ('g_grid_high', C.c_void_p), ('g_grid_color', C.c_void_p),
                 ('g_flat_low', C.c_void_p), ('g_flat_high', C.c_void_p), ('g_flat_color', C.c_void_p),
                 ('g_flat_att', C.c_void_p), ('g_rays_o', C.c_void_p), ('g_rays_d', C.c_void_p),
-                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('ray_keep', C.c_void_p)]
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('ray_keep', C.c_void_p), ('options', C.c_int)]
 
 
 class AdfpPointsBackwardArgs(C.Structure):
     _fields_ = [('stage', C.c_int), ('flags', C.c_int), ('state', AdfpTrainState), ('g_raw', C.c_void_p), ('g_w', C.c_void_p),
                 ('g_grid_low', C.c_void_p), ('g_grid_high', C.c_void_p), ('g_grid_color', C.c_void_p),
                 ('g_flat_low', C.c_void_p), ('g_flat_high', C.c_void_p), ('g_flat_color', C.c_void_p), ('g_flat_att', C.c_void_p),
-                ('g_pts', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+                ('g_pts', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('options', C.c_int)]
 
 
 class AdfpLossArgs(C.Structure):

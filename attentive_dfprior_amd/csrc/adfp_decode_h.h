@@ -278,11 +278,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
             float e[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-#ifdef ADFP_EXP_NOBM       // timing experiment only (wrong results): the Fourier rows without their 48 LDS reads per tile
-                const f32x4 bm = f32x4{0.37f * (float)(ks + 1), 1.1f * (float)(j + 1), 0.77f, 0.f};
-#else
                 const f32x4 bm = *(const f32x4*)(lds + L::P_BM + unit_of_h(ks, h, j) * 4);
-#endif
                 const float arg = fmaf(pf[2], bm.z, fmaf(pf[1], bm.y, pf[0] * bm.x));
                 e[j] = adfp_sinf(arg);
             }
@@ -297,22 +293,14 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
         unsigned mk[5] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-    #ifdef ADFP_EXP_NOBIAS     // timing experiment only: no bias reads from LDS
-            for (int r = 0; r < 16; ++r) acc[r] = 0.01f * (float)r;
-#else
             bias_init(acc, lds + L::P_BP(i), h);
-#endif
             if (i == 0) mfma_chain_h<L::KS_E>(acc, ldsu + L::P_WP(0), lane_off, eh, el);
             else if (i == 3) {
                 mfma_chain_h<L::KS_E>(acc, ldsu + L::P_WP(3), lane_off, eh, el);
                 mfma_chain_h<2>(acc, ldsu + L::P_WP(3) + L::KS_E * 512, lane_off, hh, hl);
             } else mfma_chain_h<2>(acc, ldsu + L::P_WP(i), lane_off, hh, hl);
-#ifdef ADFP_EXP_NOBIAS
-            for (int r = 0; r < 16; ++r) acc[r] = relu_f(acc[r]);
-#else
             if constexpr (TRAIN) relu_bias_mask(acc, lds + L::P_BC(i), h, mk[i]);
             else relu_bias(acc, lds + L::P_BC(i), h);
-#endif
             mfma_chain_h<L::KS_C>(acc, ldsu + L::P_WC(i), lane_off, ch, cl);
             if constexpr (TRAIN) if (srow) stage_block(srow, ST::xm(ST::SH(i)), h, acc);
             if (i < 4) {

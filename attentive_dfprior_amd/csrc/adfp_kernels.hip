@@ -792,7 +792,6 @@ struct AttArgs {
 #endif
 #define ADFP_DECH_WG (ADFP_DECH_NT == 256 ? 2 : 1)
 #include "adfp_decode_h.h"
-#include "adfp_decode_p.h"
 
 // =====================================================================================
 // attention fusion mlp_tsdf (a11) on the in-band list
@@ -1233,18 +1232,6 @@ extern "C" int adfp_debug_phases(unsigned long long* host_out, int reset) {
 }
 #endif
 
-// ADFP_DECODE=p selects the software-pipelined f16-split decoder (adfp_decode_p.h) for the two dense decoders in ray mode:
-// an experiment that measured SLOWER than the phase-separated k_decode_h (0.90 vs 0.89 ms per 100 000-ray batch with only
-// the Fourier features in the MFMA gaps, 1.06-1.42 ms with the gather pipelined as well), so the
-// default stays k_decode_h.
-static int decode_pipelined() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("ADFP_DECODE"); v = (e && e[0] == 'p') ? 1 : 0; }
-    return v;
-}
-#ifndef ADFP_DECP_NT
-#define ADFP_DECP_NT 512
-#endif
 static int decode_grid(int ntiles, int waves_per_wg, int wg_per_cu) {
     int g = (ntiles + waves_per_wg - 1) / waves_per_wg;
     const int cap = num_cu() * wg_per_cu;
@@ -1287,8 +1274,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         a.masks = nullptr; a.act = nullptr;
     } else if (sc->h_low) {
         a.packed = (const float*)sc->h_low;
-        if (decode_pipelined() && a.P.mode == ADFP_PTS_RAYS) hipLaunchKernelGGL((k_decode_p<32, 1, ROLE_LOW, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
-        else hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
+            hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
     } else {
         a.packed = sc->w_low;
         hipLaunchKernelGGL((k_decode<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
@@ -1303,8 +1289,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
             a.masks = nullptr; a.act = nullptr;
         } else if (sc->h_color) {
             a.packed = (const float*)sc->h_color;
-            if (decode_pipelined() && a.P.mode == ADFP_PTS_RAYS) hipLaunchKernelGGL((k_decode_p<32, 4, ROLE_COLOR, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
-            else hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
+            hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
         } else {
             a.packed = sc->w_color;
             hipLaunchKernelGGL((k_decode<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
@@ -1364,8 +1349,7 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
         a.g0 = make_grid(sc->low); a.g1 = a.g0;
         if (sc->h_low) {
             a.packed = (const float*)sc->h_low;
-            if (decode_pipelined() && a.P.mode == ADFP_PTS_RAYS) hipLaunchKernelGGL((k_decode_p<32, 1, ROLE_LOW, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
-        else hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
+            hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
         } else {
             a.packed = sc->w_low;
             hipLaunchKernelGGL((k_decode<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
@@ -1375,8 +1359,7 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
         a.g0 = make_grid(sc->color); a.g1 = a.g0;
         if (sc->h_color) {
             a.packed = (const float*)sc->h_color;
-            if (decode_pipelined() && a.P.mode == ADFP_PTS_RAYS) hipLaunchKernelGGL((k_decode_p<32, 4, ROLE_COLOR, ADFP_DECP_NT>), dim3(decode_grid(ntiles, ADFP_DECP_NT / 64, 1)), dim3(ADFP_DECP_NT), 0, st, a);
-            else hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
+            hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a);
         } else {
             a.packed = sc->w_color;
             hipLaunchKernelGGL((k_decode<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
@@ -1854,7 +1837,7 @@ static int zero_grad_outputs(const adfp_scene* sc, const GradOut& g, hipStream_t
 // DF.forward backward over P points: bw.g_raw holds the cotangent of raw [P,4] (the attention pass reads .w and rewrites it
 // with d/d(high+low)); g_pts (bw.g_pts, zeroed here) receives d/d position when pgrad.
 static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, int P, const adfp_train_state& state, const float* g_weight,
-                           const GradOut& go, bool pgrad, BwdWorkspace& bw, hipStream_t st) {
+                           const GradOut& go, bool pgrad, int options, BwdWorkspace& bw, hipStream_t st) {
     int rc;
     hipError_t e;
     const bool fuse = stage != ADFP_STAGE_LOW;
@@ -1883,9 +1866,9 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
             if (!fine || vox(*cand[k]) > vox(*fine)) fine = cand[k];
             if (!coarse || vox(*cand[k]) < vox(*coarse)) coarse = cand[k];
         }
-        // ADFP_SCATTER=cache keeps every grid on the in-kernel write-combining scatter (A/B switch, and what tests compare against)
-        static int force_cache = -1;
-        if (force_cache < 0) { const char* ev = getenv("ADFP_SCATTER"); force_cache = (ev && ev[0] == 'c') ? 1 : 0; }
+        // ADFP_BWD_SCATTER_IN_KERNEL keeps every grid on the in-kernel write-combining scatter (what the tests compare the sorted
+        // scatter against)
+        const bool force_cache = (options & ADFP_BWD_SCATTER_IN_KERNEL) != 0;
         if (fine && !force_cache && coarse->X >= 2 && coarse->Y >= 2 && coarse->Z >= 2 && P > 0) {
             int bits = 0;
             while ((1 << bits) < coarse->X || (1 << bits) < coarse->Y || (1 << bits) < coarse->Z) ++bits;
@@ -2029,7 +2012,7 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
     PtsDev Pd;
     Pd.mode = ADFP_PTS_RAYS; Pd.S = r->S; Pd.n = P; Pd.pts = nullptr; Pd.ro = r->rays_o; Pd.rd = r->rays_d; Pd.z = r->z_vals;
     const bool pgrad = r->g_rays_o || r->g_rays_d;
-    rc = backward_points(sc, r->stage, Pd, P, r->state, r->g_weight, go, pgrad, bw, st);
+    rc = backward_points(sc, r->stage, Pd, P, r->state, r->g_weight, go, pgrad, r->options, bw, st);
     if (rc) return rc;
     if (pgrad) {
         hipLaunchKernelGGL(k_rays_grad, dim3((r->n_rays + 3) / 4), dim3(256), 0, st, bw.g_pts, r->z_vals, r->n_rays, r->S,
@@ -2078,7 +2061,7 @@ extern "C" int adfp_eval_points_backward(const adfp_scene* sc, const adfp_points
     ADFP_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_max_reduce, dim3(1), dim3(1024), 0, st, bw.gmax_parts, ((Pd.n + 255) / 256) * 4, bw.gmax);
     ADFP_CHECK_LAUNCH();
-    rc = backward_points(sc, r->stage, Pd, Pd.n, r->state, r->g_w, go, r->g_pts != nullptr, bw, st);
+    rc = backward_points(sc, r->stage, Pd, Pd.n, r->state, r->g_w, go, r->g_pts != nullptr, r->options, bw, st);
     if (rc) return rc;
     if (r->g_pts) {
         hipError_t e = hipMemcpyAsync(r->g_pts, bw.g_pts, (size_t)Pd.n * 12, hipMemcpyDeviceToDevice, st);

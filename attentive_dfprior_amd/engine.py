@@ -36,6 +36,10 @@ def math_mode():
 
 class Engine(object):
     def __init__(self):
+        import os
+        # ADFP_BWD_* bits handed to the backward entries (adfp_backward_args.options).  ADFP_SCATTER=cache in the environment of
+        # the HOST process selects the in-kernel scatter (kernel A/B runs); the library itself reads no environment.
+        self.bwd_options = _lib.BWD_SCATTER_IN_KERNEL if os.environ.get('ADFP_SCATTER', '')[:1] == 'c' else 0
         self._ws = None
         self._grid_cache = {}    # key name -> (key, channels-last tensor)
         self._bound_cache = {}   # id -> (key, host list)
@@ -265,6 +269,7 @@ class Engine(object):
             need = L.adfp_backward_workspace_bytes(P)
             ws = torch.empty(int(need) + 1024, dtype=torch.uint8, device=dev)
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            a.options = self.bwd_options
             stream = _lib.current_stream(dev)
             check(L.adfp_eval_points_backward(C.byref(sc), C.byref(ap), C.byref(a), stream), 'adfp_eval_points_backward')
             grids = {}
@@ -410,6 +415,7 @@ class Engine(object):
             need = L.adfp_backward_workspace_bytes(N * S)
             ws = torch.empty(int(need) + 1024, dtype=torch.uint8, device=dev)
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            a.options = self.bwd_options
             stream = _lib.current_stream(dev)
             check(L.adfp_render_backward(C.byref(sc), C.byref(a), stream), 'adfp_render_backward')
             grids = {}

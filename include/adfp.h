@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 114
+#define ADFP_VERSION 115
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -288,7 +288,11 @@ typedef struct adfp_backward_args {
     void* workspace;
     size_t workspace_bytes;
     const unsigned char* ray_keep;  /* [N] or NULL: rays flagged 0 (adfp_prefilter_mask) receive no gradient at all */
+    int options;                 /* ADFP_BWD_* bits, 0 = defaults */
 } adfp_backward_args;
+/* grid gradients of the f16-split backward through the in-kernel write-combining scatter instead of the sorted scatter
+ * (k_bin_keys + radix sort + k_scatter_sorted); same values up to the order of the float atomics */
+#define ADFP_BWD_SCATTER_IN_KERNEL 1
 size_t adfp_backward_workspace_bytes(long long n_points);
 int adfp_render_backward(const adfp_scene* scene /*host*/, const adfp_backward_args* args /*host*/, void* stream);
 
@@ -312,6 +316,7 @@ typedef struct adfp_points_backward_args {
     float* g_pts;                /* [P,3] or NULL */
     void* workspace;             /* adfp_backward_workspace_bytes(P) */
     size_t workspace_bytes;
+    int options;                 /* ADFP_BWD_* bits, 0 = defaults */
 } adfp_points_backward_args;
 int adfp_eval_points_backward(const adfp_scene* scene /*host*/, const adfp_points* pts /*host*/, const adfp_points_backward_args* args /*host*/,
                               void* stream);

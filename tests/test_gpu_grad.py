@@ -38,7 +38,7 @@ def grad_close(got, ref, what, tol=GTOL, mode='f32'):
     assert_close_scale(got.detach(), ref, tol, what, flip_frac=2e-3 if last.startswith('grid') else (0.25 if is_param else 0.0))
 
 
-def run(mini, stage, warm, sd=None, n_samples=None, n_surface=None, rays=None):
+def run(mini, stage, warm, sd=None, n_samples=None, n_surface=None, rays=None, bwd_options=None):
     sd = mini.sd if sd is None else sd
     dec = A.DF()
     dec.load_state_dict(sd)
@@ -48,6 +48,8 @@ def run(mini, stage, warm, sd=None, n_samples=None, n_surface=None, rays=None):
         p.requires_grad_(True)
     rend = A.Renderer(make_cfg(n_samples or mini.n_samples, n_surface if n_surface is not None else mini.n_surface),
                       None, mini)
+    if bwd_options is not None:
+        rend._engine.bwd_options = bwd_options
     c = {k: v.to(DEV).clone().requires_grad_(True) for k, v in mini.c.items()}
     ro, rd, gd, gc = rays if rays is not None else (mini.rays_o, mini.rays_d, mini.gt_depth, mini.gt_color)
     ro, rd, gd, gc = ro.to(DEV), rd.to(DEV), gd.to(DEV), gc.to(DEV)
@@ -339,25 +341,12 @@ def test_f16_split_backward_against_the_exact_backward(mini, monkeypatch):
 
 def test_sorted_scatter_equals_cached_scatter(mini):
     """Grid gradients through k_scatter_sorted (radix sort by cell, run-length sums) and through the in-kernel write-combining
-    scatter (ADFP_SCATTER=cache is read once per process: the comparison runs in a child process)."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-    code = ('import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n'
-            'import test_gpu_grad as T, conftest\n'
-            'from attentive_dfprior_amd import synthetic\n'
-            'from oracle import adfp_oracle as O\n'
-            'mini = conftest.Mini()\n'
-            'rays = synthetic.make_ray_batch(synthetic.mini_scene(), 300, seed=8, poses=3)\n'
-            'loss, c, dec = T.run(mini, "color", True, sd=O.random_state_dict(seed=17), n_samples=48, n_surface=16, rays=rays)\n'
-            'torch.save({k: v.grad.cpu() for k, v in c.items()}, sys.argv[1])\n') % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                                                   os.path.dirname(os.path.abspath(__file__)))
+    scatter (adfp_backward_args.options = ADFP_BWD_SCATTER_IN_KERNEL, a field of the descriptor the host passes)."""
+    from attentive_dfprior_amd import _lib
+    rays = synthetic.make_ray_batch(synthetic.mini_scene(), 300, seed=8, poses=3)
     got = {}
-    with tempfile.TemporaryDirectory() as d:
-        for name, env in (('sorted', {}), ('cache', {'ADFP_SCATTER': 'cache'})):
-            path = os.path.join(d, name + '.pt')
-            subprocess.run([sys.executable, '-c', code, path], check=True, env={**os.environ, **env}, timeout=300)
-            got[name] = torch.load(path)
+    for name, opt in (('sorted', 0), ('cache', _lib.BWD_SCATTER_IN_KERNEL)):
+        loss, c, dec = run(mini, 'color', True, sd=O.random_state_dict(seed=17), n_samples=48, n_surface=16, rays=rays, bwd_options=opt)
+        got[name] = {k: v.grad.cpu() for k, v in c.items()}
     for k in got['sorted']:
         assert_close_scale(got['sorted'][k], got['cache'][k], 2e-6, f'{k}: sorted vs cached scatter')
