@@ -163,6 +163,9 @@ SYMBOLS = [
     ('adfp_render_backward', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpBackwardArgs), C.c_void_p]),
     ('adfp_decode_stage', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
+    ('adfp_decode_single', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_int, C.c_void_p, C.c_void_p]),
+    ('adfp_attention_rows', C.c_int, [C.POINTER(AdfpScene), C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
 ]
 
 _lib = None

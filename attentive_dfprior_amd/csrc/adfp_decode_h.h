@@ -229,7 +229,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
 
     const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
     const int lane_off = h * 128 + p * 4;            // words: [h][32 rows][4 words = 8 halves]
-    const int count = (ROLE == ROLE_HIGH) ? *a.count_ptr : a.P.n;
+    const int count = (ROLE == ROLE_HIGH && a.count_ptr) ? *a.count_ptr : a.P.n;
     const int ntiles = (count + 31) >> 5;
 
 #ifdef ADFP_STAMPS
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
         const int idx = tile * 32 + p;
         const bool valid = idx < count;
         int q = valid ? idx : 0;
-        if (ROLE == ROLE_HIGH) q = a.list[q];
+        if (ROLE == ROLE_HIGH && a.list) q = a.list[q];       // list == NULL: the decoder alone over every point (MLP.forward)
 
         double pt[3]; float pn[3], pf[3];
         load_point(a.P, q, pt);
@@ -338,8 +338,9 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
                 if (a.write_w) a.w[q] = 1.f;
             } else if constexpr (ROLE == ROLE_COLOR) {
                 a.raw[4ll * q + 0] = out[0]; a.raw[4ll * q + 1] = out[1]; a.raw[4ll * q + 2] = out[2];
+                if (a.single) a.raw[4ll * q + 3] = out[3];                          // MLP.forward of the colour decoder: all 4 outputs
             } else {
-                a.att_occ[idx] = out[0] + a.raw[4ll * q + 3];                        // high + low, decoder.py:342
+                a.att_occ[idx] = a.single ? out[0] : out[0] + a.raw[4ll * q + 3];    // high + low, decoder.py:342
             }
         }
         ADFP_PHASE(4);                                  // output layer + store
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
     const float* lds = (const float*)ldsu;
     const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
     const int lane_off = h * 128 + p * 4;
-    const int count = *a.count_ptr;
+    const int count = a.count_ptr ? *a.count_ptr : a.n_rows;
     const int ntiles = (count + 31) >> 5;
     float amax = 0.f;
     for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<8>(j, &s_next, ntiles)) >= 0;) {
@@ -523,8 +524,8 @@ __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
             mrow[6] = __float_as_uint(h ? a1 : a0);
         }
         if (valid && h == 0) {
-            const int q = a.list[ii];
-            const bool inb = (a.flags[q] & ADFP_F_INBOUND) != 0;
+            const int q = a.list ? a.list[ii] : ii;              // list == NULL: mlp_tsdf.forward on explicit (occ, u) rows
+            const bool inb = !a.flags || (a.flags[q] & ADFP_F_INBOUND) != 0;
             a.raw[4ll * q + 3] = (inb || !a.apply_bound) ? fused : 100.f;   // Renderer.py:64
             a.w[q] = a1;
         }

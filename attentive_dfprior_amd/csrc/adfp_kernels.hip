@@ -685,6 +685,7 @@ struct DecodeArgs {
     int* status;               // adfp_scene.status (f16x3 kernels: operand range guard) or NULL
     unsigned* masks;           // training forward (k_decode_h<..., 1>): ReLU masks, [rows][2][3] words
     float* act;                // training forward: X part of the staging rows, [rows][DecStage::NX], or NULL
+    int single;                // adfp_decode_single: one decoder alone (COLOR writes its 4th output, HIGH does not add `low`)
 };
 
 template <int CDIM, int NOUT, int ROLE, int NT>
@@ -698,14 +699,14 @@ __global__ __launch_bounds__(NT, 2) void k_decode(DecodeArgs a) {
     const int lane_off4 = h * ADFP_RG + p * 4;
     const int wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * (NT / 64);
-    const int count = (ROLE == ROLE_HIGH) ? *a.count_ptr : a.P.n;
+    const int count = (ROLE == ROLE_HIGH && a.count_ptr) ? *a.count_ptr : a.P.n;
     const int ntiles = (count + 31) >> 5;
 
     for (int tile = wave; tile < ntiles; tile += nwaves) {
         const int idx = tile * 32 + p;
         const bool valid = idx < count;
         int q = valid ? idx : 0;
-        if (ROLE == ROLE_HIGH) q = a.list[q];
+        if (ROLE == ROLE_HIGH && a.list) q = a.list[q];
 
         double pt[3]; float pn[3], pf[3];
         load_point(a.P, q, pt);
@@ -769,8 +770,9 @@ __global__ __launch_bounds__(NT, 2) void k_decode(DecodeArgs a) {
                 if (a.write_w) a.w[q] = 1.f;
             } else if constexpr (ROLE == ROLE_COLOR) {
                 a.raw[4ll * q + 0] = out[0]; a.raw[4ll * q + 1] = out[1]; a.raw[4ll * q + 2] = out[2];
+                if (a.single) a.raw[4ll * q + 3] = out[3];
             } else {
-                a.att_occ[idx] = out[0] + a.raw[4ll * q + 3];                        // high + low, decoder.py:342
+                a.att_occ[idx] = a.single ? out[0] : out[0] + a.raw[4ll * q + 3];    // high + low, decoder.py:342
             }
         }
     }
@@ -780,6 +782,7 @@ struct AttArgs {
     const float* packed; const int* list; const int* count_ptr;
     const float* att_occ; const float* att_u; const unsigned char* flags;
     float* raw; float* w; int apply_bound;
+    int n_rows;                // rows when count_ptr == NULL (adfp_attention_rows)
     int* status;
     unsigned* masks;           // training forward (k_attention_h<1>): ReLU masks + softmax weights, [rows][2][ATT_MASK_WORDS / 2]
     float* act;                // training forward: X piece of the staging rows ([rows][416]: inputs, h_0..h_3), or NULL
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(512, 2) void k_attention(AttArgs a) {
     const int lane_off4 = h * ADFP_RG + p * 4;
     const int wave = blockIdx.x * 8 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 8;
-    const int count = *a.count_ptr;
+    const int count = a.count_ptr ? *a.count_ptr : a.n_rows;
     const int ntiles = (count + 31) >> 5;
     for (int tile = wave; tile < ntiles; tile += nwaves) {
         const int idx = tile * 32 + p;
@@ -865,8 +868,8 @@ __global__ __launch_bounds__(512, 2) void k_attention(AttArgs a) {
         const float a0 = e0 / den, a1 = e1 / den;
         const float fused = a0 * occ + a1 * u;
         if (valid && h == 0) {
-            const int q = a.list[ii];
-            const bool inb = (a.flags[q] & ADFP_F_INBOUND) != 0;
+            const int q = a.list ? a.list[ii] : ii;
+            const bool inb = !a.flags || (a.flags[q] & ADFP_F_INBOUND) != 0;
             a.raw[4ll * q + 3] = (inb || !a.apply_bound) ? fused : 100.f;   // Renderer.py:64
             a.w[q] = a1;
         }
@@ -1263,7 +1266,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
     a.P = P; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
     a.list = nullptr; a.count_ptr = nullptr; a.flags = fuse ? ws.flags : nullptr;
     a.raw = raw; a.w = w; a.att_occ = nullptr; a.write_w = 1; a.apply_bound = apply_bound;   // attention overwrites w on the band
-    a.status = sc->status; a.masks = nullptr; a.act = nullptr;
+    a.status = sc->status; a.masks = nullptr; a.act = nullptr; a.single = 0;
     const int ntiles = (P.n + 31) / 32;
     // LOW on every point
     a.g0 = make_grid(sc->low); a.g1 = a.g0;
@@ -1314,7 +1317,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         ADFP_CHECK_LAUNCH();
         AttArgs t;
         t.list = ws.list; t.count_ptr = ws.counter; t.att_occ = ws.att_occ; t.att_u = ws.att_u;
-        t.flags = ws.flags; t.raw = raw; t.w = w; t.apply_bound = apply_bound; t.status = sc->status;
+        t.flags = ws.flags; t.raw = raw; t.w = w; t.apply_bound = apply_bound; t.status = sc->status; t.n_rows = 0;
         t.masks = nullptr; t.act = nullptr;
         if (sc->h_att && state && state->masks_att) {
             t.packed = (const float*)sc->h_att; t.masks = state->masks_att; t.act = state->act_att;
@@ -1341,7 +1344,7 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
     a.P = P; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
     a.list = nullptr; a.count_ptr = nullptr; a.flags = nullptr;
     a.raw = raw; a.w = w; a.att_occ = nullptr; a.write_w = 1; a.apply_bound = 1; a.status = sc->status;
-    a.masks = nullptr; a.act = nullptr;
+    a.masks = nullptr; a.act = nullptr; a.single = 0;
     const int ntiles = (P.n + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if (kind == ADFP_DEC_LOW) {
@@ -1365,6 +1368,62 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
             hipLaunchKernelGGL((k_decode<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
         }
     }
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- one sub-network alone: what `decoders.low_decoder(p, c_grid)` / `decoders.mlp(p, occ, tsdf_volume, tsdf_bnds)` compute in
+// the reference (decoder.py:177-203, :240-258).  No bound rule, no band logic.
+__global__ __launch_bounds__(256) void k_inv_tsdf(const float* __restrict__ t, float* __restrict__ u, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) u[i] = inv_tsdf(t[i]);
+}
+extern "C" int adfp_decode_single(const adfp_scene* sc, const adfp_points* pts, int kind, float* out4, void* stream) {
+    if (!sc || !pts || !out4) return ADFP_E_ARG;
+    PtsDev P; int rc = make_pts(pts, &P); if (rc) return rc;
+    if (P.n == 0) return 0;
+    DecodeArgs a;
+    a.P = P; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
+    a.list = nullptr; a.count_ptr = nullptr; a.flags = nullptr;
+    a.raw = out4; a.w = nullptr; a.att_occ = nullptr; a.write_w = 0; a.apply_bound = 0; a.status = sc->status;
+    a.masks = nullptr; a.act = nullptr; a.single = 1;
+    const int ntiles = (P.n + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == ADFP_DEC_LOW) {
+        if (!sc->low.data || !(sc->w_low || sc->h_low)) return ADFP_E_ARG;
+        a.g0 = make_grid(sc->low); a.g1 = a.g0;
+        if (sc->h_low) { a.packed = (const float*)sc->h_low; hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a); }
+        else { a.packed = sc->w_low; hipLaunchKernelGGL((k_decode<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a); }
+    } else if (kind == ADFP_DEC_COLOR) {
+        if (!sc->color.data || !(sc->w_color || sc->h_color)) return ADFP_E_ARG;
+        a.g0 = make_grid(sc->color); a.g1 = a.g0;
+        if (sc->h_color) { a.packed = (const float*)sc->h_color; hipLaunchKernelGGL((k_decode_h<32, 4, ROLE_COLOR, ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, ADFP_DECH_WG)), dim3(ADFP_DECH_NT), 0, st, a); }
+        else { a.packed = sc->w_color; hipLaunchKernelGGL((k_decode<32, 4, ROLE_COLOR, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a); }
+    } else if (kind == ADFP_DEC_HIGH) {
+        if (!sc->high.data || !sc->low.data || !(sc->w_high || sc->h_high)) return ADFP_E_ARG;
+        a.g0 = make_grid(sc->high); a.g1 = make_grid(sc->low);
+        a.att_occ = out4;                                   // HIGH writes one float per point: out4 is [P] here
+        a.raw = nullptr;
+        if (sc->h_high) { a.packed = (const float*)sc->h_high; hipLaunchKernelGGL((k_decode_h<64, 1, ROLE_HIGH, 512>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a); }
+        else { a.packed = sc->w_high; hipLaunchKernelGGL((k_decode<64, 1, ROLE_HIGH, 512>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a); }
+    } else return ADFP_E_ARG;
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int adfp_attention_rows(const adfp_scene* sc, const float* occ, const float* tsdf_val, long long n, float* out4, float* w,
+                                   float* scratch_u, void* stream) {
+    if (!sc || n < 0 || (n && (!occ || !tsdf_val || !out4 || !w || !scratch_u)) || !(sc->w_att || sc->h_att)) return ADFP_E_ARG;
+    if (n > 0x7fffffffll) return ADFP_E_UNSUPPORTED;
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_inv_tsdf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tsdf_val, scratch_u, n);
+    ADFP_CHECK_LAUNCH();
+    AttArgs t;
+    t.list = nullptr; t.count_ptr = nullptr; t.att_occ = occ; t.att_u = scratch_u; t.flags = nullptr;
+    t.raw = out4; t.w = w; t.apply_bound = 0; t.n_rows = (int)n; t.status = sc->status; t.masks = nullptr; t.act = nullptr;
+    const int ntiles = (int)((n + 31) / 32);
+    if (sc->h_att) { t.packed = (const float*)sc->h_att; hipLaunchKernelGGL(k_attention_h<0>, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t); }
+    else { t.packed = sc->w_att; hipLaunchKernelGGL(k_attention, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t); }
     ADFP_CHECK_LAUNCH();
     return 0;
 }

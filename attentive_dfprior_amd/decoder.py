@@ -43,7 +43,83 @@ class DenseLayer(nn.Linear):
             nn.init.zeros_(self.bias)
 
 
-class MLP(nn.Module):
+def pack_network(name, params, fmt='f32'):
+    """Packed image of one sub-network ('low' / 'high' / 'color' / 'att') from its parameters in state_dict order.
+    fmt: 'f32' (adfp_pack_decoder / adfp_pack_attention), 'h' (adfp_pack_*_h), 'ht' (adfp_pack_*_ht)."""
+    flat = _flat_params(params)
+    _lib.require_cuda(flat, f'{name} decoder parameters')
+    L = lib()
+    dev = flat.device
+    with torch.cuda.device(dev):
+        stream = _lib.current_stream(dev)
+        if fmt in ('h', 'ht'):
+            if name == 'att':
+                words = L.adfp_attention_packed_h_words() if fmt == 'h' else L.adfp_attention_packed_ht_words()
+                fn = L.adfp_pack_attention_h if fmt == 'h' else L.adfp_pack_attention_ht
+                packed = torch.empty(words, dtype=torch.int32, device=dev)
+                _lib.check(fn(_lib.ptr(flat), _lib.ptr(packed), _lib.status_ptr(), stream), 'adfp_pack_attention_' + fmt)
+            else:
+                kind = _lib.DEC_KIND[name]
+                words = L.adfp_decoder_packed_h_words(kind) if fmt == 'h' else L.adfp_decoder_packed_ht_words(kind)
+                fn = L.adfp_pack_decoder_h if fmt == 'h' else L.adfp_pack_decoder_ht
+                packed = torch.empty(words, dtype=torch.int32, device=dev)
+                _lib.check(fn(kind, _lib.ptr(flat), _lib.ptr(packed), _lib.status_ptr(), stream), 'adfp_pack_decoder_' + fmt)
+            return packed
+        if name == 'att':
+            assert flat.numel() == L.adfp_attention_flat_floats()
+            packed = torch.empty(L.adfp_attention_packed_floats(), dtype=torch.float32, device=dev)
+            _lib.check(L.adfp_pack_attention(_lib.ptr(flat), _lib.ptr(packed), stream), 'adfp_pack_attention')
+        else:
+            kind = _lib.DEC_KIND[name]
+            assert flat.numel() == L.adfp_decoder_flat_floats(kind)
+            packed = torch.empty(L.adfp_decoder_packed_floats(kind), dtype=torch.float32, device=dev)
+            _lib.check(L.adfp_pack_decoder(kind, _lib.ptr(flat), _lib.ptr(packed), stream), 'adfp_pack_decoder')
+    return packed
+
+
+class _SingleNet(object):
+    """Mixin of MLP / mlp_tsdf: the packed image of THIS module alone, for direct calls of a sub-network
+    (``decoders.low_decoder(p, c_grid)``, reference decoder.py:177).  The cache is dropped by deepcopy / pickling."""
+
+    def _single_packed(self, name, fmt):
+        params = tuple(self.parameters())
+        key = (_version_key(params), fmt)
+        hit = self.__dict__.get('_single')
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        packed = pack_network(name, params, fmt)
+        self.__dict__['_single'] = (key, packed)
+        return packed
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d.pop('_single', None)
+        return d
+
+    @staticmethod
+    def _refuse_autograd(*tensors_and_modules):
+        if not torch.is_grad_enabled():
+            return
+        for t in tensors_and_modules:
+            ts = t.parameters() if isinstance(t, nn.Module) else (t.values() if isinstance(t, dict) else [t])
+            if any(isinstance(x, torch.Tensor) and x.requires_grad for x in ts):
+                raise NotImplementedError(
+                    'a sub-network called on its own is inference-only in libadfp (use torch.no_grad()); '
+                    'gradients flow through the DF module (DF.forward / Renderer.render_batch_ray / eval_points)')
+
+
+_shared_engine = None
+
+
+def _engine():
+    global _shared_engine
+    if _shared_engine is None:
+        from .engine import Engine
+        _shared_engine = Engine()
+    return _shared_engine
+
+
+class MLP(_SingleNet, nn.Module):
     """Parameter container of one conv_onet decoder (reference decoder.py:91-166).
 
     Fourier-93 -> 5 x 32 ReLU layers with per-layer feature injection ``fc_c`` and a skip
@@ -79,11 +155,17 @@ class MLP(nn.Module):
         self.output_linear = DenseLayer(hidden_size, 4 if color else 1, activation='linear')
 
     def forward(self, p, c_grid=None):
-        raise NotImplementedError('the decoders are evaluated fused inside DF.forward (libadfp.so); '
-                                  'call the DF module')
+        """One decoder on its own (reference decoder.py:177-203; the embedder squeezes the batch dimension, :27): p [1,P,3] -> [P]
+        (occupancy decoders) / [P,4] (colour), no bound rule, no TSDF logic.  Inference-only here (see _refuse_autograd); ``self.bound`` must be set like
+        src/DF_Prior.py:192-194 does."""
+        self._refuse_autograd(p, c_grid, self)
+        bound = getattr(self, 'bound', None)
+        if bound is None:
+            raise RuntimeError(f'{self.name}_decoder.bound is not set (src/DF_Prior.py:192-194 assigns it in load_bound)')
+        return _engine().decode_single(self, p.reshape(-1, 3), c_grid, bound)
 
 
-class mlp_tsdf(nn.Module):
+class mlp_tsdf(_SingleNet, nn.Module):
     """Parameter container of the attention fusion MLP 2->64->128->128->64->2 (decoder.py:206-228)."""
 
     def __init__(self):
@@ -98,8 +180,11 @@ class mlp_tsdf(nn.Module):
         self.softmax = nn.Softmax(dim=1)
         self.sigmoid = nn.Sigmoid()
 
-    def forward(self, *a, **k):
-        raise NotImplementedError('mlp_tsdf is evaluated fused inside DF.forward (libadfp.so)')
+    def forward(self, p, occ, tsdf_volume, tsdf_bnds, **kwargs):
+        """The attention fusion on its own (reference decoder.py:240-258): p [1,M,3], occ [M] (or [1,M]) ->
+        (fused occupancy [M], attention weight [M]).  Inference-only here."""
+        self._refuse_autograd(p, occ, self)
+        return _engine().attention_rows(self, p.reshape(-1, 3), occ.reshape(-1), tsdf_volume, tsdf_bnds)
 
 
 def _flat_params(params):
@@ -185,57 +270,8 @@ class DF(nn.Module):
         hit = self._packed.get(slot)
         if hit is not None and hit[0] == key:
             return hit[1]
-        if fmt == 'ht':
-            flat = _flat_params(module)
-            _lib.require_cuda(flat, f'{name} decoder parameters')
-            L = lib()
-            dev = flat.device
-            with torch.cuda.device(dev):
-                if name == 'att':
-                    packed = torch.empty(L.adfp_attention_packed_ht_words(), dtype=torch.int32, device=dev)
-                    _lib.check(L.adfp_pack_attention_ht(_lib.ptr(flat), _lib.ptr(packed), _lib.status_ptr(), _lib.current_stream(dev)),
-                               'adfp_pack_attention_ht')
-                else:
-                    kind = _lib.DEC_KIND[name]
-                    packed = torch.empty(L.adfp_decoder_packed_ht_words(kind), dtype=torch.int32, device=dev)
-                    _lib.check(L.adfp_pack_decoder_ht(kind, _lib.ptr(flat), _lib.ptr(packed), _lib.status_ptr(), _lib.current_stream(dev)),
-                               'adfp_pack_decoder_ht')
-            self._packed[slot] = (key, packed)
-            return packed
-        if fmt == 'h':
-            flat = _flat_params(module)
-            _lib.require_cuda(flat, f'{name} decoder parameters')
-            L = lib()
-            dev = flat.device
-            with torch.cuda.device(dev):
-                if name == 'att':
-                    packed = torch.empty(L.adfp_attention_packed_h_words(), dtype=torch.int32, device=dev)
-                    _lib.check(L.adfp_pack_attention_h(_lib.ptr(flat), _lib.ptr(packed), _lib.status_ptr(), _lib.current_stream(dev)),
-                               'adfp_pack_attention_h')
-                else:
-                    kind = _lib.DEC_KIND[name]
-                    packed = torch.empty(L.adfp_decoder_packed_h_words(kind), dtype=torch.int32, device=dev)
-                    _lib.check(L.adfp_pack_decoder_h(kind, _lib.ptr(flat), _lib.ptr(packed), _lib.status_ptr(),
-                                                     _lib.current_stream(dev)),
-                               'adfp_pack_decoder_h')
-            self._packed[slot] = (key, packed)
-            return packed
-        flat = _flat_params(module)
-        _lib.require_cuda(flat, f'{name} decoder parameters')
-        L = lib()
-        dev = flat.device
-        with torch.cuda.device(dev):
-            stream = _lib.current_stream(dev)
-            if name == 'att':
-                assert flat.numel() == L.adfp_attention_flat_floats()
-                packed = torch.empty(L.adfp_attention_packed_floats(), dtype=torch.float32, device=dev)
-                _lib.check(L.adfp_pack_attention(_lib.ptr(flat), _lib.ptr(packed), stream), 'adfp_pack_attention')
-            else:
-                kind = _lib.DEC_KIND[name]
-                assert flat.numel() == L.adfp_decoder_flat_floats(kind)
-                packed = torch.empty(L.adfp_decoder_packed_floats(kind), dtype=torch.float32, device=dev)
-                _lib.check(L.adfp_pack_decoder(kind, _lib.ptr(flat), _lib.ptr(packed), stream), 'adfp_pack_decoder')
-        self._packed[name] = (key, packed)
+        packed = pack_network(name, module, fmt)
+        self._packed[slot] = (key, packed)
         return packed
 
     def __deepcopy__(self, memo):

@@ -40,6 +40,7 @@ class Engine(object):
         # ADFP_BWD_* bits handed to the backward entries (adfp_backward_args.options).  ADFP_SCATTER=cache in the environment of
         # the HOST process selects the in-kernel scatter (kernel A/B runs); the library itself reads no environment.
         self.bwd_options = _lib.BWD_SCATTER_IN_KERNEL if os.environ.get('ADFP_SCATTER', '')[:1] == 'c' else 0
+        self.exact_latch = {}    # network name -> True while its f16-split image is out of range (see scene())
         self._ws = None
         self._grid_cache = {}    # key name -> (key, channels-last tensor)
         self._bound_cache = {}   # id -> (key, host list)
@@ -304,6 +305,63 @@ class Engine(object):
             check(lib().adfp_sample_tsdf(C.byref(td), C.byref(b), C.byref(ap), ptr(out), _lib.current_stream(dev)),
                   'adfp_sample_tsdf')
         return out
+
+    # ---- one sub-network alone (MLP.forward / mlp_tsdf.forward, reference decoder.py:177-203, :240-258) --------------
+    def decode_single(self, mlp, pts, c, bound):
+        """pts [P,3] f64/f32 -> [P] (low / high decoder) or [P,4] (colour decoder)."""
+        _lib.require_cuda(pts, 'points')
+        dev = pts.device
+        name = mlp.name
+        use_h = math_mode() == 'f16x3' and not self.exact_latch.get(name)
+        with torch.cuda.device(dev):
+            mode = _lib.PTS_F64 if pts.dtype == torch.float64 else _lib.PTS_F32
+            if mode == _lib.PTS_F32 and pts.dtype != torch.float32:
+                pts = pts.float()
+            pts = pts.detach().contiguous()
+            P = pts.shape[0]
+            _lib.check_status()
+            sc = _lib.AdfpScene()
+            sc.status = _lib.status_word().data_ptr()
+            _lib.fill_bound(sc.bound, self.host_bound(bound, 'bound.' + name))
+            packed = mlp._single_packed(name, 'h' if use_h else 'f32')
+            setattr(sc, ('h_' if use_h else 'w_') + name, packed.data_ptr())
+            keep = []
+            for field, key in [(name, 'grid_' + name)] + ([('low', 'grid_low')] if name == 'high' else []):
+                g = self.grid_cl(key, c[key])
+                keep.append(g)
+                gd = getattr(sc, field)
+                gd.data, gd.Z, gd.Y, gd.X = g.data_ptr(), g.shape[0], g.shape[1], g.shape[2]
+            ap = _lib.AdfpPoints()
+            ap.mode, ap.n_points, ap.pts = mode, P, pts.data_ptr()
+            out = torch.empty((P,) if name == 'high' else (P, 4), dtype=torch.float32, device=dev)
+            if P:
+                check(lib().adfp_decode_single(C.byref(sc), C.byref(ap), _lib.DEC_KIND[name], ptr(out), _lib.current_stream(dev)),
+                      'adfp_decode_single')
+            return out[:, 3].contiguous() if name == 'low' else out
+
+    def attention_rows(self, mlp, pts, occ, tsdf_volume, tsdf_bnds):
+        """(fused occupancy [M], attention weight [M]) of mlp_tsdf.forward at the points pts [M,3] with occupancies occ [M]."""
+        _lib.require_cuda(pts, 'points')
+        dev = pts.device
+        use_h = math_mode() == 'f16x3' and not self.exact_latch.get('att')
+        tv = self.sample_tsdf(pts, tsdf_volume, tsdf_bnds)
+        with torch.cuda.device(dev):
+            M = tv.shape[0]
+            occ = occ.detach().to(dev, torch.float32).contiguous()
+            if occ.shape[0] != M:
+                raise RuntimeError(f'mlp_tsdf: {occ.shape[0]} occupancies for {M} points')
+            _lib.check_status()
+            sc = _lib.AdfpScene()
+            sc.status = _lib.status_word().data_ptr()
+            packed = mlp._single_packed('att', 'h' if use_h else 'f32')
+            setattr(sc, 'h_att' if use_h else 'w_att', packed.data_ptr())
+            out4 = torch.empty((M, 4), dtype=torch.float32, device=dev)
+            w = torch.empty((M,), dtype=torch.float32, device=dev)
+            u = torch.empty((M,), dtype=torch.float32, device=dev)
+            if M:
+                check(lib().adfp_attention_rows(C.byref(sc), ptr(occ), ptr(tv), M, ptr(out4), ptr(w), ptr(u), _lib.current_stream(dev)),
+                      'adfp_attention_rows')
+            return out4[:, 3].contiguous(), w
 
     # ---- a4..a13 ---------------------------------------------------------------------------
     def render_forward(self, decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage,

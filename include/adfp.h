@@ -412,6 +412,16 @@ int adfp_tsdf_stage(const adfp_scene* scene, const adfp_points* pts, unsigned ch
  * ADFP_DEC_COLOR) over every point and writes its output channel(s) of raw. */
 int adfp_decode_stage(const adfp_scene* scene, const adfp_points* pts, int kind, float* raw, float* w, void* stream);
 
+/* ---- one sub-network alone (reference: the public modules `decoders.low_decoder / high_decoder / color_decoder / mlp`) ---- */
+/* MLP.forward(p, c_grid) of src/conv_onet/models/decoder.py:177-203 for one decoder kind, no bound rule, no band logic.
+ * LOW: out4 is [P,4], the value lands in channel 3 (channels 0-2 untouched); COLOR: out4 is [P,4], all four outputs of the
+ * colour head (the renderer discards the fourth, decoder.py:351-352); HIGH (concat_feature: own grid + low grid): out4 is [P]. */
+int adfp_decode_single(const adfp_scene* scene /*host*/, const adfp_points* pts /*host*/, int kind, float* out4, void* stream);
+/* mlp_tsdf.forward of decoder.py:240-258 on explicit rows: occ [n] and the trilinear TSDF value tsdf_val [n] (adfp_sample_tsdf)
+ * -> fused occupancy out4[4 i + 3] and the attention weight w[i].  scratch_u: n floats (inv_tsdf of the rows). */
+int adfp_attention_rows(const adfp_scene* scene /*host*/, const float* occ, const float* tsdf_val, long long n, float* out4 /*[n,4]*/,
+                        float* w /*[n]*/, float* scratch_u, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -183,3 +183,20 @@ def test_frustum_mask_vs_reference_lines():
             got = O.frustum_mask_np(c2w, (Z, Y, X), depth, bound, int(H), int(W), fx, fy, cx, cy)   # [Z, Y, X]
             assert (got == ref_xyz.transpose(2, 1, 0)).all(), (k, key)
             assert 0 < ref_xyz.sum() < ref_xyz.size
+
+
+def test_oracle_subnetworks_vs_reference_golden(mini):
+    """mlp_forward / mlp_tsdf_forward against the REFERENCE's sub-modules called on their own
+    (tests/golden/make_subnet_golden.py -> mini_subnets.npz; decoder.py:177-203, :240-258)."""
+    g = mini.golden('subnets')
+    qp = mini.query_points
+    for name in ('low', 'high', 'color'):
+        got = O.mlp_forward(mini.sd, name, qp, mini.c, mini.bound)
+        assert got.shape == g[name].shape
+        assert np.abs(got.numpy() - g[name]).max() == 0.0, name
+        got32 = O.mlp_forward(mini.sd, name, qp.float(), mini.c, mini.bound)
+        assert np.abs(got32.numpy() - g[name + '_f32']).max() == 0.0, name
+    t = O.trilerp(mini.tsdf_volume, qp, mini.tsdf_bnds).reshape(-1)
+    fused, w = O.mlp_tsdf_forward(mini.sd, torch.from_numpy(g['att_occ_in']), t)
+    assert np.abs(fused.numpy() - g['att_fused']).max() <= 1e-6
+    assert np.abs(w.numpy() - g['att_w']).max() <= 1e-6
