@@ -2,8 +2,10 @@
 src/Mapper.py:374-473 with the reference's 60 iterations per frame (configs/df_prior.yaml:63), 5 000 rays per
 iteration, on the product's entry points (render_batch_ray + autograd, pre-filter, frustum mask, masked Adam).
 
-  * stability: 20 frames x 60 iterations (+ a longer first frame): every loss finite, the depth error of a FIXED
-    held-out ray set (poses between the training poses) falls by at least 20 %;
+  * stability, at BASELINE.json's full length: the 200-frame sequence mapped every 5th frame (configs/df_prior.yaml:44) = 40
+    mapping calls x 60 iterations (+ a 300-iteration first frame), through autograd AND through the fused MapperIteration:
+    every value finite, the depth error of a FIXED held-out ray set (poses between the mapped ones, all round the circle)
+    does not rise from quarter to quarter and at least halves;
   * trajectory: three Adam iterations on the same scene against the oracle's autograd + torch.optim.Adam on the
     host -- gradients within 2e-4, parameters after three steps within 2e-4 wherever the gradient is above the
     float-atomics noise floor (Adam normalises a noise-sized gradient to a full +-lr step)."""
@@ -13,7 +15,7 @@ import sys
 import pytest
 import torch
 
-from conftest import ROOT, assert_close, assert_close_scale
+from conftest import ROOT, assert_close, assert_close_scale, assert_param_grad_close
 from oracle import adfp_oracle as O
 
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
@@ -22,34 +24,43 @@ import mapping_loop as ML                                            # noqa: E40
 pytestmark = pytest.mark.gpu
 
 
-def test_office0_mapping_loop_is_stable_and_learns():
-    run = ML.MappingRun('office0', rays=5000, total_frames=200)
+EVERY_FRAME, N_FRAMES = 5, 200           # configs/df_prior.yaml:44 `every_frame: 5` over BASELINE.json's 200-frame loop = 40 mapping calls
+
+
+def full_loop(fused):
+    """The whole configs[2] loop: 40 mapping calls (frames 0, 5, ..., 195) of 60 iterations (300 on the first frame, whose
+    reference count of 1500 would only lengthen the run), 5 000 rays each; held-out depth error on poses between the
+    mapped ones, read after every quarter of the sequence."""
+    run = ML.MappingRun('office0', rays=5000, total_frames=N_FRAMES, fused=fused)
     assert tuple(run.sc.tsdf_volume.shape[2:]) == (656, 779, 738)             # [Z, Y, X]; SURVEY.md section 8: 1.51 GB
-    held = run.heldout_rays(20)
-    e0 = run.heldout_error(held)
+    calls = list(range(0, N_FRAMES, EVERY_FRAME))
+    assert len(calls) == 40
+    held = run.heldout_rays(len(calls), stride=EVERY_FRAME)
+    errs = [run.heldout_error(held)]
     hist = []
-    for f in range(20):
+    for k, f in enumerate(calls):
         hist.append(run.map_frame(f, 300 if f == 0 else 60, ML.LR_FIRST_FACTOR if f == 0 else 1.0))
-    e1 = run.heldout_error(held)
-    assert run.n_iter == 300 + 19 * 60
+        if (k + 1) % 10 == 0:
+            errs.append(run.heldout_error(held))
+    assert run.n_iter == 300 + 39 * 60
     assert all(torch.isfinite(v).all() for v in run.c.values())
     assert all(torch.isfinite(p).all() for p in run.dec.parameters())
-    print(f'held-out depth L1 per ray {e0:.4f} -> {e1:.4f}; first/last frame loss per ray {hist[0]} {hist[-1]}')
-    assert e1 <= 0.8 * e0, (e0, e1)
+    print(f'{"fused" if fused else "autograd"}: held-out depth L1 per ray by quarter {["%.4f" % e for e in errs]}; '
+          f'first/last frame loss per ray {hist[0]} {hist[-1]}')
+    for q in range(1, 5):
+        assert errs[q] <= 1.05 * errs[q - 1], f'held-out error rose in quarter {q}: {errs}'
+    assert errs[-1] <= 0.5 * errs[0], errs
     run.rend.check_overflow()
+    return errs
+
+
+def test_office0_mapping_loop_is_stable_and_learns():
+    full_loop(fused=False)
 
 
 def test_office0_mapping_loop_fused_iteration_learns_the_same():
     """The same loop through mapping.MapperIteration (device-side pre-filter mask, loss, backward, Adam; graph replay)."""
-    run = ML.MappingRun('office0', rays=5000, total_frames=200, fused=True)
-    held = run.heldout_rays(8)
-    e0 = run.heldout_error(held)
-    for f in range(8):
-        run.map_frame(f, 300 if f == 0 else 60, ML.LR_FIRST_FACTOR if f == 0 else 1.0)
-    e1 = run.heldout_error(held)
-    assert all(torch.isfinite(v).all() for v in run.c.values())
-    print(f'fused: held-out depth L1 per ray {e0:.4f} -> {e1:.4f}')
-    assert e1 <= 0.5 * e0, (e0, e1)
+    full_loop(fused=True)
 
 
 def test_three_iterations_follow_the_oracle_trajectory():
@@ -112,7 +123,10 @@ def test_three_iterations_follow_the_oracle_trajectory():
     ref.update({k: v.detach() for k, v in sdr.items()})
 
     for k, gr in r_first.items():
-        assert_close_scale(g_first[k], gr, 2e-4, f'gradient of {k} at iteration 0', flip_frac=2e-3 if k.startswith('grid') else 0.25)
+        if k.startswith('grid'):
+            assert_close_scale(g_first[k], gr, 2e-4, f'gradient of {k} at iteration 0', flip_frac=2e-3)
+        else:
+            assert_param_grad_close(g_first[k], gr, f'gradient of {k} at iteration 0')
     worst = 0.0
     for k, gr in r_first.items():
         live = gr.abs() > 1e-4 * gr.abs().max()                     # above the accumulation-order noise

@@ -8,7 +8,7 @@ import torch
 import attentive_dfprior_amd as A
 from attentive_dfprior_amd import synthetic
 from oracle import adfp_oracle as O
-from conftest import make_cfg, to_dev, assert_close_scale
+from conftest import make_cfg, to_dev, assert_close_scale, assert_param_grad_close
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -28,14 +28,15 @@ def mapper_loss(depth, color, weight, gt_depth, gt_color, stage, warm):
 MODES = ['f32', 'f16x3']      # ADFP_MATH: exact f32-input MFMA forward + backward / the default f16-split forward + backward
 
 
-def grad_close(got, ref, what, tol=GTOL, mode='f32'):
-    """2e-4 of the tensor's scale, ReLU-boundary samples aside (conftest.assert_close_scale): such a sample reaches 8 voxels
-    of a grid gradient (2e-3 of a grid's elements is generous) but a whole row -- and through W^T a little of every row -- of
-    a weight gradient.  Both modes meet them: the exact mode's summation order is not torch's either (second-seed case,
-    grid_high: 30 of 181 440 elements off by up to 4.5e-4 of the scale)."""
+def grad_close(got, ref, what, tol=GTOL, mode=None):
+    """Grid gradients: 2e-4 of the tensor's scale, ReLU-boundary samples aside (such a sample reaches 8 voxels: 2e-3 of a
+    grid's elements is generous).  Parameter gradients: conftest.assert_param_grad_close, per math mode."""
     last = what.split()[-1]
     is_param = any(t in last for t in ('decoder', 'mlp', 'weight', 'bias', '_B')) or last in ('W2',)
-    assert_close_scale(got.detach(), ref, tol, what, flip_frac=2e-3 if last.startswith('grid') else (0.25 if is_param else 0.0))
+    if is_param:
+        assert_param_grad_close(got, ref, what, mode)
+    else:
+        assert_close_scale(got.detach(), ref, tol, what, flip_frac=2e-3 if last.startswith('grid') else 0.0)
 
 
 def run(mini, stage, warm, sd=None, n_samples=None, n_surface=None, rays=None, bwd_options=None):
@@ -350,3 +351,38 @@ def test_sorted_scatter_equals_cached_scatter(mini):
         got[name] = {k: v.grad.cpu() for k, v in c.items()}
     for k in got['sorted']:
         assert_close_scale(got['sorted'][k], got['cache'][k], 2e-6, f'{k}: sorted vs cached scatter')
+
+
+def test_a_swapped_pair_of_weight_rows_fails_the_gradient_comparison(mini, monkeypatch):
+    """Negative control of the comparison itself: the backward's flat colour-decoder gradient comes back with two rows of
+    pts_linears.1.weight exchanged (what an indexing bug in k_outer_h's write-out would produce) -- the golden comparison
+    must fail, in both math modes."""
+    from attentive_dfprior_amd import engine
+    L = engine.lib()
+    orig = engine.Engine.render_backward
+
+    def swapped(self, *a, **k):
+        grids, flats, rays = orig(self, *a, **k)
+        if 'color' in flats:
+            names = [n for n, _ in A.DF().color_decoder.named_parameters()]
+            shapes = [tuple(p.shape) for _, p in A.DF().color_decoder.named_parameters()]
+            off = 0
+            for n, shp in zip(names, shapes):
+                cnt = int(np.prod(shp))
+                if n == 'pts_linears.1.weight':
+                    w = flats['color'][off:off + cnt].view(shp)
+                    r3, r5 = w[3].clone(), w[5].clone()
+                    w[3], w[5] = r5, r3
+                off += cnt
+            assert off == L.adfp_decoder_flat_floats(2)
+        return grids, flats, rays
+    monkeypatch.setattr(engine.Engine, 'render_backward', swapped)
+    for mode in MODES:
+        monkeypatch.setenv('ADFP_MATH', mode)
+        g = mini.golden('color')
+        loss, c, dec = run(mini, 'color', False)
+        p = dict(dec.named_parameters())['color_decoder.pts_linears.1.weight']
+        with pytest.raises(AssertionError):
+            grad_close(p.grad, g['g.sd.color_decoder.pts_linears.1.weight'], 'swapped color_decoder.pts_linears.1.weight', mode=mode)
+        q = dict(dec.named_parameters())['color_decoder.pts_linears.2.weight']           # an untouched tensor still passes
+        grad_close(q.grad, g['g.sd.color_decoder.pts_linears.2.weight'], 'color_decoder.pts_linears.2.weight', mode=mode)

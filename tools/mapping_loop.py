@@ -84,13 +84,13 @@ class MappingRun(object):
         torch.manual_seed(seed)
 
     # a fixed set of rays from poses BETWEEN the training poses: the held-out depth error of the map
-    def heldout_rays(self, frames, n=4000, seed=123):
+    def heldout_rays(self, frames, n=4000, seed=123, stride=1):
         sc = self.sc
         g = torch.Generator().manual_seed(seed)
         ros, rds, gds = [], [], []
         per = n // frames
         for f in range(frames):
-            c2w = circle_pose(sc, f + 0.5, self.total_frames)
+            c2w = circle_pose(sc, (f + 0.5) * stride, self.total_frames)
             depth = sc.depth_image(c2w, zero_band=0.0)
             ro, rd = common.get_rays(sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2w, self.dev)
             pick = torch.randint(sc.H * sc.W, (per,), generator=g).to(self.dev)
@@ -198,21 +198,23 @@ def main():
     ap.add_argument('--rays', type=int, default=5000)
     ap.add_argument('--scene', default='office0')
     ap.add_argument('--fused', action='store_true', help='mapping.MapperIteration (device-side iteration, graph replay)')
+    ap.add_argument('--every-frame', type=int, default=1, help='map every n-th frame of the sequence (configs/df_prior.yaml:44: 5)')
     args = ap.parse_args()
     run = MappingRun(args.scene, args.rays, args.frames, fused=args.fused)
-    held = run.heldout_rays(min(args.frames, 20))
+    calls = list(range(0, args.frames, args.every_frame))
+    held = run.heldout_rays(min(len(calls), 40), stride=args.every_frame)
     e0 = run.heldout_error(held)
     hist = []
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    for f in range(args.frames):
+    for f in calls:
         hist.append(run.map_frame(f, args.iters_first if f == 0 else args.iters, LR_FIRST_FACTOR if f == 0 else 1.0))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t_start
     e1 = run.heldout_error(held)
     q = max(1, len(hist) // 4)
     mean = lambda xs: sum(xs) / len(xs)
-    print(json.dumps({'config': f'{args.scene} mapping loop', 'frames': args.frames, 'iters_per_frame': args.iters,
+    print(json.dumps({'config': f'{args.scene} mapping loop', 'frames': args.frames, 'mapping_calls': len(calls), 'iters_per_frame': args.iters,
                       'iters_first': args.iters_first, 'rays_per_iter': args.rays, 'fused': args.fused, 'iterations': run.n_iter, 'seconds': dt,
                       'ms_per_iteration': dt / run.n_iter * 1e3,
                       'heldout_depth_l1_before': e0, 'heldout_depth_l1_after': e1,
