@@ -9,8 +9,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ADFP_LIB_PATH', os.path.join(_HERE, 'libadfp.so'))   # override: kernel A/B builds
 
-ABI_VERSION = 115                 # ADFP_VERSION of include/adfp.h this binding was written against
-STATUS_F16_RANGE = 1
+ABI_VERSION = 116                 # ADFP_VERSION of include/adfp.h this binding was written against
+STATUS_F16_RANGE = 31              # ADFP_STATUS_F16_RANGE: any of the bits below
+STATUS_RANGE_BITS = {'low': 1, 'high': 2, 'color': 4, 'att': 8, 'bwd': 16}      # ADFP_STATUS_F16_RANGE_<net>
 BWD_SCATTER_IN_KERNEL = 1        # ADFP_BWD_SCATTER_IN_KERNEL
 STAGE = {'low': 0, 'high': 1, 'color': 2}
 DEC_KIND = {'low': 0, 'high': 1, 'color': 2}
@@ -36,6 +37,7 @@ class AdfpScene(C.Structure):
                 ('w_low', C.c_void_p), ('w_high', C.c_void_p), ('w_color', C.c_void_p), ('w_att', C.c_void_p),
                 ('h_low', C.c_void_p), ('h_high', C.c_void_p), ('h_color', C.c_void_p), ('h_att', C.c_void_p),
                 ('ht_low', C.c_void_p), ('ht_high', C.c_void_p), ('ht_color', C.c_void_p), ('ht_att', C.c_void_p),
+                ('flat_low', C.c_void_p), ('flat_high', C.c_void_p), ('flat_color', C.c_void_p), ('flat_att', C.c_void_p),
                 ('status', C.c_void_p)]
 
 
@@ -151,7 +153,7 @@ SYMBOLS = [
                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     ('adfp_prefilter_mask', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_mapper_loss', C.c_int, [C.POINTER(AdfpLossArgs), C.c_void_p]),
-    ('adfp_adam_prep', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_void_p]),
+    ('adfp_adam_prep', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     ('adfp_masked_adam_dev', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int,
                                        C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     ('adfp_masked_adam_multi', C.c_int, [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]),
@@ -222,19 +224,25 @@ def require_cuda(t, name):
             'there is no CPU fallback.')
 
 
-# ---- sticky status word (adfp_scene.status) -------------------------------------------------------------
-# One word of pinned host memory per process: the kernels OR into it with a system-scope atomic (pinned host
-# memory is device-visible under HIP's unified addressing), and the host reads it without synchronising.
-# Like an asynchronous HIP error, a raised bit is reported at the NEXT call into the library -- or at once
-# by check_status(sync=True).
+# ---- sticky status words (adfp_scene.status) ---------------------------------------------------------------
+# A word of pinned host memory: the kernels OR into it with a system-scope atomic (pinned host memory is device-visible under
+# HIP's unified addressing), and the host reads it without synchronising.  Every DF module owns one (decoder.DF.status_word), so
+# that an f16-range event is attributed to the network object it happened in; sub-networks called on their own share the
+# process-wide word below.  An f16-range bit is NOT an error any more: the call that raised it repaired itself on the device
+# (adfp_scene.flat_*, csrc/adfp_fallback.h), and the host answers by switching that network to its exact image (read_status ->
+# DF._exact_latch).
 _status = None
+
+
+def new_status_word():
+    import torch
+    return torch.zeros(4, dtype=torch.int32).pin_memory()
 
 
 def status_word():
     global _status
     if _status is None:
-        import torch
-        _status = torch.zeros(4, dtype=torch.int32).pin_memory()
+        _status = new_status_word()
     return _status
 
 
@@ -242,19 +250,22 @@ def status_ptr():
     return C.c_void_p(status_word().data_ptr())
 
 
-def check_status(sync=False, device=None):
-    """Raise if an earlier call left a bit in the status word (and clear it).  sync=True waits for the device first."""
-    if _status is None:
-        return
+def read_status(word, sync=False, device=None):
+    """The bits an earlier call left in `word` (cleared on read).  sync=True waits for the device first.  Range bits are returned
+    to the caller; any other bit is an error."""
+    if word is None:
+        return 0
     if sync:
         import torch
         torch.cuda.synchronize(device)
-    v = int(_status[0])
+    v = int(word[0])
     if v:
-        _status[0] = 0
-        if v & STATUS_F16_RANGE:
-            raise RuntimeError(
-                'libadfp: an operand of the f16-split (ADFP_MATH=f16x3) decoders reached |x| >= 65504 -- a weight, a '
-                'grid feature or a hidden activation; the outputs of that call are invalid.  Re-run with '
-                'ADFP_MATH=f32 (exact f32-input MFMA, no range limit).')
-        raise RuntimeError(f'libadfp: status word {v:#x}')
+        word[0] = 0
+        if v & ~STATUS_F16_RANGE:
+            raise RuntimeError(f'libadfp: status word {v:#x}')
+    return v
+
+
+def check_status(sync=False, device=None):
+    """Process-wide word (sub-networks called on their own): returns its range bits, raises on anything else."""
+    return read_status(_status, sync, device)

@@ -47,11 +47,14 @@ ADFP_DEV void stage_block_mul(float* __restrict__ row, int col, int h, const VT&
 __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__ raw, const double* __restrict__ z, int n_rays, int S,
                                                        const double* __restrict__ g_depth, const double* __restrict__ g_var,
                                                        const float* __restrict__ g_color, float* __restrict__ g_raw,
-                                                       const unsigned char* __restrict__ keep, float* __restrict__ gmax) {
+                                                       const unsigned char* __restrict__ keep, float* __restrict__ gmax,
+                                                       const float* __restrict__ g_weight, const int* __restrict__ skip) {
     const int lane = threadIdx.x & 63;
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
-    if (keep && !keep[ray]) {                        // a ray the pre-filter dropped: no gradient, whatever its samples hold (NaN * 0)
+    // skip: the forward call was repaired by the f32 fallback (adfp_fallback.h) -- its training state is not valid, the whole
+    // call returns zero gradients
+    if ((keep && !keep[ray]) || (skip && *skip)) {                        // a ray the pre-filter dropped: no gradient, whatever its samples hold (NaN * 0)
         for (int s = lane; s < S; s += 64) *(f32x4*)(g_raw + ((long long)ray * S + s) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
         if (gmax && lane == 0) gmax[ray] = 0.f;
         return;
@@ -122,6 +125,10 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
         }
     }
     if (gmax) {                  // per-ray maximum; k_max_reduce folds them (5 000 atomics on one address cost 60 us)
+        // The cotangent of the attention-weight output enters the attention backward beside d/d raw (gl = a (ga - dot), |gl| <=
+        // |g_w| / 4): it belongs to the same scale, or a loss that lives mostly on w would push S up until the staged rows leave
+        // the f16 range.
+        if (g_weight) for (int s = lane; s < S; s += 64) mx = fmaxf(mx, fabsf(g_weight[(long long)ray * S + s]));
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         if (lane == 0) gmax[ray] = mx;
@@ -502,6 +509,7 @@ struct AttBwdArgs {
     const float* packed; const int* list; const int* count_ptr;
     const float* att_occ; const float* att_u;
     const float* g_weight;     // [P] cotangent of the attention weight output (or NULL)
+    const int* skip;           // device flag: non-zero = zero gradients for this call (see k_composite_bwd)
     float* g_raw;              // [P,4]: .w read as cotangent of the fused occupancy, then overwritten
                                //        with d/d(high+low) for the LOW backward
     float* att_g;              // per list entry: d/d(high+low) for the HIGH backward
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(256) void k_attention_bwd(AttBwdArgs a) {
         const float a0 = e0 / den, a1 = e1 / den;
         // ---- backward: out = a0 occ + a1 u, w = a1
         const float g_out = valid ? a.g_raw[4ll * q + 3] : 0.f;
-        const float g_w = (valid && a.g_weight) ? a.g_weight[q] : 0.f;
+        const float g_w = (valid && a.g_weight && !(a.skip && *a.skip)) ? a.g_weight[q] : 0.f;
         const float ga0 = g_out * occ, ga1 = g_out * u + g_w;
         const float dot = a0 * ga0 + a1 * ga1;
         const float gl0 = a0 * (ga0 - dot), gl1 = a1 * (ga1 - dot);

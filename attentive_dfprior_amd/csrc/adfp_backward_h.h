@@ -86,7 +86,7 @@ __global__ void k_pack_decoder_ht(const float* __restrict__ flat, unsigned* __re
     if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(flat[s.s0]); return; }
     const float a = s.s0 < 0 ? 0.f : flat[s.s0], b = s.s1 < 0 ? 0.f : flat[s.s1];
     if (status && !(fmaxf(fabsf(a), fabsf(b)) < 65504.0f))
-        __hip_atomic_fetch_or(status, ADFP_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_or(status, ADFP_STATUS_F16_RANGE_BWD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const float ah = f16_hi_part(a), bh = f16_hi_part(b);
     _Float16 x, y;
     if (s.kind == 1) { x = (_Float16)ah; y = (_Float16)bh; }
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
         }
     }
     if constexpr (SCAT) { if (a.g_grid) scatter_flush<CACHE>(a.g_grid, lane, sm); }
-    report_range(a.status, amax);
+    report_range(a.status, amax, ADFP_STATUS_F16_RANGE_BWD);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
         if (!more) break;
         m = nm; blk = nblk; m1 = nm1;
     }
-    report_range(b.status, amax);
+    report_range(b.status, amax, ADFP_STATUS_F16_RANGE_BWD);
     float* part = a.partial + (long long)blockIdx.x * a.part_stride;
 #pragma unroll
     for (int j = 0; j < OUTER_JW; ++j) {
@@ -666,7 +666,7 @@ __global__ void k_pack_attention_ht(const float* __restrict__ flat, unsigned* __
     if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(flat[s.s0]); return; }
     const float a = flat[s.s0], b = flat[s.s1];
     if (status && !(fmaxf(fabsf(a), fabsf(b)) < 65504.0f))
-        __hip_atomic_fetch_or(status, ADFP_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_or(status, ADFP_STATUS_F16_RANGE_BWD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const float ah = f16_hi_part(a), bh = f16_hi_part(b);
     _Float16 x, y;
     if (s.kind == 1) { x = (_Float16)ah; y = (_Float16)bh; }
@@ -684,6 +684,7 @@ struct AttBwdHArgs {
     float* stage;              // G piece of this chunk's staging rows (AttStage columns [416, 832)) or NULL
     int chunk_lo, chunk_hi;
     int* status; const float* gmax;
+    const int* skip;           // device flag: non-zero = zero gradients for this call (see k_composite_bwd)
 };
 // 16 values of a float array -> the two k-steps of a B operand
 ADFP_DEV void split16a(const float* __restrict__ v, f16x8* __restrict__ xh, f16x8* __restrict__ xl, float& amax) {
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(512) void k_attention_bwd_h(AttBwdHArgs a) {
         const float a0 = __uint_as_float(mrow[6]), a1 = __uint_as_float(mrow[13]);
         // ---- softmax / blend backward: out = a0 occ + a1 u, w = a1
         const float g_out = valid ? a.g_raw[4ll * q + 3] : 0.f;
-        const float g_w = (valid && a.g_weight) ? a.g_weight[q] : 0.f;
+        const float g_w = (valid && a.g_weight && !(a.skip && *a.skip)) ? a.g_weight[q] : 0.f;
         const float ga0 = g_out * occ, ga1 = g_out * u + g_w;
         const float dot = a0 * ga0 + a1 * ga1;
         const float gl0 = a0 * (ga0 - dot), gl1 = a1 * (ga1 - dot);
@@ -807,5 +808,5 @@ __global__ __launch_bounds__(512) void k_attention_bwd_h(AttBwdHArgs a) {
         const float g_in = a0 * g_out + gx * isc;
         if (valid && h == 0) { a.att_g[idx] = g_in; a.g_raw[4ll * q + 3] = g_in; }
     }
-    report_range(a.status, amax);
+    report_range(a.status, amax, ADFP_STATUS_F16_RANGE_BWD);
 }

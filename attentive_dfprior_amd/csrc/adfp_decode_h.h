@@ -52,7 +52,8 @@ struct DecLayoutH {
     __host__ __device__ static constexpr int P_BC(int i) { return P_WC(i) + KS_C * 512; }
     static constexpr int P_WO = P_WP(5);                              // [2][NOUT][16] f32
     static constexpr int P_BO = P_WO + 2 * NOUT * 16;
-    static constexpr int P_TOTAL = P_BO + 4;
+    static constexpr int P_FLAG = P_BO + 4;                           // word 0: non-zero = a weight is outside the f16 range
+    static constexpr int P_TOTAL = P_FLAG + 4;
 };
 
 // source of 32-bit word t of the H image: either one f32 of the flat buffer (kind 0) or a pair of
@@ -99,15 +100,26 @@ __device__ HSrc dec_h_src(int t) {
 
 __device__ __forceinline__ float f16_hi_part(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFFE000u); }
 
+// Is any parameter of the flat buffer outside the f16 range?  Evaluated by workgroup 0 alone over the whole buffer (16-33 k floats:
+// a couple of microseconds) so that the answer is ONE plain store into the image's flag word: no atomics, nothing to zero first.
+ADFP_DEV void pack_range_flag(const float* __restrict__ flat, int n_flat, unsigned* __restrict__ flag_word, int* __restrict__ status, int bit) {
+    if (blockIdx.x != 0) return;
+    int bad = 0;
+    for (int i = threadIdx.x; i < n_flat; i += blockDim.x) bad |= !(fabsf(flat[i]) < 65504.0f);
+    bad = __syncthreads_or(bad);
+    if (threadIdx.x == 0) {
+        *flag_word = bad ? 1u : 0u;
+        if (bad && status) __hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 template <int CDIM, int NOUT>
-__global__ void k_pack_decoder_h(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status) {
+__global__ void k_pack_decoder_h(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status, int bit) {
+    pack_range_flag(flat, DecLayout<CDIM, NOUT>::F_TOTAL, packed + DecLayoutH<CDIM, NOUT>::P_FLAG, status, bit);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= DecLayoutH<CDIM, NOUT>::P_TOTAL) return;
+    if (t >= DecLayoutH<CDIM, NOUT>::P_TOTAL || t == DecLayoutH<CDIM, NOUT>::P_FLAG) return;
     const HSrc s = dec_h_src<CDIM, NOUT>(t);
     if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(flat[s.s0]); return; }
     const float a = s.s0 < 0 ? 0.f : flat[s.s0], b = s.s1 < 0 ? 0.f : flat[s.s1];
-    if (status && !(fmaxf(fabsf(a), fabsf(b)) < 65504.0f))       // a weight the f16 split cannot hold
-        __hip_atomic_fetch_or(status, ADFP_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const float ah = f16_hi_part(a), bh = f16_hi_part(b);
     _Float16 x, y;
     if (s.kind == 1) { x = (_Float16)ah; y = (_Float16)bh; }
@@ -162,9 +174,13 @@ ADFP_DEV void split8(const float* __restrict__ x, f16x8& hi, f16x8& lo, float& a
 }
 #endif
 #define ADFP_F16_MAX 65504.0f
-// once per wave, after its tile loop
-ADFP_DEV void report_range(int* status, float amax) {
-    if (status && !(amax < ADFP_F16_MAX)) __hip_atomic_fetch_or(status, ADFP_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// once per wave, after its tile loop: the sticky word for the host (which network, so that it can switch that one to the exact
+// image) and the CALL's flag (device memory, zeroed by the call) that arms the f32 fallback kernel and the backward's gate
+ADFP_DEV void report_range(int* status, float amax, int bit, int* call_flag = nullptr) {
+    if (!(amax < ADFP_F16_MAX)) {
+        if (status) __hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (call_flag) __hip_atomic_fetch_or(call_flag, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // NK k-steps of a chain: acc += W[:, units of k-step] * x   with the 3-product split
@@ -235,7 +251,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
 #ifdef ADFP_STAMPS
     unsigned long long ph_[6] = {0, 0, 0, 0, 0, 0}, last_ = clock64();
 #endif
-    float amax = 0.f;                                   // max |operand| this wave has split (f16 range guard)
+    float amax = ldsu[L::P_FLAG] ? INFINITY : 0.f;      // max |operand| this wave has split (f16 range guard); a weight out of range
     for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<NT / 64>(j, &s_next, ntiles)) >= 0;) {
         ADFP_PHASE(0);                                  // ticket + loop overhead
         const int idx = tile * 32 + p;
@@ -345,7 +361,8 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
         }
         ADFP_PHASE(4);                                  // output layer + store
     }
-    report_range(a.status, amax);
+    report_range(a.status, amax, ROLE == ROLE_LOW ? ADFP_STATUS_F16_RANGE_LOW : (ROLE == ROLE_HIGH ? ADFP_STATUS_F16_RANGE_HIGH : ADFP_STATUS_F16_RANGE_COLOR),
+                 a.call_flag);
 #ifdef ADFP_STAMPS
     if (lane == 0) for (int k = 0; k < 5; ++k) atomicAdd(&g_phase[k], ph_[k]);
     const int wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
@@ -368,7 +385,8 @@ struct AttLayoutH {
     static constexpr int P_B3 = P_W3 + 2 * 8 * 512;
     static constexpr int P_WO = P_B3 + 64;                       // [2 h][2 o][32] f32
     static constexpr int P_BO = P_WO + 128;
-    static constexpr int P_TOTAL = P_BO + 4;
+    static constexpr int P_FLAG = P_BO + 4;                       // word 0: non-zero = a weight is outside the f16 range
+    static constexpr int P_TOTAL = P_FLAG + 4;
 };
 
 __device__ HSrc att_h_src(int t) {
@@ -397,13 +415,12 @@ __device__ HSrc att_h_src(int t) {
     return HSrc{0, o < 2 ? F::F_BO + o : -1, -1};
 }
 __global__ void k_pack_attention_h(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status) {
+    pack_range_flag(flat, AttLayout::F_TOTAL, packed + AttLayoutH::P_FLAG, status, ADFP_STATUS_F16_RANGE_ATT);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= AttLayoutH::P_TOTAL) return;
+    if (t >= AttLayoutH::P_TOTAL || t == AttLayoutH::P_FLAG) return;
     const HSrc s = att_h_src(t);
     if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(flat[s.s0]); return; }
     const float a = flat[s.s0], b = flat[s.s1];
-    if (status && !(fmaxf(fabsf(a), fabsf(b)) < 65504.0f))
-        __hip_atomic_fetch_or(status, ADFP_STATUS_F16_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const float ah = f16_hi_part(a), bh = f16_hi_part(b);
     _Float16 x, y;
     if (s.kind == 1) { x = (_Float16)ah; y = (_Float16)bh; }
@@ -436,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
     const int lane_off = h * 128 + p * 4;
     const int count = a.count_ptr ? *a.count_ptr : a.n_rows;
     const int ntiles = (count + 31) >> 5;
-    float amax = 0.f;
+    float amax = ldsu[A::P_FLAG] ? INFINITY : 0.f;
     for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<8>(j, &s_next, ntiles)) >= 0;) {
         const int idx = tile * 32 + p;
         const bool valid = idx < count;
@@ -530,5 +547,5 @@ __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
             a.w[q] = a1;
         }
     }
-    report_range(a.status, amax);
+    report_range(a.status, amax, ADFP_STATUS_F16_RANGE_ATT, a.call_flag);
 }

@@ -686,6 +686,7 @@ struct DecodeArgs {
     unsigned* masks;           // training forward (k_decode_h<..., 1>): ReLU masks, [rows][2][3] words
     float* act;                // training forward: X part of the staging rows, [rows][DecStage::NX], or NULL
     int single;                // adfp_decode_single: one decoder alone (COLOR writes its 4th output, HIGH does not add `low`)
+    int* call_flag;            // f16x3 kernels: the call's range flag (device memory, arms k_fallback_points) or NULL
 };
 
 template <int CDIM, int NOUT, int ROLE, int NT>
@@ -784,6 +785,7 @@ struct AttArgs {
     float* raw; float* w; int apply_bound;
     int n_rows;                // rows when count_ptr == NULL (adfp_attention_rows)
     int* status;
+    int* call_flag;            // as DecodeArgs.call_flag
     unsigned* masks;           // training forward (k_attention_h<1>): ReLU masks + softmax weights, [rows][2][ATT_MASK_WORDS / 2]
     float* act;                // training forward: X piece of the staging rows ([rows][416]: inputs, h_0..h_3), or NULL
 };
@@ -795,6 +797,7 @@ struct AttArgs {
 #endif
 #define ADFP_DECH_WG (ADFP_DECH_NT == 256 ? 2 : 1)
 #include "adfp_decode_h.h"
+#include "adfp_fallback.h"
 
 // =====================================================================================
 // attention fusion mlp_tsdf (a11) on the in-band list
@@ -1058,13 +1061,13 @@ int adfp_pack_decoder_h(int kind, const float* flat, void* packed, int* status, 
     unsigned* out = (unsigned*)packed;
     switch (kind) {
         case ADFP_DEC_LOW:
-            hipLaunchKernelGGL((k_pack_decoder_h<32, 1>), dim3((DecLayoutH<32, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status);
+            hipLaunchKernelGGL((k_pack_decoder_h<32, 1>), dim3((DecLayoutH<32, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_LOW);
             break;
         case ADFP_DEC_HIGH:
-            hipLaunchKernelGGL((k_pack_decoder_h<64, 1>), dim3((DecLayoutH<64, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status);
+            hipLaunchKernelGGL((k_pack_decoder_h<64, 1>), dim3((DecLayoutH<64, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_HIGH);
             break;
         case ADFP_DEC_COLOR:
-            hipLaunchKernelGGL((k_pack_decoder_h<32, 4>), dim3((DecLayoutH<32, 4>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status);
+            hipLaunchKernelGGL((k_pack_decoder_h<32, 4>), dim3((DecLayoutH<32, 4>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_COLOR);
             break;
         default: return ADFP_E_ARG;
     }
@@ -1256,9 +1259,15 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         e = zero_async(raw, (size_t)P.n * 16, st);
         if (e != hipSuccess) return (int)e;
     }
-    if (fuse) {
-        e = zero_async(ws.counter, 4, st);
+    // f16-split kernels in this call?  Then the call owns a range flag (counter[8]) that they raise, k_fallback_points reads, and --
+    // in a training call, where `counter` is the caller's -- the backward entries and the Adam step gate on.
+    const bool any_h = sc->h_low || (fuse && (sc->h_high || sc->h_att)) || (stage == ADFP_STAGE_COLOR && sc->h_color);
+    int* call_flag = (any_h && ws.counter) ? ws.counter + 8 : nullptr;
+    if ((fuse || any_h || state) && ws.counter) {
+        e = zero_async(ws.counter, 64, st);
         if (e != hipSuccess) return (int)e;
+    }
+    if (fuse) {
         int rc = launch_tsdf(sc, P, ws.flags, ws.list, ws.att_u, nullptr, ws.counter, nullptr, st);   // w = 1 comes from the LOW decoder
         if (rc) return rc;
     }
@@ -1266,7 +1275,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
     a.P = P; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
     a.list = nullptr; a.count_ptr = nullptr; a.flags = fuse ? ws.flags : nullptr;
     a.raw = raw; a.w = w; a.att_occ = nullptr; a.write_w = 1; a.apply_bound = apply_bound;   // attention overwrites w on the band
-    a.status = sc->status; a.masks = nullptr; a.act = nullptr; a.single = 0;
+    a.status = sc->status; a.masks = nullptr; a.act = nullptr; a.single = 0; a.call_flag = call_flag;
     const int ntiles = (P.n + 31) / 32;
     // LOW on every point
     a.g0 = make_grid(sc->low); a.g1 = a.g0;
@@ -1317,7 +1326,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         ADFP_CHECK_LAUNCH();
         AttArgs t;
         t.list = ws.list; t.count_ptr = ws.counter; t.att_occ = ws.att_occ; t.att_u = ws.att_u;
-        t.flags = ws.flags; t.raw = raw; t.w = w; t.apply_bound = apply_bound; t.status = sc->status; t.n_rows = 0;
+        t.flags = ws.flags; t.raw = raw; t.w = w; t.apply_bound = apply_bound; t.status = sc->status; t.n_rows = 0; t.call_flag = call_flag;
         t.masks = nullptr; t.act = nullptr;
         if (sc->h_att && state && state->masks_att) {
             t.packed = (const float*)sc->h_att; t.masks = state->masks_att; t.act = state->act_att;
@@ -1329,6 +1338,20 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
             t.packed = sc->w_att;
             hipLaunchKernelGGL(k_attention, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
         }
+        ADFP_CHECK_LAUNCH();
+    }
+    // the f32 repair of a call whose f16-split kernels left the f16 range (adfp_fallback.h): returns at once when the flag is clear
+    if (call_flag && sc->flat_low && (!fuse || (sc->flat_high && sc->flat_att)) && (stage != ADFP_STAGE_COLOR || sc->flat_color)) {
+        FallbackArgs f;
+        f.P = P; f.nb = a.nb; fill_bound(f.b, sc->bound);
+        f.low = make_grid(sc->low); f.high = make_grid(sc->high); f.color = make_grid(sc->color);
+        f.flat_low = sc->flat_low; f.flat_high = sc->flat_high; f.flat_color = sc->flat_color; f.flat_att = sc->flat_att;
+        f.stage = stage; f.apply_bound = apply_bound;
+        f.flags = fuse ? ws.flags : nullptr; f.list = ws.list; f.count_ptr = ws.counter; f.att_u = ws.att_u; f.att_occ = ws.att_occ;
+        f.raw = raw; f.w = w; f.call_flag = call_flag;
+        long long blocks = ((long long)P.n * (fuse ? 2 : 1) + 255) / 256;
+        const long long cap = (long long)num_cu() * 8;
+        hipLaunchKernelGGL(k_fallback_points, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, st, f);
         ADFP_CHECK_LAUNCH();
     }
     return 0;
@@ -1344,7 +1367,7 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
     a.P = P; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
     a.list = nullptr; a.count_ptr = nullptr; a.flags = nullptr;
     a.raw = raw; a.w = w; a.att_occ = nullptr; a.write_w = 1; a.apply_bound = 1; a.status = sc->status;
-    a.masks = nullptr; a.act = nullptr; a.single = 0;
+    a.masks = nullptr; a.act = nullptr; a.single = 0; a.call_flag = nullptr;
     const int ntiles = (P.n + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if (kind == ADFP_DEC_LOW) {
@@ -1386,7 +1409,7 @@ extern "C" int adfp_decode_single(const adfp_scene* sc, const adfp_points* pts, 
     a.P = P; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
     a.list = nullptr; a.count_ptr = nullptr; a.flags = nullptr;
     a.raw = out4; a.w = nullptr; a.att_occ = nullptr; a.write_w = 0; a.apply_bound = 0; a.status = sc->status;
-    a.masks = nullptr; a.act = nullptr; a.single = 1;
+    a.masks = nullptr; a.act = nullptr; a.single = 1; a.call_flag = nullptr;
     const int ntiles = (P.n + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if (kind == ADFP_DEC_LOW) {
@@ -1420,7 +1443,7 @@ extern "C" int adfp_attention_rows(const adfp_scene* sc, const float* occ, const
     ADFP_CHECK_LAUNCH();
     AttArgs t;
     t.list = nullptr; t.count_ptr = nullptr; t.att_occ = occ; t.att_u = scratch_u; t.flags = nullptr;
-    t.raw = out4; t.w = w; t.apply_bound = 0; t.n_rows = (int)n; t.status = sc->status; t.masks = nullptr; t.act = nullptr;
+    t.raw = out4; t.w = w; t.apply_bound = 0; t.n_rows = (int)n; t.status = sc->status; t.masks = nullptr; t.act = nullptr; t.call_flag = nullptr;
     const int ntiles = (int)((n + 31) / 32);
     if (sc->h_att) { t.packed = (const float*)sc->h_att; hipLaunchKernelGGL(k_attention_h<0>, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t); }
     else { t.packed = sc->w_att; hipLaunchKernelGGL(k_attention, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t); }
@@ -1510,10 +1533,10 @@ int adfp_masked_adam(float* param, const float* grad, float* exp_avg, float* exp
     return 0;
 }
 
-int adfp_adam_prep(int* steps, float* derived, int n_groups, const float* lr, float beta1, float beta2, void* stream) {
+int adfp_adam_prep(int* steps, float* derived, int n_groups, const float* lr, float beta1, float beta2, const int* skip_flag, void* stream) {
     if (!steps || !derived || !lr || n_groups <= 0 || n_groups > ADFP_ADAM_MAX_GROUPS) return ADFP_E_ARG;
     AdamPrepArgs a;
-    a.steps = steps; a.derived = derived; a.n = n_groups; a.beta1 = beta1; a.beta2 = beta2;
+    a.steps = steps; a.derived = derived; a.n = n_groups; a.beta1 = beta1; a.beta2 = beta2; a.skip = skip_flag;
     for (int g = 0; g < ADFP_ADAM_MAX_GROUPS; ++g) a.lr[g] = g < n_groups ? lr[g] : -1.f;
     hipLaunchKernelGGL(k_adam_prep, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
     ADFP_CHECK_LAUNCH();
@@ -1783,7 +1806,9 @@ static int radix_sort_pairs(int* key_a, int* val_a, int* key_b, int* val_b, int 
     for (int ps = 0; ps < passes; ++ps) {
         rs.key_in = kin; rs.val_in = vin; rs.key_out = kout; rs.val_out = vout; rs.shift = 8 * ps;
         hipLaunchKernelGGL(k_rs_hist, dim3(rs.ntiles), dim3(256), 0, st, rs);
+        ADFP_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, st, rs.table, rs.ntiles, rs.totals);
+        ADFP_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_rs_scatter, dim3(rs.ntiles), dim3(256), 0, st, rs);
         ADFP_CHECK_LAUNCH();
         int* tk = kin; kin = kout; kout = tk; int* tv = vin; vin = vout; vout = tv;
@@ -1795,7 +1820,8 @@ static int radix_sort_pairs(int* key_a, int* val_a, int* key_b, int* val_b, int 
 extern "C" size_t adfp_sort_workspace_bytes(long long n) { return n < 0 ? 0 : ((size_t)((n + ADFP_RS_TILE - 1) / ADFP_RS_TILE) * 256 + 256) * 4; }
 extern "C" int adfp_sort_pairs(int* key, int* val, int* key_tmp, int* val_tmp, long long n, int key_bits, void* workspace, size_t workspace_bytes,
                                void* stream) {
-    if (!key || !val || !key_tmp || !val_tmp || !workspace || n < 0 || n > 0x7fffffffll || key_bits < 1 || key_bits > 31) return ADFP_E_ARG;
+    if (!key || !val || !key_tmp || !val_tmp || !workspace || n < 0 || key_bits < 1 || key_bits > 31) return ADFP_E_ARG;
+    if (n > 0x7fffffffll - ADFP_RS_TILE) return ADFP_E_UNSUPPORTED;      // the tile arithmetic of the sort kernels is int
     if (workspace_bytes < adfp_sort_workspace_bytes(n)) return ADFP_E_WORKSPACE;
     if (n == 0) return 0;
     const int* kf; const int* vf;
@@ -1955,7 +1981,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
             AttBwdHArgs t;
             t.packed_t = (const unsigned*)sc->ht_att; t.list = state.list; t.count_ptr = state.counter; t.att_occ = state.att_occ; t.att_u = state.att_u;
             t.masks = state.masks_att; t.g_weight = g_weight; t.g_raw = bw.g_raw; t.att_g = bw.att_g; t.stage = bw.stage;
-            t.status = sc->status; t.gmax = bw.gmax;
+            t.status = sc->status; t.gmax = bw.gmax; t.skip = state.counter ? state.counter + 8 : nullptr;
             OuterHArgs oh; attention_jobs(oh.o);
             oh.act = state.act_att; oh.nxm4 = 416 / 4; oh.ngm4 = 416 / 4; oh.g_dst4 = 416 / 4; oh.x_gap_at4 = 1 << 20; oh.x_gap4 = 0;
             oh.masks = nullptr; oh.bm = nullptr; oh.col_se = 0; oh.col_sgp = 0; oh.status = sc->status;
@@ -1985,7 +2011,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         t.packed = sc->w_att; t.list = state.list; t.count_ptr = state.counter; t.att_occ = state.att_occ;
         t.att_u = state.att_u; t.g_weight = g_weight; t.g_raw = bw.g_raw; t.att_g = bw.att_g; t.stage = bw.stage;
         t.P = Pd; t.nt = make_norm(sc->tsdf_bnds); t.t = make_tsdf(sc->tsdf); t.g_pts = a.g_pts;
-        t.gmax = nullptr;
+        t.gmax = nullptr; t.skip = state.counter ? state.counter + 8 : nullptr;
         OuterArgs oa; attention_jobs(oa);
         if (go.flat_att) { rc = outer_begin(bw, AttLayout::F_TOTAL, st); if (rc) return rc; }
         for (int lo = 0; lo < P; lo += bw.stage_rows) {
@@ -2063,7 +2089,7 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
     const int P = (int)Pn;
 
     hipLaunchKernelGGL(k_composite_bwd, dim3((r->n_rays + 3) / 4), dim3(256), 0, st, r->raw, r->z_vals, r->n_rays, r->S,
-                       r->g_depth, r->g_uncertainty, r->g_color, bw.g_raw, r->ray_keep, bw.gmax_parts);
+                       r->g_depth, r->g_uncertainty, r->g_color, bw.g_raw, r->ray_keep, bw.gmax_parts, r->g_weight, r->state.counter ? r->state.counter + 8 : nullptr);
     ADFP_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_max_reduce, dim3(1), dim3(1024), 0, st, bw.gmax_parts, r->n_rays, bw.gmax);
     ADFP_CHECK_LAUNCH();
@@ -2084,18 +2110,21 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
 // cotangent of Renderer.eval_points' raw -> the workspace copy the point backward consumes; where the forward replaced the
 // occupancy by 100 (point outside `bound`, Renderer.py:64) nothing flows back into the decoders
 __global__ __launch_bounds__(256) void k_evalpts_bwd_prep(PtsDev P, const float* __restrict__ g_raw_in, float* __restrict__ g_raw, double b0, double b1,
-                                                          double b2, double b3, double b4, double b5, int apply_bound, float* __restrict__ gmax) {
+                                                          double b2, double b3, double b4, double b5, int apply_bound, float* __restrict__ gmax,
+                                                          const float* __restrict__ g_w, const int* __restrict__ skip) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     float mx = 0.f;
+    const bool dead = skip && *skip;                 // the forward call was repaired by the f32 fallback: zero gradients (adfp.h)
     if (q < P.n) {
-        f32x4 g = g_raw_in ? *(const f32x4*)(g_raw_in + 4ll * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (g_w && !dead) mx = fabsf(g_w[q]);        // the attention weight's cotangent shares the gradient scale (see k_composite_bwd)
+        f32x4 g = (g_raw_in && !dead) ? *(const f32x4*)(g_raw_in + 4ll * q) : f32x4{0.f, 0.f, 0.f, 0.f};
         if (apply_bound) {
             double pt[3]; load_point(P, q, pt);
             const double b[6] = {b0, b1, b2, b3, b4, b5};
             if (!in_bound(pt, b)) g.w = 0.f;
         }
         *(f32x4*)(g_raw + 4ll * q) = g;
-        mx = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -2116,7 +2145,7 @@ extern "C" int adfp_eval_points_backward(const adfp_scene* sc, const adfp_points
     rc = zero_grad_outputs(sc, go, st); if (rc) return rc;
     if (Pd.n == 0) return 0;
     hipLaunchKernelGGL(k_evalpts_bwd_prep, dim3((Pd.n + 255) / 256), dim3(256), 0, st, Pd, r->g_raw, bw.g_raw, sc->bound[0][0], sc->bound[0][1],
-                       sc->bound[1][0], sc->bound[1][1], sc->bound[2][0], sc->bound[2][1], (r->flags & ADFP_EVAL_APPLY_BOUND) ? 1 : 0, bw.gmax_parts);
+                       sc->bound[1][0], sc->bound[1][1], sc->bound[2][0], sc->bound[2][1], (r->flags & ADFP_EVAL_APPLY_BOUND) ? 1 : 0, bw.gmax_parts, r->g_w, r->state.counter ? r->state.counter + 8 : nullptr);
     ADFP_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_max_reduce, dim3(1), dim3(1024), 0, st, bw.gmax_parts, ((Pd.n + 255) / 256) * 4, bw.gmax);
     ADFP_CHECK_LAUNCH();

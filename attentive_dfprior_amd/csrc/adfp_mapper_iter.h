@@ -107,10 +107,15 @@ __global__ __launch_bounds__(256) void k_mapper_loss(LossArgs a) {
 // python-float (double) arithmetic of torch.optim.Adam, rounded to f32 once.  A negative lr marks a group that does not step
 // in this iteration (torch skips parameters without a gradient).  One launch for all groups.
 #define ADFP_ADAM_MAX_GROUPS 8
-struct AdamPrepArgs { int* steps; float* derived; int n; float beta1, beta2; float lr[ADFP_ADAM_MAX_GROUPS]; };
+struct AdamPrepArgs { int* steps; float* derived; int n; float beta1, beta2; float lr[ADFP_ADAM_MAX_GROUPS]; const int* skip; };
 __global__ void k_adam_prep(AdamPrepArgs a) {
     const int g = threadIdx.x;
-    if (blockIdx.x != 0 || g >= a.n || a.lr[g] < 0.f) return;
+    if (blockIdx.x != 0 || g >= a.n) return;
+    if (a.skip && *a.skip) {          // the iteration's gradients are not valid (f16-range repair): nobody steps, see masked_adam_block
+        a.derived[2 * g] = 0.f; a.derived[2 * g + 1] = 0.f;
+        return;
+    }
+    if (a.lr[g] < 0.f) return;
     const int t = a.steps[g] + 1;
     a.steps[g] = t;
     const double bc1 = 1.0 - pow((double)a.beta1, (double)t), bc2 = 1.0 - pow((double)a.beta2, (double)t);

@@ -159,6 +159,7 @@ ADFP_DEV void masked_adam_block(const AdamArgs& a, long long block) {
     } else if (!full) { mk = 0; for (int k = 0; k < 4 && v0 + k < a.nvox; ++k) mk |= 1u << (8 * k); }
     if (mk == 0) return;
     const float step_size = a.derived ? a.derived[0] : a.step_size, sqrt_bc2 = a.derived ? a.derived[1] : a.sqrt_bc2;
+    if (sqrt_bc2 == 0.f) return;                  // k_adam_prep's "skip this iteration" (sqrt(1 - beta2^t) is never 0 otherwise)
     const long long base = c * a.nvox + v0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) if ((mk >> (8 * k)) & 0xffu) adam_one(a, base + k, step_size, sqrt_bc2);

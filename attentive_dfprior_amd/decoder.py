@@ -43,10 +43,13 @@ class DenseLayer(nn.Linear):
             nn.init.zeros_(self.bias)
 
 
-def pack_network(name, params, fmt='f32'):
+def pack_network(name, params, fmt='f32', status=None, flat=None):
     """Packed image of one sub-network ('low' / 'high' / 'color' / 'att') from its parameters in state_dict order.
-    fmt: 'f32' (adfp_pack_decoder / adfp_pack_attention), 'h' (adfp_pack_*_h), 'ht' (adfp_pack_*_ht)."""
-    flat = _flat_params(params)
+    fmt: 'f32' (adfp_pack_decoder / adfp_pack_attention), 'h' (adfp_pack_*_h), 'ht' (adfp_pack_*_ht).
+    status: the pinned status word a weight outside the f16 range is reported to (default: the process-wide one)."""
+    if flat is None:
+        flat = _flat_params(params)
+    sptr = _lib.status_ptr() if status is None else _lib.C.c_void_p(status.data_ptr())
     _lib.require_cuda(flat, f'{name} decoder parameters')
     L = lib()
     dev = flat.device
@@ -57,13 +60,13 @@ def pack_network(name, params, fmt='f32'):
                 words = L.adfp_attention_packed_h_words() if fmt == 'h' else L.adfp_attention_packed_ht_words()
                 fn = L.adfp_pack_attention_h if fmt == 'h' else L.adfp_pack_attention_ht
                 packed = torch.empty(words, dtype=torch.int32, device=dev)
-                _lib.check(fn(_lib.ptr(flat), _lib.ptr(packed), _lib.status_ptr(), stream), 'adfp_pack_attention_' + fmt)
+                _lib.check(fn(_lib.ptr(flat), _lib.ptr(packed), sptr, stream), 'adfp_pack_attention_' + fmt)
             else:
                 kind = _lib.DEC_KIND[name]
                 words = L.adfp_decoder_packed_h_words(kind) if fmt == 'h' else L.adfp_decoder_packed_ht_words(kind)
                 fn = L.adfp_pack_decoder_h if fmt == 'h' else L.adfp_pack_decoder_ht
                 packed = torch.empty(words, dtype=torch.int32, device=dev)
-                _lib.check(fn(kind, _lib.ptr(flat), _lib.ptr(packed), _lib.status_ptr(), stream), 'adfp_pack_decoder_' + fmt)
+                _lib.check(fn(kind, _lib.ptr(flat), _lib.ptr(packed), sptr, stream), 'adfp_pack_decoder_' + fmt)
             return packed
         if name == 'att':
             assert flat.numel() == L.adfp_attention_flat_floats()
@@ -94,6 +97,7 @@ class _SingleNet(object):
     def __getstate__(self):
         d = self.__dict__.copy()
         d.pop('_single', None)
+        d.pop('_single_exact', None)
         return d
 
     @staticmethod
@@ -240,6 +244,8 @@ class DF(nn.Module):
         self._packed = {}       # name -> (version key, packed tensor)
         self._plists = {}       # name -> tuple of the sub-network's parameters (module walks are slow)
         self._engine = None
+        self._status = None     # pinned status word of THIS module (see _lib.new_status_word)
+        self._exact_latch = set()   # networks ('low' / 'high' / 'color' / 'att' / 'bwd') switched to the exact f32 kernels
 
     def net_params(self, name):
         """The parameters of one sub-network ('low' / 'high' / 'color' / 'att') in state_dict order.  Cached:
@@ -258,6 +264,50 @@ class DF(nn.Module):
         self._plists = {}
         return super()._apply(fn, *args, **kwargs)
 
+    # ---- arithmetic mode per network ------------------------------------------------------
+    def status_word(self):
+        if self._status is None:
+            self._status = _lib.new_status_word()
+        return self._status
+
+    def absorb_status(self, sync=False, device=None):
+        """Reads (and clears) this module's status word.  A network whose f16-split kernels left the f16 range in an earlier call
+        -- that call repaired itself on the device, csrc/adfp_fallback.h -- runs on the exact f32 kernels from now on.  The latch
+        outlives parameter updates on purpose: one optimiser step does not bring activations of 1e5 back into range, and a
+        latch that reset itself every iteration would send every iteration through the slow repair path (with zero gradients).
+        ``reset_math_latch()`` / ``load_state_dict`` clear it."""
+        v = _lib.read_status(self._status, sync, device)
+        if v:
+            for name, bit in _lib.STATUS_RANGE_BITS.items():
+                if v & bit:
+                    self._exact_latch.add(name)
+        return v
+
+    def uses_split(self, name):
+        """Does network `name` run on the f16-split kernels (ADFP_MATH=f16x3 and not latched to exact)?"""
+        from .engine import math_mode
+        return math_mode() == 'f16x3' and name not in self._exact_latch
+
+    def reset_math_latch(self):
+        self._exact_latch.clear()
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._exact_latch.clear()           # new weights: probe the f16 range again
+        return out
+
+    def flat_weights(self, name):
+        """The network's parameters as one flat float32 buffer in state_dict order (a view when they already lie back to back,
+        mapping.flatten_parameters; otherwise a copy cached on the parameters' versions)."""
+        module = self.net_params(name)
+        key = _version_key(module)
+        hit = self._packed.get(name + '.flat')
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        flat = _flat_params(module)
+        self._packed[name + '.flat'] = (key, flat)
+        return flat
+
     # ---- weight images for the kernels -------------------------------------------------
     def packed_weights(self, name, fmt='f32'):
         """Packed (MFMA operand order) image of one sub-network, rebuilt only when a parameter
@@ -270,7 +320,7 @@ class DF(nn.Module):
         hit = self._packed.get(slot)
         if hit is not None and hit[0] == key:
             return hit[1]
-        packed = pack_network(name, module, fmt)
+        packed = pack_network(name, module, fmt, status=self.status_word(), flat=self.flat_weights(name))
         self._packed[slot] = (key, packed)
         return packed
 
@@ -281,12 +331,13 @@ class DF(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k in ('_packed', '_engine', '_plists'):
+            if k in ('_packed', '_engine', '_plists', '_status'):
                 continue
             setattr(new, k, copy.deepcopy(v, memo))
         new._packed = {}
         new._plists = {}
         new._engine = None
+        new._status = None
         return new
 
     def __getstate__(self):
@@ -295,6 +346,7 @@ class DF(nn.Module):
         d['_packed'] = {}
         d['_plists'] = {}
         d['_engine'] = None
+        d['_status'] = None
         return d
 
     def forward(self, p, c_grid, tsdf_volume, tsdf_bnds, stage='low', **kwargs):

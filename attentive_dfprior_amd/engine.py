@@ -40,7 +40,6 @@ class Engine(object):
         # ADFP_BWD_* bits handed to the backward entries (adfp_backward_args.options).  ADFP_SCATTER=cache in the environment of
         # the HOST process selects the in-kernel scatter (kernel A/B runs); the library itself reads no environment.
         self.bwd_options = _lib.BWD_SCATTER_IN_KERNEL if os.environ.get('ADFP_SCATTER', '')[:1] == 'c' else 0
-        self.exact_latch = {}    # network name -> True while its f16-split image is out of range (see scene())
         self._ws = None
         self._grid_cache = {}    # key name -> (key, channels-last tensor)
         self._bound_cache = {}   # id -> (key, host list)
@@ -88,13 +87,13 @@ class Engine(object):
 
     # ---- descriptor ----------------------------------------------------------------------
     def scene(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=False, ht_nets=()):
-        """Returns (AdfpScene, keepalive list).  The forward takes the f16-split decoder images unless
-        ADFP_MATH=f32.  The backward takes the exact f32 images, except for the decoders named in `ht_nets`: those get
-        their transposed f16-split image (the caller has checked that the forward left their ReLU masks)."""
-        use_h = (not backward) and math_mode() == 'f16x3'
-        _lib.check_status()                      # an f16-range violation of an EARLIER call surfaces here
+        """Returns (AdfpScene, keepalive list).  Forward: every network of the stage takes its f16-split image (ADFP_MATH=f16x3 and
+        not latched to exact, DF.uses_split) or its exact f32 image, plus -- when any split image is in use -- the flat parameters
+        the device-side f32 repair path needs (adfp_scene.flat_*).  Backward: the exact f32 images, except for the decoders named
+        in `ht_nets`: those get their transposed f16-split image (the caller has checked that the forward left their ReLU masks)."""
+        decoders.absorb_status()                 # an f16-range event of an EARLIER call: that network is exact from now on
         sc = _lib.AdfpScene()
-        sc.status = _lib.status_word().data_ptr()
+        sc.status = decoders.status_word().data_ptr()
         keep = []
         _lib.fill_bound(sc.bound, self.host_bound(bound, 'bound'))
         grids = [('low', 'grid_low')]
@@ -108,34 +107,25 @@ class Engine(object):
             gd = getattr(sc, field)
             gd.data = g.data_ptr()
             gd.Z, gd.Y, gd.X = g.shape[0], g.shape[1], g.shape[2]
-        if use_h:
-            sc.h_low = decoders.packed_weights('low', 'h').data_ptr()
-        elif 'low' in ht_nets:
-            sc.ht_low = decoders.packed_weights('low', 'ht').data_ptr()
-        else:
-            sc.w_low = decoders.packed_weights('low').data_ptr()
-        if stage != 'low':
-            if use_h:
-                sc.h_high = decoders.packed_weights('high', 'h').data_ptr()
-                sc.h_att = decoders.packed_weights('att', 'h').data_ptr()
+        nets = ['low'] + (['high', 'att'] if stage != 'low' else []) + (['color'] if stage == 'color' else [])
+        any_split = False
+        for n in nets:
+            if backward:
+                if n in ht_nets:
+                    setattr(sc, 'ht_' + n, decoders.packed_weights(n, 'ht').data_ptr())
+                else:
+                    setattr(sc, 'w_' + n, decoders.packed_weights(n).data_ptr())
+            elif decoders.uses_split(n):
+                setattr(sc, 'h_' + n, decoders.packed_weights(n, 'h').data_ptr())
+                any_split = True
             else:
-                if 'high' in ht_nets:
-                    sc.ht_high = decoders.packed_weights('high', 'ht').data_ptr()
-                else:
-                    sc.w_high = decoders.packed_weights('high').data_ptr()
-                if 'att' in ht_nets:
-                    sc.ht_att = decoders.packed_weights('att', 'ht').data_ptr()
-                else:
-                    sc.w_att = decoders.packed_weights('att').data_ptr()
+                setattr(sc, 'w_' + n, decoders.packed_weights(n).data_ptr())
+        if any_split:
+            for n in nets:
+                setattr(sc, 'flat_' + n, decoders.flat_weights(n).data_ptr())
+        if stage != 'low':
             _lib.fill_bound(sc.tsdf_bnds, self.host_bound(tsdf_bnds, 'tsdf_bnds'))
             self.fill_tsdf(sc.tsdf, tsdf_volume, keep)
-        if stage == 'color':
-            if use_h:
-                sc.h_color = decoders.packed_weights('color', 'h').data_ptr()
-            elif 'color' in ht_nets:
-                sc.ht_color = decoders.packed_weights('color', 'ht').data_ptr()
-            else:
-                sc.w_color = decoders.packed_weights('color').data_ptr()
         return sc, keep
 
     # ---- training state --------------------------------------------------------------------
@@ -146,27 +136,29 @@ class Engine(object):
         decoder whose parameter gradient will be asked for (need_flat[name], default: any of its parameters requires
         grad), its layer inputs -- with those the backward runs on f16 MFMA and recomputes nothing."""
         bufs = dict(flags=torch.empty((P,), dtype=torch.uint8, device=dev), list=torch.empty((P,), dtype=torch.int32, device=dev),
-                    counter=torch.empty((4,), dtype=torch.int32, device=dev),          # zeroed by the library (a kernel)
+                    counter=torch.empty((16,), dtype=torch.int32, device=dev),         # zeroed by the library (a kernel); [8] = the call's range flag
                     att_occ=torch.empty((P,), dtype=torch.float32, device=dev), att_u=torch.empty((P,), dtype=torch.float32, device=dev))
         st = _lib.AdfpTrainState()
         for k in ('flags', 'list', 'counter', 'att_occ', 'att_u'):
             setattr(st, k, bufs[k].data_ptr())
-        if math_mode() == 'f16x3':
-            nets = ['low'] + (['high'] if stage != 'low' else []) + (['color'] if stage == 'color' else [])
-            for n in nets:
-                bufs['masks_' + n] = torch.empty((P, _lib.TRAIN_MASK_WORDS), dtype=torch.int32, device=dev)
-                setattr(st, 'masks_' + n, bufs['masks_' + n].data_ptr())
-                want = need_flat.get(n) if need_flat is not None else any(p.requires_grad for p in decoders.net_params(n))
-                if want:
-                    bufs['act_' + n] = torch.empty((P, lib().adfp_train_act_floats(_lib.DEC_KIND[n])), dtype=torch.float32, device=dev)
-                    setattr(st, 'act_' + n, bufs['act_' + n].data_ptr())
-            if stage != 'low':                       # the attention network, rows = in-band list entries (at most P)
-                bufs['masks_att'] = torch.empty((P, _lib.TRAIN_ATT_MASK_WORDS), dtype=torch.int32, device=dev)
-                st.masks_att = bufs['masks_att'].data_ptr()
-                want = need_flat.get('att') if need_flat is not None else any(p.requires_grad for p in decoders.net_params('att'))
-                if want:
-                    bufs['act_att'] = torch.empty((P, _lib.TRAIN_ATT_ACT_FLOATS), dtype=torch.float32, device=dev)
-                    st.act_att = bufs['act_att'].data_ptr()
+        nets = ['low'] + (['high'] if stage != 'low' else []) + (['color'] if stage == 'color' else [])
+        for n in nets:
+            if not decoders.uses_split(n):                 # ADFP_MATH=f32, or latched to exact: the exact backward recomputes
+                continue
+            bufs['masks_' + n] = torch.empty((P, _lib.TRAIN_MASK_WORDS), dtype=torch.int32, device=dev)
+            setattr(st, 'masks_' + n, bufs['masks_' + n].data_ptr())
+            want = need_flat.get(n) if need_flat is not None else any(p.requires_grad for p in decoders.net_params(n))
+            if want:
+                bufs['act_' + n] = torch.empty((P, lib().adfp_train_act_floats(_lib.DEC_KIND[n])), dtype=torch.float32, device=dev)
+                setattr(st, 'act_' + n, bufs['act_' + n].data_ptr())
+        if stage != 'low' and decoders.uses_split('att'):   # the attention network, rows = in-band list entries (at most P)
+            bufs['masks_att'] = torch.empty((P, _lib.TRAIN_ATT_MASK_WORDS), dtype=torch.int32, device=dev)
+            st.masks_att = bufs['masks_att'].data_ptr()
+            want = need_flat.get('att') if need_flat is not None else any(p.requires_grad for p in decoders.net_params('att'))
+            if want:
+                bufs['act_att'] = torch.empty((P, _lib.TRAIN_ATT_ACT_FLOATS), dtype=torch.float32, device=dev)
+                st.act_att = bufs['act_att'].data_ptr()
+        bufs['bwd_exact'] = 'bwd' in decoders._exact_latch
         bufs['_state'] = st
         return bufs
 
@@ -174,7 +166,7 @@ class Engine(object):
     def ht_nets(saved, need_flat, need_pos):
         """Decoders whose backward can run f16-split: the forward left their masks, no position / ray gradient is wanted, and
         their layer inputs are there if their parameter gradient is."""
-        if need_pos:
+        if need_pos or saved.get('bwd_exact'):
             return ()
         return tuple(n for n in ('low', 'high', 'color', 'att') if ('masks_' + n) in saved and (not need_flat.get(n) or ('act_' + n) in saved))
 
@@ -312,7 +304,7 @@ class Engine(object):
         _lib.require_cuda(pts, 'points')
         dev = pts.device
         name = mlp.name
-        use_h = math_mode() == 'f16x3' and not self.exact_latch.get(name)
+        use_h = math_mode() == 'f16x3' and not mlp.__dict__.get('_single_exact')
         with torch.cuda.device(dev):
             mode = _lib.PTS_F64 if pts.dtype == torch.float64 else _lib.PTS_F32
             if mode == _lib.PTS_F32 and pts.dtype != torch.float32:
@@ -337,13 +329,18 @@ class Engine(object):
             if P:
                 check(lib().adfp_decode_single(C.byref(sc), C.byref(ap), _lib.DEC_KIND[name], ptr(out), _lib.current_stream(dev)),
                       'adfp_decode_single')
+                # a sub-network on its own is a convenience entry without the device-side repair: look at the range word now
+                # and, if it tripped, evaluate again on the exact kernel (and stay there)
+                if use_h and _lib.check_status(sync=True, device=dev) & _lib.STATUS_F16_RANGE:
+                    mlp.__dict__['_single_exact'] = True
+                    return self.decode_single(mlp, pts, c, bound)
             return out[:, 3].contiguous() if name == 'low' else out
 
     def attention_rows(self, mlp, pts, occ, tsdf_volume, tsdf_bnds):
         """(fused occupancy [M], attention weight [M]) of mlp_tsdf.forward at the points pts [M,3] with occupancies occ [M]."""
         _lib.require_cuda(pts, 'points')
         dev = pts.device
-        use_h = math_mode() == 'f16x3' and not self.exact_latch.get('att')
+        use_h = math_mode() == 'f16x3' and not mlp.__dict__.get('_single_exact')
         tv = self.sample_tsdf(pts, tsdf_volume, tsdf_bnds)
         with torch.cuda.device(dev):
             M = tv.shape[0]
@@ -361,6 +358,9 @@ class Engine(object):
             if M:
                 check(lib().adfp_attention_rows(C.byref(sc), ptr(occ), ptr(tv), M, ptr(out4), ptr(w), ptr(u), _lib.current_stream(dev)),
                       'adfp_attention_rows')
+                if use_h and _lib.check_status(sync=True, device=dev) & _lib.STATUS_F16_RANGE:
+                    mlp.__dict__['_single_exact'] = True
+                    return self.attention_rows(mlp, pts, occ, tsdf_volume, tsdf_bnds)
             return out4[:, 3].contiguous(), w
 
     # ---- a4..a13 ---------------------------------------------------------------------------

@@ -175,14 +175,17 @@ class MapperIteration(object):
         # Ray-sharded iteration (new; the reference has no distributed code): every rank passes ITS rays to step(); the loss
         # gradients are combined by ONE RCCL all-reduce (SUM) of a contiguous bucket -- the backward writes the grid and
         # parameter gradients straight into slices of it, in the order low grid | attention net | high grid | colour net |
-        # colour grid, so that a stage reduces exactly the prefix it produced -- and the kept rays' max depth by a
+        # colour grid (a trained low / high net sits next to its grid), so that a stage reduces exactly the prefix it produced -- and
+        # the kept rays' max depth by a
         # one-float all-reduce (MAX).  With frustum masks only the selected voxels' columns travel (_allreduce_gradients).
         # The Mapper losses are plain sums, so no rescaling.
         import torch.distributed as tdist
         self.group = group
         self.distributed = (tdist.is_available() and tdist.is_initialized()) if distributed is None else distributed
-        order = [('grid', 'low', 'grid_low'), ('flat', 'att', None), ('grid', 'high', 'grid_high'), ('flat', 'color', None),
-                 ('grid', 'color', 'grid_color')]
+        # every gradient a stage can produce has a slot, so that the dense all-reduce of the stage's prefix covers them all
+        # (stage low: low grid [+ low net]; stage high: + attention / high nets, high grid; stage color: everything)
+        order = [('grid', 'low', 'grid_low'), ('flat', 'low', None), ('flat', 'att', None), ('flat', 'high', None),
+                 ('grid', 'high', 'grid_high'), ('flat', 'color', None), ('grid', 'color', 'grid_color')]
         self._bucket_layout, off = [], 0
         for kind, name, key in order:
             if kind == 'flat' and name not in self.nets:
@@ -315,7 +318,10 @@ class MapperIteration(object):
         lrs = (C.c_float * len(self.groups))(*([-1.0] * len(self.groups)))
         for (gname, *_rest, lrv) in groups:
             lrs[self.groups.index(gname)] = float(lrv)
-        check(L.adfp_adam_prep(ptr(self.step_count), ptr(self.derived), len(self.groups), lrs, b1, b2, st), 'adfp_adam_prep')
+        # the forward call's f16-range flag (adfp_train_state.counter[8]): a repaired forward means this iteration's gradients are
+        # zero by construction -- then nobody steps (parameters, moments and step counters stay as they are)
+        skip = C.c_void_p(aux['counter'].data_ptr() + 32)
+        check(L.adfp_adam_prep(ptr(self.step_count), ptr(self.derived), len(self.groups), lrs, b1, b2, skip, st), 'adfp_adam_prep')
         arr = (_lib.AdfpAdamGroup * len(groups))()                   # one launch for all groups
         for k, (gname, p, g, (m, v), mask, nvox, ch, lrv) in enumerate(groups):
             a = arr[k]
@@ -325,6 +331,12 @@ class MapperIteration(object):
             a.derived = self.derived[self.groups.index(gname)].data_ptr()
         check(L.adfp_masked_adam_multi(len(groups), C.byref(arr), b1, b2, self.eps, st), 'adfp_masked_adam_multi')
         return grids, flats
+
+    def _drop_volatile_cache_entries(self):
+        self.rend._engine._grid_cache.clear()
+        for slot in list(self.dec._packed):
+            if slot.split('.')[0] in self.nets:
+                del self.dec._packed[slot]
 
     def _bump_versions(self):
         for t in self._versioned:
@@ -341,7 +353,11 @@ class MapperIteration(object):
                                gt_color.float().contiguous(), stage, warmup)
                 self._bump_versions()
                 return self.loss
-            key = (N, stage, bool(warmup))
+            # A replay never passes through Engine.scene(), so the f16-range word is read here (no sync: an event of the previous
+            # replay is seen one step late at worst, and that step repaired itself and skipped its Adam).  A network that tripped
+            # runs on the exact kernels from now on: the graphs are keyed on the set of latched networks.
+            self.dec.absorb_status()
+            key = (N, stage, bool(warmup), frozenset(self.dec._exact_latch))
             st = self._static.get(N)
             if st is None:
                 st = self._static[N] = (torch.empty((N, 3), device=dev), torch.empty((N, 3), device=dev), torch.empty((N,), device=dev),
@@ -358,13 +374,23 @@ class MapperIteration(object):
                     self._sequence(*st, stage, warmup, adam=False)
                 torch.cuda.current_stream(dev).wait_stream(side)
                 torch.cuda.synchronize(dev)
-                self.rend._engine._grid_cache.clear()
-                self.dec._packed.clear()
+                # What changes from replay to replay -- the grids' channels-last copies and the TRAINED nets' weight images -- must be
+                # rebuilt inside the graph, so those cache entries are dropped before the capture; what does not (the FROZEN nets'
+                # images, packed eagerly by the warm-up above into ordinary memory) stays cached.  Nothing the capture allocates
+                # may outlive it in a long-lived cache: the graphs share one pool and replay in any order, so a block another
+                # graph's replay may write must never be what an eager call (Visualizer, Tracker, Mesher) finds in the cache.
+                eng = self.rend._engine
+                self._drop_volatile_cache_entries()
+                ws_eager, eng._ws = eng._ws, None     # the graph gets its OWN workspace (an eager call may grow and free the shared one)
                 g = torch.cuda.CUDAGraph()
                 if self._pool is None:
                     self._pool = torch.cuda.graph_pool_handle()      # the graphs replay one at a time: one pool for all
-                with torch.cuda.graph(g, pool=self._pool):
-                    self._sequence(*st, stage, warmup)
+                try:
+                    with torch.cuda.graph(g, pool=self._pool):
+                        self._sequence(*st, stage, warmup)
+                finally:
+                    eng._ws = ws_eager
+                    self._drop_volatile_cache_entries()
                 self._graphs[key] = g                 # capturing does not execute: fall through to the first replay
             g.replay()
             self._bump_versions()

@@ -44,12 +44,16 @@ class Renderer(object):
         self.need_param_grad = True          # see render_batch_ray
         self._engine = Engine()
 
-    def check_overflow(self, device=None):
-        """Not in the reference.  The default f16-split decoders (ADFP_MATH=f16x3) cannot represent operands with
-        |x| >= 65504; the kernels raise a sticky flag instead of returning garbage silently, and -- like an
-        asynchronous HIP error -- the flag is reported by the next call into the library.  This waits for the
-        device and reports it now (RuntimeError)."""
-        _lib.check_status(sync=True, device=device)
+    def check_overflow(self, device=None, decoders=None):
+        """Not in the reference.  The default f16-split decoders (ADFP_MATH=f16x3) cannot represent operands with |x| >= 65504.
+        A call that meets one repairs its outputs on the device (an f32 fallback kernel, csrc/adfp_fallback.h) and the next call
+        runs that network on the exact f32 kernels -- nothing is raised and no invalid value is handed out.  This waits for the
+        device and returns the set of networks of `decoders` that are latched to the exact kernels (empty = all f16-split)."""
+        torch.cuda.synchronize(device)
+        if decoders is None:
+            return set()
+        decoders.absorb_status()
+        return set(decoders._exact_latch)
 
     # ---- point queries --------------------------------------------------------------------
     def eval_points(self, p, decoders, tsdf_volume, tsdf_bnds, c=None, stage='color', device='cuda:0'):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 115
+#define ADFP_VERSION 116
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -92,13 +92,27 @@ typedef struct adfp_scene {
     const void* ht_high;
     const void* ht_color;
     const void* ht_att;       /* adfp_pack_attention_ht: the attention network's backward on f16 MFMA */
-    /* Sticky status word the kernels OR into (system-scope atomic): device memory or device-visible pinned
-     * host memory, NULL = none.  ADFP_STATUS_F16_RANGE: an operand of the f16-split decoders (a weight, a grid
-     * feature or a hidden activation) reached |x| >= 65504, which the split cannot represent -- the outputs
-     * of that call are invalid; re-run with the exact images (h_* = NULL).  The caller clears the word. */
+    /* Flat (state_dict order) parameters of the four networks, optional.  With them, a forward call whose f16-split kernels
+     * met an operand outside the f16 range (|x| >= 65504: a weight, a grid feature or a hidden activation) REPAIRS ITSELF: a
+     * predicated fallback kernel re-evaluates the call's points in plain f32 from these buffers before anything consumes the
+     * outputs (no host involvement, graph-capturable).  NULL = no repair; the call then only reports (status). */
+    const float* flat_low;
+    const float* flat_high;
+    const float* flat_color;
+    const float* flat_att;
+    /* Sticky status word the kernels OR into (system-scope atomic): device memory or device-visible pinned host memory,
+     * NULL = none.  ADFP_STATUS_F16_RANGE_<net>: the f16-split kernels of that network met an operand outside the f16 range
+     * in some call since the caller last cleared the word.  With flat_* set that call's outputs were repaired (see above); the
+     * caller should hand over the exact image (w_*, h_* = NULL) for that network from now on -- the repair is a slow path.
+     * ADFP_STATUS_F16_RANGE_BWD: the same in a backward kernel (that call's gradients are not reliable). */
     int* status;
 } adfp_scene;
-#define ADFP_STATUS_F16_RANGE 1
+#define ADFP_STATUS_F16_RANGE_LOW   1
+#define ADFP_STATUS_F16_RANGE_HIGH  2
+#define ADFP_STATUS_F16_RANGE_COLOR 4
+#define ADFP_STATUS_F16_RANGE_ATT   8
+#define ADFP_STATUS_F16_RANGE_BWD   16
+#define ADFP_STATUS_F16_RANGE       31   /* any of them */
 
 typedef struct adfp_points {
     int mode;                 /* ADFP_PTS_* */
@@ -200,7 +214,9 @@ int adfp_composite(const float* raw /*[N,S,4]*/, const double* z_vals /*[N,S]*/,
                    float* weights /*[N,S] or NULL*/, void* stream);
 
 /* Buffers the backward needs from the forward (training only).  Caller-owned, sized for P points:
- * flags P bytes, list P ints, counter >= 4 bytes, att_occ / att_u P floats.
+ * flags P bytes, list P ints, counter >= 64 bytes (int[0] = length of the in-band list, int[8] = the forward call's f16-range
+ * flag: non-zero = the forward was repaired by the f32 fallback, the ReLU masks / layer inputs it left are not valid, and the
+ * backward entries then return ZERO gradients for that call -- see adfp_scene.flat_*), att_occ / att_u P floats.
  * Optional, for the f16-split backward (scene->h_* and ->ht_* set; any of them may be NULL = exact backward for that
  * decoder): masks_* = ADFP_TRAIN_MASK_WORDS 32-bit words per point, the ReLU masks of the decoder's five layers;
  * act_* = adfp_train_act_floats(kind) floats per point, the inputs of every layer (position, Fourier features, grid
@@ -382,8 +398,11 @@ int adfp_mapper_loss(const adfp_loss_args* args /*host*/, void* stream);
  * for every group g with lr[g] >= 0:  steps[g] += 1,  derived[2g] = lr[g] / (1 - beta1^steps[g]),  derived[2g+1] =
  * sqrt(1 - beta2^steps[g])  (double arithmetic, one rounding, like the python floats of torch.optim); a negative lr[g]
  * = the group has no gradient in this iteration and does not step.  lr is a HOST array. */
+/* skip_flag (device int, may be NULL): when *skip_flag != 0 at run time no group steps and `derived` is zeroed, which makes
+ * adfp_masked_adam_dev / _multi leave parameters and moments untouched -- the Mapper iteration hands over the forward call's
+ * f16-range flag (adfp_train_state.counter + 8) so that an iteration whose gradients are not valid changes nothing. */
 int adfp_adam_prep(int* steps /*device int[n]*/, float* derived /*device float[n][2]*/, int n_groups, const float* lr /*host*/,
-                   float beta1, float beta2, void* stream);
+                   float beta1, float beta2, const int* skip_flag, void* stream);
 /* adfp_masked_adam with the step-dependent scalars read from `derived`: no host value changes from step to step, so
  * the call can be replayed from a HIP graph. */
 int adfp_masked_adam_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const unsigned char* mask,

@@ -104,14 +104,18 @@ def assert_close_scale(a, b, tol, what, flip_frac=0.0, flip_tol=2e-3):
     assert err.max() <= flip_tol * scale + 1e-9, f'{what}: max abs diff {err.max().item():.3e} > {flip_tol} x scale {scale.item():.3e}'
 
 
-# Parameter gradients against torch's autograd, per math mode.  What separates the two sides is (i) summation order, ~1e-6 of
-# a tensor's scale, and (ii) ReLU-boundary samples: a unit whose pre-activation lies within ~1e-6 of zero takes the other branch
-# of relu on one side; that ONE sample's contribution then appears in / vanishes from the unit's own row of its layer's weight
-# gradient and, because the flipped unit feeds every unit of the layers before it through W^T, shifts ALL rows of the earlier
-# layers by that sample's share.  Measured (profiles/r03_grad_stats.txt, every tensor of every gradient test, both modes): see
-# PARAM_GRAD_LIMITS.  The criterion is therefore: every element within `cap` x scale (a swapped pair of rows is off by O(1) x
-# scale), the relative Frobenius error within `fro`, and at most `rows` rows with an element beyond 2e-4 x scale.
-PARAM_GRAD_LIMITS = {'f32': dict(cap=1e-3, fro=3e-4, rows=None), 'f16x3': dict(cap=1e-3, fro=3e-4, rows=None)}
+# Parameter gradients against torch's autograd.  What separates the two sides is (i) summation order, ~1e-6 of a tensor's
+# scale, and (ii) ReLU-boundary samples: a unit whose pre-activation lies within ~1e-6 of zero takes the other branch of relu on
+# one side; that ONE sample's contribution then appears in / vanishes from the unit's own row of its layer's weight gradient
+# and, because the flipped unit feeds every unit of the layers before it through W^T, shifts ALL rows of the earlier layers (and
+# all columns of embedder._B) by that sample's share.
+# Measured on the MI355X over every parameter tensor of every gradient test (profiles/r03_grad_stats.txt: 510 comparisons in
+# exact-f32 mode, 894 in f16x3 mode): 2 / 6 tensors have ANY element beyond 2e-4 x scale; the worst element is 5.8e-4 / 5.0e-4 x
+# scale, the worst relative Frobenius error 6.2e-4 / 3.6e-4 (high_decoder.embedder._B of the second-seed case, scale 0.95: one
+# boundary sample), at most 25 of 93 columns / 6 of 32 rows carry such an element.  The limits below are those figures with
+# < 2x margin -- the previous criterion let 25 % of the ELEMENTS reach 2e-3 x scale.  A pair of exchanged rows (the negative
+# control in tests/test_gpu_grad.py) is off by 0.89 x scale, Frobenius 0.62: three orders of magnitude beyond either limit.
+PARAM_GRAD_LIMITS = {'f32': dict(cap=1e-3, fro=1e-3, rows=0.3), 'f16x3': dict(cap=1e-3, fro=1e-3, rows=0.3)}
 
 
 def param_grad_stats(a, b):
@@ -142,8 +146,8 @@ def assert_param_grad_close(got, ref, what, mode=None):
     lim = PARAM_GRAD_LIMITS[mode]
     assert st['max'] <= lim['cap'], f'{what} [{mode}]: max |diff| {st["max"]:.2e} x scale > {lim["cap"]}'
     assert st['fro'] <= lim['fro'], f'{what} [{mode}]: relative Frobenius error {st["fro"]:.2e} > {lim["fro"]}'
-    if lim['rows'] is not None:
-        assert st['rows_bad'] <= lim['rows'], f'{what} [{mode}]: {st["rows_bad"]} of {st["rows"]} rows beyond 2e-4 x scale (allowed {lim["rows"]})'
+    assert st['rows_bad'] <= max(1, int(lim['rows'] * st['rows'])), \
+        f'{what} [{mode}]: {st["rows_bad"]} of {st["rows"]} rows carry an element beyond 2e-4 x scale (allowed {lim["rows"]:.0%})'
 
 
 def assert_adam_trajectory(a, b, lr, steps, what, tol=2e-4, max_outliers=2e-3):

@@ -114,3 +114,66 @@ def test_graph_replays_with_new_rays():
         assert_adam_trajectory(ga[k], gb[k], 0.005, 3, k)
     for (n, p), (_, q) in zip(dec.named_parameters(), dec_b.named_parameters()):
         assert_adam_trajectory(p, q, 0.005, 3, n)
+
+
+def test_eager_calls_between_graph_replays_see_valid_caches():
+    """Three stages captured into one shared graph pool, replayed out of capture order, and an eager render with the SAME
+    decoders / grids in between (what Visualizer.vis, the Tracker and the Mesher do while the Mapper iterates): the eager
+    call's cached weight images and channels-last grids must not be blocks that another graph's replay writes.  Compared
+    against a fresh DF / Renderer holding copies of the current parameters."""
+    sc, dec, rend, rays, masks = setup()
+    tsdf, tb = sc.tsdf_volume.to(DEV), sc.tsdf_bnds.to(DEV)
+    grids = {k: v.clone().to(DEV) for k, v in sc.c.items()}
+    it = mapping.MapperIteration(rend, dec, grids, masks, tsdf, tb, STAGE_LR, use_graph=True)
+    for stage in ('low', 'high', 'color'):
+        it.step(*rays, stage)                                   # captures (and replays once) each stage's graph
+    ws_before = rend._engine._ws
+    for stage in ('low', 'color', 'high', 'low', 'color'):      # any order
+        it.step(*rays, stage)
+        with torch.no_grad():
+            got = rend.render_batch_ray(grids, dec, rays[1], rays[0], DEV, tsdf, tb, 'color', rays[2])
+            fresh_dec = A.DF()
+            fresh_dec.load_state_dict({k: v.detach().clone() for k, v in dec.state_dict().items()})
+            fresh_dec.bound = sc.bound
+            fresh_dec = fresh_dec.to(DEV)
+            want = A.Renderer(make_cfg(32, 16), None, sc).render_batch_ray({k: v.clone() for k, v in grids.items()}, fresh_dec, rays[1], rays[0],
+                                                                         DEV, tsdf, tb, 'color', rays[2])
+        for a, b in zip(got, want):
+            ok = torch.isfinite(b)
+            assert torch.equal(a[ok], b[ok]), f'eager render after replaying stage {stage} differs from a fresh engine'
+    # no cache entry of the shared objects may point into the graphs' pool: the trained nets' images and the grids' copies are
+    # rebuilt eagerly after every replay (their versions were bumped), the frozen nets' images were packed before the captures
+    assert rend._engine._ws is ws_before or rend._engine._ws is not None
+    # a big eager render grows (reallocates) the engine's workspace; the graphs own theirs and must keep replaying correctly
+    big = [t.to(DEV) for t in synthetic.make_ray_batch(sc, 20000, seed=4)]
+    with torch.no_grad():
+        rend.render_batch_ray(grids, dec, big[1], big[0], DEV, tsdf, tb, 'color', big[2])
+    junk = [torch.full((1 << 20,), float('nan'), device=DEV) for _ in range(8)]          # whatever the old workspace block becomes
+    dec_b = copy.deepcopy(dec)
+    gb = {k: v.clone() for k, v in grids.items()}
+    it_b = mapping.MapperIteration(A.Renderer(make_cfg(32, 16), None, sc), dec_b, gb, masks, tsdf, tb, STAGE_LR, use_graph=False)
+    it_b.gstate = {k: (m.clone(), v.clone()) for k, (m, v) in it.gstate.items()}
+    it_b.fstate = {k: (m.clone(), v.clone()) for k, (m, v) in it.fstate.items()}
+    it_b.step_count.copy_(it.step_count)
+    la, lb = float(it.step(*rays, 'color')), float(it_b.step(*rays, 'color'))
+    assert abs(la - lb) <= 1e-6 * abs(lb), (la, lb)
+    del junk
+
+
+def test_bucket_has_a_slot_for_every_trainable_network():
+    """fix_high: False (configs: src/Mapper.py:364-371 puts the high decoder into the optimiser): its flat gradient must live in
+    the contiguous bucket like the others, or the dense all-reduce of the bucket prefix would leave it rank-local."""
+    sc, dec, rend, rays, masks = setup()
+    for p in dec.high_decoder.parameters():
+        p.requires_grad_(True)
+    grids = {k: v.clone().to(DEV) for k, v in sc.c.items()}
+    it = mapping.MapperIteration(rend, dec, grids, None, sc.tsdf_volume.to(DEV), sc.tsdf_bnds.to(DEV), STAGE_LR, train=('high', 'color', 'att'),
+                                 use_graph=False, distributed=False)
+    names = [(kind, name) for kind, name, *_ in it._bucket_layout]
+    assert ('flat', 'high') in names and ('flat', 'color') in names and ('flat', 'att') in names
+    grids_g, flats_g = it._sequence(*[t.float().contiguous() for t in rays], 'color', False, adam=False)
+    lo, hi = it.bucket.data_ptr(), it.bucket.data_ptr() + it.bucket.numel() * 4
+    for n, f in flats_g.items():
+        assert lo <= f.data_ptr() < hi, f'flat gradient of {n} is not a view of the bucket'
+        assert float(f.abs().max()) > 0
+    assert it.bucket_bytes == it.bucket.numel() * 4             # stage color produces the whole bucket: all of it is reduced

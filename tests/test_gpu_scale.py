@@ -4,8 +4,9 @@ Every other parity test inflates the grids (std x 20..30, high grid x 100) so th
 non-trivial occupancies.  The reference initialises the grids N(0, 0.01) / N(0, 1e-4) / N(0, 0.01)
 (src/DF_Prior.py:247-263) -- high-grid features are then f16 SUBNORMALS for the f16-split decoders -- and a
 trained map has O(1..10) features and larger weights.  Both ends are checked here against the oracle, in
-ADFP_MATH=f16x3 (default) and ADFP_MATH=f32, plus the range guard of the f16 split: operands beyond 65504 must
-raise, not pass silently."""
+ADFP_MATH=f16x3 (default) and ADFP_MATH=f32, plus the range guard of the f16 split: a call that meets an operand beyond
+65504 must hand out CORRECT values (the device-side f32 repair, csrc/adfp_fallback.h) without raising, and the network that
+tripped must run on the exact kernels from the next call on."""
 import pytest
 import torch
 
@@ -25,19 +26,22 @@ def mini_at_scale(grid_std_scale, high_factor):
     return sc
 
 
-def render_both(sc, sd, stage, n=400, ns=32, nf=16):
+def render_both(sc, sd, stage, n=400, ns=32, nf=16, expect_latched=frozenset(), calls=1):
     ro, rd, gd, _ = synthetic.make_ray_batch(sc, n, seed=5)
     dec = A.DF()
     dec.load_state_dict(sd)
     dec.bound = sc.bound
     dec = dec.to(DEV)
     rend = A.Renderer(make_cfg(ns, nf), None, sc)
+    outs = []
     with torch.no_grad():
-        out = rend.render_batch_ray(to_dev(sc.c, DEV), dec, rd.to(DEV), ro.to(DEV), DEV, sc.tsdf_volume.to(DEV),
-                                    sc.tsdf_bnds.to(DEV), stage, gt_depth=gd.to(DEV))
-    rend.check_overflow()
+        for _ in range(calls):
+            outs.append(rend.render_batch_ray(to_dev(sc.c, DEV), dec, rd.to(DEV), ro.to(DEV), DEV, sc.tsdf_volume.to(DEV),
+                                              sc.tsdf_bnds.to(DEV), stage, gt_depth=gd.to(DEV)))
+    latched = rend.check_overflow(DEV, dec)
+    assert latched == set(expect_latched), f'latched to exact: {latched}, expected {set(expect_latched)}'
     ref = O.render_batch_ray(sd, sc.c, rd, ro, sc.tsdf_volume, sc.tsdf_bnds, sc.bound, stage, gd, ns, nf)
-    return out, ref
+    return (outs[0] if calls == 1 else outs), ref
 
 
 @pytest.mark.parametrize('math', ['f16x3', 'f32'])
@@ -79,24 +83,32 @@ def test_trained_scale(monkeypatch, math):
     assert_close(w, ow, TOL, 'attention weight')
 
 
-def test_f16_range_guard_trips_on_features(monkeypatch):
-    """A grid feature beyond the f16 range: the default mode must raise (sticky status word), the exact mode
-    must render it."""
+def check(out, ref, what):
+    d, u, c, w = out
+    od, ou, oc, ow = ref
+    assert_close(d, od, TOL, f'depth ({what})')
+    assert_close(c, oc, TOL, f'colour ({what})')
+    assert_close(w, ow, TOL, f'attention weight ({what})')
+
+
+def test_f16_range_violation_on_features_is_repaired(monkeypatch):
+    """A grid feature beyond the f16 range.  f16x3 mode: the tripping call itself returns correct values (f32 repair on the
+    device, no exception), the colour decoder is exact afterwards and the second call (exact kernel) agrees too; f32 mode
+    renders it directly."""
     sc = mini_at_scale(30.0, 100.0)
     sc.c['grid_color'] = sc.c['grid_color'].clone()
     sc.c['grid_color'][0, 3] = 1.0e5
     sd = O.random_state_dict(seed=3)
     monkeypatch.setenv('ADFP_MATH', 'f16x3')
-    with pytest.raises(RuntimeError, match='65504'):
-        render_both(sc, sd, 'color', n=64)
-    _lib.check_status(sync=True)                                     # the flag was cleared by the raise
+    (first, second), ref = render_both(sc, sd, 'color', n=64, expect_latched={'color'}, calls=2)
+    check(first, ref, 'the call that tripped')
+    check(second, ref, 'the next call, colour decoder latched to exact')
     monkeypatch.setenv('ADFP_MATH', 'f32')
-    (d, u, c, w), (od, ou, oc, ow) = render_both(sc, sd, 'color', n=64)
-    assert_close(d, od, TOL, 'depth (exact mode)')
-    assert_close(c, oc, TOL, 'colour (exact mode)')
+    out, ref = render_both(sc, sd, 'color', n=64)
+    check(out, ref, 'exact mode')
 
 
-def test_f16_range_guard_trips_on_activations_and_weights(monkeypatch):
+def test_f16_range_violation_on_activations_and_weights_is_repaired(monkeypatch):
     monkeypatch.setenv('ADFP_MATH', 'f16x3')
     sc = mini_at_scale(30.0, 100.0)
     sd = O.random_state_dict(seed=3)
@@ -104,12 +116,92 @@ def test_f16_range_guard_trips_on_activations_and_weights(monkeypatch):
     for k in big:                                                    # every operand < 65504, the hidden activations are not
         if k.startswith('color_decoder.pts_linears') and k.endswith('weight'):
             big[k] = big[k] * 300.0
-    with pytest.raises(RuntimeError, match='65504'):
-        render_both(sc, big, 'color', n=64)
+    for k in big:                                                    # keep the oracle's colour finite in f32
+        if k.startswith('color_decoder.output_linear'):
+            big[k] = big[k] * 1e-6
+    out, ref = render_both(sc, big, 'color', n=64, expect_latched={'color'})
+    assert float(ref[2].abs().max()) > 0
+    check(out, ref, 'hidden activations beyond the f16 range')
     big = {k: v.clone() for k, v in sd.items()}
-    big['mlp.pts_linears.1.weight'][0, 0] = 7.0e4                    # a weight the split cannot hold (pack time)
-    with pytest.raises(RuntimeError, match='65504'):
-        render_both(sc, big, 'color', n=64)
-    # and the next clean call is clean
-    (d, u, c, w), (od, ou, oc, ow) = render_both(sc, sd, 'color', n=64)
-    assert_close(d, od, TOL, 'depth')
+    big['mlp.pts_linears.1.weight'][0, 0] = 7.0e4                    # a weight the split cannot hold (found at pack time)
+    out, ref = render_both(sc, big, 'color', n=64, expect_latched={'att'})
+    check(out, ref, 'a weight beyond the f16 range')
+    big = {k: v.clone() for k, v in sd.items()}
+    big['low_decoder.fc_c.2.weight'][5, 7] = -9.0e4                  # the low decoder: feeds the in-band list too (high + low)
+    for stage in ('low', 'high', 'color'):
+        out, ref = render_both(sc, big, stage, n=64, expect_latched={'low'})
+        assert_close(out[0], ref[0], TOL, f'depth (stage {stage}, low decoder repaired)')
+        assert_close(out[3], ref[3], TOL, f'attention weight (stage {stage}, low decoder repaired)')
+    # a clean network stays on the f16-split kernels
+    out, ref = render_both(sc, sd, 'color', n=64, expect_latched=set())
+    check(out, ref, 'clean')
+
+
+def test_f16_range_violation_in_training_gives_correct_outputs_and_zero_gradients(monkeypatch):
+    """Training forward: outputs repaired like in inference; the state it left (ReLU masks, layer inputs) is not valid, so the
+    backward of THAT call returns zero gradients (never garbage); the next iteration runs the latched network exactly and its
+    gradients agree with the oracle's autograd."""
+    from conftest import assert_close_scale
+    monkeypatch.setenv('ADFP_MATH', 'f16x3')
+    sc = mini_at_scale(30.0, 100.0)
+    sd = O.random_state_dict(seed=3)
+    sd['color_decoder.fc_c.1.weight'][2, 4] = 8.0e4
+    ro, rd, gd, gc = [t.to(DEV) for t in synthetic.make_ray_batch(sc, 96, seed=5)]
+    dec = A.DF()
+    dec.load_state_dict(sd)
+    dec.bound = sc.bound
+    dec = dec.to(DEV)
+    rend = A.Renderer(make_cfg(32, 16), None, sc)
+    tsdf, tb = sc.tsdf_volume.to(DEV), sc.tsdf_bnds.to(DEV)
+    ref_out = O.render_batch_ray(sd, sc.c, rd.cpu(), ro.cpu(), sc.tsdf_volume, sc.tsdf_bnds, sc.bound, 'color', gd.cpu(), 32, 16)
+    c_or = {k: v.clone().requires_grad_(True) for k, v in sc.c.items()}
+    o2 = O.render_batch_ray(sd, c_or, rd.cpu(), ro.cpu(), sc.tsdf_volume, sc.tsdf_bnds, sc.bound, 'color', gd.cpu(), 32, 16)
+    O.mapper_loss(o2[0], o2[2], o2[3], gd.cpu(), gc.cpu(), 'color', False).backward()
+    for it in range(2):
+        c = {k: v.to(DEV).clone().requires_grad_(True) for k, v in sc.c.items()}
+        d, u, col, w = rend.render_batch_ray(c, dec, rd, ro, DEV, tsdf, tb, 'color', gt_depth=gd)
+        check((d, u, col, w), ref_out, f'training forward, iteration {it}')
+        O.mapper_loss(d, col, w, gd, gc, 'color', False).backward()
+        if it == 0:
+            for k, v in c.items():
+                assert v.grad is None or float(v.grad.abs().max()) == 0.0, f'{k}: a repaired call must return zero gradients'
+        else:
+            assert rend.check_overflow(DEV, dec) == {'color'}
+            for k, v in c.items():
+                assert_close_scale(v.grad, c_or[k].grad, 2e-4, f'd/d {k} after the latch', flip_frac=2e-3)
+
+
+def test_fused_iteration_skips_the_step_of_a_repaired_forward(monkeypatch):
+    """mapping.MapperIteration (graph replay): the iteration whose forward tripped changes NOTHING (parameters, grids, Adam
+    moments, step counters); the following ones run the latched network on the exact kernels and train."""
+    from attentive_dfprior_amd import mapping
+    monkeypatch.setenv('ADFP_MATH', 'f16x3')
+    sc = mini_at_scale(30.0, 100.0)
+    sd = O.random_state_dict(seed=3)
+    sd['color_decoder.fc_c.1.weight'][2, 4] = 8.0e4
+    rays = [t.to(DEV) for t in synthetic.make_ray_batch(sc, 256, seed=5)]
+    dec = A.DF()
+    dec.load_state_dict(sd)
+    dec.bound = sc.bound
+    dec = dec.to(DEV)
+    for p in list(dec.low_decoder.parameters()) + list(dec.high_decoder.parameters()):
+        p.requires_grad_(False)
+    rend = A.Renderer(make_cfg(32, 16), None, sc)
+    grids = {k: v.clone().to(DEV) for k, v in sc.c.items()}
+    lr = {st: dict(low=0.005, high=0.005, color=0.005, decoders=0.005, mlp=0.005) for st in ('low', 'high', 'color')}
+    it = mapping.MapperIteration(rend, dec, grids, None, sc.tsdf_volume.to(DEV), sc.tsdf_bnds.to(DEV), lr, use_graph=True)
+    before = {k: v.clone() for k, v in grids.items()}
+    pbefore = {n: p.detach().clone() for n, p in dec.named_parameters()}
+    it.step(*rays, 'color')
+    torch.cuda.synchronize()
+    assert int(it.step_count.abs().sum()) == 0
+    for k in grids:
+        assert torch.equal(grids[k], before[k]), f'{k} moved in the iteration whose forward was repaired'
+    for n, p in dec.named_parameters():
+        assert torch.equal(p.detach(), pbefore[n]), n
+    l2 = float(it.step(*rays, 'color'))                              # absorbs the status word, captures the exact graph, steps
+    assert dec._exact_latch == {'color'}
+    assert int(it.step_count.max()) == 1
+    assert any(not torch.equal(grids[k], before[k]) for k in grids)
+    l3 = float(it.step(*rays, 'color'))
+    assert l3 < l2
