@@ -79,14 +79,15 @@ __device__ HSrc dec_ht_src(int t) {
 }
 
 template <int CDIM, int NOUT>
-__global__ void k_pack_decoder_ht(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status) {
+__global__ void k_pack_decoder_ht(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status, int bit) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= DecLayoutHT<CDIM, NOUT>::P_TOTAL) return;
     const HSrc s = dec_ht_src<CDIM, NOUT>(t);
     if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(flat[s.s0]); return; }
-    const float a = s.s0 < 0 ? 0.f : flat[s.s0], b = s.s1 < 0 ? 0.f : flat[s.s1];
-    if (status && !(fmaxf(fabsf(a), fabsf(b)) < 65504.0f))
-        __hip_atomic_fetch_or(status, ADFP_STATUS_F16_RANGE_BWD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    float a = s.s0 < 0 ? 0.f : flat[s.s0], b = s.s1 < 0 ? 0.f : flat[s.s1];
+    if (status && !(fmaxf(fabsf(a), fabsf(b)) < 65504.0f))      // the same weight trips the forward image too: that network goes exact
+        __hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    a = f16_clamp(a); b = f16_clamp(b);          // out of range (flagged above / by pack_range_flag): stay finite, 0 x inf must not appear downstream
     const float ah = f16_hi_part(a), bh = f16_hi_part(b);
     _Float16 x, y;
     if (s.kind == 1) { x = (_Float16)ah; y = (_Float16)bh; }
@@ -108,6 +109,7 @@ struct DecodeBwdHArgs {
     int* status;
     const float* gmax;         // see grad_scale (WGRAD)
     float* gc_out;             // SCAT = false: [P][32] d/d c rows (row = point) for k_scatter_sorted, or NULL
+    const int* skip;           // device flag: the forward call was repaired (zero cotangents, state not valid): report nothing
 };
 
 // 16 D-layout registers -> the two k-steps of a B operand
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
         }
     }
     if constexpr (SCAT) { if (a.g_grid) scatter_flush<CACHE>(a.g_grid, lane, sm); }
-    report_range(a.status, amax, ADFP_STATUS_F16_RANGE_BWD);
+    if (!(a.skip && *a.skip)) report_range(a.status, amax, ADFP_STATUS_F16_RANGE_BWD);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -461,6 +463,7 @@ struct OuterHArgs {
     const float* bm;           // decoders: [96][4] Fourier matrix rows (the packed image's P_BM block)
     int col_se, col_sgp;       // decoders: first column of the recomputed Fourier block / of the masked d/d pre block
     int* status;
+    const int* skip;           // as DecodeBwdHArgs.skip
 };
 __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
     const OuterArgs& a = b.o;
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
         if (!more) break;
         m = nm; blk = nblk; m1 = nm1;
     }
-    report_range(b.status, amax, ADFP_STATUS_F16_RANGE_BWD);
+    if (!(b.skip && *b.skip)) report_range(b.status, amax, ADFP_STATUS_F16_RANGE_BWD);
     float* part = a.partial + (long long)blockIdx.x * a.part_stride;
 #pragma unroll
     for (int j = 0; j < OUTER_JW; ++j) {
@@ -664,9 +667,10 @@ __global__ void k_pack_attention_ht(const float* __restrict__ flat, unsigned* __
     if (t >= AttLayoutHT::P_TOTAL) return;
     const HSrc s = att_ht_src(t);
     if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(flat[s.s0]); return; }
-    const float a = flat[s.s0], b = flat[s.s1];
+    float a = flat[s.s0], b = flat[s.s1];
     if (status && !(fmaxf(fabsf(a), fabsf(b)) < 65504.0f))
-        __hip_atomic_fetch_or(status, ADFP_STATUS_F16_RANGE_BWD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_or(status, ADFP_STATUS_F16_RANGE_ATT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    a = f16_clamp(a); b = f16_clamp(b);          // out of range (flagged above / by pack_range_flag): stay finite, 0 x inf must not appear downstream
     const float ah = f16_hi_part(a), bh = f16_hi_part(b);
     _Float16 x, y;
     if (s.kind == 1) { x = (_Float16)ah; y = (_Float16)bh; }
@@ -808,5 +812,5 @@ __global__ __launch_bounds__(512) void k_attention_bwd_h(AttBwdHArgs a) {
         const float g_in = a0 * g_out + gx * isc;
         if (valid && h == 0) { a.att_g[idx] = g_in; a.g_raw[4ll * q + 3] = g_in; }
     }
-    report_range(a.status, amax, ADFP_STATUS_F16_RANGE_BWD);
+    if (!(a.skip && *a.skip)) report_range(a.status, amax, ADFP_STATUS_F16_RANGE_BWD);
 }

@@ -99,6 +99,7 @@ __device__ HSrc dec_h_src(int t) {
 }
 
 __device__ __forceinline__ float f16_hi_part(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFFE000u); }
+__device__ __forceinline__ float f16_clamp(float x) { return fminf(fmaxf(x, -65504.0f), 65504.0f); }
 
 // Is any parameter of the flat buffer outside the f16 range?  Evaluated by workgroup 0 alone over the whole buffer (16-33 k floats:
 // a couple of microseconds) so that the answer is ONE plain store into the image's flag word: no atomics, nothing to zero first.
@@ -119,7 +120,8 @@ __global__ void k_pack_decoder_h(const float* __restrict__ flat, unsigned* __res
     if (t >= DecLayoutH<CDIM, NOUT>::P_TOTAL || t == DecLayoutH<CDIM, NOUT>::P_FLAG) return;
     const HSrc s = dec_h_src<CDIM, NOUT>(t);
     if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(flat[s.s0]); return; }
-    const float a = s.s0 < 0 ? 0.f : flat[s.s0], b = s.s1 < 0 ? 0.f : flat[s.s1];
+    float a = s.s0 < 0 ? 0.f : flat[s.s0], b = s.s1 < 0 ? 0.f : flat[s.s1];
+    a = f16_clamp(a); b = f16_clamp(b);          // out of range (flagged above / by pack_range_flag): stay finite, 0 x inf must not appear downstream
     const float ah = f16_hi_part(a), bh = f16_hi_part(b);
     _Float16 x, y;
     if (s.kind == 1) { x = (_Float16)ah; y = (_Float16)bh; }
@@ -420,7 +422,8 @@ __global__ void k_pack_attention_h(const float* __restrict__ flat, unsigned* __r
     if (t >= AttLayoutH::P_TOTAL || t == AttLayoutH::P_FLAG) return;
     const HSrc s = att_h_src(t);
     if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(flat[s.s0]); return; }
-    const float a = flat[s.s0], b = flat[s.s1];
+    float a = flat[s.s0], b = flat[s.s1];
+    a = f16_clamp(a); b = f16_clamp(b);          // out of range (flagged above / by pack_range_flag): stay finite, 0 x inf must not appear downstream
     const float ah = f16_hi_part(a), bh = f16_hi_part(b);
     _Float16 x, y;
     if (s.kind == 1) { x = (_Float16)ah; y = (_Float16)bh; }

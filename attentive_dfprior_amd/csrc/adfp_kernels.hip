@@ -1088,13 +1088,13 @@ int adfp_pack_decoder_ht(int kind, const float* flat, void* packed, int* status,
     unsigned* out = (unsigned*)packed;
     switch (kind) {
         case ADFP_DEC_LOW:
-            hipLaunchKernelGGL((k_pack_decoder_ht<32, 1>), dim3((DecLayoutHT<32, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status);
+            hipLaunchKernelGGL((k_pack_decoder_ht<32, 1>), dim3((DecLayoutHT<32, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_LOW);
             break;
         case ADFP_DEC_HIGH:
-            hipLaunchKernelGGL((k_pack_decoder_ht<64, 1>), dim3((DecLayoutHT<64, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status);
+            hipLaunchKernelGGL((k_pack_decoder_ht<64, 1>), dim3((DecLayoutHT<64, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_HIGH);
             break;
         case ADFP_DEC_COLOR:
-            hipLaunchKernelGGL((k_pack_decoder_ht<32, 4>), dim3((DecLayoutHT<32, 4>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status);
+            hipLaunchKernelGGL((k_pack_decoder_ht<32, 4>), dim3((DecLayoutHT<32, 4>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_COLOR);
             break;
         default: return ADFP_E_ARG;
     }
@@ -1846,7 +1846,7 @@ static int scatter_bins(const BinPlan& bp, const DecodeBwdArgs& o, const BwdWork
 }
 
 template <int CDIM, int NOUT, int ROLE>
-static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigned* masks, const float* act, int* status, int total,
+static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigned* masks, const float* act, int* status, const int* skip, int total,
                             const int* count_ptr, float* flat, BwdWorkspace& bw, const BinPlan& bp, const unsigned char* flags, hipStream_t st) {
     if (total == 0) return 0;
     // d/d c rows + k_scatter_sorted instead of the in-kernel scatter: for a grid on one of the two lattices the points were
@@ -1856,7 +1856,7 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
     if (!binned && o.g_grid && (long long)o.g0.X * o.g0.Y * o.g0.Z >= (1ll << 27)) return ADFP_E_UNSUPPORTED;     // scatter cache slot bits
     DecodeBwdHArgs a;
     a.P = o.P; a.nb = o.nb; a.g0 = o.g0; a.packed_t = (const unsigned*)t; a.list = o.list; a.count_ptr = o.count_ptr;
-    a.g_raw = o.g_raw; a.att_g = o.att_g; a.masks = masks; a.g_grid = o.g_grid; a.stage = nullptr; a.status = status; a.gmax = bw.gmax;
+    a.g_raw = o.g_raw; a.att_g = o.att_g; a.masks = masks; a.g_grid = o.g_grid; a.stage = nullptr; a.status = status; a.gmax = bw.gmax; a.skip = skip;
     a.gc_out = binned ? bw.gc : nullptr;
     constexpr int NW = ADFP_BWDH_NT / 64;
     if (!flat) {
@@ -1869,7 +1869,7 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
     using ST = DecStage<CDIM>;
     OuterHArgs oa; decoder_jobs<CDIM, NOUT>(oa.o);
     oa.act = act; oa.nxm4 = ST::NXM / 4; oa.ngm4 = ST::NGM / 4; oa.g_dst4 = ST::SGH(0) / 4; oa.x_gap_at4 = 8; oa.x_gap4 = 24; oa.masks = masks; oa.bm = (const float*)t;   // P_BM = word 0 of the T image
-    oa.col_se = ST::SE; oa.col_sgp = ST::SGP(0); oa.status = status;
+    oa.col_se = ST::SE; oa.col_sgp = ST::SGP(0); oa.status = status; oa.skip = skip;
     a.stage = bw.stage;
     const int rows_cap = (int)((size_t)bw.stage_rows * AttStage::NCOLS / ST::NGM);
     int rc = outer_begin(bw, DecLayout<CDIM, NOUT>::F_TOTAL, st);
@@ -1984,7 +1984,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
             t.status = sc->status; t.gmax = bw.gmax; t.skip = state.counter ? state.counter + 8 : nullptr;
             OuterHArgs oh; attention_jobs(oh.o);
             oh.act = state.act_att; oh.nxm4 = 416 / 4; oh.ngm4 = 416 / 4; oh.g_dst4 = 416 / 4; oh.x_gap_at4 = 1 << 20; oh.x_gap4 = 0;
-            oh.masks = nullptr; oh.bm = nullptr; oh.col_se = 0; oh.col_sgp = 0; oh.status = sc->status;
+            oh.masks = nullptr; oh.bm = nullptr; oh.col_se = 0; oh.col_sgp = 0; oh.status = sc->status; oh.skip = t.skip;
             OuterArgs& oa = oh.o;
             const int rows_cap = bw.stage_rows * 2;               // the G piece is half a row
             if (go.flat_att) { rc = outer_begin(bw, AttLayout::F_TOTAL, st); if (rc) return rc; }
@@ -2037,7 +2037,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
             hgh.g0 = make_grid(sc->high); hgh.g1 = make_grid(sc->low); hgh.packed = sc->w_high;
             hgh.list = state.list; hgh.count_ptr = state.counter; hgh.att_g = bw.att_g; hgh.g_grid = go.grid_high;
             if (use_h(sc->ht_high, state.masks_high, state.act_high, go.flat_high))
-                rc = run_decode_bwd_h<64, 1, ROLE_HIGH>(hgh, sc->ht_high, state.masks_high, state.act_high, sc->status, P, state.counter, go.flat_high, bw, bp, state.flags, st);
+                rc = run_decode_bwd_h<64, 1, ROLE_HIGH>(hgh, sc->ht_high, state.masks_high, state.act_high, sc->status, state.counter ? state.counter + 8 : nullptr, P, state.counter, go.flat_high, bw, bp, state.flags, st);
             else rc = sc->w_high ? run_decode_bwd<64, 1, ROLE_HIGH>(hgh, P, state.counter, go.flat_high, bw, st) : ADFP_E_ARG;
             if (rc) return rc;
         }
@@ -2046,7 +2046,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         DecodeBwdArgs lw = a;
         lw.g0 = make_grid(sc->low); lw.g1 = lw.g0; lw.packed = sc->w_low; lw.g_grid = go.grid_low;
         if (use_h(sc->ht_low, state.masks_low, state.act_low, go.flat_low))
-            rc = run_decode_bwd_h<32, 1, ROLE_LOW>(lw, sc->ht_low, state.masks_low, state.act_low, sc->status, P, nullptr, go.flat_low, bw, bp, nullptr, st);
+            rc = run_decode_bwd_h<32, 1, ROLE_LOW>(lw, sc->ht_low, state.masks_low, state.act_low, sc->status, state.counter ? state.counter + 8 : nullptr, P, nullptr, go.flat_low, bw, bp, nullptr, st);
         else rc = sc->w_low ? run_decode_bwd<32, 1, ROLE_LOW>(lw, P, nullptr, go.flat_low, bw, st) : ADFP_E_ARG;
         if (rc) return rc;
     }
@@ -2054,7 +2054,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         DecodeBwdArgs cl = a;
         cl.g0 = make_grid(sc->color); cl.g1 = cl.g0; cl.packed = sc->w_color; cl.g_grid = go.grid_color;
         if (use_h(sc->ht_color, state.masks_color, state.act_color, go.flat_color))
-            rc = run_decode_bwd_h<32, 4, ROLE_COLOR>(cl, sc->ht_color, state.masks_color, state.act_color, sc->status, P, nullptr, go.flat_color, bw, bp, nullptr, st);
+            rc = run_decode_bwd_h<32, 4, ROLE_COLOR>(cl, sc->ht_color, state.masks_color, state.act_color, sc->status, state.counter ? state.counter + 8 : nullptr, P, nullptr, go.flat_color, bw, bp, nullptr, st);
         else rc = sc->w_color ? run_decode_bwd<32, 4, ROLE_COLOR>(cl, P, nullptr, go.flat_color, bw, st) : ADFP_E_ARG;
         if (rc) return rc;
     }

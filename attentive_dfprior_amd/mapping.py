@@ -357,7 +357,10 @@ class MapperIteration(object):
             # replay is seen one step late at worst, and that step repaired itself and skipped its Adam).  A network that tripped
             # runs on the exact kernels from now on: the graphs are keyed on the set of latched networks.
             self.dec.absorb_status()
-            key = (N, stage, bool(warmup), frozenset(self.dec._exact_latch))
+
+            def graph_key():
+                return (N, stage, bool(warmup), frozenset(self.dec._exact_latch))
+            key = graph_key()
             st = self._static.get(N)
             if st is None:
                 st = self._static[N] = (torch.empty((N, 3), device=dev), torch.empty((N, 3), device=dev), torch.empty((N,), device=dev),
@@ -374,6 +377,8 @@ class MapperIteration(object):
                     self._sequence(*st, stage, warmup, adam=False)
                 torch.cuda.current_stream(dev).wait_stream(side)
                 torch.cuda.synchronize(dev)
+                self.dec.absorb_status()              # the eager warm-up may have tripped the range guard: capture with that network exact
+                key = graph_key()
                 # What changes from replay to replay -- the grids' channels-last copies and the TRAINED nets' weight images -- must be
                 # rebuilt inside the graph, so those cache entries are dropped before the capture; what does not (the FROZEN nets'
                 # images, packed eagerly by the warm-up above into ordinary memory) stays cached.  Nothing the capture allocates

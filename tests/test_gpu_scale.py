@@ -172,13 +172,13 @@ def test_f16_range_violation_in_training_gives_correct_outputs_and_zero_gradient
 
 
 def test_fused_iteration_skips_the_step_of_a_repaired_forward(monkeypatch):
-    """mapping.MapperIteration (graph replay): the iteration whose forward tripped changes NOTHING (parameters, grids, Adam
-    moments, step counters); the following ones run the latched network on the exact kernels and train."""
+    """mapping.MapperIteration (graph replay).  A replay whose forward leaves the f16 range (here: a grid feature that grew to
+    1e5 between two iterations) repairs its outputs, returns zero gradients and changes NOTHING -- parameters, grids, Adam
+    moments, step counters; the following iterations run the latched network on the exact kernels and train."""
     from attentive_dfprior_amd import mapping
     monkeypatch.setenv('ADFP_MATH', 'f16x3')
     sc = mini_at_scale(30.0, 100.0)
     sd = O.random_state_dict(seed=3)
-    sd['color_decoder.fc_c.1.weight'][2, 4] = 8.0e4
     rays = [t.to(DEV) for t in synthetic.make_ray_batch(sc, 256, seed=5)]
     dec = A.DF()
     dec.load_state_dict(sd)
@@ -190,18 +190,25 @@ def test_fused_iteration_skips_the_step_of_a_repaired_forward(monkeypatch):
     grids = {k: v.clone().to(DEV) for k, v in sc.c.items()}
     lr = {st: dict(low=0.005, high=0.005, color=0.005, decoders=0.005, mlp=0.005) for st in ('low', 'high', 'color')}
     it = mapping.MapperIteration(rend, dec, grids, None, sc.tsdf_volume.to(DEV), sc.tsdf_bnds.to(DEV), lr, use_graph=True)
+    float(it.step(*rays, 'color'))                                   # captures the f16-split graph, clean
+    assert dec._exact_latch == set() and int(it.step_count.max()) == 1
+    grids['grid_color'][0, 3] = 1.0e5                                # in place, like a diverging optimiser would
+    torch.autograd.graph.increment_version(grids['grid_color'])
     before = {k: v.clone() for k, v in grids.items()}
     pbefore = {n: p.detach().clone() for n, p in dec.named_parameters()}
-    it.step(*rays, 'color')
+    mbefore = {k: (m.clone(), v.clone()) for k, (m, v) in list(it.gstate.items()) + list(it.fstate.items())}
+    it.step(*rays, 'color')                                          # replay: trips, repairs, skips
     torch.cuda.synchronize()
-    assert int(it.step_count.abs().sum()) == 0
+    assert int(it.step_count.max()) == 1 and int(it.step_count.min()) == 1
     for k in grids:
         assert torch.equal(grids[k], before[k]), f'{k} moved in the iteration whose forward was repaired'
     for n, p in dec.named_parameters():
         assert torch.equal(p.detach(), pbefore[n]), n
-    l2 = float(it.step(*rays, 'color'))                              # absorbs the status word, captures the exact graph, steps
+    for k, (m, v) in list(it.gstate.items()) + list(it.fstate.items()):
+        assert torch.equal(m, mbefore[k][0]) and torch.equal(v, mbefore[k][1]), f'Adam moments of {k} moved'
+    l3 = float(it.step(*rays, 'color'))                              # absorbs the status word, captures the exact-colour graph, steps
     assert dec._exact_latch == {'color'}
-    assert int(it.step_count.max()) == 1
+    assert int(it.step_count.max()) == 2
     assert any(not torch.equal(grids[k], before[k]) for k in grids)
-    l3 = float(it.step(*rays, 'color'))
-    assert l3 < l2
+    l4 = float(it.step(*rays, 'color'))
+    assert torch.isfinite(torch.tensor([l3, l4])).all() and l4 < l3
