@@ -136,13 +136,13 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel_prefix, samples_per_launch, fname='r02_pmc_hbm_traffic.csv'):
+def pmc_traffic(kernel_prefix, samples_per_launch, fname='r03_pmc_hbm_traffic.csv'):
     """HBM bytes per launch of one kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE,
     separate runs; the csv holds bytes per sample): the counters cannot be read from inside this process, so the figure
     is the PROFILED bytes/sample x this run's samples per launch.  Returns (bytes or None, provenance dict); the csv's
     header carries the source hash of the build it was taken from and `stale` says whether that is this build."""
     import csv
-    for name in (fname, fname.replace('r02_', 'r01_')):
+    for name in (fname, fname.replace('r03_', 'r02_'), fname.replace('r03_', 'r01_')):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             break
@@ -160,9 +160,17 @@ def pmc_traffic(kernel_prefix, samples_per_launch, fname='r02_pmc_hbm_traffic.cs
     return None, prov
 
 
+# Feature-grid scale of the bench scene.  SURVEY.md section 8d initialises the grids like src/DF_Prior.py:247-263 -- N(0, 0.01) low /
+# colour, N(0, 1e-4) high -- at which the seeded random decoders output an almost constant occupancy.  The bench multiplies them
+# (x 20, and the high grid x 100 on top: std 0.2 everywhere) so that occupancy, attention weights and colour vary along a ray like
+# with a trained map; kernel time does not depend on the values (tests/test_gpu_scale.py covers the init scale and a trained
+# scale for parity).  Named in config.workload and config.grid_init.
+GRID_STD_SCALE, GRID_HIGH_EXTRA = 20.0, 100.0
+
+
 def build_scene(A, synthetic, name, dev, H=480, W=640):
-    scene = synthetic.Scene(name, H=H, W=W, device=dev, grid_std_scale=20.0)
-    scene.c['grid_high'] = scene.c['grid_high'] * 100
+    scene = synthetic.Scene(name, H=H, W=W, device=dev, grid_std_scale=GRID_STD_SCALE)
+    scene.c['grid_high'] = scene.c['grid_high'] * GRID_HIGH_EXTRA
     sd = synthetic.seeded_state_dict(0)
     dec = A.DF()
     dec.load_state_dict(sd)
@@ -253,10 +261,18 @@ def main():
         'metric': 'rendered rays/sec (64 samples/ray), Replica room0',
         'value': value, 'unit': 'rays/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic', 'math': os.environ.get('ADFP_MATH', 'f16x3'),
+        # the arithmetic the timed path computes in: f32 values; in the default mode every decoder product is formed on f16 MFMA
+        # from a hi + lo split of both f32 operands (3 f16 products, 22-bit product mantissa, f32 accumulate, |x| < 65504 or the
+        # call repairs itself in f32); ADFP_MATH=f32 = exact f32-input MFMA, reported beside it as `value_f32`
+        'dtype': ('f32 via f16x3 split (3 f16 MFMA products per f32 product: 22-bit products, f32 accumulate)'
+                  if os.environ.get('ADFP_MATH', 'f16x3') == 'f16x3' else 'f32'),
+        'data': 'synthetic', 'math': os.environ.get('ADFP_MATH', 'f16x3'),
         'config': {'workload': f'{args.scene} synthetic box room, 640x480 full-frame render_img, stage color, '
                                '64 samples/ray (N_samples 48 + N_surface 16), ray_batch_size 100000, '
-                               'one frame per GPU per step',
+                               'one frame per GPU per step; seed-0 decoders, feature grids N(0, 0.2) '
+                               f'(the reference\'s init std x {GRID_STD_SCALE:g}, high grid x {GRID_HIGH_EXTRA:g} more)',
+                   'grid_init': {'std_scale_vs_reference_init': GRID_STD_SCALE, 'grid_high_extra_factor': GRID_HIGH_EXTRA,
+                                 'reference_init': 'N(0,0.01) low/colour, N(0,1e-4) high (src/DF_Prior.py:247-263)'},
                    'rays_per_step_per_gpu': n_rays, 'samples_per_ray': S,
                    'tsdf_voxels': list(scene.tsdf_volume.shape[2:]),
                    'grid_high': list(scene.c['grid_high'].shape[2:])},
@@ -317,6 +333,7 @@ def main():
                 dt = (time.perf_counter() - t1) / 3
             finally:
                 os.environ['ADFP_MATH'] = 'f16x3'
+            result['value_f32'] = n_rays / dt          # the headline workload with exact f32-input MFMA everywhere (ADFP_MATH=f32)
             result['exact_f32_mode'] = {
                 'value': n_rays / dt, 'unit': 'rays/s', 'ms_per_step': dt * 1e3, 'n_gpus': 1,
                 'max_abs_diff_color_vs_default_mode': float((out32[2] - color_img).abs().max()),
@@ -326,8 +343,15 @@ def main():
         el, _ = timed_loop(step, n_sus, 0)
         result['sustained'] = {'value': n_rays * n_sus / el, 'unit': 'rays/s', 'steps': n_sus, 'seconds': el,
                                'ms_per_step': el / n_sus * 1e3}
+        result['sustained']['note'] = 'the sanity bound of `value`: the same step for >= 2 s, insensitive to clock ramp and launch jitter'
+        import bench_extra as BX
         for name, leg in (('torch_gpu_baseline', lambda: torch_gpu_leg(rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF)),
-                          ('config5', lambda: config5_leg(A, synthetic, _lib, L, dev))):
+                          ('config5', lambda: config5_leg(A, synthetic, _lib, L, dev)),
+                          ('config1', lambda: BX.config1_leg(A, synthetic, scene, sd, dec, dev)),
+                          ('tracker_iteration', lambda: BX.tracker_leg(A, synthetic, scene, sd, dec, dev)),
+                          ('mesher_query', lambda: BX.mesher_leg(A, synthetic, scene, sd, dec, dev)),
+                          ('config3', lambda: BX.config3_leg(dev)),
+                          ('allreduce_model', lambda: BX.allreduce_model(scene))):
             try:
                 result[name] = leg()
             except Exception as e:
@@ -640,7 +664,7 @@ def config5_leg(A, synthetic, _lib, L, dev, n_rays=131072, NS=96, NF=32):
     t_all, t_tsdf, band = measure('pixel')
     t_all_r, t_tsdf_r, band_r = measure('random')
     by = float(TSDF_BYTES_PER_SAMPLE) * P
-    traffic, prov = pmc_traffic('k_tsdf', P, 'r02_pmc_hbm_config5.csv')
+    traffic, prov = pmc_traffic('k_tsdf', P, 'r03_pmc_hbm_config5.csv')
     return {'workload': '16 m cube, 1024^3 TSDF (4.29 GB), 128 samples/ray (96 + 32), 131 072 rays = 8 poses x 16 384 consecutive pixels '
                         '(render_img order) = one GPU\'s share of BASELINE.json configs[4]', 'value': n_rays / t_all, 'unit': 'rays/s',
             'ms_per_batch': t_all * 1e3, 'in_band_fraction': band,
