@@ -176,8 +176,10 @@ ADFP_DEV void gather16(const GridDev& g, const float pn[3], int h, float* __rest
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 const float w = (wx[dx] * wy[dy]) * wz[dz];
-                const long long vox = ((long long)zi[dz] * g.Y + yi[dy]) * g.X + xi[dx];
-                const f32x4* src = (const f32x4*)(g.data + vox * 32 + 4 * h);
+                // byte offset of the voxel line in 32 bits (the host entries refuse grids beyond 2^31 bytes): scalar base +
+                // 32-bit vector offset addressing instead of a 64-bit multiply-add chain per corner
+                const unsigned off = (((unsigned)zi[dz] * (unsigned)g.Y + (unsigned)yi[dy]) * (unsigned)g.X + (unsigned)xi[dx]) * 128u + 16u * h;
+                const f32x4* src = (const f32x4*)((const char*)g.data + off);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const f32x4 t = src[2 * v];
@@ -201,7 +203,9 @@ ADFP_DEV void gather16(const GridDev& g, const float pn[3], int h, float* __rest
 // ------------------------------------------------------------------------------------
 ADFP_DEV float adfp_turns(float x) {
     // 1/(2 pi) = C_HI + C_LO; x*C_HI - k is exact inside the fma (k = the nearest integer of it)
-    const float k = rintf(x * 0.15915494f);
+    // k = the integer nearest to x * C_HI by the magic-number addition (|x * C_HI| < 2^22; two full-rate instructions where
+    // v_mul + v_rndne cost a full-rate and a quarter-rate one): (v + 1.5 * 2^23) - 1.5 * 2^23 rounds v to an integer, ties to even
+    const float k = fmaf(x, 0.15915494f, 12582912.0f) - 12582912.0f;
     float t = fmaf(x, 0.15915494f, -k);
     return fmaf(x, 6.4206382432985265e-09f, t);
 }

@@ -950,6 +950,8 @@ static NormDev make_norm(const double b[3][2]) {
 static void fill_bound(double out[6], const double b[3][2]) {
     for (int k = 0; k < 3; ++k) { out[2 * k] = b[k][0]; out[2 * k + 1] = b[k][1]; }
 }
+// gather16 addresses a grid with 32-bit byte offsets: 16.7 M voxels (the reference's largest is 0.3 M)
+static bool grid_too_big(const adfp_grid& g) { return g.data && (long long)g.Z * g.Y * g.X * 128 >= (1ll << 31); }
 static GridDev make_grid(const adfp_grid& g) { GridDev d; d.data = g.data; d.Z = g.Z; d.Y = g.Y; d.X = g.X; return d; }
 static TsdfDev make_tsdf(const adfp_tsdf& t) {
     TsdfDev d; d.data = t.data; d.Z = t.Z; d.Y = t.Y; d.X = t.X; d.sZ = t.sZ; d.sY = t.sY; d.sX = t.sX; return d;
@@ -1361,6 +1363,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
 extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, int kind, float* raw, float* w, void* stream) {
     if (!sc || !pts || !raw || !w) return ADFP_E_ARG;
     if (kind != ADFP_DEC_LOW && kind != ADFP_DEC_COLOR) return ADFP_E_UNSUPPORTED;
+    if (grid_too_big(sc->low) || grid_too_big(sc->color)) return ADFP_E_UNSUPPORTED;
     PtsDev P; int rc = make_pts(pts, &P); if (rc) return rc;
     if (P.n == 0) return 0;
     DecodeArgs a;
@@ -1403,6 +1406,7 @@ __global__ __launch_bounds__(256) void k_inv_tsdf(const float* __restrict__ t, f
 }
 extern "C" int adfp_decode_single(const adfp_scene* sc, const adfp_points* pts, int kind, float* out4, void* stream) {
     if (!sc || !pts || !out4) return ADFP_E_ARG;
+    if (grid_too_big(sc->low) || grid_too_big(sc->high) || grid_too_big(sc->color)) return ADFP_E_UNSUPPORTED;
     PtsDev P; int rc = make_pts(pts, &P); if (rc) return rc;
     if (P.n == 0) return 0;
     DecodeArgs a;
@@ -1454,6 +1458,7 @@ extern "C" int adfp_attention_rows(const adfp_scene* sc, const float* occ, const
 static int check_scene(const adfp_scene* sc, int stage) {
     if (!sc) return ADFP_E_ARG;
     if (stage < ADFP_STAGE_LOW || stage > ADFP_STAGE_COLOR) return ADFP_E_ARG;
+    if (grid_too_big(sc->low) || grid_too_big(sc->high) || grid_too_big(sc->color)) return ADFP_E_UNSUPPORTED;
     if (!sc->low.data || !(sc->w_low || sc->h_low)) return ADFP_E_ARG;
     if (stage >= ADFP_STAGE_HIGH && (!sc->high.data || !(sc->w_high || sc->h_high) || !(sc->w_att || sc->h_att) || !sc->tsdf.data)) return ADFP_E_ARG;
     if (stage == ADFP_STAGE_COLOR && (!sc->color.data || !(sc->w_color || sc->h_color))) return ADFP_E_ARG;
@@ -2064,6 +2069,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
 static int check_backward_scene(const adfp_scene* sc, int stage) {
     if (!sc) return ADFP_E_ARG;
     if (stage < ADFP_STAGE_LOW || stage > ADFP_STAGE_COLOR) return ADFP_E_ARG;
+    if (grid_too_big(sc->low) || grid_too_big(sc->high) || grid_too_big(sc->color)) return ADFP_E_UNSUPPORTED;
     if (!sc->low.data || (stage >= ADFP_STAGE_HIGH && (!sc->high.data || !sc->tsdf.data)) || (stage == ADFP_STAGE_COLOR && !sc->color.data)) return ADFP_E_ARG;
     // every network needs its exact image or its T image (backward_points picks)
     if (!(sc->w_low || sc->ht_low) || (stage >= ADFP_STAGE_HIGH && (!(sc->w_high || sc->ht_high) || !(sc->w_att || sc->ht_att))) ||
