@@ -1487,14 +1487,18 @@ int adfp_tsdf_integrate(float* tsdf, float* weight, float* color, int dim_x, int
     if (dim_x <= 0 || dim_y <= 0 || dim_z <= 0 || im_h <= 0 || im_w <= 0 || !(voxel_size > 0) || !(trunc_margin > 0)) return ADFP_E_ARG;
     const long long n = (long long)dim_x * dim_y * dim_z;
     if (n > 0x7fffffffll) return ADFP_E_UNSUPPORTED;
-    FusionArgs a;
-    a.tsdf = tsdf; a.weight = weight; a.color = color; a.dx = dim_x; a.dy = dim_y; a.dz = dim_z;
-    for (int k = 0; k < 3; ++k) a.origin[k] = origin[k];
-    a.voxel = voxel_size;
-    for (int k = 0; k < 9; ++k) a.intr[k] = cam_intr[k];
-    for (int k = 0; k < 16; ++k) a.pose[k] = cam_pose[k];
-    a.color_im = color_im; a.depth_im = depth_im; a.im_h = im_h; a.im_w = im_w; a.trunc = trunc_margin; a.obs_w = obs_weight;
-    hipLaunchKernelGGL(k_tsdf_integrate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    FuseFrame f;
+    f.sdf = tsdf; f.wsum = weight; f.rgb = color; f.nx = dim_x; f.ny = dim_y; f.nz = dim_z;
+    for (int k = 0; k < 3; ++k) f.org[k] = origin[k];
+    f.cell = voxel_size;
+    for (int k = 0; k < 9; ++k) f.K[k] = cam_intr[k];
+    for (int k = 0; k < 16; ++k) f.T[k] = cam_pose[k];
+    f.rgb_im = color_im; f.z_im = depth_im; f.rows = im_h; f.cols = im_w; f.band = trunc_margin; f.w_obs = obs_weight;
+    const long long quads = (n + 3) / 4;                     // a lane owns four z-consecutive voxels (adfp_fusion.h)
+    const dim3 grid((unsigned)((quads + 255) / 256));
+    const bool aligned = ((((uintptr_t)tsdf) | ((uintptr_t)weight) | ((uintptr_t)color)) & 15u) == 0;
+    if (aligned) hipLaunchKernelGGL(k_fuse_frame<true>, grid, dim3(256), 0, (hipStream_t)stream, f);
+    else hipLaunchKernelGGL(k_fuse_frame<false>, grid, dim3(256), 0, (hipStream_t)stream, f);
     ADFP_CHECK_LAUNCH();
     return 0;
 }

@@ -350,6 +350,7 @@ def main():
                           ('config1', lambda: BX.config1_leg(A, synthetic, scene, sd, dec, dev)),
                           ('tracker_iteration', lambda: BX.tracker_leg(A, synthetic, scene, sd, dec, dev)),
                           ('mesher_query', lambda: BX.mesher_leg(A, synthetic, scene, sd, dec, dev)),
+                          ('tsdf_fusion', lambda: BX.fusion_leg(synthetic, scene, dev)),
                           ('config3', lambda: BX.config3_leg(dev)),
                           ('allreduce_model', lambda: BX.allreduce_model(scene))):
             try:

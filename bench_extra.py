@@ -332,6 +332,45 @@ def mesher_leg(A, synthetic, scene, sd, dec, dev, resolution=256, chunk=500000):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+def fusion_leg(synthetic, scene, dev):
+    """TSDF fusion of one 640x480 RGB-D frame into the room0-sized volume (reference
+    src/fusion.py:226-251 launches its kernel over the whole volume per frame)."""
+    import numpy as np
+    import torch
+    from attentive_dfprior_amd.fusion import TSDFVolume
+    vol = TSDFVolume(scene.tsdf_bnds.numpy(), 4.0 / 256, device=str(dev))
+    n = int(np.prod(vol._vol_dim))
+    frames = []
+    for k in range(4):
+        c2w = scene.default_c2w(offset=(0.2 * k, -0.1 * k, 0.0), yaw=0.3 + 0.5 * k, pitch=-0.1)
+        depth = scene.depth_image(c2w)
+        color = (torch.rand((scene.H, scene.W, 3), generator=torch.Generator().manual_seed(k)) * 255).floor().to(dev)
+        pose = c2w.double().cpu().numpy().copy()
+        pose[:3, 1] *= -1.0
+        pose[:3, 2] *= -1.0                                            # OpenGL -> OpenCV camera, get_tsdf.py:79-80
+        K = np.array([[scene.fx, 0, scene.cx], [0, scene.fy, scene.cy], [0, 0, 1]], dtype=np.float64)
+        frames.append((color, depth, K, pose))
+    for fr in frames[:1]:
+        vol.integrate(*fr)
+    torch.cuda.synchronize(dev)
+    ts = []
+    for fr in frames[1:]:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        vol.integrate(*fr)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+    t = sorted(ts)[len(ts) // 2]
+    touched = float((vol._weight > 0).float().mean())
+    return {'workload': f'one 640x480 RGB-D frame into the room0 volume ({tuple(int(v) for v in vol._vol_dim)} = {n} voxels, tsdf + weight + '
+                        'packed colour), whole-volume sweep like the reference', 'ms_per_frame': t * 1e3, 'voxels_per_s': n / t,
+            'fraction_of_voxels_observed_after_4_frames': touched,
+            'algorithmic_gbps': 24.0 * touched * n / t / 1e9,
+            'note': 'algorithmic bytes = 3 volumes x (4 B read + 4 B written) per observed voxel; unobserved quads are rejected on arithmetic alone'}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 def allreduce_model(scene, n_params=15899 + 33410):
     """ring all-reduce of B bytes over N GPUs moves 2 (N-1)/N B per GPU through one xGMI link direction
     (point-to-point links, the ring uses one link per neighbour): t = 2 (N-1)/N B / 153 GB/s + 2 (N-1) hops x ~5 us launch / link

@@ -13,7 +13,7 @@ from attentive_dfprior_amd import synthetic, _lib                    # noqa: E40
 from attentive_dfprior_amd.common import get_rays                    # noqa: E402
 
 
-def main(reps=8):
+def main(reps=int(os.environ.get("AB_REPS", "8"))):
     dev = torch.device('cuda:0')
     L = _lib.lib()
     scene = synthetic.Scene('room0', device=dev, grid_std_scale=20.0)

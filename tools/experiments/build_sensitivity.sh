@@ -53,9 +53,65 @@ s=s.replace('''        const h2 hp = __builtin_bit_cast(h2, __builtin_amdgcn_cvt
         lp[1] = (_Float16)__builtin_fmaf((float)hp[1], (float)neg1[0], b);
 #endif''')
 open(p,'w').write(s)
+p='adfp_device.h'
+s=open(p).read()
+s=s.replace("ADFP_DEV float relu_f(float x) { const int b = __float_as_int(x); return __int_as_float(b > 0 ? b : 0); }","""#ifdef EXP_NORELU
+ADFP_DEV float relu_f(float x) { return x; }
+#elif defined(EXP_RELUADD)
+ADFP_DEV float relu_f(float x) { return x + __builtin_fabsf(x); }
+#else
+ADFP_DEV float relu_f(float x) { const int b = __float_as_int(x); return __int_as_float(b > 0 ? b : 0); }
+#endif""")
+s=s.replace("""    const float k = fmaf(x, 0.15915494f, 12582912.0f) - 12582912.0f;
+    float t = fmaf(x, 0.15915494f, -k);
+    return fmaf(x, 6.4206382432985265e-09f, t);""","""    const float k = fmaf(x, 0.15915494f, 12582912.0f) - 12582912.0f;
+    float t = fmaf(x, 0.15915494f, -k);
+#ifdef EXP_TURN1
+    return t;
+#else
+    return fmaf(x, 6.4206382432985265e-09f, t);
+#endif""")
+s=s.replace("""ADFP_DEV float adfp_turns(float x) {""","""#ifdef EXP_VCONST
+ADFP_DEV float adfp_turns(float x) {
+    float magic = 12582912.0f, clo = 6.4206382432985265e-09f;
+    asm volatile("" : "+v"(magic), "+v"(clo));
+    const float k = fmaf(x, 0.15915494f, magic) - magic;
+    float t = fmaf(x, 0.15915494f, -k);
+    return fmaf(x, clo, t);
+}
+#define adfp_turns adfp_turns_unused
+#endif
+ADFP_DEV float adfp_turns(float x) {""")
+s=s.replace("ADFP_DEV float adfp_sinf(float x) { return __builtin_amdgcn_sinf(adfp_turns(x)); }","""#ifdef EXP_VCONST
+#undef adfp_turns
+#endif
+ADFP_DEV float adfp_sinf(float x) { return __builtin_amdgcn_sinf(adfp_turns(x)); }""")
+open(p,'w').write(s)
+p='adfp_decode_h.h'
+s=open(p).read()
+s=s.replace("""#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = x[2 * j], b = x[2 * j + 1];
+        if (CHECK) amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), amax);
+        const h2 hp = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a, b));""","""#ifdef EXP_GUARDTREE
+    if (CHECK) {
+        const float m0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x[0]), __builtin_fabsf(x[1])), __builtin_fabsf(x[2]));
+        const float m1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x[3]), __builtin_fabsf(x[4])), __builtin_fabsf(x[5]));
+        const float m2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x[6]), __builtin_fabsf(x[7])), amax);
+        amax = __builtin_fmaxf(__builtin_fmaxf(m0, m1), m2);
+    }
+#define EXP_NOGUARD 1
+#endif
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = x[2 * j], b = x[2 * j + 1];
+        if (CHECK) amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), amax);
+        const h2 hp = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a, b));""")
+s=s.replace("        if (CHECK) amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), amax);","#ifndef EXP_NOGUARD\n        if (CHECK) amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), amax);\n#endif")
+open(p,'w').write(s)
 PY
 mkdir -p "$ROOT/build"
-for n in mfma2 noldsw nosin nogather nosplit; do
+for n in ${VARIANTS:-mfma2 noldsw nosin nogather nosplit norelu reluadd turn1 noguard}; do
   D=$(echo $n | tr a-z A-Z)
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -fno-slp-vectorize -I../include -DEXP_$D -shared -fPIC \
       -o "$ROOT/build/libadfp_exp_$n.so" adfp_kernels.hip &
