@@ -176,6 +176,9 @@ ADFP_DEV void split8(const float* __restrict__ x, f16x8& hi, f16x8& lo, float& a
     }
     hi = __builtin_bit_cast(f16x8, uh);
     lo = __builtin_bit_cast(f16x8, ul);
+    // pin the running maximum here: left free, the optimiser defers the v_max3 chain to the end of the tile and keeps (spills)
+    // the f32 values it still has to look at
+    if (CHECK) asm volatile("" : "+v"(amax));
 }
 #endif
 #define ADFP_F16_MAX 65504.0f
@@ -373,6 +376,145 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
     const int wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     if (lane == 0 && wave < 8192) { g_stamps[2 * wave] = stamp0; g_stamps[2 * wave + 1] = wall_clock64(); }
 #endif
+}
+
+// =============================================================================================
+// LOW + COLOR in ONE launch (stage color, inference).  Both decoders run on every sample point of a ray batch with the same
+// position; as two launches each of them reconstructed the point (f64 o + d z), normalised it (f64), took its ticket, loaded its
+// z_vals and stored its part of the 16-byte raw row on its own (partial-line stores from two kernels: 20.6 + 16.7 B written per
+// sample for 16 B of payload, profiles/r02_pmc_hbm_traffic.csv).  Here a wave does the point work once per tile, evaluates the
+// low network and then the colour network out of two weight images that share the CU's LDS (65 + 65 KB of 160 KB; still one
+// 768-thread workgroup per CU, 3 waves per SIMD) and writes raw as ONE 16-byte store per point -- and a frame has one launch
+// tail per batch instead of two.  decode_net_h is k_decode_h's per-tile network evaluation (32-channel grids, no training
+// state), kept textually parallel to it.
+// =============================================================================================
+template <int NOUT>
+ADFP_DEV void decode_net_h(const unsigned* __restrict__ ldsu, const GridDev& g, const float pn[3], const float pf[3], int h, int lane_off,
+                           float& amax, float* __restrict__ out) {
+    // `ldsu` = the workgroup's LDS array + this network's image offset, an opaque per-tile register value at the call site (see
+    // k_decode_lc).  Every LDS access below is one of four lane-dependent bases plus an immediate below 64 KB: the weight rows
+    // (lane_off), the bias rows (4 h), the Fourier rows (16 h) and the output rows (16 NOUT h).
+    using L = DecLayoutH<32, NOUT>;
+    const unsigned* wl = ldsu + lane_off;
+    const float* bh = (const float*)ldsu + 4 * h;
+    const float* b16 = (const float*)ldsu + 16 * h;
+    const float* bw = (const float*)ldsu + 16 * NOUT * h;
+    f16x8 ch[L::KS_C], cl[L::KS_C];
+    {
+        float c[16];
+        gather16(g, pn, h, c);
+#pragma unroll
+        for (int ks = 0; ks < L::KS_C; ++ks) split8(c + 8 * ks, ch[ks], cl[ks], amax);
+    }
+    f16x8 eh[L::KS_E], el[L::KS_E];
+#pragma unroll
+    for (int ks = 0; ks < L::KS_E; ++ks) {
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 bm = *(const f32x4*)(b16 + L::P_BM + unit_of_h(ks, 0, j) * 4);       // unit_of_h(ks, h, j) = unit_of_h(ks, 0, j) + 4 h
+            const float arg = fmaf(pf[2], bm.z, fmaf(pf[1], bm.y, pf[0] * bm.x));
+            e[j] = adfp_sinf(arg);
+        }
+        split8<false>(e, eh[ks], el[ks], amax);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc;
+    f16x8 hh[2], hl[2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        bias_init(acc, bh + L::P_BP(i), 0);
+        if (i == 0) mfma_chain_h<L::KS_E>(acc, wl + L::P_WP(0), 0, eh, el);
+        else if (i == 3) {
+            mfma_chain_h<L::KS_E>(acc, wl + L::P_WP(3), 0, eh, el);
+            mfma_chain_h<2>(acc, wl + L::P_WP(3) + L::KS_E * 512, 0, hh, hl);
+        } else mfma_chain_h<2>(acc, wl + L::P_WP(i), 0, hh, hl);
+        relu_bias(acc, bh + L::P_BC(i), 0);
+        mfma_chain_h<L::KS_C>(acc, wl + L::P_WC(i), 0, ch, cl);
+        if (i < 4) {
+            float t[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = acc[r];
+            split8(t, hh[0], hl[0], amax);
+            split8(t + 8, hh[1], hl[1], amax);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        const float* wo = bw + L::P_WO + o * 16;
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s = fmaf(acc[r], wo[r], s);
+        s += __shfl_xor(s, 32);
+        out[o] = s + ((const float*)ldsu)[L::P_BO + o];
+    }
+}
+
+struct DecodeLCArgs {
+    PtsDev P; NormDev nb; double b[6];
+    GridDev g_low, g_color;
+    const unsigned* packed_low; const unsigned* packed_color;     // H images
+    const unsigned char* flags;                                   // ADFP_F_BAND per point (or NULL)
+    float* raw; float* w;
+    int write_w, apply_bound;
+    int* status; int* call_flag;
+};
+template <int NT>
+__global__ __launch_bounds__(NT, NT / 256) void k_decode_lc(DecodeLCArgs a) {
+    using LL = DecLayoutH<32, 1>;
+    using LC = DecLayoutH<32, 4>;
+    __shared__ __attribute__((aligned(16))) unsigned lds_all[LL::P_TOTAL + LC::P_TOTAL];      // the low image, then the colour image
+    __shared__ int s_next;
+    unsigned* lds_low = lds_all;
+    unsigned* lds_col = lds_all + LL::P_TOTAL;
+    for (int i = threadIdx.x; i < LL::P_TOTAL / 4; i += NT) ((u32x4*)lds_low)[i] = ((const u32x4*)a.packed_low)[i];
+    for (int i = threadIdx.x; i < LC::P_TOTAL / 4; i += NT) ((u32x4*)lds_col)[i] = ((const u32x4*)a.packed_color)[i];
+    if (threadIdx.x == 0) s_next = NT / 64;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+    const int lane_off = h * 128 + p * 4;
+    const int count = a.P.n;
+    const int ntiles = (count + 31) >> 5;
+    float amax_low = lds_low[LL::P_FLAG] ? INFINITY : 0.f, amax_col = lds_col[LC::P_FLAG] ? INFINITY : 0.f;
+    // The second image lies beyond the 64 KB reach of a ds_read's immediate offset.  With its address a compile-time constant the
+    // compiler materialised one address register per distinct offset and hoisted them all out of the tile loop (109 spilled
+    // VGPRs); with the image's word offset an opaque register value every access is (offset + lane term) + small immediate again.
+    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<NT / 64>(j, &s_next, ntiles)) >= 0;) {
+        const int idx = tile * 32 + p;
+        const bool valid = idx < count;
+        const int q = valid ? idx : 0;
+        float pn[3], pf[3];
+        bool pnan, keep_occ;                            // everything the f64 point is needed for, so that it dies before the networks
+        {
+            double pt[3];
+            load_point(a.P, q, pt);
+            normalize3(a.nb, pt, pn);
+            pf[0] = (float)pt[0]; pf[1] = (float)pt[1]; pf[2] = (float)pt[2];   // p.float() decoder.py:189
+            pnan = (pt[0] != pt[0]) | (pt[1] != pt[1]) | (pt[2] != pt[2]);
+            const unsigned f = a.flags ? a.flags[q] : 0u;
+            // in-band points keep the true low value for the HIGH pass; the attention pass overwrites them afterwards
+            keep_occ = (f & ADFP_F_BAND) || in_bound(pt, a.b) || !a.apply_bound;           // Renderer.py:64
+        }
+        float occ[1], rgb[4];
+        int off_low = 0, off_col = LL::P_TOTAL;        // word offsets of the two images in lds_all, opaque and per tile: nothing that
+        asm volatile("" : "+v"(off_low), "+v"(off_col));   // derives from them is loop invariant (hoisted address registers were spilled)
+        const unsigned* img_low = lds_all + off_low;
+        const unsigned* img_col = lds_all + off_col;
+        decode_net_h<1>(img_low, a.g_low, pn, pf, h, lane_off, amax_low, occ);
+        // the colour network starts here, not earlier: without the opaque pass the optimiser hoists its trilinear set-up and
+        // gather above the low network's layers and the two networks' operand sets no longer fit 168 registers
+        asm volatile("" : "+v"(pn[0]), "+v"(pn[1]), "+v"(pn[2]), "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2]), "+v"(occ[0]));
+        __builtin_amdgcn_sched_barrier(0);
+        decode_net_h<4>(img_col, a.g_color, pn, pf, h, lane_off, amax_col, rgb);
+        if (valid && h == 0) {
+            const float nanv = __builtin_nanf("");     // a NaN position renders NaN like the reference's (nan_point_outputs)
+            const float o = pnan ? nanv : (keep_occ ? occ[0] : 100.f);
+            *(f32x4*)(a.raw + 4ll * q) = pnan ? f32x4{nanv, nanv, nanv, o} : f32x4{rgb[0], rgb[1], rgb[2], o};
+            if (a.write_w) a.w[q] = 1.f;
+        }
+    }
+    report_range(a.status, amax_low, ADFP_STATUS_F16_RANGE_LOW, a.call_flag);
+    report_range(a.status, amax_col, ADFP_STATUS_F16_RANGE_COLOR, a.call_flag);
 }
 
 // =============================================================================================

@@ -22,7 +22,7 @@ struct NormDev {          // p_n = ((p - lo) / (hi - lo)) * 2 - 1     (common.py
     double inv[3];        // 1 / (hi - lo)
 };
 
-struct GridDev { const float* data; int Z, Y, X; };
+struct GridDev { const float* data; int Z, Y, X; float fZ1, fY1, fX1; };     // f*1 = (float)(dim - 1), from the host: stays in SGPRs
 struct TsdfDev { const float* data; int Z, Y, X; long long sZ, sY, sX; };
 
 struct PtsDev {
@@ -162,11 +162,23 @@ ADFP_DEV float trilerp_pair_finish(const TriPair& r, f32x2_u p00, f32x2_u p01, f
 // 16 of the 32 channels of a channels-last feature voxel grid: lane-half `h` takes the channels
 // kmapH(r,h) = 8q+4h .. 8q+4h+3 (q = 0..3), i.e. four 16-B pieces of each 128-B voxel line; the
 // two halves of a lane pair cover the whole line (c[r] <-> channel kmapH(r, h)).
+// tri_axis with (float)(size - 1) handed in: the int -> float conversion of a kernel argument is loop invariant, gets hoisted into
+// a VGPR and -- in a kernel at its register budget -- spilled; as a float argument it is an SGPR operand
+ADFP_DEV void tri_axis_f(float pn, int size, float fsize1, int& i0, int& i1, float& w0, float& w1) {
+    float c = ((pn + 1.f) / 2.f) * fsize1;
+    c = fminf(fmaxf(c, 0.f), fsize1);
+    const float f = floorf(c);
+    i0 = (int)f;
+    w1 = c - f;
+    w0 = (f + 1.f) - c;
+    i1 = i0 + 1;
+    if (i1 > size - 1) { i1 = size - 1; w1 = 0.f; }
+}
 ADFP_DEV void gather16(const GridDev& g, const float pn[3], int h, float* __restrict__ c) {
     int xi[2], yi[2], zi[2]; float wx[2], wy[2], wz[2];
-    tri_axis(pn[0], g.X, xi[0], xi[1], wx[0], wx[1]);
-    tri_axis(pn[1], g.Y, yi[0], yi[1], wy[0], wy[1]);
-    tri_axis(pn[2], g.Z, zi[0], zi[1], wz[0], wz[1]);
+    tri_axis_f(pn[0], g.X, g.fX1, xi[0], xi[1], wx[0], wx[1]);
+    tri_axis_f(pn[1], g.Y, g.fY1, yi[0], yi[1], wy[0], wy[1]);
+    tri_axis_f(pn[2], g.Z, g.fZ1, zi[0], zi[1], wz[0], wz[1]);
 #pragma unroll
     for (int k = 0; k < 16; ++k) c[k] = 0.f;
 #pragma unroll

@@ -952,7 +952,11 @@ static void fill_bound(double out[6], const double b[3][2]) {
 }
 // gather16 addresses a grid with 32-bit byte offsets: 16.7 M voxels (the reference's largest is 0.3 M)
 static bool grid_too_big(const adfp_grid& g) { return g.data && (long long)g.Z * g.Y * g.X * 128 >= (1ll << 31); }
-static GridDev make_grid(const adfp_grid& g) { GridDev d; d.data = g.data; d.Z = g.Z; d.Y = g.Y; d.X = g.X; return d; }
+static GridDev make_grid(const adfp_grid& g) {
+    GridDev d; d.data = g.data; d.Z = g.Z; d.Y = g.Y; d.X = g.X;
+    d.fZ1 = (float)(g.Z - 1); d.fY1 = (float)(g.Y - 1); d.fX1 = (float)(g.X - 1);
+    return d;
+}
 static TsdfDev make_tsdf(const adfp_tsdf& t) {
     TsdfDev d; d.data = t.data; d.Z = t.Z; d.Y = t.Y; d.X = t.X; d.sZ = t.sZ; d.sY = t.sY; d.sX = t.sX; return d;
 }
@@ -1279,9 +1283,21 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
     a.raw = raw; a.w = w; a.att_occ = nullptr; a.write_w = 1; a.apply_bound = apply_bound;   // attention overwrites w on the band
     a.status = sc->status; a.masks = nullptr; a.act = nullptr; a.single = 0; a.call_flag = call_flag;
     const int ntiles = (P.n + 31) / 32;
+    // stage color, inference, both networks f16-split: LOW and COLOR on every point in ONE launch (k_decode_lc)
+    const bool fused_lc = stage == ADFP_STAGE_COLOR && !state && sc->h_low && sc->h_color;
+    if (fused_lc) {
+        DecodeLCArgs f;
+        f.P = P; f.nb = a.nb; fill_bound(f.b, sc->bound);
+        f.g_low = make_grid(sc->low); f.g_color = make_grid(sc->color);
+        f.packed_low = (const unsigned*)sc->h_low; f.packed_color = (const unsigned*)sc->h_color;
+        f.flags = a.flags; f.raw = raw; f.w = w; f.write_w = 1; f.apply_bound = apply_bound; f.status = sc->status; f.call_flag = call_flag;
+        hipLaunchKernelGGL((k_decode_lc<ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, 1)), dim3(ADFP_DECH_NT), 0, st, f);
+        ADFP_CHECK_LAUNCH();
+    }
     // LOW on every point
     a.g0 = make_grid(sc->low); a.g1 = a.g0;
-    if (sc->h_low && state && state->masks_low) {              // training forward: leaves the ReLU masks (+ layer inputs)
+    if (fused_lc) {
+    } else if (sc->h_low && state && state->masks_low) {              // training forward: leaves the ReLU masks (+ layer inputs)
         a.packed = (const float*)sc->h_low; a.masks = state->masks_low; a.act = state->act_low;
         if (a.act) hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, 512, 2>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, 512, 1>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
@@ -1294,7 +1310,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         hipLaunchKernelGGL((k_decode<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
     }
     ADFP_CHECK_LAUNCH();
-    if (stage == ADFP_STAGE_COLOR) {
+    if (stage == ADFP_STAGE_COLOR && !fused_lc) {
         a.g0 = make_grid(sc->color); a.g1 = a.g0;
         if (sc->h_color && state && state->masks_color) {
             a.packed = (const float*)sc->h_color; a.masks = state->masks_color; a.act = state->act_color;
@@ -1362,10 +1378,21 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
 // bench hook: ONE decoder kernel (LOW or COLOR) over every point, nothing else.
 extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, int kind, float* raw, float* w, void* stream) {
     if (!sc || !pts || !raw || !w) return ADFP_E_ARG;
-    if (kind != ADFP_DEC_LOW && kind != ADFP_DEC_COLOR) return ADFP_E_UNSUPPORTED;
+    if (kind != ADFP_DEC_LOW && kind != ADFP_DEC_COLOR && kind != ADFP_DEC_LOW_COLOR) return ADFP_E_UNSUPPORTED;
     if (grid_too_big(sc->low) || grid_too_big(sc->color)) return ADFP_E_UNSUPPORTED;
     PtsDev P; int rc = make_pts(pts, &P); if (rc) return rc;
     if (P.n == 0) return 0;
+    if (kind == ADFP_DEC_LOW_COLOR) {                  // the fused launch of stage color (f16-split images only)
+        if (!sc->low.data || !sc->color.data || !sc->h_low || !sc->h_color) return ADFP_E_ARG;
+        DecodeLCArgs f;
+        f.P = P; f.nb = make_norm(sc->bound); fill_bound(f.b, sc->bound);
+        f.g_low = make_grid(sc->low); f.g_color = make_grid(sc->color);
+        f.packed_low = (const unsigned*)sc->h_low; f.packed_color = (const unsigned*)sc->h_color;
+        f.flags = nullptr; f.raw = raw; f.w = w; f.write_w = 1; f.apply_bound = 1; f.status = sc->status; f.call_flag = nullptr;
+        hipLaunchKernelGGL((k_decode_lc<ADFP_DECH_NT>), dim3(decode_grid((P.n + 31) / 32, ADFP_DECH_NT / 64, 1)), dim3(ADFP_DECH_NT), 0, (hipStream_t)stream, f);
+        ADFP_CHECK_LAUNCH();
+        return 0;
+    }
     DecodeArgs a;
     a.P = P; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
     a.list = nullptr; a.count_ptr = nullptr; a.flags = nullptr;

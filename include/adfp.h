@@ -427,8 +427,10 @@ int adfp_sort_pairs(int* key, int* val, int* key_tmp, int* val_tmp, long long n,
 int adfp_tsdf_stage(const adfp_scene* scene, const adfp_points* pts, unsigned char* flags,
                     int* list, float* att_u, float* w, int* counter, void* stream);
 
-/* Per-stage timing hook for bench.py: runs ONLY one decoder kernel (kind = ADFP_DEC_LOW or
- * ADFP_DEC_COLOR) over every point and writes its output channel(s) of raw. */
+/* Per-stage timing hook for bench.py: runs ONLY one decoder kernel (kind = ADFP_DEC_LOW or ADFP_DEC_COLOR, or
+ * ADFP_DEC_LOW_COLOR = the fused low + colour launch that stage color uses with f16-split images) over every point and
+ * writes its output channel(s) of raw. */
+#define ADFP_DEC_LOW_COLOR 3
 int adfp_decode_stage(const adfp_scene* scene, const adfp_points* pts, int kind, float* raw, float* w, void* stream);
 
 /* ---- one sub-network alone (reference: the public modules `decoders.low_decoder / high_decoder / color_decoder / mlp`) ---- */

@@ -62,6 +62,8 @@ def main(reps=int(os.environ.get("AB_REPS", "8"))):
     res = {'lib': os.path.basename(_lib.LIB_PATH)}
     res['color_ms'] = timed(lambda: L.adfp_decode_stage(C.byref(sc), C.byref(ap), 2, _lib.ptr(raw), _lib.ptr(wb), st))
     res['low_ms'] = timed(lambda: L.adfp_decode_stage(C.byref(sc), C.byref(ap), 0, _lib.ptr(raw), _lib.ptr(wb), st))
+    if L.adfp_decode_stage(C.byref(sc), C.byref(ap), 3, _lib.ptr(raw), _lib.ptr(wb), st) == 0:      # the fused low + colour launch
+        res['low_color_ms'] = timed(lambda: L.adfp_decode_stage(C.byref(sc), C.byref(ap), 3, _lib.ptr(raw), _lib.ptr(wb), st))
     res['tsdf_ms'] = timed(lambda: L.adfp_tsdf_stage(C.byref(sc), C.byref(ap), _lib.ptr(flags), _lib.ptr(lst), _lib.ptr(attu),
                                                      None, _lib.ptr(cnt), st))
     res['batch_ms'] = timed(lambda: eng.render_forward(dec, scene.c, ro, rd, gd, scene.tsdf_volume, tsdf_bnds, scene.bound, 'color', 48, 16))
