@@ -52,8 +52,11 @@ struct DecLayoutH {
     __host__ __device__ static constexpr int P_BC(int i) { return P_WC(i) + KS_C * 512; }
     static constexpr int P_WO = P_WP(5);                              // [2][NOUT][16] f32
     static constexpr int P_BO = P_WO + 2 * NOUT * 16;
-    static constexpr int P_FLAG = P_BO + 4;                           // word 0: non-zero = a weight is outside the f16 range
-    static constexpr int P_TOTAL = P_FLAG + 4;
+    // one word per 256-word block of the pack kernel: non-zero = that block met a weight outside the f16 range (image_out_of_range)
+    static constexpr int P_FLAG = P_BO + 4;
+    static constexpr int NFLAG = (((P_FLAG + 511) / 256) + 3) & ~3;
+    static constexpr int P_TOTAL = P_FLAG + NFLAG;
+    static_assert((P_TOTAL + 255) / 256 <= NFLAG, "one flag word per pack block");
 };
 
 // source of 32-bit word t of the H image: either one f32 of the flat buffer (kind 0) or a pair of
@@ -101,26 +104,34 @@ __device__ HSrc dec_h_src(int t) {
 __device__ __forceinline__ float f16_hi_part(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFFE000u); }
 __device__ __forceinline__ float f16_clamp(float x) { return fminf(fmaxf(x, -65504.0f), 65504.0f); }
 
-// Is any parameter of the flat buffer outside the f16 range?  Evaluated by workgroup 0 alone over the whole buffer (16-33 k floats:
-// a couple of microseconds) so that the answer is ONE plain store into the image's flag word: no atomics, nothing to zero first.
-ADFP_DEV void pack_range_flag(const float* __restrict__ flat, int n_flat, unsigned* __restrict__ flag_word, int* __restrict__ status, int bit) {
-    if (blockIdx.x != 0) return;
-    int bad = 0;
-    for (int i = threadIdx.x; i < n_flat; i += blockDim.x) bad |= !(fabsf(flat[i]) < 65504.0f);
-    bad = __syncthreads_or(bad);
+// Range flags of an H image: every workgroup of the pack kernel (NFLAG of them, one per 256 words; the grid is exactly NFLAG blocks)
+// ORs what its own threads saw and stores ONE word -- plain stores, nothing to zero first, no serial sweep over the parameters.
+// The decoder kernels OR the NFLAG words once per workgroup while they wait for their LDS image anyway.
+template <int P_FLAG, int NFLAG>
+ADFP_DEV bool image_out_of_range(const unsigned* ldsu) {
+    const int bad = (int)threadIdx.x < NFLAG ? (int)ldsu[P_FLAG + threadIdx.x] : 0;
+    return __syncthreads_or(bad) != 0;
+}
+ADFP_DEV void pack_block_flag(bool bad, unsigned* __restrict__ flag_word, int* __restrict__ status, int bit) {
+    const int any = __syncthreads_or(bad ? 1 : 0);
     if (threadIdx.x == 0) {
-        *flag_word = bad ? 1u : 0u;
-        if (bad && status) __hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        *flag_word = any ? 1u : 0u;
+        if (any && status) __hip_atomic_fetch_or(status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 template <int CDIM, int NOUT>
 __global__ void k_pack_decoder_h(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status, int bit) {
-    pack_range_flag(flat, DecLayout<CDIM, NOUT>::F_TOTAL, packed + DecLayoutH<CDIM, NOUT>::P_FLAG, status, bit);
+    using L = DecLayoutH<CDIM, NOUT>;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= DecLayoutH<CDIM, NOUT>::P_TOTAL || t == DecLayoutH<CDIM, NOUT>::P_FLAG) return;
-    const HSrc s = dec_h_src<CDIM, NOUT>(t);
-    if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(flat[s.s0]); return; }
-    float a = s.s0 < 0 ? 0.f : flat[s.s0], b = s.s1 < 0 ? 0.f : flat[s.s1];
+    HSrc s{0, -1, -1};
+    float a = 0.f, b = 0.f;
+    if (t < L::P_FLAG) {
+        s = dec_h_src<CDIM, NOUT>(t);
+        a = s.s0 < 0 ? 0.f : flat[s.s0]; b = s.s1 < 0 ? 0.f : flat[s.s1];
+    }
+    pack_block_flag(!(fmaxf(fabsf(a), fabsf(b)) < 65504.0f), packed + L::P_FLAG + blockIdx.x, status, bit);      // every f32 word and every weight passes through here once
+    if (t >= L::P_FLAG) return;
+    if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(a); return; }
     a = f16_clamp(a); b = f16_clamp(b);          // out of range (flagged above / by pack_range_flag): stay finite, 0 x inf must not appear downstream
     const float ah = f16_hi_part(a), bh = f16_hi_part(b);
     _Float16 x, y;
@@ -259,7 +270,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
 #ifdef ADFP_STAMPS
     unsigned long long ph_[6] = {0, 0, 0, 0, 0, 0}, last_ = clock64();
 #endif
-    float amax = ldsu[L::P_FLAG] ? INFINITY : 0.f;      // max |operand| this wave has split (f16 range guard); a weight out of range
+    float amax = image_out_of_range<L::P_FLAG, L::NFLAG>(ldsu) ? INFINITY : 0.f;      // max |operand| this wave has split (f16 range guard); a weight out of range
     for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<NT / 64>(j, &s_next, ntiles)) >= 0;) {
         ADFP_PHASE(0);                                  // ticket + loop overhead
         const int idx = tile * 32 + p;
@@ -475,7 +486,8 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc(DecodeLCArgs a) {
     const int lane_off = h * 128 + p * 4;
     const int count = a.P.n;
     const int ntiles = (count + 31) >> 5;
-    float amax_low = lds_low[LL::P_FLAG] ? INFINITY : 0.f, amax_col = lds_col[LC::P_FLAG] ? INFINITY : 0.f;
+    float amax_low = image_out_of_range<LL::P_FLAG, LL::NFLAG>(lds_low) ? INFINITY : 0.f;
+    float amax_col = image_out_of_range<LC::P_FLAG, LC::NFLAG>(lds_col) ? INFINITY : 0.f;
     // The second image lies beyond the 64 KB reach of a ds_read's immediate offset.  With its address a compile-time constant the
     // compiler materialised one address register per distinct offset and hoisted them all out of the tile loop (109 spilled
     // VGPRs); with the image's word offset an opaque register value every access is (offset + lane term) + small immediate again.
@@ -532,8 +544,10 @@ struct AttLayoutH {
     static constexpr int P_B3 = P_W3 + 2 * 8 * 512;
     static constexpr int P_WO = P_B3 + 64;                       // [2 h][2 o][32] f32
     static constexpr int P_BO = P_WO + 128;
-    static constexpr int P_FLAG = P_BO + 4;                       // word 0: non-zero = a weight is outside the f16 range
-    static constexpr int P_TOTAL = P_FLAG + 4;
+    static constexpr int P_FLAG = P_BO + 4;                       // range flags, one word per pack block (see DecLayoutH)
+    static constexpr int NFLAG = (((P_FLAG + 511) / 256) + 3) & ~3;
+    static constexpr int P_TOTAL = P_FLAG + NFLAG;
+    static_assert((P_TOTAL + 255) / 256 <= NFLAG, "one flag word per pack block");
 };
 
 __device__ HSrc att_h_src(int t) {
@@ -562,12 +576,17 @@ __device__ HSrc att_h_src(int t) {
     return HSrc{0, o < 2 ? F::F_BO + o : -1, -1};
 }
 __global__ void k_pack_attention_h(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status) {
-    pack_range_flag(flat, AttLayout::F_TOTAL, packed + AttLayoutH::P_FLAG, status, ADFP_STATUS_F16_RANGE_ATT);
+    using L = AttLayoutH;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= AttLayoutH::P_TOTAL || t == AttLayoutH::P_FLAG) return;
-    const HSrc s = att_h_src(t);
-    if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(flat[s.s0]); return; }
-    float a = flat[s.s0], b = flat[s.s1];
+    HSrc s{0, -1, -1};
+    float a = 0.f, b = 0.f;
+    if (t < L::P_FLAG) {
+        s = att_h_src(t);
+        a = s.s0 < 0 ? 0.f : flat[s.s0]; b = s.s1 < 0 ? 0.f : flat[s.s1];
+    }
+    pack_block_flag(!(fmaxf(fabsf(a), fabsf(b)) < 65504.0f), packed + L::P_FLAG + blockIdx.x, status, ADFP_STATUS_F16_RANGE_ATT);
+    if (t >= L::P_FLAG) return;
+    if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(a); return; }
     a = f16_clamp(a); b = f16_clamp(b);          // out of range (flagged above / by pack_range_flag): stay finite, 0 x inf must not appear downstream
     const float ah = f16_hi_part(a), bh = f16_hi_part(b);
     _Float16 x, y;
@@ -601,7 +620,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
     const int lane_off = h * 128 + p * 4;
     const int count = a.count_ptr ? *a.count_ptr : a.n_rows;
     const int ntiles = (count + 31) >> 5;
-    float amax = ldsu[A::P_FLAG] ? INFINITY : 0.f;
+    float amax = image_out_of_range<A::P_FLAG, A::NFLAG>(ldsu) ? INFINITY : 0.f;
     for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<8>(j, &s_next, ntiles)) >= 0;) {
         const int idx = tile * 32 + p;
         const bool valid = idx < count;

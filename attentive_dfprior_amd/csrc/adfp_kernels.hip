@@ -1067,13 +1067,13 @@ int adfp_pack_decoder_h(int kind, const float* flat, void* packed, int* status, 
     unsigned* out = (unsigned*)packed;
     switch (kind) {
         case ADFP_DEC_LOW:
-            hipLaunchKernelGGL((k_pack_decoder_h<32, 1>), dim3((DecLayoutH<32, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_LOW);
+            hipLaunchKernelGGL((k_pack_decoder_h<32, 1>), dim3(DecLayoutH<32, 1>::NFLAG), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_LOW);
             break;
         case ADFP_DEC_HIGH:
-            hipLaunchKernelGGL((k_pack_decoder_h<64, 1>), dim3((DecLayoutH<64, 1>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_HIGH);
+            hipLaunchKernelGGL((k_pack_decoder_h<64, 1>), dim3(DecLayoutH<64, 1>::NFLAG), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_HIGH);
             break;
         case ADFP_DEC_COLOR:
-            hipLaunchKernelGGL((k_pack_decoder_h<32, 4>), dim3((DecLayoutH<32, 4>::P_TOTAL + 255) / 256), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_COLOR);
+            hipLaunchKernelGGL((k_pack_decoder_h<32, 4>), dim3(DecLayoutH<32, 4>::NFLAG), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_COLOR);
             break;
         default: return ADFP_E_ARG;
     }
@@ -1117,7 +1117,7 @@ long long adfp_train_act_floats(int kind) {
 long long adfp_attention_packed_h_words(void) { return AttLayoutH::P_TOTAL; }
 int adfp_pack_attention_h(const float* flat, void* packed, int* status, void* stream) {
     if (!flat || !packed) return ADFP_E_ARG;
-    hipLaunchKernelGGL(k_pack_attention_h, dim3((AttLayoutH::P_TOTAL + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat, (unsigned*)packed, status);
+    hipLaunchKernelGGL(k_pack_attention_h, dim3(AttLayoutH::NFLAG), dim3(256), 0, (hipStream_t)stream, flat, (unsigned*)packed, status);
     ADFP_CHECK_LAUNCH();
     return 0;
 }

@@ -549,6 +549,9 @@ def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, N
 
     t_color = timed(lambda b: _lib.check(L.adfp_decode_stage(C.byref(sc), C.byref(b[0]), 2, _lib.ptr(raw), _lib.ptr(wbuf), st), 'decode'))
     t_low = timed(lambda b: _lib.check(L.adfp_decode_stage(C.byref(sc), C.byref(b[0]), 0, _lib.ptr(raw), _lib.ptr(wbuf), st), 'decode'))
+    # the launch stage color actually uses in the default mode: low + colour decoder fused (k_decode_lc)
+    t_lc = timed(lambda b: _lib.check(L.adfp_decode_stage(C.byref(sc), C.byref(b[0]), 3, _lib.ptr(raw), _lib.ptr(wbuf), st), 'decode')) \
+        if sc.h_low and sc.h_color else None
     t_tsdf = timed(lambda b: _lib.check(L.adfp_tsdf_stage(C.byref(sc), C.byref(b[0]), _lib.ptr(flags), _lib.ptr(lst), _lib.ptr(attu),
                                                           None, _lib.ptr(cnt), st), 'tsdf'))
     t_all = timed(lambda b: eng.render_forward(dec, scene.c, b[1], b[2], b[3], scene.tsdf_volume, tsdf_bnds, scene.bound,
@@ -564,17 +567,21 @@ def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, N
                 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS,
                 'frac_algorithmic': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None}
     else:
-        ex = F16X3_FLOP_COLOR * pts_per_launch / t_color / 1e12
-        roof = {'kernel': 'k_decode_h<32,4,COLOR> (colour decoder, f16 MFMA with 3-product f32 operand split)',
+        # dominant kernel of the default mode: the fused low + colour launch (2 x 90 f16 MFMAs per 32-point tile)
+        fl_color = 2.0 * (MAC_LOW + MAC_COLOR) * pts_per_launch
+        t_color_alone, t_color = t_color, t_lc
+        ach = fl_color / t_color / 1e12
+        ex = 2.0 * F16X3_FLOP_COLOR * pts_per_launch / t_color / 1e12
+        roof = {'kernel': 'k_decode_lc<768> (low + colour decoder in one launch, f16 MFMA with 3-product f32 operand split)',
                 'bound': 'mfma', 'achieved': ex, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': ex / PEAK_F16_MFMA_TFLOPS, 'frac_algorithmic': ach / PEAK_F16_MFMA_TFLOPS, 'traffic': None,
-                'note': 'achieved / frac = EXECUTED f16 MFMA FLOP (3 products per f32 product + K padding = 2.96 x algorithmic) '
-                        'against the 2.4 GHz dense-f16 spec peak; frac_algorithmic = algorithmic FLOP (2 x 15 575 per sample, '
+                'note': 'achieved / frac = EXECUTED f16 MFMA FLOP (3 products per f32 product + K padding = 2.97 x algorithmic) '
+                        'against the 2.4 GHz dense-f16 spec peak; frac_algorithmic = algorithmic FLOP (2 x (15 479 + 15 575) per sample, '
                         'SURVEY.md section 8d) against the same peak; algorithmic_f32_tflops / frac_of_f32_mfma_peak = the same '
                         'algorithmic FLOP against the f32-input MFMA peak the exact mode is bound by',
                 'algorithmic_f32_tflops': ach, 'f32_mfma_peak_tflops': PEAK_F32_MFMA_TFLOPS,
                 'frac_of_f32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS}
-    kname = 'void k_decode<32, 4, 2' if math_mode() == 'f32' else 'void k_decode_h<32, 4, 2'
+    kname = 'void k_decode<32, 4, 2' if math_mode() == 'f32' else 'void k_decode_lc<'
     roof['traffic'], prov = pmc_traffic(kname, pts_per_launch)
     roof['traffic_source'] = dict(prov, note='PROFILED bytes/sample (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes) x this run\'s '
                                              'samples per launch; stale = the csv was taken from a different build of the kernels')
@@ -589,8 +596,9 @@ def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, N
                           'frac': by / t_tsdf / 1e9 / PEAK_HBM_GBPS, 'traffic': tsdf_traffic,
                           'real_hbm_gbps': (tsdf_traffic / t_tsdf / 1e9) if tsdf_traffic else None,
                           'bytes_per_launch': by, 'avg_launch_ms': t_tsdf * 1e3},
-        'stage_avg_launch_ms': {'color_decoder': t_color * 1e3, 'low_decoder': t_low * 1e3, 'tsdf': t_tsdf * 1e3,
-                                'whole_render_batch_ray': t_all * 1e3},
+        'stage_avg_launch_ms': {'low_color_decoder_fused': (t_lc * 1e3) if t_lc else None,
+                                'color_decoder_alone': (t_color_alone if math_mode() != 'f32' else t_color) * 1e3,
+                                'low_decoder_alone': t_low * 1e3, 'tsdf': t_tsdf * 1e3, 'whole_render_batch_ray': t_all * 1e3},
         'in_band_fraction': band_frac,
         'useful_tflops_whole_frame': useful / t_all / 1e12,
     }
