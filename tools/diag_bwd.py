@@ -69,7 +69,7 @@ def main():
             scale = ref[k].abs().max().item()
             err = (got[k] - ref[k]).abs().max().item()
             rel = err / max(scale, 1e-30)
-            if rel > 1e-4:
+            if rel > float(os.environ.get('DIAG_TOL', '1e-4')):
                 print(f'{k:44s} rel {rel:.2e}  scale {scale:.2e}')
             if worst is None or rel > worst[1]:
                 worst = (k, rel)
