@@ -9,10 +9,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ADFP_LIB_PATH', os.path.join(_HERE, 'libadfp.so'))   # override: kernel A/B builds
 
-ABI_VERSION = 116                 # ADFP_VERSION of include/adfp.h this binding was written against
+ABI_VERSION = 117                 # ADFP_VERSION of include/adfp.h this binding was written against
 STATUS_F16_RANGE = 31              # ADFP_STATUS_F16_RANGE: any of the bits below
 STATUS_RANGE_BITS = {'low': 1, 'high': 2, 'color': 4, 'att': 8, 'bwd': 16}      # ADFP_STATUS_F16_RANGE_<net>
 BWD_SCATTER_IN_KERNEL = 1        # ADFP_BWD_SCATTER_IN_KERNEL
+BWD_GRIDS_PREZEROED = 2          # ADFP_BWD_GRIDS_PREZEROED
 STAGE = {'low': 0, 'high': 1, 'color': 2}
 DEC_KIND = {'low': 0, 'high': 1, 'color': 2}
 PTS_RAYS, PTS_F64, PTS_F32 = 0, 1, 2
@@ -62,6 +63,11 @@ TRAIN_ATT_ACT_FLOATS = 416        # ADFP_TRAIN_ATT_ACT_FLOATS
 class AdfpAdamGroup(C.Structure):
     _fields_ = [('param', C.c_void_p), ('grad', C.c_void_p), ('exp_avg', C.c_void_p), ('exp_avg_sq', C.c_void_p),
                 ('mask', C.c_void_p), ('nvox', C.c_longlong), ('channels', C.c_int), ('derived', C.c_void_p)]
+
+
+class AdfpAdamClGroup(C.Structure):
+    _fields_ = [('param_cl', C.c_void_p), ('param_cm', C.c_void_p), ('grad_cl', C.c_void_p), ('exp_avg_cl', C.c_void_p),
+                ('exp_avg_sq_cl', C.c_void_p), ('mask', C.c_void_p), ('nvox', C.c_longlong), ('derived', C.c_void_p)]
 
 
 class AdfpRenderArgs(C.Structure):
@@ -157,6 +163,7 @@ SYMBOLS = [
     ('adfp_masked_adam_dev', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int,
                                        C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     ('adfp_masked_adam_multi', C.c_int, [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    ('adfp_adam_grids_cl', C.c_int, [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     ('adfp_sort_workspace_bytes', C.c_size_t, [C.c_longlong]),
     ('adfp_sort_pairs', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     ('adfp_tsdf_stage', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_void_p, C.c_void_p,

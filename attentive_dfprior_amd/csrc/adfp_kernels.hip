@@ -1609,6 +1609,24 @@ int adfp_masked_adam_multi(int n_groups, const adfp_adam_group* groups, float be
     ADFP_CHECK_LAUNCH();
     return 0;
 }
+int adfp_adam_grids_cl(int n_groups, const adfp_adam_cl_group* groups, float beta1, float beta2, float eps, void* stream) {
+    if (n_groups < 0 || n_groups > ADFP_ADAM_CL_MULTI || (n_groups && !groups)) return ADFP_E_ARG;
+    AdamClMultiArgs m; m.n = 0; m.first_block[0] = 0;
+    for (int k = 0; k < n_groups; ++k) {
+        const adfp_adam_cl_group& g = groups[k];
+        if (!g.param_cl || !g.param_cm || !g.grad_cl || !g.exp_avg_cl || !g.exp_avg_sq_cl || !g.derived || g.nvox < 0) return ADFP_E_ARG;
+        if (g.nvox == 0) continue;
+        AdamClArgs& a = m.g[m.n];
+        a.p_cl = g.param_cl; a.p_cm = g.param_cm; a.g_cl = g.grad_cl; a.m_cl = g.exp_avg_cl; a.v_cl = g.exp_avg_sq_cl; a.mask = g.mask;
+        a.nvox = g.nvox; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.derived = g.derived;
+        m.first_block[m.n + 1] = m.first_block[m.n] + (unsigned)((g.nvox + 63) / 64);
+        ++m.n;
+    }
+    if (m.n == 0) return 0;
+    hipLaunchKernelGGL(k_adam_cl_multi, dim3(m.first_block[m.n]), dim3(256), 0, (hipStream_t)stream, m);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
 int adfp_prefilter_mask(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double* bound_dev,
                         unsigned char* keep, float* depth_max, void* stream) {
     if (!rays_o || !rays_d || !gt_depth || !bound_dev || !keep || !depth_max || n_rays <= 0) return ADFP_E_ARG;
@@ -1942,11 +1960,12 @@ static int run_decode_bwd(DecodeBwdArgs a, int total, const int* count_ptr, floa
 // gradient outputs shared by the two backward entries
 struct GradOut { float* grid_low; float* grid_high; float* grid_color; float* flat_low; float* flat_high; float* flat_color; float* flat_att; };
 
-static int zero_grad_outputs(const adfp_scene* sc, const GradOut& g, hipStream_t st) {
+static int zero_grad_outputs(const adfp_scene* sc, const GradOut& g, int options, hipStream_t st) {
+    const bool zg = !(options & ADFP_BWD_GRIDS_PREZEROED);
     struct { float* p; size_t n; } zs[7] = {
-        {g.grid_low, (size_t)sc->low.Z * sc->low.Y * sc->low.X * 32},
-        {g.grid_high, (size_t)sc->high.Z * sc->high.Y * sc->high.X * 32},
-        {g.grid_color, (size_t)sc->color.Z * sc->color.Y * sc->color.X * 32},
+        {zg ? g.grid_low : nullptr, (size_t)sc->low.Z * sc->low.Y * sc->low.X * 32},
+        {zg ? g.grid_high : nullptr, (size_t)sc->high.Z * sc->high.Y * sc->high.X * 32},
+        {zg ? g.grid_color : nullptr, (size_t)sc->color.Z * sc->color.Y * sc->color.X * 32},
         {g.flat_low, (size_t)DecLayout<32, 1>::F_TOTAL}, {g.flat_high, (size_t)DecLayout<64, 1>::F_TOTAL},
         {g.flat_color, (size_t)DecLayout<32, 4>::F_TOTAL}, {g.flat_att, (size_t)AttLayout::F_TOTAL}};
     ZeroBatch zb;
@@ -2121,7 +2140,7 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
     if (fuse && (!r->state.flags || !r->state.list || !r->state.counter || !r->state.att_occ || !r->state.att_u)) return ADFP_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     const GradOut go = {r->g_grid_low, r->g_grid_high, r->g_grid_color, r->g_flat_low, r->g_flat_high, r->g_flat_color, r->g_flat_att};
-    rc = zero_grad_outputs(sc, go, st); if (rc) return rc;       // every non-NULL output is zeroed, then accumulated into
+    rc = zero_grad_outputs(sc, go, r->options, st); if (rc) return rc;       // every non-NULL output is zeroed, then accumulated into
     if (r->n_rays == 0) return 0;
     const int P = (int)Pn;
 
@@ -2179,7 +2198,7 @@ extern "C" int adfp_eval_points_backward(const adfp_scene* sc, const adfp_points
     if (fuse && (!r->state.flags || !r->state.list || !r->state.counter || !r->state.att_occ || !r->state.att_u)) return ADFP_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     const GradOut go = {r->g_grid_low, r->g_grid_high, r->g_grid_color, r->g_flat_low, r->g_flat_high, r->g_flat_color, r->g_flat_att};
-    rc = zero_grad_outputs(sc, go, st); if (rc) return rc;
+    rc = zero_grad_outputs(sc, go, r->options, st); if (rc) return rc;
     if (Pd.n == 0) return 0;
     hipLaunchKernelGGL(k_evalpts_bwd_prep, dim3((Pd.n + 255) / 256), dim3(256), 0, st, Pd, r->g_raw, bw.g_raw, sc->bound[0][0], sc->bound[0][1],
                        sc->bound[1][0], sc->bound[1][1], sc->bound[2][0], sc->bound[2][1], (r->flags & ADFP_EVAL_APPLY_BOUND) ? 1 : 0, bw.gmax_parts, r->g_w, r->state.counter ? r->state.counter + 8 : nullptr);

@@ -164,3 +164,55 @@ ADFP_DEV void masked_adam_block(const AdamArgs& a, long long block) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) if ((mk >> (8 * k)) & 0xffu) adam_one(a, base + k, step_size, sqrt_bc2);
 }
+
+// Adam on channels-last state (adfp_adam_grids_cl): a workgroup owns 64 consecutive voxels = 2 048 consecutive floats of every
+// channels-last buffer (coalesced 16-byte accesses), steps the masked ones, zeroes the gradient it consumed, and writes the new
+// parameters through to the reference-layout grid [32][nvox] via a padded LDS tile so that those stores are 256-byte runs per
+// channel.  Arithmetic = adam_one, element for element what torch.optim.Adam does.
+struct AdamClArgs {
+    float* p_cl; float* p_cm; float* g_cl; float* m_cl; float* v_cl; const unsigned char* mask; long long nvox;
+    float beta1, beta2, eps; const float* derived;
+};
+#define ADFP_ADAM_CL_MULTI 8
+struct AdamClMultiArgs { AdamClArgs g[ADFP_ADAM_CL_MULTI]; unsigned first_block[ADFP_ADAM_CL_MULTI + 1]; int n; };
+__global__ __launch_bounds__(256) void k_adam_cl_multi(AdamClMultiArgs m) {
+    __shared__ float tile[32][65];
+    __shared__ unsigned char s_mask[64];
+    int j = 0;
+    while (j + 1 < m.n && blockIdx.x >= m.first_block[j + 1]) ++j;
+    const AdamClArgs& a = m.g[j];
+    const long long v0 = ((long long)blockIdx.x - m.first_block[j]) * 64;
+    const int nv = a.nvox - v0 < 64 ? (int)(a.nvox - v0) : 64;
+    if (threadIdx.x < 64) s_mask[threadIdx.x] = ((int)threadIdx.x < nv && (!a.mask || a.mask[v0 + threadIdx.x])) ? 1 : 0;
+    __syncthreads();
+    const float step_size = a.derived[0], sqrt_bc2 = a.derived[1];
+    const bool stepping = sqrt_bc2 != 0.f;                    // k_adam_prep's "skip this iteration"
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e4 = threadIdx.x + 256 * k;                 // f32x4 index inside the block's 64 x 32 floats
+        const int vl = e4 >> 3, c0 = (e4 & 7) * 4;
+        if (vl >= nv) continue;
+        const long long off = (v0 + vl) * 32 + c0;
+        const f32x4 g = *(const f32x4*)(a.g_cl + off);
+        *(f32x4*)(a.g_cl + off) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!stepping || !s_mask[vl]) continue;
+        any = true;
+        f32x4 p = *(const f32x4*)(a.p_cl + off), mo = *(const f32x4*)(a.m_cl + off), vo = *(const f32x4*)(a.v_cl + off);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float mm = __fadd_rn(__fmul_rn(mo[q], a.beta1), __fmul_rn(g[q], 1.f - a.beta1));
+            const float vv = __fadd_rn(__fmul_rn(vo[q], a.beta2), __fmul_rn(__fmul_rn(1.f - a.beta2, g[q]), g[q]));
+            const float denom = __fadd_rn(__fdiv_rn(sqrtf(vv), sqrt_bc2), a.eps);
+            p[q] = __fadd_rn(p[q], __fdiv_rn(__fmul_rn(-step_size, mm), denom));
+            mo[q] = mm; vo[q] = vv;
+            tile[c0 + q][vl] = p[q];
+        }
+        *(f32x4*)(a.p_cl + off) = p; *(f32x4*)(a.m_cl + off) = mo; *(f32x4*)(a.v_cl + off) = vo;
+    }
+    if (!__syncthreads_or(any ? 1 : 0)) return;                // nothing stepped in this block: the reference-layout grid is untouched
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;    // 64 voxels x 4 channel rows per pass
+    if (tx < nv && s_mask[tx])
+#pragma unroll
+        for (int c = ty; c < 32; c += 4) a.p_cm[(long long)c * a.nvox + v0 + tx] = tile[c][tx];
+}

@@ -60,6 +60,12 @@ class Engine(object):
         self._bound_cache[slot] = (key, val, t.untyped_storage())     # pins the storage, see grid_cl
         return val
 
+    def adopt_grid_cl(self, name, g, shadow):
+        """`shadow` IS the channels-last copy of grid `g` as it stands (the caller keeps it coherent: mapping.MapperIteration updates
+        both in one Adam kernel): the next scene() finds it in the cache instead of re-laying the grid out."""
+        key = (g.data_ptr(), g._version, tuple(g.shape), tuple(g.stride()))
+        self._grid_cache[name] = (key, shadow, g.untyped_storage(), 'adopted')      # never recycled as a re-layout destination
+
     def grid_cl(self, name, g):
         """channels-last copy of a [1,32,Z,Y,X] grid, converted by adfp_relayout_grid."""
         _lib.require_cuda(g, name)
@@ -74,7 +80,7 @@ class Engine(object):
             src = src.float()
         src = src.contiguous()
         Z, Y, X = src.shape[2:]
-        if hit is not None and hit[1].shape == (Z, Y, X, 32) and hit[1].device == src.device:
+        if hit is not None and len(hit) == 3 and hit[1].shape == (Z, Y, X, 32) and hit[1].device == src.device:
             dst = hit[1]
         else:
             dst = torch.empty((Z, Y, X, 32), dtype=torch.float32, device=src.device)
@@ -423,11 +429,15 @@ class Engine(object):
 
     # ---- a15 -------------------------------------------------------------------------------
     def render_backward(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, saved, g_depth, g_unc, g_color,
-                        g_weight, need_grid, need_flat, need_rays=False, ray_keep=None, out_grids=None, out_flats=None):
+                        g_weight, need_grid, need_flat, need_rays=False, ray_keep=None, out_grids=None, out_flats=None,
+                        out_grids_cl=None, grids_prezeroed=False):
         """saved: the aux dict of render_forward(train=True).  need_grid / need_flat: dicts of bools.
         out_grids / out_flats: optional caller-owned result tensors (name -> [1,32,Z,Y,X] / flat), e.g. slices of one
         gradient bucket that is all-reduced as it stands.
-        Returns (grid grads dict in the reference's [1,32,Z,Y,X] layout, flat parameter grads dict)."""
+        out_grids_cl: caller-owned CHANNELS-LAST gradient tensors (name -> [Z,Y,X,32]): the kernels' own layout, handed back as
+        it is (no re-layout); grids_prezeroed = they are all zero on entry (mapping.MapperIteration keeps them so).
+        Returns (grid grads dict in the reference's [1,32,Z,Y,X] layout -- or channels-last for out_grids_cl --, flat parameter
+        grads dict)."""
         ro = saved['rays_o']
         dev = ro.device
         L = lib()
@@ -453,9 +463,14 @@ class Engine(object):
             if ray_keep is not None:
                 a.ray_keep = ray_keep.data_ptr()
             grids_cl, flats = {}, {}
+            direct = {}
             for name, key in (('low', 'grid_low'), ('high', 'grid_high'), ('color', 'grid_color')):
                 if need_grid.get(name):
                     Z, Y, X = c[key].shape[2:]
+                    if out_grids_cl and name in out_grids_cl:
+                        direct[name] = out_grids_cl[name]
+                        setattr(a, 'g_grid_' + name, direct[name].data_ptr())
+                        continue
                     grids_cl[name] = torch.empty((Z, Y, X, 32), dtype=torch.float32, device=dev)
                     setattr(a, 'g_grid_' + name, grids_cl[name].data_ptr())
             sizes = {'low': L.adfp_decoder_flat_floats(0), 'high': L.adfp_decoder_flat_floats(1),
@@ -473,10 +488,10 @@ class Engine(object):
             need = L.adfp_backward_workspace_bytes(N * S)
             ws = torch.empty(int(need) + 1024, dtype=torch.uint8, device=dev)
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-            a.options = self.bwd_options
+            a.options = self.bwd_options | (_lib.BWD_GRIDS_PREZEROED if (grids_prezeroed and not grids_cl) else 0)
             stream = _lib.current_stream(dev)
             check(L.adfp_render_backward(C.byref(sc), C.byref(a), stream), 'adfp_render_backward')
-            grids = {}
+            grids = dict(direct)
             for name, g in grids_cl.items():
                 Z, Y, X = g.shape[:3]
                 out = out_grids[name] if out_grids and name in out_grids else torch.empty((1, 32, Z, Y, X), dtype=torch.float32, device=dev)

@@ -158,7 +158,15 @@ class MapperIteration(object):
             if g.dtype != torch.float32 or not g.is_contiguous():
                 raise ValueError(f'{k}: expected a contiguous float32 grid')
         self.masks = {k: (None if masks is None or masks.get(k) is None else masks[k].to(dev, torch.uint8).contiguous()) for k in c}
-        self.gstate = {k: (torch.zeros_like(g), torch.zeros_like(g)) for k, g in c.items()}
+        # The grids' optimiser state lives in the kernels' CHANNELS-LAST layout [Z,Y,X,32]: a shadow copy of each grid (what the
+        # render kernels read), both Adam moments and the gradient.  adfp_adam_grids_cl steps the shadow, writes the new values
+        # through to the reference-layout grid in `c` (what the rest of the system sees) and zeroes the gradient it consumed --
+        # per grid and iteration that replaces the forward's re-layout, the backward's re-layout and a zero fill.
+        def cl_like(g):
+            return torch.zeros((g.shape[2], g.shape[3], g.shape[4], g.shape[1]), dtype=torch.float32, device=dev)
+        self.shadow = {k: cl_like(g) for k, g in c.items()}
+        self._shadow_version = {k: None for k in c}              # c[k]._version the shadow was last made coherent with
+        self.gstate = {k: (cl_like(g), cl_like(g)) for k, g in c.items()}
         self.nets = tuple(train)
         attr = {'low': 'low_decoder', 'high': 'high_decoder', 'color': 'color_decoder', 'att': 'mlp'}
         self.flat = {n: flatten_parameters(getattr(decoders, attr[n])) for n in self.nets}
@@ -193,7 +201,7 @@ class MapperIteration(object):
             n = c[key].numel() if kind == 'grid' else self.flat[name].numel()
             self._bucket_layout.append((kind, name, key, off, n))
             off += n
-        self.bucket = torch.empty(off, dtype=torch.float32, device=dev)
+        self.bucket = torch.zeros(off, dtype=torch.float32, device=dev)      # grid slots: channels-last, kept all-zero between iterations
         self._index = {}
         if self.distributed:
             self._build_index()
@@ -233,9 +241,9 @@ class MapperIteration(object):
             tdist.all_reduce(self.bucket[:end], op=tdist.ReduceOp.SUM, group=self.group)
             return end * 4
         parts = [f for f in flats.values()]
-        for n, g in grids.items():
+        for n, g in grids.items():                       # channels-last [Z,Y,X,32]: a selected voxel is one 128-byte row
             idx = self._index.get(key[n])
-            parts.append(g.reshape(-1) if idx is None else g.reshape(g.shape[1], -1).index_select(1, idx).reshape(-1))
+            parts.append(g.reshape(-1) if idx is None else g.reshape(-1, 32).index_select(0, idx).reshape(-1))
         buf = torch.cat(parts)
         tdist.all_reduce(buf, op=tdist.ReduceOp.SUM, group=self.group)
         off = 0
@@ -248,9 +256,8 @@ class MapperIteration(object):
                 g.reshape(-1).copy_(buf[off:off + g.numel()])
                 off += g.numel()
             else:
-                ch = g.shape[1]
-                g.reshape(ch, -1).index_copy_(1, idx, buf[off:off + ch * idx.numel()].reshape(ch, -1))
-                off += ch * idx.numel()
+                g.reshape(-1, 32).index_copy_(0, idx, buf[off:off + 32 * idx.numel()].reshape(-1, 32))
+                off += 32 * idx.numel()
         return buf.numel() * 4
 
     # ---- the kernel sequence ------------------------------------------------------------------------------------------
@@ -265,6 +272,7 @@ class MapperIteration(object):
         if self.distributed:
             import torch.distributed as tdist
             tdist.all_reduce(dmax, op=tdist.ReduceOp.MAX, group=self.group)       # the far clamp sees the whole batch (Renderer.py:159)
+        self._sync_shadows()
         used = {'low': ('low',), 'high': ('low', 'high', 'att'), 'color': ('low', 'high', 'color', 'att')}[stage]
         need_grid = {k: (k in used) for k in ('low', 'high', 'color')}
         need_flat = {n: (n in used and n in self.nets) for n in ('low', 'high', 'color', 'att')}
@@ -287,36 +295,42 @@ class MapperIteration(object):
         for kind, name, key, off, n in self._bucket_layout:
             view = self.bucket[off:off + n]
             if kind == 'grid' and need_grid[name]:
-                out_grids[name] = view.view(self.c[key].shape)
+                g = self.c[key]
+                out_grids[name] = view.view(g.shape[2], g.shape[3], g.shape[4], g.shape[1])       # channels-last
                 end = off + n
             elif kind == 'flat' and need_flat[name]:
                 out_flats[name] = view
                 end = off + n
         grids, flats, _ = eng.render_backward(dec, self.c, self.tsdf, self.tsdf_bnds, rend.bound, stage, aux, g_depth, None,
                                               g_color if stage == 'color' else None, g_weight, need_grid, need_flat, ray_keep=keep,
-                                              out_grids=out_grids, out_flats=out_flats)
+                                              out_grids_cl=out_grids, out_flats=out_flats, grids_prezeroed=True)
         self.bucket_bytes = end * 4
         if self.distributed:
             import torch.distributed as tdist
             self.bucket_bytes = self._allreduce_gradients(grids, flats, end)
             tdist.all_reduce(self.loss, op=tdist.ReduceOp.SUM, group=self.group)
         if not adam:
-            return grids, flats
+            # no optimiser step follows (tests / warm-up before a capture): leave the bucket's grid slots zero for the next call.
+            # The caller gets copies in the reference layout.
+            ret = {n: g.permute(3, 0, 1, 2).unsqueeze(0).contiguous() for n, g in grids.items()}
+            for g in grids.values():
+                g.zero_()
+            return ret, flats
         lr = self.stage_lr[stage]
         b1, b2 = self.betas
         # Adam (src/Mapper.py:374-378, :472): a group whose parameters received no gradient in this stage is skipped by torch
         # (grad is None) and is skipped here; a group with lr 0 still advances its moments
-        groups = []
+        groups, cl_groups = [], []
         for name, key in (('low', 'grid_low'), ('high', 'grid_high'), ('color', 'grid_color')):
             if name in grids:
                 g = self.c[key]
-                groups.append((key, g, grids[name], self.gstate[key], self.masks[key], g.shape[2] * g.shape[3] * g.shape[4], g.shape[1], lr[name]))
+                cl_groups.append((key, g, grids[name], self.gstate[key], self.masks[key], g.shape[2] * g.shape[3] * g.shape[4], lr[name]))
         for n in self.nets:
             if n in flats:
                 f = self.flat[n]
                 groups.append((n, f, flats[n], self.fstate[n], None, f.numel(), 1, lr['decoders' if n in ('high', 'color') else 'mlp']))
         lrs = (C.c_float * len(self.groups))(*([-1.0] * len(self.groups)))
-        for (gname, *_rest, lrv) in groups:
+        for (gname, *_rest, lrv) in groups + cl_groups:
             lrs[self.groups.index(gname)] = float(lrv)
         # the forward call's f16-range flag (adfp_train_state.counter[8]): a repaired forward means this iteration's gradients are
         # zero by construction -- then nobody steps (parameters, moments and step counters stay as they are)
@@ -329,8 +343,31 @@ class MapperIteration(object):
             a.mask = mask.data_ptr() if mask is not None else None
             a.nvox, a.channels = int(nvox), int(ch)
             a.derived = self.derived[self.groups.index(gname)].data_ptr()
-        check(L.adfp_masked_adam_multi(len(groups), C.byref(arr), b1, b2, self.eps, st), 'adfp_masked_adam_multi')
+        if groups:
+            check(L.adfp_masked_adam_multi(len(groups), C.byref(arr), b1, b2, self.eps, st), 'adfp_masked_adam_multi')
+        carr = (_lib.AdfpAdamClGroup * max(1, len(cl_groups)))()
+        for k, (gname, g, grad, (m, v), mask, nvox, lrv) in enumerate(cl_groups):
+            a = carr[k]
+            a.param_cl, a.param_cm, a.grad_cl = self.shadow[gname].data_ptr(), g.data_ptr(), grad.data_ptr()
+            a.exp_avg_cl, a.exp_avg_sq_cl = m.data_ptr(), v.data_ptr()
+            a.mask = mask.data_ptr() if mask is not None else None
+            a.nvox = int(nvox)
+            a.derived = self.derived[self.groups.index(gname)].data_ptr()
+        if cl_groups:
+            check(L.adfp_adam_grids_cl(len(cl_groups), C.byref(carr), b1, b2, self.eps, st), 'adfp_adam_grids_cl')
         return grids, flats
+
+    def _sync_shadows(self):
+        """Before a forward: every grid's channels-last shadow is what the engine's layout cache holds for it.  A grid somebody
+        else wrote since our last step (its version is not the one we left) is re-laid out into the shadow first."""
+        eng = self.rend._engine
+        for k, g in self.c.items():
+            if self._shadow_version[k] != g._version:
+                with torch.cuda.device(self.dev):
+                    Z, Y, X = g.shape[2:]
+                    check(lib().adfp_relayout_grid(ptr(g), ptr(self.shadow[k]), 32, Z, Y, X, _lib.current_stream(self.dev)), 'adfp_relayout_grid')
+                self._shadow_version[k] = g._version
+            eng.adopt_grid_cl(k, g, self.shadow[k])
 
     def _drop_volatile_cache_entries(self):
         self.rend._engine._grid_cache.clear()
@@ -341,6 +378,9 @@ class MapperIteration(object):
     def _bump_versions(self):
         for t in self._versioned:
             torch.autograd.graph.increment_version(t)        # updated through raw pointers: invalidate (data_ptr, _version) caches
+        for k, g in self.c.items():                          # ... except the shadows: the Adam kernel kept them coherent
+            self._shadow_version[k] = g._version
+            self.rend._engine.adopt_grid_cl(k, g, self.shadow[k])
 
     @torch.no_grad()
     def step(self, rays_o, rays_d, gt_depth, gt_color, stage, warmup=False):
@@ -357,6 +397,7 @@ class MapperIteration(object):
             # replay is seen one step late at worst, and that step repaired itself and skipped its Adam).  A network that tripped
             # runs on the exact kernels from now on: the graphs are keyed on the set of latched networks.
             self.dec.absorb_status()
+            self._sync_shadows()             # a grid somebody else wrote since our last step is re-laid out here, outside the graph
 
             def graph_key():
                 return (N, stage, bool(warmup), frozenset(self.dec._exact_latch))

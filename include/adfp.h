@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 116
+#define ADFP_VERSION 117
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -309,6 +309,9 @@ typedef struct adfp_backward_args {
 /* grid gradients of the f16-split backward through the in-kernel write-combining scatter instead of the sorted scatter
  * (k_bin_keys + radix sort + k_scatter_sorted); same values up to the order of the float atomics */
 #define ADFP_BWD_SCATTER_IN_KERNEL 1
+/* the caller guarantees that the g_grid_* buffers are all zero on entry (adfp_adam_grids_cl leaves them so): the call does not
+ * zero them again */
+#define ADFP_BWD_GRIDS_PREZEROED 2
 size_t adfp_backward_workspace_bytes(long long n_points);
 int adfp_render_backward(const adfp_scene* scene /*host*/, const adfp_backward_args* args /*host*/, void* stream);
 
@@ -415,6 +418,23 @@ typedef struct adfp_adam_group {
     const float* derived;        /* this group's {step size, sqrt(bias correction 2)} from adfp_adam_prep */
 } adfp_adam_group;
 int adfp_masked_adam_multi(int n_groups, const adfp_adam_group* groups /*host*/, float beta1, float beta2, float eps, void* stream);
+/* The same step on feature grids whose optimiser state lives in the KERNELS' layout: gradient (as adfp_render_backward writes it),
+ * both moments and a shadow copy of the parameters are channels-last [nvox][32]; the reference-layout grid [32][nvox] that the
+ * rest of the system sees (the Tracker reads it from another process, src/Tracker.py:144-147) is written through.  One launch
+ * replaces, per grid and iteration, the forward's re-layout of the updated grid, the backward's re-layout of the gradient and
+ * the zeroing of the gradient buffer: every gradient element is set to zero as it is consumed (masked or not), so the buffer
+ * can go straight into the next adfp_render_backward with ADFP_BWD_GRIDS_PREZEROED.  A skipped step (derived == {0, 0},
+ * adfp_adam_prep's skip_flag) still zeroes the gradient.  Up to 8 grids per launch. */
+typedef struct adfp_adam_cl_group {
+    float* param_cl;             /* [nvox][32] shadow of the grid the render kernels read */
+    float* param_cm;             /* [32][nvox] the reference-layout grid, written through on the masked voxels */
+    float* grad_cl;              /* [nvox][32], consumed and zeroed */
+    float* exp_avg_cl; float* exp_avg_sq_cl;
+    const unsigned char* mask;   /* [nvox] or NULL */
+    long long nvox;
+    const float* derived;        /* {step size, sqrt(bias correction 2)} from adfp_adam_prep */
+} adfp_adam_cl_group;
+int adfp_adam_grids_cl(int n_groups, const adfp_adam_cl_group* groups /*host*/, float beta1, float beta2, float eps, void* stream);
 
 /* Stable radix sort of n (key, value) int pairs by the low key_bits bits of the (non-negative) keys, in place (key_tmp / val_tmp:
  * n ints each).  What the f16-split backward orders the sample points with (by grid cell, adfp_sort.h); exported for testing. */
