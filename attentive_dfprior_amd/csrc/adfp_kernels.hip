@@ -796,6 +796,9 @@ struct AttArgs {
 #define ADFP_DECH_NT 768
 #endif
 #define ADFP_DECH_WG (ADFP_DECH_NT == 256 ? 2 : 1)
+#ifndef ADFP_HIGH_NT
+#define ADFP_HIGH_NT 512
+#endif
 #include "adfp_decode_h.h"
 #include "adfp_fallback.h"
 
@@ -1168,9 +1171,18 @@ int adfp_prefilter_rays(const float* rays_o, const float* rays_d, const float* g
     return 0;
 }
 
+static int sample_rays_impl(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double bound[3][2],
+                            int n_samples, int n_surface, int lindisp, float perturb, const float* t_rand, const float* depth_max,
+                            double* z_vals, void* scratch, void* stream, bool scratch_is_zero);
 int adfp_sample_rays(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double bound[3][2],
                      int n_samples, int n_surface, int lindisp, float perturb, const float* t_rand, const float* depth_max,
                      double* z_vals, void* scratch, void* stream) {
+    return sample_rays_impl(rays_o, rays_d, gt_depth, n_rays, bound, n_samples, n_surface, lindisp, perturb, t_rand, depth_max, z_vals,
+                            scratch, stream, false);
+}
+static int sample_rays_impl(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double bound[3][2],
+                            int n_samples, int n_surface, int lindisp, float perturb, const float* t_rand, const float* depth_max,
+                            double* z_vals, void* scratch, void* stream, bool scratch_is_zero) {
     if (!rays_o || !rays_d || !z_vals || !bound || n_rays < 0 || n_samples <= 0 || n_surface < 0) return ADFP_E_ARG;
     if (perturb > 0.f && !t_rand) return ADFP_E_ARG;
     if (n_samples + n_surface > ADFP_MAX_SAMPLES) return ADFP_E_UNSUPPORTED;
@@ -1183,8 +1195,7 @@ int adfp_sample_rays(const float* rays_o, const float* rays_d, const float* gt_d
     a.n_rays = n_rays; a.n_samples = n_samples; a.n_surface = n_surface; a.lindisp = lindisp; a.perturb = perturb; a.z = z_vals;
     if (gt_depth && !depth_max) {
         if (!scratch) return ADFP_E_ARG;
-        hipError_t e = zero_async(scratch, 16, st);
-        if (e != hipSuccess) return (int)e;
+        if (!scratch_is_zero) { hipError_t e = zero_async(scratch, 16, st); if (e != hipSuccess) return (int)e; }
         int blocks = (n_rays + 2047) / 2048; if (blocks > 64) blocks = 64;     // few blocks: the cost is the atomics' latency
         hipLaunchKernelGGL(k_depth_max, dim3(blocks), dim3(256), 0, st, gt_depth, n_rays, (unsigned*)scratch);
         ADFP_CHECK_LAUNCH();
@@ -1252,7 +1263,7 @@ static int decode_grid(int ntiles, int waves_per_wg, int wg_per_cu) {
 }
 
 static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, int apply_bound, float* raw, float* w, Workspace& ws_in, hipStream_t st,
-                            const adfp_train_state* state = nullptr) {
+                            const adfp_train_state* state = nullptr, bool ws_counter_is_zero = false) {
     if (P.n == 0) return 0;
     Workspace ws = ws_in;
     if (state) {       // training: the backward needs these buffers after the call returns
@@ -1269,7 +1280,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
     // in a training call, where `counter` is the caller's -- the backward entries and the Adam step gate on.
     const bool any_h = sc->h_low || (fuse && (sc->h_high || sc->h_att)) || (stage == ADFP_STAGE_COLOR && sc->h_color);
     int* call_flag = (any_h && ws.counter) ? ws.counter + 8 : nullptr;
-    if ((fuse || any_h || state) && ws.counter) {
+    if ((fuse || any_h || state) && ws.counter && !(ws_counter_is_zero && !state)) {      // (a training call's counter is the caller's buffer)
         e = zero_async(ws.counter, 64, st);
         if (e != hipSuccess) return (int)e;
     }
@@ -1336,7 +1347,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
             a.masks = nullptr; a.act = nullptr;
         } else if (sc->h_high) {
             a.packed = (const float*)sc->h_high;
-            hipLaunchKernelGGL((k_decode_h<64, 1, ROLE_HIGH, 512>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
+            hipLaunchKernelGGL((k_decode_h<64, 1, ROLE_HIGH, ADFP_HIGH_NT>), dim3(decode_grid(ntiles, ADFP_HIGH_NT / 64, 1)), dim3(ADFP_HIGH_NT), 0, st, a);
         } else {
             a.packed = sc->w_high;
             hipLaunchKernelGGL((k_decode<64, 1, ROLE_HIGH, 512>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
@@ -1676,12 +1687,15 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
     hipStream_t st = (hipStream_t)stream;
     double* z = r->z_vals ? r->z_vals : ws.z;
     float* raw = r->raw ? r->raw : ws.raw;
-    rc = adfp_sample_rays(r->rays_o, r->rays_d, r->gt_depth, r->n_rays, scene->bound, r->n_samples, r->n_surface, r->lindisp,
-                          r->perturb, r->t_rand, r->depth_max, z, (char*)ws.counter + 64, stream);
+    // ONE zero fill for the call's small device words: the in-band counter and range flag (bytes 0-63) and the depth-max
+    // reduction's scratch (bytes 64-79) share the first 256 bytes of the workspace
+    { hipError_t e = zero_async(ws.counter, 128, st); if (e != hipSuccess) return (int)e; }
+    rc = sample_rays_impl(r->rays_o, r->rays_d, r->gt_depth, r->n_rays, scene->bound, r->n_samples, r->n_surface, r->lindisp,
+                          r->perturb, r->t_rand, r->depth_max, z, (char*)ws.counter + 64, stream, true);
     if (rc) return rc;
     PtsDev P;
     P.mode = ADFP_PTS_RAYS; P.S = S; P.n = (int)Pn; P.pts = nullptr; P.ro = r->rays_o; P.rd = r->rays_d; P.z = z;
-    rc = eval_points_impl(scene, P, r->stage, 1, raw, r->weight, ws, st, r->state);
+    rc = eval_points_impl(scene, P, r->stage, 1, raw, r->weight, ws, st, r->state, true);
     if (rc) return rc;
     return adfp_composite(raw, z, r->n_rays, S, r->depth, r->uncertainty, r->color, nullptr, stream);
 }
