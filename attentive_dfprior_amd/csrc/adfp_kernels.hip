@@ -799,6 +799,7 @@ struct AttArgs {
 #ifndef ADFP_HIGH_NT
 #define ADFP_HIGH_NT 512
 #endif
+#define ADFP_LC_NT ADFP_DECH_NT
 #include "adfp_decode_h.h"
 #include "adfp_fallback.h"
 
@@ -1302,7 +1303,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         f.g_low = make_grid(sc->low); f.g_color = make_grid(sc->color);
         f.packed_low = (const unsigned*)sc->h_low; f.packed_color = (const unsigned*)sc->h_color;
         f.flags = a.flags; f.raw = raw; f.w = w; f.write_w = 1; f.apply_bound = apply_bound; f.status = sc->status; f.call_flag = call_flag;
-        hipLaunchKernelGGL((k_decode_lc<ADFP_DECH_NT>), dim3(decode_grid(ntiles, ADFP_DECH_NT / 64, 1)), dim3(ADFP_DECH_NT), 0, st, f);
+        hipLaunchKernelGGL((k_decode_lc<ADFP_LC_NT>), dim3(decode_grid(ntiles, ADFP_LC_NT / 64, 1)), dim3(ADFP_LC_NT), 0, st, f);
         ADFP_CHECK_LAUNCH();
     }
     // LOW on every point
@@ -1400,7 +1401,7 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
         f.g_low = make_grid(sc->low); f.g_color = make_grid(sc->color);
         f.packed_low = (const unsigned*)sc->h_low; f.packed_color = (const unsigned*)sc->h_color;
         f.flags = nullptr; f.raw = raw; f.w = w; f.write_w = 1; f.apply_bound = 1; f.status = sc->status; f.call_flag = nullptr;
-        hipLaunchKernelGGL((k_decode_lc<ADFP_DECH_NT>), dim3(decode_grid((P.n + 31) / 32, ADFP_DECH_NT / 64, 1)), dim3(ADFP_DECH_NT), 0, (hipStream_t)stream, f);
+        hipLaunchKernelGGL((k_decode_lc<ADFP_LC_NT>), dim3(decode_grid((P.n + 31) / 32, ADFP_LC_NT / 64, 1)), dim3(ADFP_LC_NT), 0, (hipStream_t)stream, f);
         ADFP_CHECK_LAUNCH();
         return 0;
     }
