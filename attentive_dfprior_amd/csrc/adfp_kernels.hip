@@ -361,9 +361,27 @@ __global__ __launch_bounds__(256) void k_depth_max(const float* __restrict__ d, 
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
+// max(gt_depth) per segment of `seg` consecutive rays (render_img's ray batches): blockIdx.y = segment, blockIdx.x = slice of it;
+// ordered-uint atomicMax into out[segment] (zeroed by the caller), like k_depth_max
+__global__ __launch_bounds__(256) void k_depth_max_seg(const float* __restrict__ d, int n, int seg, unsigned* __restrict__ out) {
+    const int lo = blockIdx.y * seg, hi = lo + seg < n ? lo + seg : n;
+    unsigned m = 0;
+    for (int i = lo + blockIdx.x * 256 + threadIdx.x; i < hi; i += gridDim.x * 256) {
+        const unsigned v = f2ord(d[i]);
+        m = v > m ? v : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned v = __shfl_xor(m, o);
+        m = v > m ? v : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out + blockIdx.y, m);
+}
+
 struct SampleArgs {
     const float* ro; const float* rd; const float* depth; const float* t_rand;
-    const float* dmax_f;        // device float (caller-provided) or NULL
+    const float* dmax_f;        // device float(s) (caller-provided or k_depth_max_seg) or NULL
+    int dmax_seg;               // > 0: dmax_f[ray / dmax_seg] (one maximum per segment of rays), 0: dmax_f[0]
     const unsigned* dmax_ord;   // ordered-uint reduction result or NULL
     double b[6];                // bound lo/hi per axis
     int n_rays, n_samples, n_surface, lindisp;
@@ -430,7 +448,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
     if (active) {
         rs.trand = a.t_rand ? a.t_rand + (long long)ray * a.n_samples : nullptr;
         float dmaxf = 0.f;
-        if (rs.has_depth) dmaxf = a.dmax_f ? *a.dmax_f : ord2f(*a.dmax_ord);
+        if (rs.has_depth) { const int sg = a.dmax_seg > 0 ? ray / a.dmax_seg : 0; dmaxf = a.dmax_f ? a.dmax_f[sg] : ord2f(a.dmax_ord[sg]); }
         rs.dmax = (double)dmaxf;
         rs.dep = rs.has_depth ? a.depth[ray] : 0.f;
         rs.nearf = __fmul_rn(rs.dep, 0.01f);
@@ -1174,7 +1192,7 @@ int adfp_prefilter_rays(const float* rays_o, const float* rays_d, const float* g
 
 static int sample_rays_impl(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double bound[3][2],
                             int n_samples, int n_surface, int lindisp, float perturb, const float* t_rand, const float* depth_max,
-                            double* z_vals, void* scratch, void* stream, bool scratch_is_zero);
+                            double* z_vals, void* scratch, void* stream, bool scratch_is_zero, int segment = 0);
 int adfp_sample_rays(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double bound[3][2],
                      int n_samples, int n_surface, int lindisp, float perturb, const float* t_rand, const float* depth_max,
                      double* z_vals, void* scratch, void* stream) {
@@ -1183,7 +1201,7 @@ int adfp_sample_rays(const float* rays_o, const float* rays_d, const float* gt_d
 }
 static int sample_rays_impl(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double bound[3][2],
                             int n_samples, int n_surface, int lindisp, float perturb, const float* t_rand, const float* depth_max,
-                            double* z_vals, void* scratch, void* stream, bool scratch_is_zero) {
+                            double* z_vals, void* scratch, void* stream, bool scratch_is_zero, int segment) {
     if (!rays_o || !rays_d || !z_vals || !bound || n_rays < 0 || n_samples <= 0 || n_surface < 0) return ADFP_E_ARG;
     if (perturb > 0.f && !t_rand) return ADFP_E_ARG;
     if (n_samples + n_surface > ADFP_MAX_SAMPLES) return ADFP_E_UNSUPPORTED;
@@ -1191,10 +1209,19 @@ static int sample_rays_impl(const float* rays_o, const float* rays_d, const floa
     hipStream_t st = (hipStream_t)stream;
     SampleArgs a;
     a.ro = rays_o; a.rd = rays_d; a.depth = gt_depth; a.t_rand = perturb > 0.f ? t_rand : nullptr;
-    a.dmax_f = depth_max; a.dmax_ord = nullptr;
+    a.dmax_f = depth_max; a.dmax_ord = nullptr; a.dmax_seg = segment > 0 ? segment : 0;
     fill_bound(a.b, bound);
     a.n_rays = n_rays; a.n_samples = n_samples; a.n_surface = n_surface; a.lindisp = lindisp; a.perturb = perturb; a.z = z_vals;
-    if (gt_depth && !depth_max) {
+    if (gt_depth && !depth_max && segment > 0) {        // one maximum per segment, into the scratch (48 floats of room)
+        if (!scratch) return ADFP_E_ARG;
+        const int nseg = (n_rays + segment - 1) / segment;
+        if (nseg > 48) return ADFP_E_UNSUPPORTED;
+        if (!scratch_is_zero) { hipError_t e = zero_async(scratch, 192, st); if (e != hipSuccess) return (int)e; }
+        int per = (segment + 2047) / 2048; if (per > 16) per = 16;     // few blocks per segment: the cost is the atomics' latency
+        hipLaunchKernelGGL(k_depth_max_seg, dim3(per, nseg), dim3(256), 0, st, gt_depth, n_rays, segment, (unsigned*)scratch);
+        ADFP_CHECK_LAUNCH();
+        a.dmax_ord = (const unsigned*)scratch;
+    } else if (gt_depth && !depth_max) {
         if (!scratch) return ADFP_E_ARG;
         if (!scratch_is_zero) { hipError_t e = zero_async(scratch, 16, st); if (e != hipSuccess) return (int)e; }
         int blocks = (n_rays + 2047) / 2048; if (blocks > 64) blocks = 64;     // few blocks: the cost is the atomics' latency
@@ -1675,7 +1702,7 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
     if (!r) return ADFP_E_ARG;
     int rc = check_scene(scene, r->stage); if (rc) return rc;
     if (!r->rays_o || !r->rays_d || !r->depth || !r->uncertainty || !r->color || !r->weight || !r->workspace) return ADFP_E_ARG;
-    if (r->n_rays < 0 || r->n_samples <= 0 || r->n_surface < 0) return ADFP_E_ARG;
+    if (r->n_rays < 0 || r->n_samples <= 0 || r->n_surface < 0 || r->depth_max_segment < 0) return ADFP_E_ARG;
     if (r->state && r->stage != ADFP_STAGE_LOW &&
         (!r->state->flags || !r->state->list || !r->state->counter || !r->state->att_occ || !r->state->att_u)) return ADFP_E_ARG;
     const int S = r->n_samples + (r->gt_depth ? r->n_surface : 0);
@@ -1689,10 +1716,10 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
     double* z = r->z_vals ? r->z_vals : ws.z;
     float* raw = r->raw ? r->raw : ws.raw;
     // ONE zero fill for the call's small device words: the in-band counter and range flag (bytes 0-63) and the depth-max
-    // reduction's scratch (bytes 64-79) share the first 256 bytes of the workspace
-    { hipError_t e = zero_async(ws.counter, 128, st); if (e != hipSuccess) return (int)e; }
+    // reduction's scratch (bytes 64-255: up to 48 per-segment maxima) share the first 256 bytes of the workspace
+    { hipError_t e = zero_async(ws.counter, 256, st); if (e != hipSuccess) return (int)e; }
     rc = sample_rays_impl(r->rays_o, r->rays_d, r->gt_depth, r->n_rays, scene->bound, r->n_samples, r->n_surface, r->lindisp,
-                          r->perturb, r->t_rand, r->depth_max, z, (char*)ws.counter + 64, stream, true);
+                          r->perturb, r->t_rand, r->depth_max, z, (char*)ws.counter + 64, stream, true, r->depth_max_segment);
     if (rc) return rc;
     PtsDev P;
     P.mode = ADFP_PTS_RAYS; P.S = S; P.n = (int)Pn; P.pts = nullptr; P.ro = r->rays_o; P.rd = r->rays_d; P.z = z;

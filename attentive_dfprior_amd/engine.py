@@ -372,7 +372,7 @@ class Engine(object):
     # ---- a4..a13 ---------------------------------------------------------------------------
     def render_forward(self, decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage,
                        n_samples, n_surface, lindisp=False, perturb=0.0, t_rand=None, depth_max=None,
-                       want_aux=False, train=False, need_flat=None):
+                       want_aux=False, train=False, need_flat=None, depth_max_segment=0):
         _lib.require_cuda(rays_o, 'rays_o')
         dev = rays_o.device
         with torch.cuda.device(dev):
@@ -404,8 +404,9 @@ class Engine(object):
             if perturb > 0:
                 t_rand = t_rand.to(dev, torch.float32).contiguous()
                 a.t_rand = t_rand.data_ptr()
+            a.depth_max_segment = int(depth_max_segment)
             if depth_max is not None:
-                depth_max = depth_max.to(dev, torch.float32).reshape(1).contiguous()
+                depth_max = depth_max.to(dev, torch.float32).reshape(-1).contiguous()
                 a.depth_max = depth_max.data_ptr()
             a.depth = depth.data_ptr()
             a.uncertainty = unc.data_ptr()

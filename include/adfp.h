@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 117
+#define ADFP_VERSION 118
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -262,6 +262,12 @@ typedef struct adfp_render_args {
     void* workspace;
     size_t workspace_bytes;
     const adfp_train_state* state;  /* NULL for inference; else the forward leaves its state here */
+    /* > 0: the call's rays are consecutive SEGMENTS of this many rays, each with its own max(gt_depth) for the far clamp and the
+     * zero-depth surface range -- what Renderer.render_img's ray batches have (src/utils/Renderer.py:294-313: every 100 000-ray
+     * batch clamps `far` with its own maximum) -- so that a whole frame is ONE call with the batched loop's results bit for bit.
+     * depth_max, when given, then holds one float per segment; otherwise the maxima are reduced here (at most 48 segments).
+     * 0: one maximum for the whole call (render_batch_ray). */
+    int depth_max_segment;
 } adfp_render_args;
 
 int adfp_render_forward(const adfp_scene* scene /*host*/, const adfp_render_args* args /*host*/, void* stream);

@@ -420,3 +420,28 @@ def test_get_samples_rng_stream_is_torch_randint(mini):
     jj, ii = idx // W, idx % W
     oro, ord_ = O.get_rays_from_uv(ii.float().cpu(), jj.float().cpu(), mini.c2w, mini.fx, mini.fy, mini.cx, mini.cy)
     assert (rd.cpu() - ord_).abs().max() <= 2e-7 * ord_.abs().max() and torch.equal(ro.cpu(), oro)
+
+
+def test_render_img_single_call_equals_the_batched_loop_bit_for_bit(mini, gm):
+    """render_img renders the frame as ONE call with a max(gt_depth) per ray_batch_size segment (adfp_render_args.depth_max_segment);
+    the reference's loop gives every batch its own maximum (src/utils/Renderer.py:294-313).  Same values, bit for bit -- also
+    when the last segment is ragged and when a segment's maximum is far below the frame's."""
+    from attentive_dfprior_amd.common import get_rays
+    dimg = mini.depth_img.to(DEV).clone()
+    dimg[: mini.H // 3] *= 0.35                                   # the first segments see a much smaller maximum than the rest
+    c2w = mini.c2w.to(DEV)
+    for bs in (1000, 700):                                        # 3 072 rays: 4 segments (72-ray tail) / 5 segments (272-ray tail)
+        rend = A.Renderer(make_cfg(mini.n_samples, mini.n_surface), None, mini, ray_batch_size=bs)
+        with torch.no_grad():
+            d1, u1, c1 = rend.render_img(gm.c, gm.dec, c2w, DEV, gm.tsdf, gm.tsdf_bnds, 'color', gt_depth=dimg)
+            ro, rd = get_rays(mini.H, mini.W, mini.fx, mini.fy, mini.cx, mini.cy, c2w, DEV)
+            ro, rd, gd = ro.reshape(-1, 3), rd.reshape(-1, 3), dimg.reshape(-1)
+            parts = [rend.render_batch_ray(gm.c, gm.dec, rd[i:i + bs], ro[i:i + bs], DEV, gm.tsdf, gm.tsdf_bnds, 'color', gt_depth=gd[i:i + bs])
+                     for i in range(0, ro.shape[0], bs)]
+        assert torch.equal(d1.reshape(-1), torch.cat([p[0] for p in parts]))
+        assert torch.equal(u1.reshape(-1), torch.cat([p[1] for p in parts]))
+        assert torch.equal(c1.reshape(-1, 3), torch.cat([p[2] for p in parts]))
+        # and the segment maxima matter: one maximum for the whole frame gives other values
+        with torch.no_grad():
+            whole = rend.render_batch_ray(gm.c, gm.dec, rd, ro, DEV, gm.tsdf, gm.tsdf_bnds, 'color', gt_depth=gd)
+        assert not torch.equal(whole[0], d1.reshape(-1))
