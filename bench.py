@@ -268,8 +268,8 @@ def main():
                   if os.environ.get('ADFP_MATH', 'f16x3') == 'f16x3' else 'f32'),
         'data': 'synthetic', 'math': os.environ.get('ADFP_MATH', 'f16x3'),
         'config': {'workload': f'{args.scene} synthetic box room, 640x480 full-frame render_img, stage color, '
-                               '64 samples/ray (N_samples 48 + N_surface 16), ray_batch_size 100000, '
-                               'one frame per GPU per step; seed-0 decoders, feature grids N(0, 0.2) '
+                               '64 samples/ray (N_samples 48 + N_surface 16), ray_batch_size 100000 (per-batch far clamp, '
+                               'rendered as one call with a depth maximum per 100 000-ray segment), one frame per GPU per step; seed-0 decoders, feature grids N(0, 0.2) '
                                f'(the reference\'s init std x {GRID_STD_SCALE:g}, high grid x {GRID_HIGH_EXTRA:g} more)',
                    'grid_init': {'std_scale_vs_reference_init': GRID_STD_SCALE, 'grid_high_extra_factor': GRID_HIGH_EXTRA,
                                  'reference_init': 'N(0,0.01) low/colour, N(0,1e-4) high (src/DF_Prior.py:247-263)'},
@@ -496,9 +496,10 @@ def dist_legs(dist, A, synthetic, rend, dec, scene, tsdf_bnds, dev, args):
 # ----------------------------------------------------------------------------------------------------------
 def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF, reps=5):
     """HIP-event time of the individual kernels, each launched alone on torch's current stream
-    (the stream the library launches on), over EXACTLY the launch mix of one frame: the
-    reference's ray batches (3 x 100 000 + 1 x 7 200 rays at 640x480), so that the average launch
-    duration equals what `rocprofv3 --kernel-trace --stats` reports for the same command."""
+    (the stream the library launches on), over EXACTLY the launch mix of one frame -- since round 3 ONE
+    launch per kernel for the whole 307 200-ray frame (render_img carries the reference's 100 000-ray
+    batches as depth-max segments) -- so that the average launch duration equals what
+    `rocprofv3 --kernel-trace --stats` reports for the same command."""
     import torch
     from attentive_dfprior_amd.common import get_rays
     eng = rend._engine
@@ -507,13 +508,19 @@ def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, N
     ro_all, rd_all, gd_all = ro_all.reshape(-1, 3), rd_all.reshape(-1, 3), gt_depth.reshape(-1)
     sc, keep = eng.scene(dec, scene.c, scene.tsdf_volume, tsdf_bnds, scene.bound, 'color')
     batches, n_band, n_pts = [], 0, 0
-    for i in range(0, ro_all.shape[0], rend.ray_batch_size):
-        ro = ro_all[i:i + rend.ray_batch_size].contiguous()
-        rd = rd_all[i:i + rend.ray_batch_size].contiguous()
-        gd = gd_all[i:i + rend.ray_batch_size].contiguous()
+    # the launch structure of render_img: ONE call for the whole frame, the reference's ray batches carried as depth-max segments
+    # (a frame too large for one call would fall back to the batch loop)
+    nseg = (ro_all.shape[0] + rend.ray_batch_size - 1) // rend.ray_batch_size
+    one_call = nseg <= 48 and ro_all.shape[0] * S < 2 ** 31
+    step_rays = ro_all.shape[0] if one_call else rend.ray_batch_size
+    seg = rend.ray_batch_size if one_call else 0
+    for i in range(0, ro_all.shape[0], step_rays):
+        ro = ro_all[i:i + step_rays].contiguous()
+        rd = rd_all[i:i + step_rays].contiguous()
+        gd = gd_all[i:i + step_rays].contiguous()
         with torch.no_grad():
             d, u, c, w, aux = eng.render_forward(dec, scene.c, ro, rd, gd, scene.tsdf_volume, tsdf_bnds, scene.bound,
-                                                 'color', NS, NF, want_aux=True)
+                                                 'color', NS, NF, want_aux=True, depth_max_segment=seg)
         P = ro.shape[0] * S
         n_band += int((w != 1).sum())
         n_pts += P
@@ -555,7 +562,7 @@ def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, N
     t_tsdf = timed(lambda b: _lib.check(L.adfp_tsdf_stage(C.byref(sc), C.byref(b[0]), _lib.ptr(flags), _lib.ptr(lst), _lib.ptr(attu),
                                                           None, _lib.ptr(cnt), st), 'tsdf'))
     t_all = timed(lambda b: eng.render_forward(dec, scene.c, b[1], b[2], b[3], scene.tsdf_volume, tsdf_bnds, scene.bound,
-                                               'color', NS, NF))
+                                               'color', NS, NF, depth_max_segment=seg))
     pts_per_launch = n_pts / nl
     fl_color = 2.0 * MAC_COLOR * pts_per_launch
     ach = fl_color / t_color / 1e12
@@ -573,12 +580,14 @@ def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, N
         ach = fl_color / t_color / 1e12
         ex = 2.0 * F16X3_FLOP_COLOR * pts_per_launch / t_color / 1e12
         roof = {'kernel': 'k_decode_lc<768> (low + colour decoder in one launch, f16 MFMA with 3-product f32 operand split)',
-                'bound': 'mfma', 'achieved': ex, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ex / PEAK_F16_MFMA_TFLOPS, 'frac_algorithmic': ach / PEAK_F16_MFMA_TFLOPS, 'traffic': None,
-                'note': 'achieved / frac = EXECUTED f16 MFMA FLOP (3 products per f32 product + K padding = 2.97 x algorithmic) '
-                        'against the 2.4 GHz dense-f16 spec peak; frac_algorithmic = algorithmic FLOP (2 x (15 479 + 15 575) per sample, '
-                        'SURVEY.md section 8d) against the same peak; algorithmic_f32_tflops / frac_of_f32_mfma_peak = the same '
-                        'algorithmic FLOP against the f32-input MFMA peak the exact mode is bound by',
+                'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ach / PEAK_F16_MFMA_TFLOPS, 'frac_algorithmic': ach / PEAK_F16_MFMA_TFLOPS,
+                'executed_tflops': ex, 'frac_executed': ex / PEAK_F16_MFMA_TFLOPS, 'traffic': None,
+                'note': 'achieved / frac = ALGORITHMIC FLOP (2 x (15 479 + 15 575) per sample, SURVEY.md section 8d) per launch / the '
+                        'kernel\'s average launch duration, against the dense-f16 MFMA peak -- the pipe the kernel executes on; '
+                        'executed_tflops / frac_executed = the f16 MFMA FLOP actually issued (3 products per f32 product + K padding = '
+                        '2.97 x algorithmic); algorithmic_f32_tflops / frac_of_f32_mfma_peak = the same algorithmic FLOP against the '
+                        'f32-input MFMA peak the exact mode is bound by',
                 'algorithmic_f32_tflops': ach, 'f32_mfma_peak_tflops': PEAK_F32_MFMA_TFLOPS,
                 'frac_of_f32_mfma_peak': ach / PEAK_F32_MFMA_TFLOPS}
     kname = 'void k_decode<32, 4, 2' if math_mode() == 'f32' else 'void k_decode_lc<'
