@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ADFP_LIB_PATH', os.path.join(_HERE, 'libadfp.so'))   # override: kernel A/B builds
 
-ABI_VERSION = 118                 # ADFP_VERSION of include/adfp.h this binding was written against
+ABI_VERSION = 119                 # ADFP_VERSION of include/adfp.h this binding was written against
 STATUS_F16_RANGE = 31              # ADFP_STATUS_F16_RANGE: any of the bits below
 STATUS_RANGE_BITS = {'low': 1, 'high': 2, 'color': 4, 'att': 8, 'bwd': 16}      # ADFP_STATUS_F16_RANGE_<net>
 BWD_SCATTER_IN_KERNEL = 1        # ADFP_BWD_SCATTER_IN_KERNEL
@@ -106,6 +106,12 @@ class AdfpLossArgs(C.Structure):
                 ('g_color', C.c_void_p), ('g_weight', C.c_void_p)]
 
 
+class AdfpTrackLossArgs(C.Structure):
+    _fields_ = [('n_rays', C.c_int), ('handle_dynamic', C.c_int), ('w_color_loss', C.c_float),
+                ('depth', C.c_void_p), ('uncertainty', C.c_void_p), ('color', C.c_void_p), ('gt_depth', C.c_void_p),
+                ('gt_color', C.c_void_p), ('keep', C.c_void_p), ('loss', C.c_void_p), ('g_depth', C.c_void_p), ('g_color', C.c_void_p)]
+
+
 Bound = (C.c_double * 2) * 3
 
 # every symbol include/adfp.h declares: (name, restype, argtypes)
@@ -165,6 +171,12 @@ SYMBOLS = [
                                        C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     ('adfp_masked_adam_multi', C.c_int, [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     ('adfp_adam_grids_cl', C.c_int, [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    ('adfp_camera_from_tensor', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_camera_from_tensor_backward', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_select_pixels', C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_tracker_loss', C.c_int, [C.POINTER(AdfpTrackLossArgs), C.c_void_p]),
+    ('adfp_track_keep_best', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_sort_workspace_bytes', C.c_size_t, [C.c_longlong]),
     ('adfp_sort_pairs', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     ('adfp_tsdf_stage', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_void_p, C.c_void_p,

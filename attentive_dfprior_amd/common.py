@@ -5,7 +5,9 @@ coordinate normalisation).  Signatures and argument meaning follow the reference
 
 Ray generation on a GPU device and compositing run in libadfp.so.  Pixel selection keeps
 ``torch.randint`` as its RNG so the index stream is the reference's (src/common.py:101).
-Pose utilities (quad2rotation ... src/common.py:139-203) are tracker-only and out of scope.
+The pose utilities of the Tracker (quad2rotation, get_camera_from_tensor, get_tensor_from_camera, src/common.py:139-203) are
+plain torch / numpy here -- host API; inside the fused tracking iteration (tracking.TrackerIteration) the same conversion and its
+backward are device kernels (adfp_camera_from_tensor).
 """
 import ctypes as C
 
@@ -138,6 +140,51 @@ def filter_rays_in_bound(batch_rays_o, batch_rays_d, batch_gt_depth, batch_gt_co
         keep = idx[:int(cnt.item())].long()
     return (batch_rays_o.index_select(0, keep), batch_rays_d.index_select(0, keep),
             batch_gt_depth.index_select(0, keep), batch_gt_color.index_select(0, keep))
+
+
+def quad2rotation(quad):
+    """Batch of quaternions (r, i, j, k), not necessarily unit -> rotation matrices [B,3,3], differentiable
+    (reference src/common.py:139-163)."""
+    qr, qi, qj, qk = quad[:, 0], quad[:, 1], quad[:, 2], quad[:, 3]
+    two_s = 2.0 / (quad * quad).sum(-1)
+    rows = [1 - two_s * (qj ** 2 + qk ** 2), two_s * (qi * qj - qk * qr), two_s * (qi * qk + qj * qr),
+            two_s * (qi * qj + qk * qr), 1 - two_s * (qi ** 2 + qk ** 2), two_s * (qj * qk - qi * qr),
+            two_s * (qi * qk - qj * qr), two_s * (qj * qk + qi * qr), 1 - two_s * (qi ** 2 + qj ** 2)]
+    return torch.stack(rows, -1).reshape(-1, 3, 3)
+
+
+def get_camera_from_tensor(inputs):
+    """Quaternion + translation [7] or [B,7] -> [3,4] / [B,3,4] camera-to-world (reference src/common.py:166-178)."""
+    single = inputs.dim() == 1
+    if single:
+        inputs = inputs.unsqueeze(0)
+    RT = torch.cat([quad2rotation(inputs[:, :4]), inputs[:, 4:, None]], 2)
+    return RT[0] if single else RT
+
+
+def get_tensor_from_camera(RT, Tquad=False):
+    """Camera-to-world matrix -> float32 [7] quaternion (r, i, j, k; r >= 0 branch by the largest diagonal term) + translation, on
+    the matrix's device (reference src/common.py:181-203, which goes through mathutils' Matrix.to_quaternion; the same
+    rotation either way, q and -q being one rotation)."""
+    dev = RT.device if isinstance(RT, torch.Tensor) else None
+    M = RT.detach().cpu().numpy() if isinstance(RT, torch.Tensor) else np.asarray(RT)
+    R, T = M[:3, :3].astype(np.float64), M[:3, 3].astype(np.float64)
+    tr = R[0, 0] + R[1, 1] + R[2, 2]
+    if tr > 0:
+        s = 2.0 * np.sqrt(1.0 + tr)
+        q = [0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s]
+    else:
+        k = int(np.argmax(np.diag(R)))
+        a, b = (k + 1) % 3, (k + 2) % 3
+        s = 2.0 * np.sqrt(1.0 + R[k, k] - R[a, a] - R[b, b])
+        v = [0.0, 0.0, 0.0]
+        v[k], v[a], v[b] = 0.25 * s, (R[a, k] + R[k, a]) / s, (R[b, k] + R[k, b]) / s
+        q = [(R[b, a] - R[a, b]) / s] + v
+    q = np.asarray(q)
+    if q[0] < 0:
+        q = -q
+    out = torch.from_numpy(np.concatenate([T, q] if Tquad else [q, T])).float()
+    return out.to(dev) if dev is not None and dev.type != 'cpu' else out
 
 
 def random_select(l, k):

@@ -949,6 +949,7 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
 #include "adfp_fusion.h"
 #include "adfp_mapping.h"
 #include "adfp_mapper_iter.h"
+#include "adfp_tracker_iter.h"
 
 // =====================================================================================
 // host side: C ABI
@@ -1684,6 +1685,46 @@ int adfp_mapper_loss(const adfp_loss_args* l, void* stream) {
     a.depth = l->depth; a.color = l->color; a.weight = l->weight; a.gt_depth = l->gt_depth; a.gt_color = l->gt_color; a.keep = l->keep;
     a.loss = l->loss; a.g_depth = l->g_depth; a.g_color = l->g_color; a.g_weight = l->g_weight;
     hipLaunchKernelGGL(k_mapper_loss, dim3((l->n_rays + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);      // one thread per ray
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
+int adfp_camera_from_tensor(const float* cam, float* c2w, void* stream) {
+    if (!cam || !c2w) return ADFP_E_ARG;
+    hipLaunchKernelGGL(k_camera_from_tensor, dim3(1), dim3(64), 0, (hipStream_t)stream, cam, c2w);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+int adfp_camera_from_tensor_backward(const float* cam, const float* g_c2w, float* g_cam, void* stream) {
+    if (!cam || !g_c2w || !g_cam) return ADFP_E_ARG;
+    hipLaunchKernelGGL(k_camera_from_tensor_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, cam, g_c2w, g_cam);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+int adfp_select_pixels(const long long* idx, int n, int H0, int H1, int W0, int W1, int H, int W, const float* depth_img, const float* color_img,
+                       float* pix_i, float* pix_j, float* gt_depth, float* gt_color, void* stream) {
+    if (n < 0 || H0 < 0 || W0 < 0 || H1 > H || W1 > W || H1 <= H0 || W1 <= W0) return ADFP_E_ARG;
+    if (n == 0) return 0;
+    if (!idx || !depth_img || !color_img || !pix_i || !pix_j || !gt_depth || !gt_color) return ADFP_E_ARG;
+    hipLaunchKernelGGL(k_select_pixels, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, idx, n, H0, W0, W1 - W0, W, depth_img, color_img,
+                       pix_i, pix_j, gt_depth, gt_color);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+int adfp_track_keep_best(const double* loss, const float* cam, double* best_loss, float* best_cam, void* stream) {
+    if (!loss || !cam || !best_loss || !best_cam) return ADFP_E_ARG;
+    hipLaunchKernelGGL(k_keep_best, dim3(1), dim3(64), 0, (hipStream_t)stream, loss, cam, best_loss, best_cam);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+int adfp_tracker_loss(const adfp_track_loss_args* l, void* stream) {
+    if (!l || !l->depth || !l->uncertainty || !l->color || !l->gt_depth || !l->gt_color || !l->g_depth || !l->g_color || l->n_rays < 0) return ADFP_E_ARG;
+    if (l->n_rays > ADFP_TRACK_MAX_RAYS) return ADFP_E_UNSUPPORTED;
+    TrackLossArgs a;
+    a.n = l->n_rays; a.handle_dynamic = l->handle_dynamic; a.w_color = l->w_color_loss;
+    a.depth = l->depth; a.unc = l->uncertainty; a.color = l->color; a.gd = l->gt_depth; a.gc = l->gt_color; a.keep = l->keep;
+    a.loss = l->loss; a.g_depth = l->g_depth; a.g_color = l->g_color;
+    hipLaunchKernelGGL(k_tracker_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
     ADFP_CHECK_LAUNCH();
     return 0;
 }

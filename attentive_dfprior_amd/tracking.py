@@ -1,0 +1,237 @@
+"""
+The Tracker's iteration as ONE fixed kernel sequence (reference src/Tracker.py:75-134, Tracker.optimize_cam_in_batch, and the
+loop around it, :236-263), replayable from a HIP graph -- the camera-tracking counterpart of mapping.MapperIteration.
+
+The reference-shaped way (common.get_samples -> common.filter_rays_in_bound -> Renderer.render_batch_ray -> torch loss ->
+loss.backward() -> torch.optim.Adam) works against this package too and is what tests compare with; at the Tracker's 200 - 1000
+rays it is bound by host dispatch (about forty small launches, two host read-backs and the autograd engine per iteration), not
+by the GPU.  Here the iteration is
+
+    adfp_camera_from_tensor          quaternion + translation -> c2w                                   (src/common.py:139-178)
+    adfp_select_pixels               the torch.randint draw -> pixel coordinates, sensor depth, colour  (src/common.py:94-124)
+    adfp_rays_from_uv                rays                                                               (src/common.py:76-91)
+    adfp_prefilter_mask              the bounding-box pre-filter as a keep flag + the kept rays' far clamp   (Tracker.py:100-109)
+    adfp_render_forward              stage color, training state kept                                   (Tracker.py:111-113)
+    adfp_tracker_loss                loss, outlier mask (median), cotangents                            (Tracker.py:115-129)
+    adfp_render_backward             -> d loss / d rays_o, rays_d only (decoders and grids are frozen)
+    adfp_rays_from_uv_backward       -> d loss / d c2w
+    adfp_camera_from_tensor_backward -> d loss / d camera tensor
+    adfp_adam_prep + adfp_masked_adam_multi      torch.optim.Adam on the 7 pose parameters             (Tracker.py:131-133)
+    adfp_track_keep_best             candidate_cam_tensor                                              (Tracker.py:261-263)
+
+with no host read-back anywhere: dropped rays are rendered and get no gradient (a kept ray's result does not depend on its
+neighbours -- the far clamp is taken over the kept rays only), the loss stays on the device.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import lib, ptr, check
+
+
+class TrackerIteration(object):
+    """
+    it = TrackerIteration(renderer, decoders, c, tsdf_volume, tsdf_bnds, H, W, fx, fy, cx, cy, ignore_edge_h, ignore_edge_w)
+    for every frame:
+        it.new_frame(camera_tensor, gt_depth, gt_color)           # fresh Adam, like the reference (src/Tracker.py:219-229)
+        for cam_iter in range(num_cam_iters):
+            loss = it.step(tracking_pixels)                       # device float64, no sync
+        c2w = common.get_camera_from_tensor(it.best_camera_tensor)
+
+    cam_lr, seperate_LR      tracking.lr / tracking.seperate_LR (sic) of the reference's config: with seperate_LR the translation steps
+                             with cam_lr and the quaternion with 0.2 cam_lr (:225-226)
+    use_color, w_color_loss  tracking.use_color_in_tracking / tracking.w_color_loss
+    handle_dynamic           tracking.handle_dynamic
+    """
+
+    def __init__(self, renderer, decoders, c, tsdf_volume, tsdf_bnds, H, W, fx, fy, cx, cy, ignore_edge_h=0, ignore_edge_w=0,
+                 cam_lr=1e-3, seperate_LR=False, use_color=True, w_color_loss=0.5, handle_dynamic=True,
+                 betas=(0.9, 0.999), eps=1e-8, use_graph=True):
+        self.rend, self.dec, self.c = renderer, decoders, c
+        self.tsdf, self.tsdf_bnds = tsdf_volume, tsdf_bnds
+        self.H, self.W, self.intr = int(H), int(W), (float(fx), float(fy), float(cx), float(cy))
+        self.window = (int(ignore_edge_h), int(H) - int(ignore_edge_h), int(ignore_edge_w), int(W) - int(ignore_edge_w))
+        self.cam_lr, self.separate = float(cam_lr), bool(seperate_LR)
+        self.w_color = float(w_color_loss) if use_color else 0.0
+        self.handle_dynamic = bool(handle_dynamic)
+        self.betas, self.eps, self.use_graph = betas, eps, use_graph
+        self.dev = dev = next(iter(c.values())).device
+        for k, g in c.items():
+            _lib.require_cuda(g, k)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.cam = torch.zeros(7, **f32)                       # the pose being optimised: quaternion (r, i, j, k) + translation
+        self.best_cam = torch.zeros(7, **f32)
+        self.best_loss = torch.full((1,), float('inf'), dtype=torch.float64, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.exp_avg, self.exp_avg_sq, self.g_cam = torch.zeros(7, **f32), torch.zeros(7, **f32), torch.zeros(7, **f32)
+        self.c2w, self.g_c2w = torch.zeros(16, **f32), torch.zeros(16, **f32)
+        self.depth_img = torch.zeros((self.H, self.W), **f32)
+        self.color_img = torch.zeros((self.H, self.W, 3), **f32)
+        # Adam groups as torch.optim.Adam sees them: [T, quaternion] with seperate_LR, else the one 7-vector
+        self.n_groups = 2 if self.separate else 1
+        self.step_count = torch.zeros(self.n_groups, dtype=torch.int32, device=dev)
+        self.derived = torch.empty((self.n_groups, 2), **f32)
+        self.bound_dev = torch.as_tensor(renderer.bound).to(dev, torch.float64).contiguous()
+        self._graphs, self._pick, self._pool = {}, {}, None
+
+    # ---- per frame ----------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def new_frame(self, camera_tensor, gt_depth, gt_color):
+        """camera_tensor [7] (common.get_tensor_from_camera of the initial guess); gt_depth [H,W], gt_color [H,W,3].  Everything is
+        copied into buffers the captured graphs read, so those stay valid from frame to frame."""
+        self.cam.copy_(camera_tensor.detach().reshape(7))
+        self.best_cam.copy_(self.cam)
+        self.best_loss.fill_(float('inf'))
+        self.depth_img.copy_(gt_depth)
+        self.color_img.copy_(gt_color)
+        for t in (self.exp_avg, self.exp_avg_sq):
+            t.zero_()
+        self.step_count.zero_()
+
+    @property
+    def camera_tensor(self):
+        return self.cam
+
+    @property
+    def best_camera_tensor(self):
+        """The pose of the lowest-loss iteration so far (candidate_cam_tensor, src/Tracker.py:261-263)."""
+        return self.best_cam
+
+    # ---- the kernel sequence ------------------------------------------------------------------------------------------
+    def _sequence(self, pick, adam=True):
+        L = lib()
+        dev, eng, dec, rend = self.dev, self.rend._engine, self.dec, self.rend
+        st = _lib.current_stream(dev)
+        n = pick.shape[0]
+        fx, fy, cx, cy = self.intr
+        H0, H1, W0, W1 = self.window
+        f32 = dict(dtype=torch.float32, device=dev)
+        check(L.adfp_camera_from_tensor(ptr(self.cam), ptr(self.c2w), st), 'adfp_camera_from_tensor')
+        pi, pj, gd = torch.empty(n, **f32), torch.empty(n, **f32), torch.empty(n, **f32)
+        gc = torch.empty((n, 3), **f32)
+        check(L.adfp_select_pixels(ptr(pick), n, H0, H1, W0, W1, self.H, self.W, ptr(self.depth_img), ptr(self.color_img),
+                                   ptr(pi), ptr(pj), ptr(gd), ptr(gc), st), 'adfp_select_pixels')
+        ro, rd = torch.empty((n, 3), **f32), torch.empty((n, 3), **f32)
+        check(L.adfp_rays_from_uv(ptr(pi), ptr(pj), n, fx, fy, cx, cy, ptr(self.c2w), ptr(ro), ptr(rd), st), 'adfp_rays_from_uv')
+        keep = torch.empty((n,), dtype=torch.uint8, device=dev)
+        dmax = torch.empty((1,), **f32)
+        check(L.adfp_prefilter_mask(ptr(ro), ptr(rd), ptr(gd), n, ptr(self.bound_dev), ptr(keep), ptr(dmax), st), 'adfp_prefilter_mask')
+        no_flat = {k: False for k in ('low', 'high', 'color', 'att')}
+        depth, unc, color, weight, aux = eng.render_forward(dec, self.c, ro, rd, gd, self.tsdf, self.tsdf_bnds, rend.bound, 'color',
+                                                            rend.N_samples, rend.N_surface, rend.lindisp, rend.perturb, None, dmax,
+                                                            train=True, need_flat=no_flat)
+        la = _lib.AdfpTrackLossArgs()
+        la.n_rays, la.handle_dynamic, la.w_color_loss = n, 1 if self.handle_dynamic else 0, self.w_color
+        la.depth, la.uncertainty, la.color = depth.data_ptr(), unc.data_ptr(), color.data_ptr()
+        la.gt_depth, la.gt_color, la.keep = gd.data_ptr(), gc.data_ptr(), keep.data_ptr()
+        g_depth = torch.empty((n,), dtype=torch.float64, device=dev)
+        g_color = torch.empty((n, 3), **f32)
+        la.loss, la.g_depth, la.g_color = self.loss.data_ptr(), g_depth.data_ptr(), g_color.data_ptr()
+        check(L.adfp_tracker_loss(C.byref(la), st), 'adfp_tracker_loss')
+        none = {k: False for k in ('low', 'high', 'color')}
+        _, _, (g_ro, g_rd) = eng.render_backward(dec, self.c, self.tsdf, self.tsdf_bnds, rend.bound, 'color', aux, g_depth, None,
+                                                 g_color, None, none, no_flat, need_rays=True, ray_keep=keep)
+        check(L.adfp_rays_from_uv_backward(ptr(pi), ptr(pj), n, fx, fy, cx, cy, ptr(g_ro), ptr(g_rd), ptr(self.g_c2w), st),
+              'adfp_rays_from_uv_backward')
+        check(L.adfp_camera_from_tensor_backward(ptr(self.cam), ptr(self.g_c2w), ptr(self.g_cam), st), 'adfp_camera_from_tensor_backward')
+        if not adam:
+            return
+        if self.separate:
+            # camera_tensor = cat([quad, T]) is rebuilt BEFORE the step in the reference loop (:237-238), so the candidate it
+            # clones after the step is the pose this loss was measured at
+            check(L.adfp_track_keep_best(ptr(self.loss), ptr(self.cam), ptr(self.best_loss), ptr(self.best_cam), st), 'adfp_track_keep_best')
+        b1, b2 = self.betas
+        lrs = (C.c_float * self.n_groups)(*([self.cam_lr, self.cam_lr * 0.2] if self.separate else [self.cam_lr]))
+        # a forward repaired for an f16-range event has zero gradients by construction: nobody steps then (adfp_train_state.counter[8])
+        skip = C.c_void_p(aux['counter'].data_ptr() + 32)
+        check(L.adfp_adam_prep(ptr(self.step_count), ptr(self.derived), self.n_groups, lrs, b1, b2, skip, st), 'adfp_adam_prep')
+        parts = [(4, 3), (0, 4)] if self.separate else [(0, 7)]              # (offset, length) of each group inside the 7-vector
+        arr = (_lib.AdfpAdamGroup * len(parts))()
+        for k, (off, cnt) in enumerate(parts):
+            a = arr[k]
+            a.param, a.grad = self.cam.data_ptr() + 4 * off, self.g_cam.data_ptr() + 4 * off
+            a.exp_avg, a.exp_avg_sq = self.exp_avg.data_ptr() + 4 * off, self.exp_avg_sq.data_ptr() + 4 * off
+            a.mask, a.nvox, a.channels = None, cnt, 1
+            a.derived = self.derived[k].data_ptr()
+        check(L.adfp_masked_adam_multi(len(parts), C.byref(arr), b1, b2, self.eps, st), 'adfp_masked_adam_multi')
+        if not self.separate:
+            # the one-tensor optimiser updates camera_tensor in place: the reference's candidate is the pose AFTER the step
+            check(L.adfp_track_keep_best(ptr(self.loss), ptr(self.cam), ptr(self.best_loss), ptr(self.best_cam), st), 'adfp_track_keep_best')
+
+    @torch.no_grad()
+    def gradient(self, batch_size, pick=None):
+        """d loss / d camera tensor at the current pose without stepping (tests, diagnostics): (loss, g [7]) device tensors."""
+        with torch.cuda.device(self.dev):
+            self._sequence(self._draw(batch_size) if pick is None else pick.to(self.dev, torch.int64).contiguous(), adam=False)
+        return self.loss.clone(), self.g_cam.clone()
+
+    def _draw(self, n):
+        H0, H1, W0, W1 = self.window
+        return torch.randint((H1 - H0) * (W1 - W0), (n,), device=self.dev)         # the reference's RNG call (src/common.py:101)
+
+    @torch.no_grad()
+    def step(self, batch_size, pick=None):
+        """One iteration on `batch_size` random pixels (or the given window indices `pick`, int64); returns the loss as a device
+        float64 tensor -- reading it synchronises; the reference reads it every iteration (loss.item(), :134), the fused loop does
+        not need to: the best pose is tracked on the device."""
+        dev = self.dev
+        with torch.cuda.device(dev):
+            n = int(batch_size)
+            if pick is None:
+                pick = self._draw(n)
+            if not self.use_graph:
+                self._sequence(pick.to(dev, torch.int64).contiguous())
+                return self.loss
+            self.dec.absorb_status()                        # a replay never passes through Engine.scene(): see MapperIteration.step
+
+            def graph_key():
+                return (n, frozenset(self.dec._exact_latch), self._scene_token())
+            key = graph_key()
+            buf = self._pick.get(n)
+            if buf is None:
+                buf = self._pick[n] = torch.empty((n,), dtype=torch.int64, device=dev)
+            buf.copy_(pick)
+            g = self._graphs.get(key)
+            if g is None:
+                # warm the host-side caches (packed weight images, channels-last grids, bounds) eagerly, without stepping: the Tracker's
+                # networks and grids are frozen, so everything the caches hold stays valid and none of it is rebuilt in the graph
+                for _ in range(2):                         # a second pass if the first one latched a network onto the exact kernels
+                    side = torch.cuda.Stream(device=dev)
+                    side.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(side):
+                        self._sequence(buf, adam=False)
+                    torch.cuda.current_stream(dev).wait_stream(side)
+                    torch.cuda.synchronize(dev)
+                    self.dec.absorb_status()
+                    if graph_key() == key:
+                        break
+                    key = graph_key()
+                self._graphs = {k: v for k, v in self._graphs.items() if k[2] == key[2]}      # graphs of replaced scene tensors are dead
+                eng = self.rend._engine
+                ws_eager, eng._ws = eng._ws, None           # the graph owns its workspace
+                g = torch.cuda.CUDAGraph()
+                if self._pool is None:
+                    self._pool = torch.cuda.graph_pool_handle()
+                try:
+                    with torch.cuda.graph(g, pool=self._pool):
+                        self._sequence(buf)
+                finally:
+                    eng._ws = ws_eager
+                self._graphs[key] = g
+            g.replay()
+            return self.loss
+
+    def _scene_token(self):
+        """Identity + version of everything a captured graph has baked in (the grids' channels-last copies and the packed weight
+        images are made from these outside the graph): a graph is replayed only against the very tensors it was captured with."""
+        ts = list(self.c.values()) + list(self.dec.parameters()) + [self.tsdf]
+        return hash(tuple((t.data_ptr(), t._version) for t in ts))
+
+    def update_para(self, decoders=None, c=None):
+        """Tracker.update_para_from_mapping (src/Tracker.py:136-147) hands over fresh copies of the decoders and grids; graphs
+        captured against the old ones are dropped at the next step (they are keyed on the tensors' identity and version)."""
+        if decoders is not None:
+            self.dec = decoders
+        if c is not None:
+            self.c = c

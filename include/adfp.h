@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 118
+#define ADFP_VERSION 119
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -441,6 +441,42 @@ typedef struct adfp_adam_cl_group {
     const float* derived;        /* {step size, sqrt(bias correction 2)} from adfp_adam_prep */
 } adfp_adam_cl_group;
 int adfp_adam_grids_cl(int n_groups, const adfp_adam_cl_group* groups /*host*/, float beta1, float beta2, float eps, void* stream);
+
+/* ---- One Tracker iteration as a fixed, sync-free kernel sequence (src/Tracker.py:75-134) ---------------------------------- */
+/* Camera tensor (quaternion r, i, j, k + translation, 7 floats ON THE DEVICE) -> camera-to-world [4,4] row-major, and the
+ * cotangent of c2w (rows 0-2) -> the cotangent of the 7 parameters: get_camera_from_tensor / quad2rotation of
+ * src/common.py:139-178 and their autograd.  The pose the Tracker optimises reaches the renderer only through these. */
+int adfp_camera_from_tensor(const float* cam /*[7] device*/, float* c2w /*[16] device*/, void* stream);
+int adfp_camera_from_tensor_backward(const float* cam, const float* g_c2w /*[16]*/, float* g_cam /*[7]*/, void* stream);
+/* The n sampled pixels of get_sample_uv (src/common.py:94-124): idx[t] indexes the window [H0,H1) x [W0,W1) in row-major
+ * order (the caller's ONE torch.randint draw); out: pixel coordinates as floats (pix_i = column, pix_j = row, what
+ * adfp_rays_from_uv takes), sensor depth [n] and colour [n,3] gathered from the [H,W] / [H,W,3] fp32 images. */
+int adfp_select_pixels(const long long* idx /*[n] int64 device*/, int n, int H0, int H1, int W0, int W1, int H, int W,
+                       const float* depth_img, const float* color_img, float* pix_i, float* pix_j, float* gt_depth, float* gt_color,
+                       void* stream);
+/* The tracking loss (src/Tracker.py:115-129) and its cotangents:
+ *   tmp = |gt_depth - depth| / sqrt(uncertainty + 1e-10)        (float64, uncertainty detached)
+ *   mask = keep & (gt_depth > 0) [& tmp < 10 median(tmp over the kept rays) when handle_dynamic]
+ *   loss = sum_mask tmp + w_color_loss sum_mask |gt_color - color|
+ * torch.median's lower-middle element; at most 8192 rays (one workgroup).  loss (device double) is WRITTEN, not accumulated. */
+typedef struct adfp_track_loss_args {
+    int n_rays;
+    int handle_dynamic;          /* configs/df_prior.yaml:28 */
+    float w_color_loss;          /* :31 */
+    const double* depth;         /* [N] */
+    const double* uncertainty;   /* [N] */
+    const float* color;          /* [N,3] */
+    const float* gt_depth;       /* [N] */
+    const float* gt_color;       /* [N,3] */
+    const unsigned char* keep;   /* [N] or NULL: the bounding-box pre-filter of :100-109 as a keep flag (adfp_prefilter_mask) */
+    double* loss;                /* device double or NULL */
+    double* g_depth;             /* [N] out */
+    float* g_color;              /* [N,3] out */
+} adfp_track_loss_args;
+int adfp_tracker_loss(const adfp_track_loss_args* args /*host*/, void* stream);
+/* The iteration loop's running best (src/Tracker.py:261-263): if *loss < *best_loss then *best_loss = *loss and best_cam[0..7) =
+ * cam[0..7); all four on the device, NaN never wins.  Start best_loss at +inf (the reference's 1e10). */
+int adfp_track_keep_best(const double* loss, const float* cam, double* best_loss, float* best_cam, void* stream);
 
 /* Stable radix sort of n (key, value) int pairs by the low key_bits bits of the (non-negative) keys, in place (key_tmp / val_tmp:
  * n ints each).  What the f16-split backward orders the sample points with (by grid cell, adfp_sort.h); exported for testing. */

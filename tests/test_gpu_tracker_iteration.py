@@ -1,0 +1,307 @@
+"""GPU: the fused Tracker iteration (tracking.TrackerIteration; reference src/Tracker.py:75-134 and the loop at :236-263).
+Piece by piece against torch / the oracle, then the whole iteration against the reference-shaped sequence of calls
+(get_samples -> pre-filter -> render_batch_ray -> loss -> backward -> torch.optim.Adam) on the same pixel draws."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import attentive_dfprior_amd as A
+from attentive_dfprior_amd import _lib, common, synthetic
+from attentive_dfprior_amd._lib import lib, ptr, check
+from attentive_dfprior_amd.tracking import TrackerIteration
+from oracle import adfp_oracle as O
+from conftest import make_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+EDGE = 4
+
+
+def stream():
+    return _lib.current_stream(torch.device(DEV))
+
+
+def test_camera_from_tensor_and_its_backward_match_torch_autograd():
+    g = torch.Generator().manual_seed(0)
+    for k in range(8):
+        cam = torch.randn(7, generator=g)
+        if k % 2:
+            cam[:4] /= cam[:4].norm()                        # unit quaternions, what the Tracker starts from
+        cam_t = cam.clone().requires_grad_(True)
+        RT = common.get_camera_from_tensor(cam_t)            # [3,4]
+        G = torch.randn(3, 4, generator=g)
+        (RT * G).sum().backward()
+        d_cam, d_c2w, d_g = cam.to(DEV), torch.empty(16, device=DEV), torch.empty(7, device=DEV)
+        g_c2w = torch.zeros(4, 4)
+        g_c2w[:3] = G
+        g_c2w[3] = 7.0                                       # the bottom row carries no gradient
+        check(lib().adfp_camera_from_tensor(ptr(d_cam), ptr(d_c2w), stream()), 'fwd')
+        check(lib().adfp_camera_from_tensor_backward(ptr(d_cam), ptr(g_c2w.to(DEV)), ptr(d_g), stream()), 'bwd')
+        got = d_c2w.cpu().reshape(4, 4)
+        assert torch.equal(got[3], torch.tensor([0., 0., 0., 1.]))
+        assert (got[:3] - RT.detach()).abs().max() <= 2e-6 * max(1.0, RT.detach().abs().max().item())
+        ref = cam_t.grad
+        assert (d_g.cpu() - ref).abs().max() <= 1e-5 * max(1.0, ref.abs().max().item()), (d_g.cpu(), ref)
+
+
+def test_get_tensor_from_camera_round_trip():
+    g = torch.Generator().manual_seed(5)
+    for _ in range(12):
+        cam = torch.randn(7, generator=g)
+        RT = common.get_camera_from_tensor(cam)
+        t = common.get_tensor_from_camera(RT)
+        assert t.dtype == torch.float32 and t.shape == (7,) and abs(t[:4].norm().item() - 1) < 1e-5 and t[0] >= 0
+        assert (common.get_camera_from_tensor(t) - RT).abs().max() < 1e-5
+        tq = common.get_tensor_from_camera(RT, Tquad=True)
+        assert torch.equal(tq[:3], t[4:]) and torch.equal(tq[3:], t[:4])
+
+
+def test_select_pixels_is_get_sample_uv_on_the_same_draw():
+    H, W = 48, 64
+    g = torch.Generator().manual_seed(1)
+    depth, color = torch.rand(H, W, generator=g).to(DEV), torch.rand(H, W, 3, generator=g).to(DEV)
+    H0, H1, W0, W1 = 5, H - 3, 7, W - 9
+    n = 333
+    torch.manual_seed(11)
+    i, j, d, c = common.get_sample_uv(H0, H1, W0, W1, n, depth, color, device=DEV)
+    torch.manual_seed(11)
+    pick = torch.randint((H1 - H0) * (W1 - W0), (n,), device=DEV)
+    pi, pj, gd = (torch.empty(n, device=DEV) for _ in range(3))
+    gc = torch.empty(n, 3, device=DEV)
+    check(lib().adfp_select_pixels(ptr(pick), n, H0, H1, W0, W1, H, W, ptr(depth), ptr(color), ptr(pi), ptr(pj), ptr(gd), ptr(gc), stream()), 'select')
+    assert torch.equal(pi, i) and torch.equal(pj, j) and torch.equal(gd, d) and torch.equal(gc, c)
+    assert lib().adfp_select_pixels(ptr(pick), n, H0, H + 1, W0, W1, H, W, ptr(depth), ptr(color), ptr(pi), ptr(pj), ptr(gd), ptr(gc), stream()) == -1
+
+
+def run_loss(depth, unc, color, gd, gc, keep, handle_dynamic, w_color):
+    n = depth.shape[0]
+    la = _lib.AdfpTrackLossArgs()
+    d, u, c, g1, g2 = depth.to(DEV), unc.to(DEV), color.to(DEV), gd.to(DEV), gc.to(DEV)
+    k = None if keep is None else keep.to(DEV, torch.uint8)
+    loss = torch.full((1,), -1.0, dtype=torch.float64, device=DEV)
+    g_d, g_c = torch.empty(n, dtype=torch.float64, device=DEV), torch.empty(n, 3, device=DEV)
+    la.n_rays, la.handle_dynamic, la.w_color_loss = n, int(handle_dynamic), w_color
+    la.depth, la.uncertainty, la.color, la.gt_depth, la.gt_color = d.data_ptr(), u.data_ptr(), c.data_ptr(), g1.data_ptr(), g2.data_ptr()
+    la.keep = None if k is None else k.data_ptr()
+    la.loss, la.g_depth, la.g_color = loss.data_ptr(), g_d.data_ptr(), g_c.data_ptr()
+    check(lib().adfp_tracker_loss(C.byref(la), stream()), 'adfp_tracker_loss')
+    return loss.cpu(), g_d.cpu(), g_c.cpu()
+
+
+@pytest.mark.parametrize('n', [1, 2, 199, 200, 1000, 5000])
+@pytest.mark.parametrize('handle_dynamic', [True, False])
+def test_tracker_loss_matches_the_reference_formula(n, handle_dynamic):
+    g = torch.Generator().manual_seed(n)
+    depth = (torch.rand(n, generator=g, dtype=torch.float64) * 3).requires_grad_(True)
+    unc = torch.rand(n, generator=g, dtype=torch.float64) * 0.1
+    color = torch.rand(n, 3, generator=g).requires_grad_(True)
+    gd = torch.rand(n, generator=g) * 3
+    gd[torch.rand(n, generator=g) < 0.1] = 0.0
+    out = torch.rand(n, generator=g) < 0.05
+    gd = torch.where(out, gd + 40.0, gd)                       # outliers the median mask removes
+    gc = torch.rand(n, 3, generator=g)
+    keep = torch.rand(n, generator=g) < 0.8
+    if n <= 2:
+        keep[:] = True
+    for kp in (None, keep):
+        depth.grad = color.grad = None
+        sel = slice(None) if kp is None else kp
+        ref = O.tracker_loss(depth[sel], unc[sel], color[sel], gd[sel], gc[sel], handle_dynamic=handle_dynamic, w_color_loss=0.5)
+        ref.backward()
+        loss, g_d, g_c = run_loss(depth.detach(), unc, color.detach(), gd, gc, kp, handle_dynamic, 0.5)
+        assert abs(loss.item() - ref.item()) <= 1e-6 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+        assert torch.equal(g_d, depth.grad), (g_d - depth.grad).abs().max()
+        assert torch.equal(g_c, color.grad)
+
+
+def test_tracker_loss_edge_cases():
+    # all rays dropped: zero loss, zero cotangents; NaN depth poisons the median like torch.median (mask all False -> loss 0)
+    n = 64
+    z = torch.zeros(n, dtype=torch.float64)
+    loss, g_d, g_c = run_loss(z + 1, z + 0.01, torch.zeros(n, 3), torch.ones(n) * 2, torch.zeros(n, 3), torch.zeros(n, dtype=torch.bool), True, 0.5)
+    assert loss.item() == 0 and not g_d.any() and not g_c.any()
+    d = z + 1
+    d[3] = float('nan')
+    ref = O.tracker_loss(d, z + 0.01, torch.zeros(n, 3), torch.ones(n) * 2, torch.ones(n, 3), handle_dynamic=True)
+    loss, g_d, g_c = run_loss(d, z + 0.01, torch.zeros(n, 3), torch.ones(n) * 2, torch.ones(n, 3), None, True, 0.5)
+    assert ref.item() == 0 and loss.item() == 0 and not g_d.any()
+    la = _lib.AdfpTrackLossArgs()
+    la.n_rays = 8193
+    la.depth = la.uncertainty = la.color = la.gt_depth = la.gt_color = la.g_depth = la.g_color = 8
+    assert lib().adfp_tracker_loss(C.byref(la), stream()) == -2
+
+
+def test_keep_best_follows_the_reference_comparison():
+    best_l = torch.full((1,), float('inf'), dtype=torch.float64, device=DEV)
+    best_c = torch.zeros(7, device=DEV)
+    seen = []
+    for l in (5.0, 7.0, float('nan'), 3.0, 3.0, 4.0):
+        cam = torch.full((7,), float(len(seen)), device=DEV)
+        seen.append(l)
+        check(lib().adfp_track_keep_best(ptr(torch.tensor([l], dtype=torch.float64, device=DEV)), ptr(cam), ptr(best_l), ptr(best_c), stream()), 'keep_best')
+    assert best_l.item() == 3.0 and torch.equal(best_c.cpu(), torch.full((7,), 3.0))
+
+
+class Bench:
+    def __init__(self, n_samples=16, n_surface=8):
+        self.sc = sc = synthetic.mini_scene(device=DEV)
+        self.dec = A.DF()
+        self.dec.load_state_dict(O.random_state_dict(3))
+        self.dec.bound = sc.bound
+        self.dec = self.dec.to(DEV)
+        for p in self.dec.parameters():
+            p.requires_grad_(False)
+        self.rend = A.Renderer(make_cfg(n_samples, n_surface), None, sc)
+        self.c2w = sc.default_c2w()
+        self.depth = sc.depth_image(self.c2w, zero_band=0.05).to(DEV).float()
+        self.color = torch.rand((sc.H, sc.W, 3), generator=torch.Generator().manual_seed(0)).to(DEV)
+        self.tb = sc.tsdf_bnds.to(DEV)
+        cam = common.get_tensor_from_camera(self.c2w.cpu())
+        cam[4:] += torch.tensor([0.012, -0.008, 0.01])
+        cam[:4] += torch.tensor([0.0, 0.004, -0.003, 0.002])
+        self.cam0 = cam.to(DEV)
+
+    def iteration(self, **kw):
+        sc = self.sc
+        it = TrackerIteration(self.rend, self.dec, sc.c, sc.tsdf_volume, self.tb, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, EDGE, EDGE, **kw)
+        it.new_frame(self.cam0, self.depth, self.color)
+        return it
+
+    def picks(self, n, count, seed=2):
+        g = torch.Generator().manual_seed(seed)
+        return [torch.randint((self.sc.H - 2 * EDGE) * (self.sc.W - 2 * EDGE), (n,), generator=g).to(DEV) for _ in range(count)]
+
+    def reference_shaped(self, cam, pick, handle_dynamic=True, w_color=0.5):
+        """optimize_cam_in_batch up to loss.backward(), through the package's reference-shaped API (src/Tracker.py:91-131)."""
+        sc = self.sc
+        H, W = sc.H, sc.W
+        c2w = common.get_camera_from_tensor(cam)
+        Ww = W - 2 * EDGE
+        jj, ii = (pick // Ww + EDGE).float(), (pick % Ww + EDGE).float()
+        gd, gc = self.depth[jj.long(), ii.long()], self.color[jj.long(), ii.long()]
+        ro, rd = common.get_rays_from_uv(ii, jj, c2w, H, W, sc.fx, sc.fy, sc.cx, sc.cy, DEV)
+        ro, rd, gd, gc = common.filter_rays_in_bound(ro, rd, gd, gc, sc.bound.to(DEV))
+        d, u, col, _ = self.rend.render_batch_ray(sc.c, self.dec, rd, ro, DEV, sc.tsdf_volume, self.tb, 'color', gt_depth=gd)
+        return O.tracker_loss(d, u.detach(), col, gd, gc, handle_dynamic=handle_dynamic, w_color_loss=w_color), ro.shape[0]
+
+
+@pytest.fixture(scope='module')
+def tb():
+    return Bench()
+
+
+def test_fused_gradient_equals_the_reference_shaped_iteration(tb):
+    it = tb.iteration(use_graph=False)
+    for n, pick in zip((200, 1000), tb.picks(1000, 2)):
+        pick = pick[:n]
+        loss, g = it.gradient(n, pick)
+        cam = tb.cam0.clone().requires_grad_(True)
+        ref, kept = tb.reference_shaped(cam, pick)
+        ref.backward()
+        assert 0 < kept <= n
+        assert abs(loss.item() - ref.item()) <= 1e-6 * abs(ref.item()), (loss.item(), ref.item())
+        scale = cam.grad.abs().max().item()
+        assert (g - cam.grad).abs().max().item() <= 2e-4 * scale, (g, cam.grad)        # float atomics order differs (keep flag vs compaction)
+
+
+def test_fused_gradient_against_the_oracle(tb):
+    """The whole chain on the CPU oracle with torch autograd: camera tensor -> c2w -> rays -> render -> Tracker loss."""
+    sc = tb.sc
+    it = tb.iteration(use_graph=False)
+    pick = tb.picks(300, 1, seed=9)[0]
+    loss, g = it.gradient(300, pick)
+    cam = tb.cam0.cpu().clone().requires_grad_(True)
+    c2w = common.get_camera_from_tensor(cam)
+    Ww = sc.W - 2 * EDGE
+    pk = pick.cpu()
+    jj, ii = (pk // Ww + EDGE).float(), (pk % Ww + EDGE).float()
+    gd, gc = tb.depth.cpu()[jj.long(), ii.long()], tb.color.cpu()[jj.long(), ii.long()]
+    ro, rd = O.get_rays_from_uv(ii, jj, c2w, sc.fx, sc.fy, sc.cx, sc.cy)
+    keep = O.prefilter_mask(ro.detach(), rd.detach(), gd, sc.bound)
+    d, u, col, _ = O.render_batch_ray(O.random_state_dict(3), {k: v.cpu() for k, v in sc.c.items()}, rd[keep], ro[keep], sc.tsdf_volume.cpu(),
+                                      sc.tsdf_bnds, sc.bound, 'color', gd[keep], 16, 8)
+    ref = O.tracker_loss(d, u.detach(), col, gd[keep], gc[keep])
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 2e-4 * abs(ref.item()), (loss.item(), ref.item())
+    scale = cam.grad.abs().max().item()
+    assert (g.cpu() - cam.grad).abs().max().item() <= 2e-3 * scale, (g.cpu(), cam.grad)
+
+
+@pytest.mark.parametrize('separate', [False, True])
+def test_ten_iterations_follow_torch_adam(tb, separate):
+    """num_cam_iters = 10 (configs/df_prior.yaml:27) of the fused iteration vs the same loop with torch.optim.Adam: the pose
+    trajectories and the best candidate agree."""
+    n, iters = 200, 10
+    picks = tb.picks(n, iters, seed=4)
+    it = tb.iteration(use_graph=False, seperate_LR=separate)
+    if separate:
+        quad, T = tb.cam0[:4].clone().requires_grad_(True), tb.cam0[4:].clone().requires_grad_(True)
+        opt = torch.optim.Adam([{'params': [T], 'lr': 1e-3}, {'params': [quad], 'lr': 1e-3 * 0.2}])
+    else:
+        cam = tb.cam0.clone().requires_grad_(True)
+        opt = torch.optim.Adam([cam], lr=1e-3)
+    best, cand = 1e10, None
+    for k in range(iters):
+        if separate:
+            cam = torch.cat([quad, T], 0)
+        opt.zero_grad()
+        loss, _ = tb.reference_shaped(cam, picks[k])
+        loss.backward()
+        opt.step()
+        l_f = it.step(n, picks[k]).item()
+        assert abs(l_f - loss.item()) <= 1e-4 * abs(loss.item()), (k, l_f, loss.item())
+        if loss.item() < best:
+            best, cand = loss.item(), cam.clone().detach()
+        now = torch.cat([quad, T], 0).detach() if separate else cam.detach()
+        assert (it.camera_tensor - now).abs().max().item() <= 2e-5, (k, it.camera_tensor, now)
+    assert (it.best_camera_tensor - cand).abs().max().item() <= 2e-5
+    assert abs(it.best_loss.item() - best) <= 1e-4 * best
+    assert (it.camera_tensor - tb.cam0).abs().max().item() > 1e-3              # it did move
+
+
+def test_graph_replay_equals_the_eager_sequence(tb):
+    n, iters = 200, 6
+    picks = tb.picks(n, iters, seed=6)
+    a, b = tb.iteration(use_graph=False), tb.iteration(use_graph=True)
+    for k in range(iters):
+        la, lb = a.step(n, picks[k]), b.step(n, picks[k])
+        assert abs(la.item() - lb.item()) <= 1e-9 * abs(la.item())
+        assert (a.camera_tensor - b.camera_tensor).abs().max().item() <= 1e-7
+    assert len(b._graphs) == 1
+    # a new frame reuses the graph; replaced grids (update_para_from_mapping) do not
+    b.new_frame(tb.cam0, tb.depth, tb.color)
+    a.new_frame(tb.cam0, tb.depth, tb.color)
+    assert (a.step(n, picks[0]) - b.step(n, picks[0])).abs().item() <= 1e-9 * a.loss.abs().item() and len(b._graphs) == 1
+    c2 = {k: (v * 1.01).contiguous() for k, v in tb.sc.c.items()}
+    a.update_para(c=c2)
+    b.update_para(c=c2)
+    la, lb = a.step(n, picks[1]), b.step(n, picks[1])
+    assert abs(la.item() - lb.item()) <= 1e-9 * abs(la.item()) and len(b._graphs) == 1
+    # ... and an in-place change of a grid is seen too (the Mapper writes the shared grids in place)
+    c2['grid_low'].mul_(1.02)
+    la, lb = a.step(n, picks[2]), b.step(n, picks[2])
+    assert abs(la.item() - lb.item()) <= 1e-9 * abs(la.item())
+
+
+def test_tracking_converges_towards_the_true_pose():
+    """A rendering-consistent target: the sensor images are what the scene renders from the true pose, so the true pose minimises the
+    loss; 30 fused iterations from a perturbed start reduce the pose error."""
+    tb = Bench()
+    sc = tb.sc
+    with torch.no_grad():
+        d, u, col = tb.rend.render_img(sc.c, tb.dec, tb.c2w.to(DEV), DEV, sc.tsdf_volume, tb.tb, 'color', gt_depth=tb.depth)
+    true = common.get_tensor_from_camera(tb.c2w.cpu()).to(DEV)
+    it = TrackerIteration(tb.rend, tb.dec, sc.c, sc.tsdf_volume, tb.tb, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, EDGE, EDGE, cam_lr=2e-3)
+    start = true.clone()
+    start[4:] += torch.tensor([0.03, -0.02, 0.025], device=DEV)
+    it.new_frame(start, d.float(), col.float())
+    torch.manual_seed(0)
+    first = None
+    for k in range(40):
+        l = it.step(1000)
+        first = l.item() if first is None else first
+    err0, err1 = (start[4:] - true[4:]).norm().item(), (it.best_camera_tensor[4:] - true[4:]).norm().item()
+    assert it.best_loss.item() < first
+    assert err1 < 0.6 * err0, (err0, err1)
