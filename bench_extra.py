@@ -234,9 +234,16 @@ def tracker_leg(A, synthetic, scene, sd, dec, dev):
                 return loss
             t_it, loss = _wall(it, 30, dev, warm=5)
             kept = int(frac[0])
-            # algorithmic FLOP of the iteration: forward + backward (2x forward) of the four networks on kept x S samples
+            # the same iteration as ONE captured kernel sequence (tracking.TrackerIteration): no autograd engine, no host read-back
+            from attentive_dfprior_amd.tracking import TrackerIteration
+            fused = TrackerIteration(rend, dec, scene.c, scene.tsdf_volume, tb, H, W, scene.fx, scene.fy, scene.cx, scene.cy, edge, edge)
+            cam0 = _tensor_from_c2w(c2w_gt).to(dev)
+            cam0[4:] += 0.01
+            fused.new_frame(cam0, depth, color)
+            t_f, loss_f = _wall(lambda: fused.step(n), 100, dev, warm=5)
+            # algorithmic FLOP of the iteration: forward + the input-gradient chain (1x forward) of the four networks on n x S samples
             band = 0.17
-            flop = 3.0 * 2.0 * (MAC_LOW + MAC_COLOR + band * (MAC_HIGH + MAC_ATT)) * kept * S
+            flop = 2.0 * 2.0 * (MAC_LOW + MAC_COLOR + band * (MAC_HIGH + MAC_ATT)) * n * S         # no weight gradients: frozen nets
             # the oracle on the host cores: the same iteration with torch autograd
             cam_c = cam.detach().cpu().clone().requires_grad_(True)
             c_cpu = {k: v.cpu() for k, v in scene.c.items()}
@@ -257,11 +264,16 @@ def tracker_leg(A, synthetic, scene, sd, dec, dev):
                 O.tracker_loss(d, u.detach(), col, gd, gc).backward()
             cores = _threads_for_oracle(oracle_it)
             t_o = min(_cpu_time(oracle_it) for _ in range(2))
-            out['by_batch'][str(n)] = {'rays_sampled': n, 'rays_after_prefilter': kept, 'ms_per_iteration': t_it * 1e3, 'rays_per_s': kept / t_it,
-                                       'final_loss': float(loss), 'algorithmic_tflops': flop / t_it / 1e12,
-                                       'frac_of_f32_mfma_peak': flop / t_it / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                       'note': 'a ray / pose gradient takes the exact f32-input MFMA backward (include/adfp.h); at a few '
-                                               'hundred rays the iteration is bound by host dispatch + kernel launch latency, not by the GPU',
+            out['by_batch'][str(n)] = {'rays_sampled': n, 'rays_after_prefilter': kept,
+                                       'ms_per_iteration': t_f * 1e3, 'rays_per_s': n / t_f, 'final_loss': float(loss_f),
+                                       'algorithmic_tflops': flop / t_f / 1e12,
+                                       'frac_of_f32_mfma_peak': flop / t_f / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                       'path': 'tracking.TrackerIteration: one HIP-graph replay per iteration (the n sampled rays are rendered, '
+                                               'the pre-filter is a keep flag; the pose gradient takes the exact f32-input MFMA backward)',
+                                       'reference_shaped_calls': {'ms_per_iteration': t_it * 1e3, 'final_loss': float(loss.detach()),
+                                                                  'note': 'get_samples -> filter_rays_in_bound -> render_batch_ray -> torch loss -> '
+                                                                          'backward() -> torch.optim.Adam against this package: bound by host dispatch '
+                                                                          'and two read-backs, not by the GPU'},
                                        'cpu_baseline': {'ms_per_iteration': t_o * 1e3, 'rays_per_s': kept / t_o, 'cores': cores, 'kind': 'port'}}
     finally:
         for p in dec.parameters():

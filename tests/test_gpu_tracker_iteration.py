@@ -112,7 +112,8 @@ def test_tracker_loss_matches_the_reference_formula(n, handle_dynamic):
         ref.backward()
         loss, g_d, g_c = run_loss(depth.detach(), unc, color.detach(), gd, gc, kp, handle_dynamic, 0.5)
         assert abs(loss.item() - ref.item()) <= 1e-6 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
-        assert torch.equal(g_d, depth.grad), (g_d - depth.grad).abs().max()
+        assert (g_d - depth.grad).abs().max() <= 4e-16 * depth.grad.abs().max(), (g_d - depth.grad).abs().max()     # 1 ulp: host vs device sqrt / divide
+        assert torch.equal(g_d == 0, depth.grad == 0)
         assert torch.equal(g_c, color.grad)
 
 
