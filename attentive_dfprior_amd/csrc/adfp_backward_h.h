@@ -110,6 +110,7 @@ struct DecodeBwdHArgs {
     const float* gmax;         // see grad_scale (WGRAD)
     float* gc_out;             // SCAT = false: [P][32] d/d c rows (row = point) for k_scatter_sorted, or NULL
     const int* skip;           // device flag: the forward call was repaired (zero cotangents, state not valid): report nothing
+    float* g_pts;              // PGRAD: [P,3] d/d sample position, accumulated (g0.data = the own grid, channels-last, is read then)
 };
 
 // 16 D-layout registers -> the two k-steps of a B operand
@@ -133,8 +134,12 @@ ADFP_DEV void stage_block_scaled(float* __restrict__ row, int col, int h, const 
 // scatter structures limit the workgroup to 6 waves).  SCAT = false: the kernel only writes d/d c, one 128-B row per point
 // (a.gc_out), and k_scatter_sorted adds the rows to the grid gradient in spatial order -- the path the host takes whenever the
 // grid fits the binning (run_decode_bwd_h).
-template <int CDIM, int NOUT, int ROLE, bool WGRAD, bool SCAT, int NT>
+// PGRAD (the Tracker: pose gradients, networks and grids frozen -- only with WGRAD = SCAT = false): d/d position through the
+// Fourier features (the d/d e blocks of layers 3 and 0 stay in 48 accumulators; cos(p @ B) and the 3-vector product on the VALU
+// in f32) and through the trilinear lookup of the own grid (d/d c against the eight corner rows, as the exact kernel does).
+template <int CDIM, int NOUT, int ROLE, bool WGRAD, bool SCAT, int NT, bool PGRAD = false>
 __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
+    static_assert(!PGRAD || (!WGRAD && !SCAT), "the position gradient comes without weight / grid gradients");
     using LT = DecLayoutHT<CDIM, NOUT>;
     using ST = DecStage<CDIM>;
     constexpr int NW = NT / 64;
@@ -224,6 +229,13 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
         f32x16 gc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) gc[r] = 0.f;
+        f32x16 gep[PGRAD ? 3 : 1];                           // PGRAD: d/d e, the three 32-feature blocks
+        if constexpr (PGRAD) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gep[b][r] = 0.f;
+        }
 
 #pragma unroll
         for (int i = 4; i >= 0; --i) {
@@ -239,8 +251,14 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
                 const int keep = ((int)(mk[i] << (16 + r))) >> 31;                   // v_bfe_i32: -1 where unit r was active
                 gp[r] = __uint_as_float(__float_as_uint(gh[r]) & (unsigned)keep);
             }
-            if (i == 0 && !WGRAD) break;                                              // layer 0 only feeds d/d e
+            if (i == 0 && !WGRAD && !PGRAD) break;                                    // layer 0 only feeds d/d e
             split16(gp, xh, xl, amax);                                                // |gp| <= |gh|: already range-checked
+            if constexpr (PGRAD) {
+                if (i == 3 || i == 0) {
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) mfma_chain_h<2>(gep[b], ldsu + LT::T_WP(i, b), lane_off, xh, xl);
+                }
+            }
             if constexpr (WGRAD) {
                 // d/d e reaches the Fourier features through layers 3 and 0.  Layer 3's share waits in the row's SGA columns
                 // (raw) until layer 0 adds its own and multiplies by cos(p @ B): d/d (p @ B), what d/d embedder._B needs --
@@ -286,7 +304,51 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
                 gh = gn;
             }
         }
-        if constexpr (SCAT) {
+        if constexpr (PGRAD) {
+            float pf[3] = {(float)pt[0], (float)pt[1], (float)pt[2]};
+            const bool pnan = (pt[0] != pt[0]) | (pt[1] != pt[1]) | (pt[2] != pt[2]);         // decoded at the origin by the forward
+            if (pnan) { pf[0] = 0.f; pf[1] = 0.f; pf[2] = 0.f; }
+            // through the Fourier features: d/dp_k = sum_j B[k][j] cos(p @ B)_j d/d e_j
+            float gpos[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x4 bm = *(const f32x4*)(lds + LT::P_BM + (32 * b + kmapH(r, h)) * 4);
+                    const float arg = fmaf(pf[2], bm.z, fmaf(pf[1], bm.y, pf[0] * bm.x));
+                    const float ga = gep[b][r] * __builtin_amdgcn_cosf(adfp_turns(arg));
+                    gpos[0] = fmaf(ga, bm.x, gpos[0]); gpos[1] = fmaf(ga, bm.y, gpos[1]); gpos[2] = fmaf(ga, bm.z, gpos[2]);
+                }
+            // through the trilinear lookup of the OWN grid (the high decoder's low-grid features are under no_grad in the
+            // reference, decoder.py:182-187)
+            int xi[2], yi[2], zi[2]; float wx[2], wy[2], wz[2], dcx, dcy, dcz;
+            tri_axis_d(pn[0], a.g0.X, (float)(2.0 * a.nb.inv[0]), xi[0], xi[1], wx[0], wx[1], dcx);
+            tri_axis_d(pn[1], a.g0.Y, (float)(2.0 * a.nb.inv[1]), yi[0], yi[1], wy[0], wy[1], dcy);
+            tri_axis_d(pn[2], a.g0.Z, (float)(2.0 * a.nb.inv[2]), zi[0], zi[1], wz[0], wz[1], dcz);
+            float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int ka = k & 1, kb = (k >> 1) & 1, kc = k >> 2;
+                const long long vox = ((long long)zi[kc] * a.g0.Y + yi[kb]) * a.g0.X + xi[ka];
+                const f32x4* src = (const f32x4*)(a.g0.data + vox * 32 + 4 * h);
+                float sdot = 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const f32x4 t = src[2 * v];
+                    sdot = fmaf(t.x, gc[4 * v + 0], sdot); sdot = fmaf(t.y, gc[4 * v + 1], sdot);
+                    sdot = fmaf(t.z, gc[4 * v + 2], sdot); sdot = fmaf(t.w, gc[4 * v + 3], sdot);
+                }
+                gx = fmaf(sdot, (ka ? 1.f : -1.f) * wy[kb] * wz[kc], gx);
+                gy = fmaf(sdot, (kb ? 1.f : -1.f) * wx[ka] * wz[kc], gy);
+                gz = fmaf(sdot, (kc ? 1.f : -1.f) * wx[ka] * wy[kb], gz);
+            }
+            gpos[0] = fmaf(gx, dcx, gpos[0]); gpos[1] = fmaf(gy, dcy, gpos[1]); gpos[2] = fmaf(gz, dcz, gpos[2]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gpos[k] += __shfl_xor(gpos[k], 32);
+            if (valid && h == 0) {
+                a.g_pts[3ll * q + 0] += gpos[0] * isc; a.g_pts[3ll * q + 1] += gpos[1] * isc; a.g_pts[3ll * q + 2] += gpos[2] * isc;
+            }
+        } else if constexpr (SCAT) {
             if (a.g_grid) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gc[r] *= isc;
@@ -689,13 +751,14 @@ struct AttBwdHArgs {
     int chunk_lo, chunk_hi;
     int* status; const float* gmax;
     const int* skip;           // device flag: non-zero = zero gradients for this call (see k_composite_bwd)
+    PtsDev P; NormDev nt; TsdfDev t; float* g_pts;     // PGRAD: d/d position through inv_tsdf = f(trilerp(TSDF)), accumulated
 };
 // 16 values of a float array -> the two k-steps of a B operand
 ADFP_DEV void split16a(const float* __restrict__ v, f16x8* __restrict__ xh, f16x8* __restrict__ xl, float& amax) {
     split8(v, xh[0], xl[0], amax);
     split8(v + 8, xh[1], xl[1], amax);
 }
-template <bool WGRAD>
+template <bool WGRAD, bool PGRAD = false>
 __global__ __launch_bounds__(512) void k_attention_bwd_h(AttBwdHArgs a) {
     using T = AttLayoutHT;
     using ST = AttStage;
@@ -791,7 +854,7 @@ __global__ __launch_bounds__(512) void k_attention_bwd_h(AttBwdHArgs a) {
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) split16a(gp1 + 16 * ob, xh + 2 * ob, xl + 2 * ob, amax);
         // ---- layer 0: d/d pre_0 = mask . (W1^T gp1); d/d occ_in through the 2 -> 64 layer
-        float gx = 0.f;
+        float gx = 0.f, gxu = 0.f;
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
             f32x16 acc;
@@ -805,12 +868,33 @@ __global__ __launch_bounds__(512) void k_attention_bwd_h(AttBwdHArgs a) {
                 const int keep = ((int)(mk[0] << (16 * ib + r))) >> 31;
                 g0[r] = __uint_as_float(__float_as_uint(acc[r]) & (unsigned)keep);
                 gx = fmaf(lds[T::P_A0 + (32 * ib + kmapH(r, h)) * 4], g0[r], gx);
+                if (PGRAD) gxu = fmaf(lds[T::P_A0 + (32 * ib + kmapH(r, h)) * 4 + 1], g0[r], gxu);     // d/d u through layer 0
             }
             if (WGRAD && valid) stage_block_mul(srow, ST::AG0 + 32 * ib, h, g0, 0, ssc);
         }
         gx += __shfl_xor(gx, 32);
         const float g_in = a0 * g_out + gx * isc;
         if (valid && h == 0) { a.att_g[idx] = g_in; a.g_raw[4ll * q + 3] = g_in; }
+        if constexpr (PGRAD) {
+            gxu += __shfl_xor(gxu, 32);
+            const float g_u = a1 * g_out + gxu * isc;
+            if (valid && h == 0) {                       // as k_attention_bwd: u = clamp(-0.1 log(1/(s + 1e-8) - 1 + 1e-7), +-100), s = clamp(1 - (t + 1)/2, 0, 1)
+                double pt[3]; float pn[3], dn[3], gt[3];
+                load_point(a.P, q, pt);
+                normalize3(a.nt, pt, pn);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dn[k] = (float)(2.0 * a.nt.inv[k]);
+                const float tv = trilerp_scalar_grad(a.t, pn, dn, gt);
+                const float sr = 1.f - (tv + 1.f) / 2.f;
+                const float scl = fminf(fmaxf(sr, 0.f), 1.f);
+                const float se = scl + 1e-8f;
+                const float vv = (1.f / se) - 1.f + 1e-7f;
+                const float ur = -0.1f * logf(vv);
+                const float du_dt = (sr > 0.f && sr < 1.f && ur > -100.f && ur < 100.f) ? -0.05f / (vv * se * se) : 0.f;
+                const float g_t = g_u * du_dt;
+                a.g_pts[3ll * q + 0] += g_t * gt[0]; a.g_pts[3ll * q + 1] += g_t * gt[1]; a.g_pts[3ll * q + 2] += g_t * gt[2];
+            }
+        }
     }
     if (!(a.skip && *a.skip)) report_range(a.status, amax, ADFP_STATUS_F16_RANGE_BWD);
 }

@@ -1995,7 +1995,15 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
     a.P = o.P; a.nb = o.nb; a.g0 = o.g0; a.packed_t = (const unsigned*)t; a.list = o.list; a.count_ptr = o.count_ptr;
     a.g_raw = o.g_raw; a.att_g = o.att_g; a.masks = masks; a.g_grid = o.g_grid; a.stage = nullptr; a.status = status; a.gmax = bw.gmax; a.skip = skip;
     a.gc_out = binned ? bw.gc : nullptr;
+    a.g_pts = o.g_pts;
     constexpr int NW = ADFP_BWDH_NT / 64;
+    if (o.g_pts) {                                      // position gradient only (backward_points' use_h): frozen network and grid
+        if (flat || o.g_grid) return ADFP_E_ARG;
+        a.chunk_lo = 0; a.chunk_hi = total;
+        hipLaunchKernelGGL((k_decode_bwd_h<CDIM, NOUT, ROLE, false, false, 512, true>), dim3(decode_grid((total + 31) / 32, 8, 1)), dim3(512), 0, st, a);
+        ADFP_CHECK_LAUNCH();
+        return 0;
+    }
     if (!flat) {
         a.chunk_lo = 0; a.chunk_hi = total;
         if (o.g_grid && !binned) hipLaunchKernelGGL((k_decode_bwd_h<CDIM, NOUT, ROLE, false, true, ADFP_BWDH_NT>), dim3(decode_grid((total + 31) / 32, NW, 1)), dim3(ADFP_BWDH_NT), 0, st, a);
@@ -2069,18 +2077,19 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
     a.list = nullptr; a.count_ptr = nullptr; a.g_raw = bw.g_raw; a.att_g = nullptr; a.stage = nullptr;
     a.g_pts = pgrad ? bw.g_pts : nullptr;
     if (pgrad) { e = zero_async(bw.g_pts, (size_t)P * 12, st); if (e != hipSuccess) return (int)e; }
-    // a decoder takes the f16-split backward when its T image and the forward's masks are there, no position gradient is
-    // wanted, and -- if its weight gradients are -- the forward also left the layer inputs
-    auto use_h = [&](const void* t, const unsigned* masks, const float* act, const float* flat) {
-        return t && masks && !pgrad && (!flat || act);
+    // a decoder takes the f16-split backward when its T image and the forward's masks are there and -- if its weight gradients
+    // are wanted -- the forward also left the layer inputs.  A position gradient comes from the f16-split kernels only on its own
+    // (the Tracker: networks and grids frozen); together with weight or grid gradients (bundle adjustment) the exact kernels run.
+    auto use_h = [&](const void* t, const unsigned* masks, const float* act, const float* flat, const float* grid = nullptr) {
+        return t && masks && (!flat || act) && (!pgrad || (!flat && !grid));
     };
     // The grid gradients of the decoders that take the f16-split backward are scattered in spatial order (k_scatter_sorted): one
     // radix sort of the points by (coarsest such grid's cell, finest grid's cell inside it), shared by all of them.
     BinPlan bp; bp.ok = false;
     {
-        const bool h_low = go.grid_low && use_h(sc->ht_low, state.masks_low, state.act_low, go.flat_low);
-        const bool h_high = fuse && go.grid_high && use_h(sc->ht_high, state.masks_high, state.act_high, go.flat_high);
-        const bool h_color = stage == ADFP_STAGE_COLOR && go.grid_color && use_h(sc->ht_color, state.masks_color, state.act_color, go.flat_color);
+        const bool h_low = go.grid_low && use_h(sc->ht_low, state.masks_low, state.act_low, go.flat_low, go.grid_low);
+        const bool h_high = fuse && go.grid_high && use_h(sc->ht_high, state.masks_high, state.act_high, go.flat_high, go.grid_high);
+        const bool h_color = stage == ADFP_STAGE_COLOR && go.grid_color && use_h(sc->ht_color, state.masks_color, state.act_color, go.flat_color, go.grid_color);
         const adfp_grid* fine = nullptr; const adfp_grid* coarse = nullptr;
         auto vox = [](const adfp_grid& g) { return (long long)g.X * g.Y * g.Z; };
         const adfp_grid* cand[3] = {h_low ? &sc->low : nullptr, h_high ? &sc->high : nullptr, h_color ? &sc->color : nullptr};
@@ -2120,6 +2129,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
             t.packed_t = (const unsigned*)sc->ht_att; t.list = state.list; t.count_ptr = state.counter; t.att_occ = state.att_occ; t.att_u = state.att_u;
             t.masks = state.masks_att; t.g_weight = g_weight; t.g_raw = bw.g_raw; t.att_g = bw.att_g; t.stage = bw.stage;
             t.status = sc->status; t.gmax = bw.gmax; t.skip = state.counter ? state.counter + 8 : nullptr;
+            t.P = Pd; t.nt = make_norm(sc->tsdf_bnds); t.t = make_tsdf(sc->tsdf); t.g_pts = a.g_pts;
             OuterHArgs oh; attention_jobs(oh.o);
             oh.act = state.act_att; oh.nxm4 = 416 / 4; oh.ngm4 = 416 / 4; oh.g_dst4 = 416 / 4; oh.x_gap_at4 = 1 << 20; oh.x_gap4 = 0;
             oh.masks = nullptr; oh.bm = nullptr; oh.col_se = 0; oh.col_sgp = 0; oh.status = sc->status; oh.skip = t.skip;
@@ -2131,6 +2141,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
                 t.chunk_lo = lo; t.chunk_hi = hi;
                 const int ntiles = (hi - lo + 31) / 32;
                 if (go.flat_att) hipLaunchKernelGGL(k_attention_bwd_h<true>, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
+                else if (pgrad) hipLaunchKernelGGL((k_attention_bwd_h<false, true>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
                 else hipLaunchKernelGGL(k_attention_bwd_h<false>, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
                 ADFP_CHECK_LAUNCH();
                 if (go.flat_att) {
@@ -2174,7 +2185,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
             DecodeBwdArgs hgh = a;
             hgh.g0 = make_grid(sc->high); hgh.g1 = make_grid(sc->low); hgh.packed = sc->w_high;
             hgh.list = state.list; hgh.count_ptr = state.counter; hgh.att_g = bw.att_g; hgh.g_grid = go.grid_high;
-            if (use_h(sc->ht_high, state.masks_high, state.act_high, go.flat_high))
+            if (use_h(sc->ht_high, state.masks_high, state.act_high, go.flat_high, go.grid_high))
                 rc = run_decode_bwd_h<64, 1, ROLE_HIGH>(hgh, sc->ht_high, state.masks_high, state.act_high, sc->status, state.counter ? state.counter + 8 : nullptr, P, state.counter, go.flat_high, bw, bp, state.flags, st);
             else rc = sc->w_high ? run_decode_bwd<64, 1, ROLE_HIGH>(hgh, P, state.counter, go.flat_high, bw, st) : ADFP_E_ARG;
             if (rc) return rc;
@@ -2183,7 +2194,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
     if (go.grid_low || go.flat_low || pgrad) {
         DecodeBwdArgs lw = a;
         lw.g0 = make_grid(sc->low); lw.g1 = lw.g0; lw.packed = sc->w_low; lw.g_grid = go.grid_low;
-        if (use_h(sc->ht_low, state.masks_low, state.act_low, go.flat_low))
+        if (use_h(sc->ht_low, state.masks_low, state.act_low, go.flat_low, go.grid_low))
             rc = run_decode_bwd_h<32, 1, ROLE_LOW>(lw, sc->ht_low, state.masks_low, state.act_low, sc->status, state.counter ? state.counter + 8 : nullptr, P, nullptr, go.flat_low, bw, bp, nullptr, st);
         else rc = sc->w_low ? run_decode_bwd<32, 1, ROLE_LOW>(lw, P, nullptr, go.flat_low, bw, st) : ADFP_E_ARG;
         if (rc) return rc;
@@ -2191,7 +2202,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
     if (stage == ADFP_STAGE_COLOR && (go.grid_color || go.flat_color || pgrad)) {
         DecodeBwdArgs cl = a;
         cl.g0 = make_grid(sc->color); cl.g1 = cl.g0; cl.packed = sc->w_color; cl.g_grid = go.grid_color;
-        if (use_h(sc->ht_color, state.masks_color, state.act_color, go.flat_color))
+        if (use_h(sc->ht_color, state.masks_color, state.act_color, go.flat_color, go.grid_color))
             rc = run_decode_bwd_h<32, 4, ROLE_COLOR>(cl, sc->ht_color, state.masks_color, state.act_color, sc->status, state.counter ? state.counter + 8 : nullptr, P, nullptr, go.flat_color, bw, bp, nullptr, st);
         else rc = sc->w_color ? run_decode_bwd<32, 4, ROLE_COLOR>(cl, P, nullptr, go.flat_color, bw, st) : ADFP_E_ARG;
         if (rc) return rc;

@@ -169,12 +169,19 @@ class Engine(object):
         return bufs
 
     @staticmethod
-    def ht_nets(saved, need_flat, need_pos):
-        """Decoders whose backward can run f16-split: the forward left their masks, no position / ray gradient is wanted, and
-        their layer inputs are there if their parameter gradient is."""
-        if need_pos or saved.get('bwd_exact'):
+    def ht_nets(saved, need_flat, need_pos, need_grid=None):
+        """Decoders whose backward can run f16-split: the forward left their masks, and their layer inputs if their parameter
+        gradient is wanted.  A position / ray gradient comes from the f16-split kernels only for a network whose own parameter
+        and grid gradients are NOT wanted (the Tracker: everything frozen but the pose); bundle adjustment takes the exact ones."""
+        if saved.get('bwd_exact'):
             return ()
-        return tuple(n for n in ('low', 'high', 'color', 'att') if ('masks_' + n) in saved and (not need_flat.get(n) or ('act_' + n) in saved))
+        need_grid = need_grid or {}
+
+        def ok(n):
+            if ('masks_' + n) not in saved or (need_flat.get(n) and ('act_' + n) not in saved):
+                return False
+            return not (need_pos and (need_flat.get(n) or need_grid.get(n)))
+        return tuple(n for n in ('low', 'high', 'color', 'att') if ok(n))
 
     @staticmethod
     def fill_tsdf(td, tsdf_volume, keep):
@@ -243,7 +250,7 @@ class Engine(object):
         with torch.cuda.device(dev):
             P = pts.shape[0]
             sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=True,
-                                  ht_nets=self.ht_nets(saved, need_flat, need_pts))
+                                  ht_nets=self.ht_nets(saved, need_flat, need_pts, need_grid))
             ap = _lib.AdfpPoints()
             ap.mode, ap.n_points, ap.pts = saved['mode'], P, pts.data_ptr()
             a = _lib.AdfpPointsBackwardArgs()
@@ -445,7 +452,7 @@ class Engine(object):
         with torch.cuda.device(dev):
             N, S = ro.shape[0], saved['S']
             sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=True,
-                                  ht_nets=self.ht_nets(saved, need_flat, need_rays))
+                                  ht_nets=self.ht_nets(saved, need_flat, need_rays, need_grid))
             a = _lib.AdfpBackwardArgs()
             a.stage = _lib.STAGE[stage]
             a.n_rays, a.S = N, S

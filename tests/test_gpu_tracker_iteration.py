@@ -230,6 +230,40 @@ def test_fused_gradient_against_the_oracle(tb):
     assert (g.cpu() - cam.grad).abs().max().item() <= 2e-3 * scale, (g.cpu(), cam.grad)
 
 
+def test_f16_split_pose_gradient_equals_the_exact_backward(tb):
+    """With everything but the pose frozen the ray gradient comes from the f16-split backward kernels (k_decode_bwd_h / k_attention_bwd_h,
+    PGRAD); latching the backward onto the exact f32-input MFMA kernels must give the same pose gradient to f32 rounding."""
+    it = tb.iteration(use_graph=False)
+    pick = tb.picks(1000, 1, seed=21)[0]
+    assert not tb.dec._exact_latch
+    loss, g = it.gradient(1000, pick)
+    tb.dec._exact_latch.add('bwd')
+    try:
+        loss_x, g_x = it.gradient(1000, pick)
+    finally:
+        tb.dec._exact_latch.discard('bwd')
+    assert loss.item() == loss_x.item()                       # same forward
+    scale = g_x.abs().max().item()
+    diff = (g - g_x).abs().max().item()
+    assert 0 < diff <= 2e-5 * scale, (diff, scale, g, g_x)    # two different kernel families, one answer
+
+
+def test_tracker_loss_with_many_equal_values():
+    """Ties: the radix select must land on the tied value when the median falls inside a run of equal tmp."""
+    n = 600
+    g = torch.Generator().manual_seed(3)
+    depth = torch.full((n,), 1.0, dtype=torch.float64).requires_grad_(True)
+    unc = torch.full((n,), 0.04, dtype=torch.float64)
+    gd = 1.0 + torch.randint(0, 4, (n,), generator=g).float() * 0.25           # four distinct values, ~150 rays each
+    gd[::50] = 90.0
+    color, gc = torch.rand(n, 3, generator=g).requires_grad_(True), torch.rand(n, 3, generator=g)
+    ref = O.tracker_loss(depth, unc, color, gd, gc)
+    ref.backward()
+    loss, g_d, g_c = run_loss(depth.detach(), unc, color.detach(), gd, gc, None, True, 0.5)
+    assert abs(loss.item() - ref.item()) <= 1e-9 * abs(ref.item())
+    assert torch.equal(g_d == 0, depth.grad == 0) and torch.equal(g_c, color.grad)
+
+
 @pytest.mark.parametrize('separate', [False, True])
 def test_ten_iterations_follow_torch_adam(tb, separate):
     """num_cam_iters = 10 (configs/df_prior.yaml:27) of the fused iteration vs the same loop with torch.optim.Adam: the pose
