@@ -260,7 +260,7 @@ def test_tracker_loss_with_many_equal_values():
     ref = O.tracker_loss(depth, unc, color, gd, gc)
     ref.backward()
     loss, g_d, g_c = run_loss(depth.detach(), unc, color.detach(), gd, gc, None, True, 0.5)
-    assert abs(loss.item() - ref.item()) <= 1e-9 * abs(ref.item())
+    assert abs(loss.item() - ref.item()) <= 1e-6 * abs(ref.item())           # the reference sums the colour term in float32
     assert torch.equal(g_d == 0, depth.grad == 0) and torch.equal(g_c, color.grad)
 
 
