@@ -14,6 +14,7 @@ STATUS_F16_RANGE = 31              # ADFP_STATUS_F16_RANGE: any of the bits belo
 STATUS_RANGE_BITS = {'low': 1, 'high': 2, 'color': 4, 'att': 8, 'bwd': 16}      # ADFP_STATUS_F16_RANGE_<net>
 BWD_SCATTER_IN_KERNEL = 1        # ADFP_BWD_SCATTER_IN_KERNEL
 BWD_GRIDS_PREZEROED = 2          # ADFP_BWD_GRIDS_PREZEROED
+BWD_STAGED_WGRAD = 4             # ADFP_BWD_STAGED_WGRAD
 STAGE = {'low': 0, 'high': 1, 'color': 2}
 DEC_KIND = {'low': 0, 'high': 1, 'color': 2}
 PTS_RAYS, PTS_F64, PTS_F32 = 0, 1, 2

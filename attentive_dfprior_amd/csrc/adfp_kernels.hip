@@ -946,6 +946,14 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
 #include "adfp_sort.h"
 #include "adfp_backward.h"
 #include "adfp_backward_h.h"
+#include "adfp_backward_fused.h"
+#ifdef ADFP_STAMPS
+extern "C" int adfp_debug_phases_fused(unsigned long long* host_out, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_fused), 64);
+    if (!rc && reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_fused), z, 64); }
+    return rc;
+}
+#endif
 #include "adfp_fusion.h"
 #include "adfp_mapping.h"
 #include "adfp_mapper_iter.h"
@@ -1984,7 +1992,7 @@ static int scatter_bins(const BinPlan& bp, const DecodeBwdArgs& o, const BwdWork
 
 template <int CDIM, int NOUT, int ROLE>
 static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigned* masks, const float* act, int* status, const int* skip, int total,
-                            const int* count_ptr, float* flat, BwdWorkspace& bw, const BinPlan& bp, const unsigned char* flags, hipStream_t st) {
+                            const int* count_ptr, float* flat, BwdWorkspace& bw, const BinPlan& bp, const unsigned char* flags, int options, hipStream_t st) {
     if (total == 0) return 0;
     // d/d c rows + k_scatter_sorted instead of the in-kernel scatter: for a grid on one of the two lattices the points were
     // sorted by (k_bin_keys); a third lattice keeps the in-kernel scatter
@@ -2003,6 +2011,24 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
         hipLaunchKernelGGL((k_decode_bwd_h<CDIM, NOUT, ROLE, false, false, 512, true>), dim3(decode_grid((total + 31) / 32, 8, 1)), dim3(512), 0, st, a);
         ADFP_CHECK_LAUNCH();
         return 0;
+    }
+    if constexpr (CDIM == 32) {
+        // weight gradients inside the chain kernel (adfp_backward_fused.h): no staging rows, no k_outer_h.  Needs the grid
+        // gradient on the sorted scatter (or not wanted): the in-kernel scatter's LDS structures do not fit beside the reduction copy.
+        if (flat && !count_ptr && (binned || !o.g_grid) && !(options & ADFP_BWD_STAGED_WGRAD)) {
+            DecodeBwdFArgs f;
+            f.P = o.P; f.nb = o.nb; f.packed_t = (const unsigned*)t; f.g_raw = o.g_raw; f.masks = masks; f.act = act;
+            f.gc_out = binned ? bw.gc : nullptr; f.total = total; f.status = status; f.gmax = bw.gmax; f.skip = skip;
+            f.partial = bw.partial; f.part_stride = bw.part_stride;
+            int rc = outer_begin(bw, DecLayout<CDIM, NOUT>::F_TOTAL, st);
+            if (rc) return rc;
+            const int ntiles = (total + 31) / 32, nwg = (ntiles + 3) / 4;
+            hipLaunchKernelGGL((k_decode_bwd_fused<NOUT, ROLE>), dim3(nwg < OUTER_NSLOT ? nwg : OUTER_NSLOT), dim3(256), 0, st, f);
+            ADFP_CHECK_LAUNCH();
+            rc = outer_end_scaled(bw, DecLayout<CDIM, NOUT>::F_TOTAL, flat, st);
+            if (rc) return rc;
+            return binned ? scatter_bins(bp, o, bw, flags, st) : 0;
+        }
     }
     if (!flat) {
         a.chunk_lo = 0; a.chunk_hi = total;
@@ -2186,7 +2212,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
             hgh.g0 = make_grid(sc->high); hgh.g1 = make_grid(sc->low); hgh.packed = sc->w_high;
             hgh.list = state.list; hgh.count_ptr = state.counter; hgh.att_g = bw.att_g; hgh.g_grid = go.grid_high;
             if (use_h(sc->ht_high, state.masks_high, state.act_high, go.flat_high, go.grid_high))
-                rc = run_decode_bwd_h<64, 1, ROLE_HIGH>(hgh, sc->ht_high, state.masks_high, state.act_high, sc->status, state.counter ? state.counter + 8 : nullptr, P, state.counter, go.flat_high, bw, bp, state.flags, st);
+                rc = run_decode_bwd_h<64, 1, ROLE_HIGH>(hgh, sc->ht_high, state.masks_high, state.act_high, sc->status, state.counter ? state.counter + 8 : nullptr, P, state.counter, go.flat_high, bw, bp, state.flags, options, st);
             else rc = sc->w_high ? run_decode_bwd<64, 1, ROLE_HIGH>(hgh, P, state.counter, go.flat_high, bw, st) : ADFP_E_ARG;
             if (rc) return rc;
         }
@@ -2195,7 +2221,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         DecodeBwdArgs lw = a;
         lw.g0 = make_grid(sc->low); lw.g1 = lw.g0; lw.packed = sc->w_low; lw.g_grid = go.grid_low;
         if (use_h(sc->ht_low, state.masks_low, state.act_low, go.flat_low, go.grid_low))
-            rc = run_decode_bwd_h<32, 1, ROLE_LOW>(lw, sc->ht_low, state.masks_low, state.act_low, sc->status, state.counter ? state.counter + 8 : nullptr, P, nullptr, go.flat_low, bw, bp, nullptr, st);
+            rc = run_decode_bwd_h<32, 1, ROLE_LOW>(lw, sc->ht_low, state.masks_low, state.act_low, sc->status, state.counter ? state.counter + 8 : nullptr, P, nullptr, go.flat_low, bw, bp, nullptr, options, st);
         else rc = sc->w_low ? run_decode_bwd<32, 1, ROLE_LOW>(lw, P, nullptr, go.flat_low, bw, st) : ADFP_E_ARG;
         if (rc) return rc;
     }
@@ -2203,7 +2229,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         DecodeBwdArgs cl = a;
         cl.g0 = make_grid(sc->color); cl.g1 = cl.g0; cl.packed = sc->w_color; cl.g_grid = go.grid_color;
         if (use_h(sc->ht_color, state.masks_color, state.act_color, go.flat_color, go.grid_color))
-            rc = run_decode_bwd_h<32, 4, ROLE_COLOR>(cl, sc->ht_color, state.masks_color, state.act_color, sc->status, state.counter ? state.counter + 8 : nullptr, P, nullptr, go.flat_color, bw, bp, nullptr, st);
+            rc = run_decode_bwd_h<32, 4, ROLE_COLOR>(cl, sc->ht_color, state.masks_color, state.act_color, sc->status, state.counter ? state.counter + 8 : nullptr, P, nullptr, go.flat_color, bw, bp, nullptr, options, st);
         else rc = sc->w_color ? run_decode_bwd<32, 4, ROLE_COLOR>(cl, P, nullptr, go.flat_color, bw, st) : ADFP_E_ARG;
         if (rc) return rc;
     }

@@ -318,6 +318,10 @@ typedef struct adfp_backward_args {
 /* the caller guarantees that the g_grid_* buffers are all zero on entry (adfp_adam_grids_cl leaves them so): the call does not
  * zero them again */
 #define ADFP_BWD_GRIDS_PREZEROED 2
+/* weight gradients of the 32-channel decoders through the staged two-kernel path (cotangent blocks written per point, k_outer_h)
+ * instead of inside the chain kernel (k_decode_bwd_fused); same values up to the summation order.  What the tests compare the
+ * fused kernel against. */
+#define ADFP_BWD_STAGED_WGRAD 4
 size_t adfp_backward_workspace_bytes(long long n_points);
 int adfp_render_backward(const adfp_scene* scene /*host*/, const adfp_backward_args* args /*host*/, void* stream);
 

@@ -358,6 +358,25 @@ def test_sorted_scatter_equals_cached_scatter(mini):
         assert_close_scale(got['sorted'][k], got['cache'][k], 2e-6, f'{k}: sorted vs cached scatter')
 
 
+@pytest.mark.parametrize('stage', ['low', 'color'])
+def test_fused_weight_gradients_equal_the_staged_path(mini, stage):
+    """The 32-channel decoders' weight gradients from inside the chain kernel (k_decode_bwd_fused: blocks transposed by MFMA,
+    accumulators resident across tiles) against the staged two-kernel path (ADFP_BWD_STAGED_WGRAD: cotangent blocks written per
+    point, k_outer_h): the same forward state, the same 3-product split -- only the summation order over the points differs."""
+    from attentive_dfprior_amd import _lib
+    rays = synthetic.make_ray_batch(synthetic.mini_scene(), 700, seed=5, poses=3)
+    got = {}
+    for name, opt in (('fused', 0), ('staged', _lib.BWD_STAGED_WGRAD)):
+        loss, c, dec = run(mini, stage, stage != 'color', sd=O.random_state_dict(seed=23), n_samples=48, n_surface=16, rays=rays, bwd_options=opt)
+        got[name] = {n: p.grad.detach().cpu().clone() for n, p in dec.named_parameters() if p.grad is not None}
+        got[name].update({k: v.grad.cpu() for k, v in c.items() if v.grad is not None})
+    assert set(got['fused']) == set(got['staged']) and any(k.startswith('low_decoder') for k in got['fused'])
+    for k in got['fused']:
+        assert_close_scale(got['fused'][k], got['staged'][k], 3e-6, f'{k}: fused vs staged weight gradients')
+        if stage == 'color' and k.startswith('color_decoder'):
+            assert got['fused'][k].abs().max() > 0, k
+
+
 def test_a_swapped_pair_of_weight_rows_fails_the_gradient_comparison(mini, monkeypatch):
     """Negative control of the comparison itself: the backward's flat colour-decoder gradient comes back with two rows of
     pts_linears.1.weight exchanged (what an indexing bug in k_outer_h's write-out would produce) -- the golden comparison
