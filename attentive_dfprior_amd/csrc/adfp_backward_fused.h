@@ -187,9 +187,9 @@ __global__ __launch_bounds__(256) void k_decode_bwd_fused(DecodeBwdFArgs a) {
         sm.go[3] = 0.f;
     };
     Small cur;
+    if (wave < ntiles) fetch_small(wave, cur);
     for (int tile = wave; tile < ntiles; tile += nwaves) {
         ADFP_PHASE(0);                                           // loop overhead
-        fetch_small(tile, cur);
         const int loc = tile * 32 + p;
         const bool valid = loc < a.total;
         const int q = valid ? loc : 0;
@@ -331,6 +331,7 @@ __global__ __launch_bounds__(256) void k_decode_bwd_fused(DecodeBwdFArgs a) {
         }
         ADFP_PHASE(4);                                           // the five layers
         if (a.gc_out && valid) stage_block_scaled(a.gc_out + 32ll * q, 0, h, gc, isc);
+        if (more) fetch_small(tnext, cur);                       // the next tile's inputs, in flight during the Fourier blocks
 
         // ---------------- the Fourier blocks: layers 0 and 3 against sin(p @ B); embedder._B through cos(p @ B) ----------------
         // computed in the transposed layout: lane = feature 32 b + p, registers = the points kmapH(r, h), positions from the table
