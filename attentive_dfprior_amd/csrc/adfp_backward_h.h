@@ -15,7 +15,9 @@
 //   k_scatter_sorted  adds the d/d c rows to the grid gradient in spatial order (run-length sums in registers)
 //   k_outer_h         weight gradients on f16 MFMA from the two row pieces (X from the forward, G from here)
 //
-// d/d position (the Tracker's pose gradient) stays on the exact kernel.
+// d/d position (the Tracker's pose gradient: networks and grids frozen) comes from the PGRAD variants of the two chain kernels;
+// together with grid or weight gradients (bundle adjustment) it stays on the exact kernel.  The 32-channel decoders' weight
+// gradients are formed inside adfp_backward_fused.h's kernel; k_outer_h serves the high decoder and the attention network.
 #pragma once
 #include "adfp_decode_h.h"
 #include "adfp_backward.h"
