@@ -350,13 +350,27 @@ __global__ __launch_bounds__(256) void k_decode_bwd_fused(DecodeBwdFArgs a) {
         }
         int pl = p;                                              // opaque per tile: what depends on it is recomputed, not hoisted out of the
         asm volatile("" : "+v"(pl));                             // tile loop and spilled (the per-lane constants below are 30 registers)
+        // the positions as the B operand of the embedder._B products: lane FSLOT_EB(b, k) carries coordinate k of the 16 points, for
+        // all three b at once (masked to one b's lanes below); every other lane zero
+        f16x8 pkh[2], pkl[2];
+        {
+            const int ks3 = pl - FSLOT_EB(0, 0);                 // 0..8 in the slot lanes
+            const int kc = ks3 - 3 * (ks3 >= 3) - 3 * (ks3 >= 6);
+            const bool inslot = ks3 >= 0 && ks3 < 9;
+            const unsigned mx = (inslot && kc == 0) ? ~0u : 0u, my = (inslot && kc == 1) ? ~0u : 0u, mz = (inslot && kc == 2) ? ~0u : 0u;
+            float pk[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const f32x4 pv = *(const f32x4*)(ptab + 4 * kmapH(r, h));
+                pk[r] = __uint_as_float((__float_as_uint(pv.x) & mx) | (__float_as_uint(pv.y) & my) | (__float_as_uint(pv.z) & mz));
+            }
+            split16v<false>(pk, pkh, pkl, amax);
+        }
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
             const f32x4 bm = *(const f32x4*)(lds + LT::P_BM + (32 * b + pl) * 4);
             const bool real = 32 * b + pl < 93;                  // the three padding features are not inputs
-            const int kslot = pl - FSLOT_EB(b, 0);               // 0..2: this lane carries coordinate kslot in the embedder._B product
-            const unsigned mx = kslot == 0 ? ~0u : 0u, my = kslot == 1 ? ~0u : 0u, mz = kslot == 2 ? ~0u : 0u;     // branch-free select below
-            float e[16], cs[16], pk[16];
+            float e[16], cs[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const f32x4 pv = *(const f32x4*)(ptab + 4 * kmapH(r, h));
@@ -365,7 +379,6 @@ __global__ __launch_bounds__(256) void k_decode_bwd_fused(DecodeBwdFArgs a) {
                 adfp_sincosf(arg, sn, c1);
                 e[r] = real ? sn : 0.f;
                 cs[r] = c1 * pv.w;                               // cos(p @ B) times the point's scale
-                pk[r] = __uint_as_float((__float_as_uint(pv.x) & mx) | (__float_as_uint(pv.y) & my) | (__float_as_uint(pv.z) & mz));
             }
             f16x8 eTh[2], eTl[2];
             split16v<false>(e, eTh, eTl, amax);
@@ -384,7 +397,13 @@ __global__ __launch_bounds__(256) void k_decode_bwd_fused(DecodeBwdFArgs a) {
             for (int r = 0; r < 16; ++r) ga[r] *= cs[r];
             f16x8 aTh[2], aTl[2], bTh[2], bTl[2];
             split16v(ga, aTh, aTl, amax);
-            split16v<false>(pk, bTh, bTl, amax);
+            const bool mine = pl >= FSLOT_EB(b, 0) && pl <= FSLOT_EB(b, 2);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                bTh[ks] = mine ? pkh[ks] : __builtin_bit_cast(f16x8, z);
+                bTl[ks] = mine ? pkl[ks] : __builtin_bit_cast(f16x8, z);
+            }
             // [row = feature 32 b + j][column FSLOT_EB(b, k)] += sum_p d/d(p @ B)_j x_k
             outer_job(acc[15], aTh, aTl, bTh, bTl);
         }
