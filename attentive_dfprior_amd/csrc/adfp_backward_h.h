@@ -431,17 +431,22 @@ struct ScatterSortedArgs {
 // point computes cell and weights of the wave's 128 points; phase B: lane = channel).  A run that the range boundary cuts is
 // added in pieces, which is harmless: atomics on ONE line cost ~17 ns each (tools/micro/atomic_rates.hip), and even the cells
 // around the camera, where every ray starts, are cut into a few hundred pieces.  (Longer ranges per wave only lengthen the
-// critical path: 128 points 1.90 ms per iteration, 1 024 points 2.15 ms.  Collecting the pieces in records and merging them in a
-// second kernel cost more than the atomics it saved.)
+// critical path: 128 points 1.90 ms per iteration, 1 024 points 2.15 ms; shorter ones cut more runs: 64 points per wave
+// (-DADFP_SCATTER_PPW=64) 71 us per grid against 46.  Collecting the pieces in records and merging them in a second kernel cost
+// more than the atomics it saved.)
+#ifndef ADFP_SCATTER_PPW
+#define ADFP_SCATTER_PPW 128          // sorted points per wave (two halves)
+#endif
 __global__ __launch_bounds__(64) void k_scatter_sorted(ScatterSortedArgs a) {
-    __shared__ int s_q[128];
-    __shared__ int s_cell[128];                   // x0 | y0 << 10 | z0 << 20
-    __shared__ __attribute__((aligned(16))) float s_w[128][8];     // the 8 corner weights (wx wy) wz, corner k = dx + 2 dy + 4 dz
+    constexpr int PPW = ADFP_SCATTER_PPW, PPH = PPW / 2;
+    __shared__ int s_q[PPW];
+    __shared__ int s_cell[PPW];                   // x0 | y0 << 10 | z0 << 20
+    __shared__ __attribute__((aligned(16))) float s_w[PPW][8];     // the 8 corner weights (wx wy) wz, corner k = dx + 2 dy + 4 dz
     const int lane = threadIdx.x & 63, ch = lane & 31, h = lane >> 5;
-    const int w0 = blockIdx.x * 128;
+    const int w0 = blockIdx.x * PPW;
     // ---- phase A
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < PPW / 64; ++b) {
         const int i = w0 + 64 * b + lane;
         int q = -1, cell = -1;
         float w[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -483,16 +488,16 @@ __global__ __launch_bounds__(64) void k_scatter_sorted(ScatterSortedArgs a) {
             acc[k] = 0.f;
         }
     };
-    for (int j0 = 0; j0 < 64; j0 += 16) {
+    for (int j0 = 0; j0 < PPH; j0 += 16) {
         float gv[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {             // the rows of the next 16 points, fetched together
-            const int q = s_q[64 * h + j0 + j];
+            const int q = s_q[PPH * h + j0 + j];
             gv[j] = q >= 0 ? a.gc[32ll * q + ch] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int pi = 64 * h + j0 + j;
+            const int pi = PPH * h + j0 + j;
             const float g = gv[j];
             const unsigned long long nz = __ballot(g != 0.f);
             if ((unsigned)(nz >> (32 * h)) == 0u) continue;       // no gradient from this point (a dropped ray, a point outside the band)
