@@ -110,8 +110,26 @@ def get_sample_uv(H0, H1, W0, W1, n, depth, color, device='cuda:0'):
 
 
 def get_samples(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, c2w, depth, color, device):
-    """n random rays of one frame with their depth / colour (reference src/common.py:127-136)."""
-    i, j, sample_depth, sample_color = get_sample_uv(H0, H1, W0, W1, n, depth, color, device=device)
+    """n random rays of one frame with their depth / colour (reference src/common.py:127-136).
+
+    On the GPU the reference's dozen torch ops (two linspaces, a meshgrid, two window slices, the draw, four gathers) are ONE
+    draw -- the same ``torch.randint`` call on the same range, so the index stream is the reference's -- and ONE kernel
+    (``adfp_select_pixels``: pixel coordinates, sensor depth and colour of the drawn pixels), followed by the ray kernel."""
+    dev = torch.device(device)
+    if (dev.type == 'cuda' and isinstance(depth, torch.Tensor) and depth.is_cuda and color.is_cuda
+            and depth.dtype == torch.float32 and color.dtype == torch.float32 and depth.dim() == 2 and tuple(color.shape) == (depth.shape[0], depth.shape[1], 3)):
+        Hd, Wd = depth.shape
+        with torch.cuda.device(depth.device):
+            pick = torch.randint((H1 - H0) * (W1 - W0), (n,), device=depth.device).clamp(0, (H1 - H0) * (W1 - W0))     # src/common.py:101-102
+            d, c = depth.contiguous(), color.contiguous()
+            i = torch.empty((n,), dtype=torch.float32, device=depth.device)
+            j = torch.empty_like(i)
+            sample_depth = torch.empty_like(i)
+            sample_color = torch.empty((n, 3), dtype=torch.float32, device=depth.device)
+            check(lib().adfp_select_pixels(ptr(pick), n, H0, H1, W0, W1, Hd, Wd, ptr(d), ptr(c), ptr(i), ptr(j), ptr(sample_depth),
+                                           ptr(sample_color), _lib.current_stream(depth.device)), 'adfp_select_pixels')
+    else:
+        i, j, sample_depth, sample_color = get_sample_uv(H0, H1, W0, W1, n, depth, color, device=device)
     rays_o, rays_d = get_rays_from_uv(i, j, c2w, H, W, fx, fy, cx, cy, device)
     return rays_o, rays_d, sample_depth, sample_color
 

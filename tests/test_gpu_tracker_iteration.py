@@ -75,6 +75,27 @@ def test_select_pixels_is_get_sample_uv_on_the_same_draw():
     assert lib().adfp_select_pixels(ptr(pick), n, H0, H + 1, W0, W1, H, W, ptr(depth), ptr(color), ptr(pi), ptr(pj), ptr(gd), ptr(gc), stream()) == -1
 
 
+def test_get_samples_fast_path_equals_the_reference_composition():
+    """common.get_samples on the GPU (one draw + adfp_select_pixels + the ray kernel) against get_sample_uv + get_rays_from_uv,
+    the reference's own composition (src/common.py:127-136), on the same generator state."""
+    sc = synthetic.mini_scene(device=DEV)
+    H, W = sc.H, sc.W
+    g = torch.Generator().manual_seed(4)
+    depth, color = torch.rand(H, W, generator=g).to(DEV), torch.rand(H, W, 3, generator=g).to(DEV)
+    c2w = sc.default_c2w()
+    for (H0, H1, W0, W1) in ((0, H, 0, W), (EDGE, H - EDGE, EDGE, W - EDGE)):
+        torch.manual_seed(5)
+        ro, rd, gd, gc = common.get_samples(H0, H1, W0, W1, 500, H, W, sc.fx, sc.fy, sc.cx, sc.cy, c2w, depth, color, DEV)
+        torch.manual_seed(5)
+        i, j, d2, c2 = common.get_sample_uv(H0, H1, W0, W1, 500, depth, color, device=DEV)
+        ro2, rd2 = common.get_rays_from_uv(i, j, c2w, H, W, sc.fx, sc.fy, sc.cx, sc.cy, DEV)
+        assert torch.equal(ro, ro2) and torch.equal(rd, rd2) and torch.equal(gd, d2) and torch.equal(gc, c2)
+    # the generic path (here: a float64 depth image) still works
+    torch.manual_seed(5)
+    ro3, rd3, gd3, gc3 = common.get_samples(0, H, 0, W, 500, H, W, sc.fx, sc.fy, sc.cx, sc.cy, c2w, depth.double(), color, DEV)
+    assert gd3.dtype == torch.float64 and ro3.shape == (500, 3)
+
+
 def run_loss(depth, unc, color, gd, gc, keep, handle_dynamic, w_color):
     n = depth.shape[0]
     la = _lib.AdfpTrackLossArgs()
