@@ -377,6 +377,21 @@ def test_fused_weight_gradients_equal_the_staged_path(mini, stage):
             assert got['fused'][k].abs().max() > 0, k
 
 
+@pytest.mark.parametrize('n_rays', [1, 5, 67])
+def test_fused_weight_gradients_on_ragged_point_counts(mini, n_rays):
+    """Point counts that do not fill a 32-point tile, a wave or a workgroup (1 x 40 = 40 points: one partial second tile; 5 x 40 =
+    200; 67 x 40 = 2 680 = 83.75 tiles): the fused kernel's idle waves, clamped DMA rows and zeroed tail lanes."""
+    from attentive_dfprior_amd import _lib
+    rays = synthetic.make_ray_batch(synthetic.mini_scene(), n_rays, seed=9, poses=1, zero_frac=0.0)
+    got = {}
+    for name, opt in (('fused', 0), ('staged', _lib.BWD_STAGED_WGRAD)):
+        loss, c, dec = run(mini, 'color', False, sd=O.random_state_dict(seed=29), n_samples=24, n_surface=16, rays=rays, bwd_options=opt)
+        got[name] = {n: p.grad.detach().cpu().clone() for n, p in dec.named_parameters() if p.grad is not None}
+    for k in got['fused']:
+        assert torch.isfinite(got['fused'][k]).all(), k
+        assert_close_scale(got['fused'][k], got['staged'][k], 3e-6, f'{k}: fused vs staged, {n_rays} rays')
+
+
 def test_a_swapped_pair_of_weight_rows_fails_the_gradient_comparison(mini, monkeypatch):
     """Negative control of the comparison itself: the backward's flat colour-decoder gradient comes back with two rows of
     pts_linears.1.weight exchanged (what an indexing bug in k_outer_h's write-out would produce) -- the golden comparison

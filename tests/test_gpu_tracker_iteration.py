@@ -317,6 +317,19 @@ def test_ten_iterations_follow_torch_adam(tb, separate):
     assert (it.camera_tensor - tb.cam0).abs().max().item() > 1e-3              # it did move
 
 
+@pytest.mark.parametrize('handle_dynamic,use_color', [(False, True), (True, False), (False, False)])
+def test_loss_options_follow_the_reference(tb, handle_dynamic, use_color):
+    """tracking.handle_dynamic / tracking.use_color_in_tracking (src/Tracker.py:116-129)."""
+    it = tb.iteration(use_graph=False, handle_dynamic=handle_dynamic, use_color=use_color)
+    pick = tb.picks(400, 1, seed=31)[0]
+    loss, g = it.gradient(400, pick)
+    cam = tb.cam0.clone().requires_grad_(True)
+    ref, kept = tb.reference_shaped(cam, pick, handle_dynamic=handle_dynamic, w_color=0.5 if use_color else 0.0)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-6 * abs(ref.item())
+    assert (g - cam.grad).abs().max().item() <= 2e-4 * cam.grad.abs().max().item()
+
+
 def test_graph_replay_equals_the_eager_sequence(tb):
     n, iters = 200, 6
     picks = tb.picks(n, iters, seed=6)
