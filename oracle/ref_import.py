@@ -32,6 +32,8 @@ def _to_cpu_shim(self, *args, **kwargs):
     for i, a in enumerate(args):
         if isinstance(a, str) and a.startswith('cuda'):
             args[i] = 'cpu'
+        elif isinstance(a, int) and not isinstance(a, bool) and a < 0:      # .to(t.get_device()) of a CPU tensor (src/common.py:152)
+            args[i] = 'cpu'
     if isinstance(kwargs.get('device'), str) and kwargs['device'].startswith('cuda'):
         kwargs['device'] = 'cpu'
     return _orig_to(self, *args, **kwargs)

@@ -46,6 +46,23 @@ def test_camera_from_tensor_and_its_backward_match_torch_autograd():
         assert (d_g.cpu() - ref).abs().max() <= 1e-5 * max(1.0, ref.abs().max().item()), (d_g.cpu(), ref)
 
 
+def test_camera_kernels_match_the_reference_golden():
+    """adfp_camera_from_tensor and its backward against the reference's own get_camera_from_tensor + autograd
+    (tests/golden/mini_pose.npz, made by tests/golden/make_pose_golden.py from src/common.py:139-178)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mini_pose.npz'))
+    for k in range(g['cam'].shape[0]):
+        d_cam = torch.from_numpy(g['cam'][k]).to(DEV)
+        d_c2w, d_g = torch.empty(16, device=DEV), torch.empty(7, device=DEV)
+        g_c2w = torch.zeros(4, 4)
+        g_c2w[:3] = torch.from_numpy(g['cot'][k])
+        check(lib().adfp_camera_from_tensor(ptr(d_cam), ptr(d_c2w), stream()), 'fwd')
+        check(lib().adfp_camera_from_tensor_backward(ptr(d_cam), ptr(g_c2w.to(DEV)), ptr(d_g), stream()), 'bwd')
+        ref, ref_g = g['c2w'][k], g['g_cam'][k]
+        assert np.abs(d_c2w.cpu().numpy().reshape(4, 4)[:3] - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+        assert np.abs(d_g.cpu().numpy() - ref_g).max() <= 2e-5 * max(1.0, np.abs(ref_g).max())
+
+
 def test_get_tensor_from_camera_round_trip():
     g = torch.Generator().manual_seed(5)
     for _ in range(12):

@@ -200,3 +200,22 @@ def test_oracle_subnetworks_vs_reference_golden(mini):
     fused, w = O.mlp_tsdf_forward(mini.sd, torch.from_numpy(g['att_occ_in']), t)
     assert np.abs(fused.numpy() - g['att_fused']).max() <= 1e-6
     assert np.abs(w.numpy() - g['att_w']).max() <= 1e-6
+
+
+def test_pose_utilities_match_the_reference():
+    """common.quad2rotation / get_camera_from_tensor (the host-side pose utilities of the Tracker) and their autograd against what the
+    reference's own functions returned (tests/golden/mini_pose.npz, src/common.py:139-178); get_tensor_from_camera inverts them (the
+    reference's goes through mathutils, which the image lacks: pinned by the round trip instead)."""
+    import os
+    from attentive_dfprior_amd import common
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mini_pose.npz'))
+    cam, cot = torch.from_numpy(g['cam']), torch.from_numpy(g['cot'])
+    assert np.abs(common.get_camera_from_tensor(cam).numpy() - g['c2w_batched']).max() <= 1e-6
+    for k in range(cam.shape[0]):
+        t = cam[k].clone().requires_grad_(True)
+        RT = common.get_camera_from_tensor(t)
+        (RT * cot[k]).sum().backward()
+        assert np.abs(RT.detach().numpy() - g['c2w'][k]).max() <= 1e-6 * max(1.0, np.abs(g['c2w'][k]).max())
+        assert np.abs(t.grad.numpy() - g['g_cam'][k]).max() <= 2e-5 * max(1.0, np.abs(g['g_cam'][k]).max())
+        back = common.get_camera_from_tensor(common.get_tensor_from_camera(torch.from_numpy(g['c2w'][k])))
+        assert np.abs(back.numpy() - g['c2w'][k]).max() <= 1e-5 * max(1.0, np.abs(g['c2w'][k]).max())
