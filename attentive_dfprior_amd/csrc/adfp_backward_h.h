@@ -437,13 +437,22 @@ struct ScatterSortedArgs {
 #ifndef ADFP_SCATTER_PPW
 #define ADFP_SCATTER_PPW 128          // sorted points per wave (two halves)
 #endif
-__global__ __launch_bounds__(64) void k_scatter_sorted(ScatterSortedArgs a) {
-    constexpr int PPW = ADFP_SCATTER_PPW, PPH = PPW / 2;
-    __shared__ int s_q[PPW];
-    __shared__ int s_cell[PPW];                   // x0 | y0 << 10 | z0 << 20
-    __shared__ __attribute__((aligned(16))) float s_w[PPW][8];     // the 8 corner weights (wx wy) wz, corner k = dx + 2 dy + 4 dz
-    const int lane = threadIdx.x & 63, ch = lane & 31, h = lane >> 5;
-    const int w0 = blockIdx.x * PPW;
+#define ADFP_SCATTER_NW 4             // waves per workgroup: the runs that the eight half-wave ranges of a workgroup cut are merged in LDS
+// Round 3: the cells around the camera receive the first samples of EVERY ray (15 000 points in one coarse cell of a 5 000-ray
+// batch), and each of the ~230 half-wave ranges that cell is cut into ended in 8 atomics on the SAME 8 lines -- serialised at
+// ~17 ns each, the critical path of the launch (62 us for the coarse grid against 20 us for a masked fine one).  A workgroup is
+// now four waves = eight consecutive ranges: a range adds its INTERIOR runs to memory as before, but parks its first and its
+// last run (the two that may continue next door) in LDS; after a barrier half a wave walks the sixteen records in order and
+// adds up neighbours of one cell before they go to memory -- one set of atomics per cell and workgroup instead of one per range.
+__global__ __launch_bounds__(64 * ADFP_SCATTER_NW) void k_scatter_sorted(ScatterSortedArgs a) {
+    constexpr int PPW = ADFP_SCATTER_PPW, PPH = PPW / 2, NW = ADFP_SCATTER_NW;
+    __shared__ int s_q[NW][PPW];
+    __shared__ int s_cell[NW][PPW];                   // x0 | y0 << 10 | z0 << 20
+    __shared__ __attribute__((aligned(16))) float s_w[NW][PPW][8];     // the 8 corner weights (wx wy) wz, corner k = dx + 2 dy + 4 dz
+    __shared__ float s_rec[NW * 4][8][32];            // edge records: [range * 2 + (first | last)][corner][channel]
+    __shared__ int s_rcell[NW * 4];
+    const int lane = threadIdx.x & 63, ch = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+    const int w0 = (blockIdx.x * NW + wv) * PPW;
     // ---- phase A
 #pragma unroll
     for (int b = 0; b < PPW / 64; ++b) {
@@ -464,11 +473,11 @@ __global__ __launch_bounds__(64) void k_scatter_sorted(ScatterSortedArgs a) {
             tri_axis(pn[2], a.g.Z, z0, z1, w[4], w[5]);
             cell = x0 | (y0 << 10) | (z0 << 20);
         }
-        s_q[64 * b + lane] = q; s_cell[64 * b + lane] = cell;
+        s_q[wv][64 * b + lane] = q; s_cell[wv][64 * b + lane] = cell;
         f32x4 lo4, hi4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { lo4[k] = (w[k & 1] * w[2 + (k >> 1)]) * w[4]; hi4[k] = (w[k & 1] * w[2 + (k >> 1)]) * w[5]; }
-        *(f32x4*)&s_w[64 * b + lane][0] = lo4; *(f32x4*)&s_w[64 * b + lane][4] = hi4;
+        *(f32x4*)&s_w[wv][64 * b + lane][0] = lo4; *(f32x4*)&s_w[wv][64 * b + lane][4] = hi4;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -476,23 +485,36 @@ __global__ __launch_bounds__(64) void k_scatter_sorted(ScatterSortedArgs a) {
     // ---- phase B: a run of points in one cell is summed in registers
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int cur = -1;
-    auto flush = [&]() {
-        if (cur < 0) return;
-        const int x0 = cur & 1023, y0 = (cur >> 10) & 1023, z0 = cur >> 20;
+    bool first_parked = false;
+    const int range = wv * 2 + h;                  // 0 .. 2 NW - 1, in sorted order
+    auto to_memory = [&](int cell, const float* v) {
+        const int x0 = cell & 1023, y0 = (cell >> 10) & 1023, z0 = cell >> 20;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            if (acc[k] != 0.f) {                   // a far-face corner (clamped onto its neighbour) has weight 0: never set
+            if (v[k] != 0.f) {                     // a far-face corner (clamped onto its neighbour) has weight 0: never set
                 const int x = x0 + (k & 1), y = y0 + ((k >> 1) & 1), z = z0 + (k >> 2);
-                atomicAdd(a.g_grid + ((long long)(z * a.g.Y + y) * a.g.X + x) * 32 + ch, acc[k]);
+                atomicAdd(a.g_grid + ((long long)(z * a.g.Y + y) * a.g.X + x) * 32 + ch, v[k]);
             }
-            acc[k] = 0.f;
         }
     };
+    auto park = [&](int slot) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s_rec[slot][k][ch] = acc[k];
+        if (ch == 0) s_rcell[slot] = cur;
+    };
+    auto flush = [&]() {                           // a run ends inside the range
+        if (cur < 0) return;
+        if (!first_parked) { park(range * 2); first_parked = true; }     // the range's first run may continue the previous range's last
+        else to_memory(cur, acc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    };
+    if (ch == 0) { s_rcell[range * 2] = -1; s_rcell[range * 2 + 1] = -1; }
     for (int j0 = 0; j0 < PPH; j0 += 16) {
         float gv[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {             // the rows of the next 16 points, fetched together
-            const int q = s_q[PPH * h + j0 + j];
+            const int q = s_q[wv][PPH * h + j0 + j];
             gv[j] = q >= 0 ? a.gc[32ll * q + ch] : 0.f;
         }
 #pragma unroll
@@ -501,14 +523,33 @@ __global__ __launch_bounds__(64) void k_scatter_sorted(ScatterSortedArgs a) {
             const float g = gv[j];
             const unsigned long long nz = __ballot(g != 0.f);
             if ((unsigned)(nz >> (32 * h)) == 0u) continue;       // no gradient from this point (a dropped ray, a point outside the band)
-            const int cell = s_cell[pi];
+            const int cell = s_cell[wv][pi];
             if (cell != cur) { flush(); cur = cell; }
-            const f32x4 wl = *(const f32x4*)&s_w[pi][0], wh = *(const f32x4*)&s_w[pi][4];
+            const f32x4 wl = *(const f32x4*)&s_w[wv][pi][0], wh = *(const f32x4*)&s_w[wv][pi][4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { acc[k] += g * wl[k]; acc[4 + k] += g * wh[k]; }
         }
     }
-    flush();
+    if (cur >= 0) park(range * 2 + (first_parked ? 1 : 0));       // the range's last run (its only one: the first slot)
+    __syncthreads();
+    // ---- merge: the sixteen edge records in sorted order, neighbours of one cell added up before they go to memory
+    if (threadIdx.x < 32) {
+        float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int mc = -1;
+        for (int r = 0; r < NW * 4; ++r) {
+            const int c = s_rcell[r];
+            if (c < 0) continue;
+            if (c != mc) {
+                if (mc >= 0) to_memory(mc, m);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m[k] = 0.f;
+                mc = c;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m[k] += s_rec[r][k][ch];
+        }
+        if (mc >= 0) to_memory(mc, m);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1985,7 +1985,7 @@ static int scatter_bins(const BinPlan& bp, const DecodeBwdArgs& o, const BwdWork
     ScatterSortedArgs s;
     s.P = o.P; s.nb = o.nb; s.g = o.g0; s.gc = bw.gc; s.g_grid = o.g_grid; s.perm = bp.perm; s.n = o.P.n; s.flags = flags; s.flag_mask = ADFP_F_BAND;
     if (o.g0.X > 1023 || o.g0.Y > 1023 || o.g0.Z > 1023) return ADFP_E_UNSUPPORTED;          // packed cell coordinates
-    hipLaunchKernelGGL(k_scatter_sorted, dim3((o.P.n + ADFP_SCATTER_PPW - 1) / ADFP_SCATTER_PPW), dim3(64), 0, st, s);
+    hipLaunchKernelGGL(k_scatter_sorted, dim3((o.P.n + ADFP_SCATTER_PPW * ADFP_SCATTER_NW - 1) / (ADFP_SCATTER_PPW * ADFP_SCATTER_NW)), dim3(64 * ADFP_SCATTER_NW), 0, st, s);
     ADFP_CHECK_LAUNCH();
     return 0;
 }
