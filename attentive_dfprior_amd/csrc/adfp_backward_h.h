@@ -427,17 +427,17 @@ struct ScatterSortedArgs {
     const int* perm; int n;    // the points in sorted order
     const unsigned char* flags; unsigned flag_mask;      // HIGH: only points with (flags[q] & flag_mask) carry a row
 };
-// One wave per workgroup; half h of wave w owns the 64 consecutive sorted points [128 w + 64 h, + 64) (phase A: one lane per
-// point computes cell and weights of the wave's 128 points; phase B: lane = channel).  A run that the range boundary cuts is
-// added in pieces, which is harmless: atomics on ONE line cost ~17 ns each (tools/micro/atomic_rates.hip), and even the cells
-// around the camera, where every ray starts, are cut into a few hundred pieces.  (Longer ranges per wave only lengthen the
-// critical path: 128 points 1.90 ms per iteration, 1 024 points 2.15 ms; shorter ones cut more runs: 64 points per wave
-// (-DADFP_SCATTER_PPW=64) 71 us per grid against 46.  Collecting the pieces in records and merging them in a second kernel cost
-// more than the atomics it saved.)
+// Half h of wave w owns the 64 consecutive sorted points [128 w + 64 h, + 64) (phase A: one lane per point computes cell and
+// weights of the wave's 128 points; phase B: lane = channel).  A run that a range boundary cuts is added in pieces.  (Longer ranges
+// per wave only lengthen the critical path: 128 points 1.90 ms per iteration, 1 024 points 2.15 ms; shorter ones cut more runs: 64
+// points per wave (-DADFP_SCATTER_PPW=64) 71 us per grid against 46.  Collecting the pieces in records and merging them in a
+// SECOND kernel cost more than the atomics it saved; merging them inside the workgroup, below, did not.)
 #ifndef ADFP_SCATTER_PPW
 #define ADFP_SCATTER_PPW 128          // sorted points per wave (two halves)
 #endif
+#ifndef ADFP_SCATTER_NW
 #define ADFP_SCATTER_NW 4             // waves per workgroup: the runs that the eight half-wave ranges of a workgroup cut are merged in LDS
+#endif
 // Round 3: the cells around the camera receive the first samples of EVERY ray (15 000 points in one coarse cell of a 5 000-ray
 // batch), and each of the ~230 half-wave ranges that cell is cut into ended in 8 atomics on the SAME 8 lines -- serialised at
 // ~17 ns each, the critical path of the launch (62 us for the coarse grid against 20 us for a masked fine one).  A workgroup is
