@@ -606,14 +606,17 @@ ADFP_DEV float relu_mask(float v, unsigned& m) {
 // 1 / 2, out-block ob in word ob >> 1, its register r at bit 31 - 16 (ob & 1) - r; word 5: layer 3 likewise) and the softmax
 // weight (half 0: a0, half 1: a1) -- and, when a.act is set, the layer inputs (AttStage columns [0, 416)).
 #define ADFP_ATT_MASK_WORDS 14
-template <int TRAIN>
-__global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
+// NT = 512 (two waves per SIMD, 256 registers each) for inference; the TRAIN variant needs ~330 registers (masks, the staged layer
+// inputs held until their stores issue) and spilled 79 of them at 512 threads -- it runs at NT = 256, one wave per SIMD with the
+// whole register file, on the 54 000 in-band rows of an iteration (1.7 tiles per wave either way).
+template <int TRAIN, int NT = 512>
+__global__ __launch_bounds__(NT) void k_attention_h(AttArgs a) {
     using A = AttLayoutH;
     using ST = AttStage;
     __shared__ __attribute__((aligned(16))) unsigned ldsu[A::P_TOTAL];
     __shared__ int s_next;
-    for (int i = threadIdx.x; i < A::P_TOTAL / 4; i += 512) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed)[i];
-    if (threadIdx.x == 0) s_next = 8;
+    for (int i = threadIdx.x; i < A::P_TOTAL / 4; i += NT) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed)[i];
+    if (threadIdx.x == 0) s_next = NT / 64;
     __syncthreads();
     const float* lds = (const float*)ldsu;
     const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
@@ -621,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_h(AttArgs a) {
     const int count = a.count_ptr ? *a.count_ptr : a.n_rows;
     const int ntiles = (count + 31) >> 5;
     float amax = image_out_of_range<A::P_FLAG, A::NFLAG>(ldsu) ? INFINITY : 0.f;
-    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<8>(j, &s_next, ntiles)) >= 0;) {
+    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<NT / 64>(j, &s_next, ntiles)) >= 0;) {
         const int idx = tile * 32 + p;
         const bool valid = idx < count;
         const int ii = valid ? idx : 0;

@@ -1396,7 +1396,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         t.masks = nullptr; t.act = nullptr;
         if (sc->h_att && state && state->masks_att) {
             t.packed = (const float*)sc->h_att; t.masks = state->masks_att; t.act = state->act_att;
-            hipLaunchKernelGGL(k_attention_h<1>, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
+            hipLaunchKernelGGL((k_attention_h<1, 256>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
         } else if (sc->h_att) {
             t.packed = (const float*)sc->h_att;
             hipLaunchKernelGGL(k_attention_h<0>, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
