@@ -210,8 +210,32 @@ def lib():
             fn.argtypes = args
         if handle.adfp_version() != ABI_VERSION:
             raise RuntimeError(f'{LIB_PATH} is ABI version {handle.adfp_version()}, this package binds {ABI_VERSION}: rebuild it')
+        if HOST_TIMING is not None:
+            class _Timed(object):
+                pass
+            t = _Timed()
+            for name, _, _ in SYMBOLS:
+                setattr(t, name, timed(getattr(handle, name), name))
+            handle = t
         _lib = handle
     return _lib
+
+
+# ADFP_HOST_TIMING=1: host seconds spent inside each C entry point (name -> [calls, seconds]); tools/host_breakdown.py prints it
+HOST_TIMING = {} if os.environ.get('ADFP_HOST_TIMING') else None
+
+
+def timed(fn, name):
+    import time
+
+    def call(*a):
+        t0 = time.perf_counter()
+        rc = fn(*a)
+        e = HOST_TIMING.setdefault(name, [0, 0.0])
+        e[0] += 1
+        e[1] += time.perf_counter() - t0
+        return rc
+    return call
 
 
 def check(rc, what):
@@ -227,8 +251,39 @@ def ptr(t):
 
 
 def current_stream(device):
+    """The raw hipStream_t of torch's current stream on `device` (torch.cuda.current_stream(device).cuda_stream costs ~7 us of
+    Python object construction per call; a training iteration asks a dozen times)."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+    if idx is None:
+        idx = torch._C._cuda_getDevice()
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
+
+
+class device_guard(object):
+    """`with device_guard(dev):` = `with torch.cuda.device(dev):` -- the kernels launch on the CURRENT HIP device -- without the
+    per-call argument parsing: switches only when `dev` is not the current device already."""
+    __slots__ = ('idx', 'prev')
+
+    def __init__(self, dev):
+        self.idx = dev.index if dev.index is not None else -1
+        self.prev = -1
+
+    def __enter__(self):
+        import torch
+        if self.idx >= 0:
+            cur = torch._C._cuda_getDevice()
+            if cur != self.idx:
+                torch._C._cuda_setDevice(self.idx)
+                self.prev = cur
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            import torch
+            torch._C._cuda_setDevice(self.prev)
+            self.prev = -1
+        return False
 
 
 def fill_bound(dst, values):
@@ -271,17 +326,26 @@ def status_ptr():
     return C.c_void_p(status_word().data_ptr())
 
 
+_status_views = {}
+
+
 def read_status(word, sync=False, device=None):
     """The bits an earlier call left in `word` (cleared on read).  sync=True waits for the device first.  Range bits are returned
-    to the caller; any other bit is an error."""
+    to the caller; any other bit is an error.  The word is read through a ctypes view of the pinned memory: indexing the tensor
+    costs two dispatcher calls per render call."""
     if word is None:
         return 0
     if sync:
         import torch
         torch.cuda.synchronize(device)
-    v = int(word[0])
+    addr = word.data_ptr()
+    view = _status_views.get(addr)
+    if view is None or view[1]() is not word:
+        import weakref
+        view = _status_views[addr] = (C.c_int.from_address(addr), weakref.ref(word))
+    v = view[0].value
     if v:
-        word[0] = 0
+        view[0].value = 0
         if v & ~STATUS_F16_RANGE:
             raise RuntimeError(f'libadfp: status word {v:#x}')
     return v

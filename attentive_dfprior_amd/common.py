@@ -30,7 +30,7 @@ def get_rays(H, W, fx, fy, cx, cy, c2w, device):
     dev = torch.device(device)
     if dev.type == 'cuda':
         m = c2w.detach().to(dev, torch.float32).contiguous()
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             ro = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
             rd = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
             check(lib().adfp_get_rays(H, W, fx, fy, cx, cy, ptr(m), ptr(ro), ptr(rd), _lib.current_stream(dev)),
@@ -55,7 +55,7 @@ class _RaysFromUV(torch.autograd.Function):
         n = i.numel()
         pi, pj = i.detach().reshape(-1).float().contiguous(), j.detach().reshape(-1).float().contiguous()
         m = c2w.detach().to(dev, torch.float32).contiguous()
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             ro = torch.empty((n, 3), dtype=torch.float32, device=dev)
             rd = torch.empty((n, 3), dtype=torch.float32, device=dev)
             check(lib().adfp_rays_from_uv(ptr(pi), ptr(pj), n, fx, fy, cx, cy, ptr(m), ptr(ro), ptr(rd), _lib.current_stream(dev)),
@@ -68,7 +68,7 @@ class _RaysFromUV(torch.autograd.Function):
     def backward(ctx, g_o, g_d):
         pi, pj, fx, fy, cx, cy = ctx.pix
         dev = pi.device
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             g = torch.empty((4, 4), dtype=torch.float32, device=dev)
             go = None if g_o is None else g_o.float().contiguous()
             gd = None if g_d is None else g_d.float().contiguous()
@@ -119,7 +119,7 @@ def get_samples(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, c2w, depth, color, devi
     if (dev.type == 'cuda' and isinstance(depth, torch.Tensor) and depth.is_cuda and color.is_cuda
             and depth.dtype == torch.float32 and color.dtype == torch.float32 and depth.dim() == 2 and tuple(color.shape) == (depth.shape[0], depth.shape[1], 3)):
         Hd, Wd = depth.shape
-        with torch.cuda.device(depth.device):
+        with _lib.device_guard(depth.device):
             pick = torch.randint((H1 - H0) * (W1 - W0), (n,), device=depth.device).clamp(0, (H1 - H0) * (W1 - W0))     # src/common.py:101-102
             d, c = depth.contiguous(), color.contiguous()
             i = torch.empty((n,), dtype=torch.float32, device=depth.device)
@@ -146,7 +146,7 @@ def filter_rays_in_bound(batch_rays_o, batch_rays_d, batch_gt_depth, batch_gt_co
     _lib.require_cuda(batch_rays_o, 'batch_rays_o')
     dev = batch_rays_o.device
     n = batch_rays_o.shape[0]
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         ro = batch_rays_o.detach().float().contiguous()
         rd = batch_rays_d.detach().float().contiguous()
         gd = batch_gt_depth.detach().float().contiguous()
@@ -171,8 +171,37 @@ def quad2rotation(quad):
     return torch.stack(rows, -1).reshape(-1, 3, 3)
 
 
+class _CameraFromTensor(torch.autograd.Function):
+    """adfp_camera_from_tensor / _backward: ONE camera tensor on the GPU -> [3,4] camera-to-world in one launch each way.  The
+    reference's quad2rotation is ~40 small torch ops forward and as many autograd nodes backward (src/common.py:139-178) -- a
+    quarter of a 200-ray tracking iteration's host time; same float32 arithmetic, operation by operation (mini_pose.npz)."""
+
+    @staticmethod
+    def forward(ctx, cam):
+        dev = cam.device
+        t = cam.detach().contiguous()
+        with _lib.device_guard(dev):
+            m = torch.empty((4, 4), dtype=torch.float32, device=dev)
+            check(lib().adfp_camera_from_tensor(ptr(t), ptr(m), _lib.current_stream(dev)), 'adfp_camera_from_tensor')
+        ctx.cam = t
+        return m[:3]
+
+    @staticmethod
+    def backward(ctx, g):
+        t = ctx.cam
+        dev = t.device
+        with _lib.device_guard(dev):
+            g12 = g.float().contiguous()          # the kernel reads rows 0-2 of a row-major [*,4] cotangent: 12 floats
+            out = torch.empty((7,), dtype=torch.float32, device=dev)
+            check(lib().adfp_camera_from_tensor_backward(ptr(t), ptr(g12), ptr(out), _lib.current_stream(dev)),
+                  'adfp_camera_from_tensor_backward')
+        return out
+
+
 def get_camera_from_tensor(inputs):
     """Quaternion + translation [7] or [B,7] -> [3,4] / [B,3,4] camera-to-world (reference src/common.py:166-178)."""
+    if inputs.dim() == 1 and inputs.is_cuda and inputs.dtype == torch.float32 and inputs.shape[0] == 7:
+        return _CameraFromTensor.apply(inputs)
     single = inputs.dim() == 1
     if single:
         inputs = inputs.unsqueeze(0)
@@ -230,7 +259,7 @@ def raw2outputs_nerf_color(raw, z_vals, rays_d, occupancy=False, device='cuda:0'
     _lib.require_cuda(raw, 'raw')
     dev = raw.device
     N, S = raw.shape[0], raw.shape[1]
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         r = raw.detach().float().contiguous()
         z = z_vals.detach().to(torch.float64).contiguous()
         depth = torch.empty((N,), dtype=torch.float64, device=dev)

@@ -43,39 +43,56 @@ class DenseLayer(nn.Linear):
             nn.init.zeros_(self.bias)
 
 
-def pack_network(name, params, fmt='f32', status=None, flat=None):
+_PACK_SIZES = {}
+
+
+def _pack_size(name, fmt):
+    """Element count of a packed image (int32 words for the f16-split images, floats for the exact one); constants of the library."""
+    hit = _PACK_SIZES.get((name, fmt))
+    if hit is None:
+        L = lib()
+        if name == 'att':
+            hit = {'h': L.adfp_attention_packed_h_words, 'ht': L.adfp_attention_packed_ht_words, 'f32': L.adfp_attention_packed_floats}[fmt]()
+        else:
+            kind = _lib.DEC_KIND[name]
+            hit = {'h': L.adfp_decoder_packed_h_words, 'ht': L.adfp_decoder_packed_ht_words, 'f32': L.adfp_decoder_packed_floats}[fmt](kind)
+        _PACK_SIZES[(name, fmt)] = hit = int(hit)
+    return hit
+
+
+def pack_network(name, params, fmt='f32', status=None, flat=None, out=None):
     """Packed image of one sub-network ('low' / 'high' / 'color' / 'att') from its parameters in state_dict order.
     fmt: 'f32' (adfp_pack_decoder / adfp_pack_attention), 'h' (adfp_pack_*_h), 'ht' (adfp_pack_*_ht).
-    status: the pinned status word a weight outside the f16 range is reported to (default: the process-wide one)."""
+    status: the pinned status word a weight outside the f16 range is reported to (default: the process-wide one).
+    out: an image of the same network and format to overwrite (a training iteration re-packs the trained networks every step:
+    same-stream ordering makes the in-place rebuild safe, and the image keeps its address)."""
     if flat is None:
         flat = _flat_params(params)
     sptr = _lib.status_ptr() if status is None else _lib.C.c_void_p(status.data_ptr())
     _lib.require_cuda(flat, f'{name} decoder parameters')
     L = lib()
     dev = flat.device
-    with torch.cuda.device(dev):
+    n = _pack_size(name, fmt)
+    dtype = torch.float32 if fmt == 'f32' else torch.int32
+    if out is not None and (out.numel() != n or out.dtype != dtype or out.device != dev):
+        out = None
+    with _lib.device_guard(dev):
         stream = _lib.current_stream(dev)
+        packed = out if out is not None else torch.empty(n, dtype=dtype, device=dev)
         if fmt in ('h', 'ht'):
             if name == 'att':
-                words = L.adfp_attention_packed_h_words() if fmt == 'h' else L.adfp_attention_packed_ht_words()
                 fn = L.adfp_pack_attention_h if fmt == 'h' else L.adfp_pack_attention_ht
-                packed = torch.empty(words, dtype=torch.int32, device=dev)
                 _lib.check(fn(_lib.ptr(flat), _lib.ptr(packed), sptr, stream), 'adfp_pack_attention_' + fmt)
             else:
                 kind = _lib.DEC_KIND[name]
-                words = L.adfp_decoder_packed_h_words(kind) if fmt == 'h' else L.adfp_decoder_packed_ht_words(kind)
                 fn = L.adfp_pack_decoder_h if fmt == 'h' else L.adfp_pack_decoder_ht
-                packed = torch.empty(words, dtype=torch.int32, device=dev)
                 _lib.check(fn(kind, _lib.ptr(flat), _lib.ptr(packed), sptr, stream), 'adfp_pack_decoder_' + fmt)
-            return packed
-        if name == 'att':
+        elif name == 'att':
             assert flat.numel() == L.adfp_attention_flat_floats()
-            packed = torch.empty(L.adfp_attention_packed_floats(), dtype=torch.float32, device=dev)
             _lib.check(L.adfp_pack_attention(_lib.ptr(flat), _lib.ptr(packed), stream), 'adfp_pack_attention')
         else:
             kind = _lib.DEC_KIND[name]
             assert flat.numel() == L.adfp_decoder_flat_floats(kind)
-            packed = torch.empty(L.adfp_decoder_packed_floats(kind), dtype=torch.float32, device=dev)
             _lib.check(L.adfp_pack_decoder(kind, _lib.ptr(flat), _lib.ptr(packed), stream), 'adfp_pack_decoder')
     return packed
 
@@ -210,8 +227,26 @@ def _flat_params(params):
     return torch.cat([p.detach().reshape(-1).float() for p in params])
 
 
+_data_ptr = torch.Tensor.data_ptr
+_version_of = torch.Tensor._version.__get__
+
+
 def _version_key(params):
-    return tuple((p.data_ptr(), p._version) for p in params)
+    """(addresses, versions) of a parameter tuple: what a cached conversion of them is valid for."""
+    return tuple(map(_data_ptr, params)), tuple(map(_version_of, params))
+
+
+def _home_in_one_buffer(params):
+    """Re-home float32 CUDA parameters in ONE contiguous buffer, state_dict order: every nn.Parameter keeps its identity (optimisers,
+    state_dict, deepcopy and pickling see the same objects / names / values) and becomes a view of the buffer, so the flat
+    image the pack kernels and the f32 repair path read IS the parameters -- no torch.cat per optimiser step."""
+    flat = torch.cat([p.detach().reshape(-1) for p in params])
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.data = flat[off:off + n].view(p.shape)
+        off += n
+    return flat
 
 
 _NET_ATTR = {'low': 'low_decoder', 'high': 'high_decoder', 'color': 'color_decoder', 'att': 'mlp'}
@@ -296,31 +331,49 @@ class DF(nn.Module):
         self._exact_latch.clear()           # new weights: probe the f16 range again
         return out
 
-    def flat_weights(self, name):
-        """The network's parameters as one flat float32 buffer in state_dict order (a view when they already lie back to back,
-        mapping.flatten_parameters; otherwise a copy cached on the parameters' versions)."""
+    def flat_weights(self, name, key=None):
+        """The network's parameters as one flat float32 buffer in state_dict order.  Float32 parameters on the GPU are re-homed
+        in one buffer on first use (_home_in_one_buffer), after which this is a VIEW of the live parameters (cached on their
+        addresses); anything else (half / double parameters) is a copy cached on the parameters' versions."""
         module = self.net_params(name)
-        key = _version_key(module)
+        if key is None:
+            key = _version_key(module)
         hit = self._packed.get(name + '.flat')
-        if hit is not None and hit[0] == key:
+        if hit is not None and hit[0] == key[0] and (hit[2] or hit[3] == key[1]):
             return hit[1]
         flat = _flat_params(module)
-        self._packed[name + '.flat'] = (key, flat)
+        is_view = flat.untyped_storage().data_ptr() == module[0].untyped_storage().data_ptr()
+        if not is_view and all(p.is_cuda and p.dtype == torch.float32 for p in module):
+            flat = _home_in_one_buffer(module)
+            is_view = True
+            key = _version_key(module)
+            self._packed = {k: v for k, v in self._packed.items() if k.split('.')[0] != name}    # images keyed on the old addresses
+        self._packed[name + '.flat'] = (key[0], flat, is_view, key[1])
         return flat
 
+    def net_key(self, name):
+        """(addresses, versions) of the network's parameters; hand it to packed_weights / flat_weights to compute it once per call."""
+        return _version_key(self.net_params(name))
+
     # ---- weight images for the kernels -------------------------------------------------
-    def packed_weights(self, name, fmt='f32'):
+    def packed_weights(self, name, fmt='f32', key=None):
         """Packed (MFMA operand order) image of one sub-network, rebuilt only when a parameter
         changed (optimizer step bumps Parameter._version).  fmt 'f32' = exact f32-input MFMA image,
         'h' = f16 hi/lo split image of the forward decoders (adfp_pack_decoder_h), 'ht' = the transposed split image of
-        the f16 backward (adfp_pack_decoder_ht / adfp_pack_attention_ht)."""
+        the f16 backward (adfp_pack_decoder_ht / adfp_pack_attention_ht).  key: net_key(name) if the caller has it already.
+        A stale image is rebuilt IN PLACE (same address; stream order protects kernels already queued on it)."""
         module = self.net_params(name)
-        key = _version_key(module)
+        if key is None:
+            key = _version_key(module)
         slot = name if fmt == 'f32' else name + '.' + fmt
         hit = self._packed.get(slot)
         if hit is not None and hit[0] == key:
             return hit[1]
-        packed = pack_network(name, module, fmt, status=self.status_word(), flat=self.flat_weights(name))
+        flat = self.flat_weights(name, key)
+        if module[0].data_ptr() != key[0][0]:
+            key = _version_key(module)             # flat_weights re-homed the parameters: new addresses
+        hit = self._packed.get(slot)
+        packed = pack_network(name, module, fmt, status=self.status_word(), flat=flat, out=None if hit is None else hit[1])
         self._packed[slot] = (key, packed)
         return packed
 

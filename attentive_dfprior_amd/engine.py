@@ -24,6 +24,27 @@ def _host_bound(t):
     return [[float(v) for v in row] for row in t.detach().to('cpu', torch.float64).tolist()]
 
 
+_ACT_FLOATS = {}
+_SLAB_LAYOUTS = {}        # (P, stage, mode, ...) -> carve-up of the training slab (Engine.train_state)
+_FLAT_FLOATS = {}
+
+
+def _flat_floats(name):
+    hit = _FLAT_FLOATS.get(name)
+    if hit is None:
+        L = lib()
+        hit = _FLAT_FLOATS[name] = int(L.adfp_attention_flat_floats() if name == 'att' else L.adfp_decoder_flat_floats(_lib.DEC_KIND[name]))
+    return hit
+
+
+
+def _train_act_floats(name):
+    hit = _ACT_FLOATS.get(name)
+    if hit is None:
+        hit = _ACT_FLOATS[name] = int(lib().adfp_train_act_floats(_lib.DEC_KIND[name]))
+    return hit
+
+
 def math_mode():
     """ADFP_MATH=f16x3 (default): forward decoders on f16 MFMA with a 3-product operand split;
     ADFP_MATH=f32: exact f32-input MFMA everywhere."""
@@ -34,13 +55,37 @@ def math_mode():
     return m
 
 
+class _PrivateWorkspaces(object):
+    def __init__(self, engine):
+        self.e = engine
+
+    def __enter__(self):
+        self.saved = (self.e._ws, self.e._bws)
+        self.e._ws = self.e._bws = None
+        return self
+
+    def __exit__(self, *exc):
+        self.e._ws, self.e._bws = self.saved
+        return False
+
+
+_STAGE_NETS = {'low': ('low',), 'high': ('low', 'high', 'att'), 'color': ('low', 'high', 'att', 'color')}
+_STAGE_GRIDS = {'low': (('low', 'grid_low'),), 'high': (('low', 'grid_low'), ('high', 'grid_high')),
+                'color': (('low', 'grid_low'), ('high', 'grid_high'), ('color', 'grid_color'))}
+
+
+def _align256(n):
+    return (n + 255) & ~255
+
+
 class Engine(object):
     def __init__(self):
         import os
         # ADFP_BWD_* bits handed to the backward entries (adfp_backward_args.options).  ADFP_SCATTER=cache in the environment of
         # the HOST process selects the in-kernel scatter (kernel A/B runs); the library itself reads no environment.
         self.bwd_options = _lib.BWD_SCATTER_IN_KERNEL if os.environ.get('ADFP_SCATTER', '')[:1] == 'c' else 0
-        self._ws = None
+        self._ws = None          # forward scratch, grow-only (stream order makes the reuse safe)
+        self._bws = None         # backward scratch, same
         self._grid_cache = {}    # key name -> (key, channels-last tensor)
         self._bound_cache = {}   # id -> (key, host list)
 
@@ -51,8 +96,21 @@ class Engine(object):
             self._ws = torch.empty(int(need * 1.25) + 1024, dtype=torch.uint8, device=device)
         return self._ws
 
+    def bwd_workspace(self, n_points, device):
+        """Scratch of the backward entries (adfp_backward_workspace_bytes: ~190 B per point).  Kept across calls like the forward's:
+        a training iteration used to allocate it afresh in every backward."""
+        need = lib().adfp_backward_workspace_bytes(int(n_points))
+        if self._bws is None or self._bws.numel() < need or self._bws.device != device:
+            self._bws = torch.empty(int(need * 1.25) + 1024, dtype=torch.uint8, device=device)
+        return self._bws
+
+    def private_workspaces(self):
+        """`with engine.private_workspaces():` -- a HIP-graph capture gets workspaces of its OWN (allocated from the graph's pool
+        inside the capture), and the eager ones come back afterwards: an eager call may grow and free the shared buffers."""
+        return _PrivateWorkspaces(self)
+
     def host_bound(self, t, slot):
-        key = (t.data_ptr(), t._version, str(t.device))
+        key = (t.data_ptr(), t._version, t.device)
         hit = self._bound_cache.get(slot)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -63,7 +121,7 @@ class Engine(object):
     def adopt_grid_cl(self, name, g, shadow):
         """`shadow` IS the channels-last copy of grid `g` as it stands (the caller keeps it coherent: mapping.MapperIteration updates
         both in one Adam kernel): the next scene() finds it in the cache instead of re-laying the grid out."""
-        key = (g.data_ptr(), g._version, tuple(g.shape), tuple(g.stride()))
+        key = (g.data_ptr(), g._version, g.shape, g.stride())
         self._grid_cache[name] = (key, shadow, g.untyped_storage(), 'adopted')      # never recycled as a re-layout destination
 
     def grid_cl(self, name, g):
@@ -71,7 +129,7 @@ class Engine(object):
         _lib.require_cuda(g, name)
         if g.dim() != 5 or g.shape[0] != 1 or g.shape[1] != 32:
             raise RuntimeError(f'{name}: expected [1,32,Z,Y,X], got {tuple(g.shape)}')
-        key = (g.data_ptr(), g._version, tuple(g.shape), tuple(g.stride()))
+        key = (g.data_ptr(), g._version, g.shape, g.stride())
         hit = self._grid_cache.get(name)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -92,43 +150,49 @@ class Engine(object):
         return dst
 
     # ---- descriptor ----------------------------------------------------------------------
-    def scene(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=False, ht_nets=()):
+    def scene(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=False, ht_nets=(), keys=None):
         """Returns (AdfpScene, keepalive list).  Forward: every network of the stage takes its f16-split image (ADFP_MATH=f16x3 and
         not latched to exact, DF.uses_split) or its exact f32 image, plus -- when any split image is in use -- the flat parameters
         the device-side f32 repair path needs (adfp_scene.flat_*).  Backward: the exact f32 images, except for the decoders named
-        in `ht_nets`: those get their transposed f16-split image (the caller has checked that the forward left their ReLU masks)."""
+        in `ht_nets`: those get their transposed f16-split image (the caller has checked that the forward left their ReLU masks).
+        keys: {net: DF.net_key(net)} when the caller has them (a backward re-uses its forward's: parameters must not change in
+        between); filled in for the stage's networks otherwise."""
         decoders.absorb_status()                 # an f16-range event of an EARLIER call: that network is exact from now on
         sc = _lib.AdfpScene()
         sc.status = decoders.status_word().data_ptr()
         keep = []
         _lib.fill_bound(sc.bound, self.host_bound(bound, 'bound'))
-        grids = [('low', 'grid_low')]
-        if stage != 'low':
-            grids.append(('high', 'grid_high'))
-        if stage == 'color':
-            grids.append(('color', 'grid_color'))
-        for field, key in grids:
+        for field, key in _STAGE_GRIDS[stage]:
             g = self.grid_cl(key, c[key])
             keep.append(g)
             gd = getattr(sc, field)
             gd.data = g.data_ptr()
             gd.Z, gd.Y, gd.X = g.shape[0], g.shape[1], g.shape[2]
-        nets = ['low'] + (['high', 'att'] if stage != 'low' else []) + (['color'] if stage == 'color' else [])
+        nets = _STAGE_NETS[stage]
+        if keys is None:
+            keys = {}
+        split = math_mode() == 'f16x3'
+        latch = decoders._exact_latch
         any_split = False
         for n in nets:
+            k = keys.get(n)
+            if k is None:
+                k = keys[n] = decoders.net_key(n)
             if backward:
                 if n in ht_nets:
-                    setattr(sc, 'ht_' + n, decoders.packed_weights(n, 'ht').data_ptr())
+                    setattr(sc, 'ht_' + n, decoders.packed_weights(n, 'ht', k).data_ptr())
                 else:
-                    setattr(sc, 'w_' + n, decoders.packed_weights(n).data_ptr())
-            elif decoders.uses_split(n):
-                setattr(sc, 'h_' + n, decoders.packed_weights(n, 'h').data_ptr())
+                    setattr(sc, 'w_' + n, decoders.packed_weights(n, 'f32', k).data_ptr())
+            elif split and n not in latch:
+                setattr(sc, 'h_' + n, decoders.packed_weights(n, 'h', k).data_ptr())
                 any_split = True
             else:
-                setattr(sc, 'w_' + n, decoders.packed_weights(n).data_ptr())
+                setattr(sc, 'w_' + n, decoders.packed_weights(n, 'f32', k).data_ptr())
+            if decoders.net_params(n)[0].data_ptr() != k[0][0]:
+                keys[n] = decoders.net_key(n)    # first use re-homed the parameters in one buffer (DF.flat_weights)
         if any_split:
             for n in nets:
-                setattr(sc, 'flat_' + n, decoders.flat_weights(n).data_ptr())
+                setattr(sc, 'flat_' + n, decoders.flat_weights(n, keys[n]).data_ptr())
         if stage != 'low':
             _lib.fill_bound(sc.tsdf_bnds, self.host_bound(tsdf_bnds, 'tsdf_bnds'))
             self.fill_tsdf(sc.tsdf, tsdf_volume, keep)
@@ -136,37 +200,59 @@ class Engine(object):
 
     # ---- training state --------------------------------------------------------------------
     @staticmethod
-    def train_state(P, stage, dev, decoders, need_flat=None):
+    def train_state(P, stage, dev, decoders, need_flat=None, extra=()):
         """The caller-owned buffers a training forward leaves for the backward (adfp_train_state): always the TSDF stage's
         flags / in-band list / attention inputs; in f16x3 mode also the ReLU masks of every decoder of the stage and, for a
         decoder whose parameter gradient will be asked for (need_flat[name], default: any of its parameters requires
-        grad), its layer inputs -- with those the backward runs on f16 MFMA and recomputes nothing."""
-        bufs = dict(flags=torch.empty((P,), dtype=torch.uint8, device=dev), list=torch.empty((P,), dtype=torch.int32, device=dev),
-                    counter=torch.empty((16,), dtype=torch.int32, device=dev),         # zeroed by the library (a kernel); [8] = the call's range flag
-                    att_occ=torch.empty((P,), dtype=torch.float32, device=dev), att_u=torch.empty((P,), dtype=torch.float32, device=dev))
+        grad), its layer inputs -- with those the backward runs on f16 MFMA and recomputes nothing.
+        ONE allocation (`slab`, uint8) carved at 256-byte boundaries: `offsets[name]` = byte offset, `ptrs[name]` = device address;
+        `extra` = further (name, bytes) regions the caller wants in the same slab (render_forward: z_vals, raw)."""
+        split = math_mode() == 'f16x3'
+        latch = decoders._exact_latch
+        if need_flat is None:
+            need_flat = {n: any(p.requires_grad for p in decoders.net_params(n)) for n in _STAGE_NETS[stage]}
+        lkey = (P, stage, split, tuple(sorted(latch)), tuple(bool(need_flat.get(n)) for n in ('low', 'high', 'color', 'att')), extra)
+        lay = _SLAB_LAYOUTS.get(lkey)
+        if lay is None:
+            regions = [('counter', 64), ('flags', P), ('list', 4 * P), ('att_occ', 4 * P), ('att_u', 4 * P)]
+            regions += list(extra)
+            nets = ['low'] + (['high'] if stage != 'low' else []) + (['color'] if stage == 'color' else [])
+            for n in nets:
+                if not split or n in latch:                    # ADFP_MATH=f32, or latched to exact: the exact backward recomputes
+                    continue
+                regions.append(('masks_' + n, 4 * _lib.TRAIN_MASK_WORDS * P))
+                if need_flat.get(n):
+                    regions.append(('act_' + n, 4 * _train_act_floats(n) * P))
+            if stage != 'low' and split and 'att' not in latch:   # the attention network, rows = in-band list entries (at most P)
+                regions.append(('masks_att', 4 * _lib.TRAIN_ATT_MASK_WORDS * P))
+                if need_flat.get('att'):
+                    regions.append(('act_att', 4 * _lib.TRAIN_ATT_ACT_FLOATS * P))
+            offsets, off = {}, 0
+            for name, nbytes in regions:
+                offsets[name] = off
+                off += _align256(nbytes)
+            if len(_SLAB_LAYOUTS) > 256:
+                _SLAB_LAYOUTS.clear()
+            lay = _SLAB_LAYOUTS[lkey] = (offsets, dict(regions), max(off, 256), tuple(n for n, _ in regions if n not in ('z_vals', 'raw')),
+                                         {name: True for name in offsets})
+        offsets, sizes, total, fields, present = lay
+        slab = torch.empty((total,), dtype=torch.uint8, device=dev)
+        base = slab.data_ptr()
+        ptrs = {name: base + o for name, o in offsets.items()}
         st = _lib.AdfpTrainState()
-        for k in ('flags', 'list', 'counter', 'att_occ', 'att_u'):
-            setattr(st, k, bufs[k].data_ptr())
-        nets = ['low'] + (['high'] if stage != 'low' else []) + (['color'] if stage == 'color' else [])
-        for n in nets:
-            if not decoders.uses_split(n):                 # ADFP_MATH=f32, or latched to exact: the exact backward recomputes
-                continue
-            bufs['masks_' + n] = torch.empty((P, _lib.TRAIN_MASK_WORDS), dtype=torch.int32, device=dev)
-            setattr(st, 'masks_' + n, bufs['masks_' + n].data_ptr())
-            want = need_flat.get(n) if need_flat is not None else any(p.requires_grad for p in decoders.net_params(n))
-            if want:
-                bufs['act_' + n] = torch.empty((P, lib().adfp_train_act_floats(_lib.DEC_KIND[n])), dtype=torch.float32, device=dev)
-                setattr(st, 'act_' + n, bufs['act_' + n].data_ptr())
-        if stage != 'low' and decoders.uses_split('att'):   # the attention network, rows = in-band list entries (at most P)
-            bufs['masks_att'] = torch.empty((P, _lib.TRAIN_ATT_MASK_WORDS), dtype=torch.int32, device=dev)
-            st.masks_att = bufs['masks_att'].data_ptr()
-            want = need_flat.get('att') if need_flat is not None else any(p.requires_grad for p in decoders.net_params('att'))
-            if want:
-                bufs['act_att'] = torch.empty((P, _lib.TRAIN_ATT_ACT_FLOATS), dtype=torch.float32, device=dev)
-                st.act_att = bufs['act_att'].data_ptr()
-        bufs['bwd_exact'] = 'bwd' in decoders._exact_latch
-        bufs['_state'] = st
+        for name in fields:
+            setattr(st, name, ptrs[name])
+        bufs = dict(present)                              # presence flags (Engine.ht_nets asks for 'masks_<net>' / 'act_<net>')
+        bufs['slab'], bufs['offsets'], bufs['ptrs'], bufs['sizes'] = slab, offsets, ptrs, sizes
+        bufs['counter_ptr'], bufs['bwd_exact'], bufs['_state'] = ptrs['counter'], 'bwd' in latch, st
         return bufs
+
+    @staticmethod
+    def state_tensor(saved, name, dtype, shape=None):
+        """A region of the training slab as a tensor (tests / diagnostics: e.g. the ReLU mask words 'masks_color' as int32)."""
+        nbytes = saved['sizes'][name]
+        t = saved['slab'][saved['offsets'][name]: saved['offsets'][name] + nbytes].view(dtype)
+        return t if shape is None else t.view(shape)
 
     @staticmethod
     def ht_nets(saved, need_flat, need_pos, need_grid=None):
@@ -212,7 +298,7 @@ class Engine(object):
                             need_flat=None):
         dev = pts.device
         saved = None
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             if pts.dtype == torch.float64:
                 mode = _lib.PTS_F64
             else:
@@ -225,7 +311,8 @@ class Engine(object):
             w = torch.empty((P,), dtype=torch.float32, device=dev)
             if P == 0:
                 return raw, w, saved
-            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage)
+            keys = {}
+            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, keys=keys)
             ap = _lib.AdfpPoints()
             ap.mode = mode
             ap.n_points = P
@@ -234,7 +321,7 @@ class Engine(object):
             st = None
             if train:
                 saved = self.train_state(P, stage, dev, decoders, need_flat)
-                saved.update(pts=pts, mode=mode)
+                saved.update(pts=pts, mode=mode, keys=keys)
                 st = saved['_state']
             check(lib().adfp_eval_points_train(C.byref(sc), C.byref(ap), _lib.STAGE[stage], 1 if apply_bound_rule else 0,
                                                ptr(raw), ptr(w), ptr(ws), ws.numel(), C.byref(st) if st is not None else None,
@@ -247,10 +334,10 @@ class Engine(object):
         pts = saved['pts']
         dev = pts.device
         L = lib()
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             P = pts.shape[0]
             sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=True,
-                                  ht_nets=self.ht_nets(saved, need_flat, need_pts, need_grid))
+                                  ht_nets=self.ht_nets(saved, need_flat, need_pts, need_grid), keys=saved.get('keys'))
             ap = _lib.AdfpPoints()
             ap.mode, ap.n_points, ap.pts = saved['mode'], P, pts.data_ptr()
             a = _lib.AdfpPointsBackwardArgs()
@@ -264,16 +351,13 @@ class Engine(object):
                     Z, Y, X = c[key].shape[2:]
                     grids_cl[name] = torch.empty((Z, Y, X, 32), dtype=torch.float32, device=dev)
                     setattr(a, 'g_grid_' + name, grids_cl[name].data_ptr())
-            sizes = {'low': L.adfp_decoder_flat_floats(0), 'high': L.adfp_decoder_flat_floats(1),
-                     'color': L.adfp_decoder_flat_floats(2), 'att': L.adfp_attention_flat_floats()}
             for name in ('low', 'high', 'color', 'att'):
                 if need_flat.get(name):
-                    flats[name] = torch.empty((sizes[name],), dtype=torch.float32, device=dev)
+                    flats[name] = torch.empty((_flat_floats(name),), dtype=torch.float32, device=dev)
                     setattr(a, 'g_flat_' + name, flats[name].data_ptr())
             g_pts = torch.empty((P, 3), dtype=torch.float32, device=dev) if need_pts else None
             a.g_pts = _lib.ptr(g_pts)
-            need = L.adfp_backward_workspace_bytes(P)
-            ws = torch.empty(int(need) + 1024, dtype=torch.uint8, device=dev)
+            ws = self.bwd_workspace(P, dev)
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
             a.options = self.bwd_options
             stream = _lib.current_stream(dev)
@@ -289,7 +373,7 @@ class Engine(object):
     def sample_tsdf(self, pts, tsdf_volume, tsdf_bnds):
         _lib.require_cuda(pts, 'points')
         dev = pts.device
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             mode = _lib.PTS_F64 if pts.dtype == torch.float64 else _lib.PTS_F32
             if mode == _lib.PTS_F32 and pts.dtype != torch.float32:
                 pts = pts.float()
@@ -318,7 +402,7 @@ class Engine(object):
         dev = pts.device
         name = mlp.name
         use_h = math_mode() == 'f16x3' and not mlp.__dict__.get('_single_exact')
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             mode = _lib.PTS_F64 if pts.dtype == torch.float64 else _lib.PTS_F32
             if mode == _lib.PTS_F32 and pts.dtype != torch.float32:
                 pts = pts.float()
@@ -355,7 +439,7 @@ class Engine(object):
         dev = pts.device
         use_h = math_mode() == 'f16x3' and not mlp.__dict__.get('_single_exact')
         tv = self.sample_tsdf(pts, tsdf_volume, tsdf_bnds)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             M = tv.shape[0]
             occ = occ.detach().to(dev, torch.float32).contiguous()
             if occ.shape[0] != M:
@@ -382,22 +466,30 @@ class Engine(object):
                        want_aux=False, train=False, need_flat=None, depth_max_segment=0):
         _lib.require_cuda(rays_o, 'rays_o')
         dev = rays_o.device
-        with torch.cuda.device(dev):
-            ro = rays_o.detach().float().contiguous()
-            rd = rays_d.detach().float().contiguous()
+        f32 = torch.float32
+        with _lib.device_guard(dev):
+            ro = rays_o.detach()
+            if ro.dtype != f32 or not ro.is_contiguous():
+                ro = ro.float().contiguous()
+            rd = rays_d.detach()
+            if rd.dtype != f32 or not rd.is_contiguous():
+                rd = rd.float().contiguous()
             N = ro.shape[0]
             gd = None
             if gt_depth is not None:
-                gd = gt_depth.detach().reshape(-1).float().contiguous()
+                gd = gt_depth.detach().reshape(-1)
+                if gd.dtype != f32 or not gd.is_contiguous():
+                    gd = gd.float().contiguous()
             S = n_samples + (n_surface if gd is not None else 0)
             depth = torch.empty((N,), dtype=torch.float64, device=dev)
             unc = torch.empty((N,), dtype=torch.float64, device=dev)
-            color = torch.empty((N, 3), dtype=torch.float32, device=dev)
-            weight = torch.empty((N, S, 1), dtype=torch.float32, device=dev)
+            color = torch.empty((N, 3), dtype=f32, device=dev)
+            weight = torch.empty((N, S, 1), dtype=f32, device=dev)
             aux = None
             if N == 0:
                 return depth, unc, color, weight, aux
-            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage)
+            keys = {}
+            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, keys=keys)
             a = _lib.AdfpRenderArgs()
             a.stage = _lib.STAGE[stage]
             a.n_rays = N
@@ -409,26 +501,31 @@ class Engine(object):
             a.rays_d = rd.data_ptr()
             a.gt_depth = gd.data_ptr() if gd is not None else None
             if perturb > 0:
-                t_rand = t_rand.to(dev, torch.float32).contiguous()
+                t_rand = t_rand.to(dev, f32).contiguous()
                 a.t_rand = t_rand.data_ptr()
             a.depth_max_segment = int(depth_max_segment)
             if depth_max is not None:
-                depth_max = depth_max.to(dev, torch.float32).reshape(-1).contiguous()
+                depth_max = depth_max.to(dev, f32).reshape(-1).contiguous()
                 a.depth_max = depth_max.data_ptr()
             a.depth = depth.data_ptr()
             a.uncertainty = unc.data_ptr()
             a.color = color.data_ptr()
             a.weight = weight.data_ptr()
-            if want_aux or train:
+            if train:
+                # buffers the backward reads after this call returns (never the shared workspace): one slab
+                P = N * S
+                aux = self.train_state(P, stage, dev, decoders, need_flat, extra=(('z_vals', 8 * P), ('raw', 16 * P)))
+                a.z_vals, a.raw = aux['ptrs']['z_vals'], aux['ptrs']['raw']
+                aux.update(rays_o=ro, rays_d=rd, S=S, N=N, keys=keys)
+                a.state = C.pointer(aux['_state'])
+                if want_aux:
+                    aux['z_vals'] = self.state_tensor(aux, 'z_vals', torch.float64, (N, S))
+                    aux['raw'] = self.state_tensor(aux, 'raw', f32, (N, S, 4))
+            elif want_aux:
                 aux = {'z_vals': torch.empty((N, S), dtype=torch.float64, device=dev),
-                       'raw': torch.empty((N, S, 4), dtype=torch.float32, device=dev)}
+                       'raw': torch.empty((N, S, 4), dtype=f32, device=dev)}
                 a.z_vals = aux['z_vals'].data_ptr()
                 a.raw = aux['raw'].data_ptr()
-            if train:
-                # buffers the backward reads after this call returns (never the shared workspace)
-                aux.update(self.train_state(N * S, stage, dev, decoders, need_flat))
-                aux.update(rays_o=ro, rays_d=rd, S=S)
-                a.state = C.pointer(aux['_state'])
             ws = self.workspace(N * S, dev)
             a.workspace = ws.data_ptr()
             a.workspace_bytes = ws.numel()
@@ -449,23 +546,26 @@ class Engine(object):
         ro = saved['rays_o']
         dev = ro.device
         L = lib()
-        with torch.cuda.device(dev):
+        f32 = torch.float32
+        with _lib.device_guard(dev):
             N, S = ro.shape[0], saved['S']
             sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=True,
-                                  ht_nets=self.ht_nets(saved, need_flat, need_rays, need_grid))
+                                  ht_nets=self.ht_nets(saved, need_flat, need_rays, need_grid), keys=saved.get('keys'))
             a = _lib.AdfpBackwardArgs()
             a.stage = _lib.STAGE[stage]
             a.n_rays, a.S = N, S
             a.rays_o, a.rays_d = ro.data_ptr(), saved['rays_d'].data_ptr()
-            a.z_vals, a.raw = saved['z_vals'].data_ptr(), saved['raw'].data_ptr()
+            a.z_vals, a.raw = saved['ptrs']['z_vals'], saved['ptrs']['raw']
             a.state = saved['_state']
 
             def prep(t, dtype):
                 if t is None:
                     return None
-                return t.detach().to(dev, dtype).contiguous()
-            gd, gu, gc, gw = prep(g_depth, torch.float64), prep(g_unc, torch.float64), prep(g_color, torch.float32), \
-                prep(g_weight, torch.float32)
+                t = t.detach()
+                if t.dtype != dtype or t.device != dev:
+                    t = t.to(dev, dtype)
+                return t if t.is_contiguous() else t.contiguous()
+            gd, gu, gc, gw = prep(g_depth, torch.float64), prep(g_unc, torch.float64), prep(g_color, f32), prep(g_weight, f32)
             a.g_depth, a.g_uncertainty = _lib.ptr(gd), _lib.ptr(gu)
             a.g_color, a.g_weight = _lib.ptr(gc), _lib.ptr(gw)
             if ray_keep is not None:
@@ -479,22 +579,19 @@ class Engine(object):
                         direct[name] = out_grids_cl[name]
                         setattr(a, 'g_grid_' + name, direct[name].data_ptr())
                         continue
-                    grids_cl[name] = torch.empty((Z, Y, X, 32), dtype=torch.float32, device=dev)
+                    grids_cl[name] = torch.empty((Z, Y, X, 32), dtype=f32, device=dev)
                     setattr(a, 'g_grid_' + name, grids_cl[name].data_ptr())
-            sizes = {'low': L.adfp_decoder_flat_floats(0), 'high': L.adfp_decoder_flat_floats(1),
-                     'color': L.adfp_decoder_flat_floats(2), 'att': L.adfp_attention_flat_floats()}
             for name in ('low', 'high', 'color', 'att'):
                 if need_flat.get(name):
                     flats[name] = out_flats[name] if out_flats and name in out_flats else \
-                        torch.empty((sizes[name],), dtype=torch.float32, device=dev)
+                        torch.empty((_flat_floats(name),), dtype=f32, device=dev)
                     setattr(a, 'g_flat_' + name, flats[name].data_ptr())
             g_ro = g_rd = None
             if need_rays:
-                g_ro = torch.empty((N, 3), dtype=torch.float32, device=dev)
-                g_rd = torch.empty((N, 3), dtype=torch.float32, device=dev)
+                g_ro = torch.empty((N, 3), dtype=f32, device=dev)
+                g_rd = torch.empty((N, 3), dtype=f32, device=dev)
                 a.g_rays_o, a.g_rays_d = g_ro.data_ptr(), g_rd.data_ptr()
-            need = L.adfp_backward_workspace_bytes(N * S)
-            ws = torch.empty(int(need) + 1024, dtype=torch.uint8, device=dev)
+            ws = self.bwd_workspace(N * S, dev)
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
             a.options = self.bwd_options | (_lib.BWD_GRIDS_PREZEROED if (grids_prezeroed and not grids_cl) else 0)
             stream = _lib.current_stream(dev)
@@ -502,7 +599,7 @@ class Engine(object):
             grids = dict(direct)
             for name, g in grids_cl.items():
                 Z, Y, X = g.shape[:3]
-                out = out_grids[name] if out_grids and name in out_grids else torch.empty((1, 32, Z, Y, X), dtype=torch.float32, device=dev)
+                out = out_grids[name] if out_grids and name in out_grids else torch.empty((1, 32, Z, Y, X), dtype=f32, device=dev)
                 check(L.adfp_relayout_grid_back(ptr(g), ptr(out), 32, Z, Y, X, stream), 'adfp_relayout_grid_back')
                 grids[name] = out
         return grids, flats, (g_ro, g_rd)

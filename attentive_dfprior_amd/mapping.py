@@ -334,7 +334,7 @@ class MapperIteration(object):
             lrs[self.groups.index(gname)] = float(lrv)
         # the forward call's f16-range flag (adfp_train_state.counter[8]): a repaired forward means this iteration's gradients are
         # zero by construction -- then nobody steps (parameters, moments and step counters stay as they are)
-        skip = C.c_void_p(aux['counter'].data_ptr() + 32)
+        skip = C.c_void_p(aux['counter_ptr'] + 32)
         check(L.adfp_adam_prep(ptr(self.step_count), ptr(self.derived), len(self.groups), lrs, b1, b2, skip, st), 'adfp_adam_prep')
         arr = (_lib.AdfpAdamGroup * len(groups))()                   # one launch for all groups
         for k, (gname, p, g, (m, v), mask, nvox, ch, lrv) in enumerate(groups):
@@ -427,15 +427,14 @@ class MapperIteration(object):
                 # graph's replay may write must never be what an eager call (Visualizer, Tracker, Mesher) finds in the cache.
                 eng = self.rend._engine
                 self._drop_volatile_cache_entries()
-                ws_eager, eng._ws = eng._ws, None     # the graph gets its OWN workspace (an eager call may grow and free the shared one)
                 g = torch.cuda.CUDAGraph()
                 if self._pool is None:
                     self._pool = torch.cuda.graph_pool_handle()      # the graphs replay one at a time: one pool for all
                 try:
-                    with torch.cuda.graph(g, pool=self._pool):
-                        self._sequence(*st, stage, warmup)
+                    with eng.private_workspaces():    # the graph gets its OWN workspaces (an eager call may grow and free the shared ones)
+                        with torch.cuda.graph(g, pool=self._pool):
+                            self._sequence(*st, stage, warmup)
                 finally:
-                    eng._ws = ws_eager
                     self._drop_volatile_cache_entries()
                 self._graphs[key] = g                 # capturing does not execute: fall through to the first replay
             g.replay()

@@ -144,7 +144,7 @@ class TrackerIteration(object):
         b1, b2 = self.betas
         lrs = (C.c_float * self.n_groups)(*([self.cam_lr, self.cam_lr * 0.2] if self.separate else [self.cam_lr]))
         # a forward repaired for an f16-range event has zero gradients by construction: nobody steps then (adfp_train_state.counter[8])
-        skip = C.c_void_p(aux['counter'].data_ptr() + 32)
+        skip = C.c_void_p(aux['counter_ptr'] + 32)
         check(L.adfp_adam_prep(ptr(self.step_count), ptr(self.derived), self.n_groups, lrs, b1, b2, skip, st), 'adfp_adam_prep')
         parts = [(4, 3), (0, 4)] if self.separate else [(0, 7)]              # (offset, length) of each group inside the 7-vector
         arr = (_lib.AdfpAdamGroup * len(parts))()
@@ -209,15 +209,12 @@ class TrackerIteration(object):
                     key = graph_key()
                 self._graphs = {k: v for k, v in self._graphs.items() if k[2] == key[2]}      # graphs of replaced scene tensors are dead
                 eng = self.rend._engine
-                ws_eager, eng._ws = eng._ws, None           # the graph owns its workspace
                 g = torch.cuda.CUDAGraph()
                 if self._pool is None:
                     self._pool = torch.cuda.graph_pool_handle()
-                try:
+                with eng.private_workspaces():              # the graph owns its workspaces
                     with torch.cuda.graph(g, pool=self._pool):
                         self._sequence(buf)
-                finally:
-                    eng._ws = ws_eager
                 self._graphs[key] = g
             g.replay()
             return self.loss

@@ -223,7 +223,7 @@ def tracker_leg(A, synthetic, scene, sd, dec, dev):
 
             def it():
                 opt.zero_grad()
-                c2w = _camera_from_tensor(cam)
+                c2w = common.get_camera_from_tensor(cam)
                 ro, rd, gd, gc = common.get_samples(edge, H - edge, edge, W - edge, n, H, W, scene.fx, scene.fy, scene.cx, scene.cy, c2w, depth, color, dev)
                 ro, rd, gd, gc = common.filter_rays_in_bound(ro, rd, gd, gc, bound)
                 d, u, col, _ = rend.render_batch_ray(scene.c, dec, rd, ro, dev, scene.tsdf_volume, tb, 'color', gt_depth=gd)

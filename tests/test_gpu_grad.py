@@ -306,10 +306,10 @@ def _grads_of_case(mini, monkeypatch, mode, no_masks=False):
     if no_masks:
         orig = engine.Engine.train_state
 
-        def without_masks(P, stage, dev, decoders, need_flat=None):
+        def without_masks(P, stage, dev, decoders, need_flat=None, **kw):
             monkeypatch.setenv('ADFP_MATH', 'f32')
             try:
-                return orig(P, stage, dev, decoders, need_flat)
+                return orig(P, stage, dev, decoders, need_flat, **kw)
             finally:
                 monkeypatch.setenv('ADFP_MATH', mode)
         monkeypatch.setattr(engine.Engine, 'train_state', staticmethod(without_masks))
