@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ADFP_LIB_PATH', os.path.join(_HERE, 'libadfp.so'))   # override: kernel A/B builds
 
-ABI_VERSION = 119                 # ADFP_VERSION of include/adfp.h this binding was written against
+ABI_VERSION = 120                 # ADFP_VERSION of include/adfp.h this binding was written against
 STATUS_F16_RANGE = 31              # ADFP_STATUS_F16_RANGE: any of the bits below
 STATUS_RANGE_BITS = {'low': 1, 'high': 2, 'color': 4, 'att': 8, 'bwd': 16}      # ADFP_STATUS_F16_RANGE_<net>
 BWD_SCATTER_IN_KERNEL = 1        # ADFP_BWD_SCATTER_IN_KERNEL
@@ -53,7 +53,8 @@ class AdfpTrainState(C.Structure):
                 ('att_occ', C.c_void_p), ('att_u', C.c_void_p),
                 ('masks_low', C.c_void_p), ('masks_high', C.c_void_p), ('masks_color', C.c_void_p),
                 ('act_low', C.c_void_p), ('act_high', C.c_void_p), ('act_color', C.c_void_p),
-                ('masks_att', C.c_void_p), ('act_att', C.c_void_p)]
+                ('masks_att', C.c_void_p), ('act_att', C.c_void_p),
+                ('dbg_masks_low', C.c_void_p), ('dbg_masks_high', C.c_void_p), ('dbg_masks_color', C.c_void_p), ('dbg_masks_att', C.c_void_p)]
 
 
 TRAIN_MASK_WORDS = 6              # ADFP_TRAIN_MASK_WORDS

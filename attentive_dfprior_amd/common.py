@@ -216,6 +216,13 @@ def get_tensor_from_camera(RT, Tquad=False):
     dev = RT.device if isinstance(RT, torch.Tensor) else None
     M = RT.detach().cpu().numpy() if isinstance(RT, torch.Tensor) else np.asarray(RT)
     R, T = M[:3, :3].astype(np.float64), M[:3, 3].astype(np.float64)
+    # mathutils' Matrix.to_quaternion normalises the matrix first (unit-length axis vectors; a left-handed one is negated) and
+    # returns a unit quaternion: the constant-speed guess delta @ pre_c2w (src/Tracker.py:213-215) is only orthonormal up to
+    # accumulated float error, and the raw quaternion components are what Adam steps on and the error log prints
+    norms = np.linalg.norm(R, axis=0)
+    R = R / np.where(norms > 0, norms, 1.0)
+    if np.linalg.det(R) < 0:
+        R = -R
     tr = R[0, 0] + R[1, 1] + R[2, 2]
     if tr > 0:
         s = 2.0 * np.sqrt(1.0 + tr)
@@ -228,6 +235,7 @@ def get_tensor_from_camera(RT, Tquad=False):
         v[k], v[a], v[b] = 0.25 * s, (R[a, k] + R[k, a]) / s, (R[b, k] + R[k, b]) / s
         q = [(R[b, a] - R[a, b]) / s] + v
     q = np.asarray(q)
+    q = q / np.linalg.norm(q)
     if q[0] < 0:
         q = -q
     out = torch.from_numpy(np.concatenate([T, q] if Tquad else [q, T])).float()

@@ -298,6 +298,7 @@ struct DecodeBwdArgs {
     float* stage;              // staging rows of this chunk (WGRAD) or NULL
     float* g_pts;              // [P,3] d/d sample position, accumulated (PGRAD) or NULL
     int chunk_lo, chunk_hi;    // point / list-entry range handled by this launch
+    unsigned* dbg_masks;       // debug export of the recomputed ReLU decisions (adfp_train_state.dbg_masks_*) or NULL
 };
 
 // lane row j of a transposed chain -> offset of in-unit j inside its in-block of the image
@@ -389,6 +390,12 @@ __global__ __launch_bounds__(NT) void k_decode_bwd(DecodeBwdArgs a) {
             mfma_chain<L::KSC>(acc, lds + L::P_WC(i), lane_off, c);
             hcur = acc;
             if (WGRAD && valid) stage_block(srow, ST::SH(i), h, hcur);
+        }
+        if (a.dbg_masks && valid) {     // the training forward's layout (k_decode_h<TRAIN>): register r of layer i at bit 15 - r of its 16-bit field
+            unsigned* mrow = a.dbg_masks + ((long long)idx * 2 + h) * 3;
+            mrow[0] = (__brev(mask[0]) >> 16) | (__brev(mask[1]) & 0xFFFF0000u);
+            mrow[1] = (__brev(mask[2]) >> 16) | (__brev(mask[3]) & 0xFFFF0000u);
+            mrow[2] = __brev(mask[4]) >> 16;
         }
 
         // ---------------- cotangent of the decoder output ----------------
@@ -518,6 +525,7 @@ struct AttBwdArgs {
     // PGRAD: the fused occupancy depends on the sample position through u = inv_tsdf(tsdf(p)) (decoder.py:241-248)
     PtsDev P; NormDev nt; TsdfDev t; float* g_pts;
     const float* gmax;         // non-NULL: the staged GRADIENT blocks are multiplied by grad_scale(gmax) (for k_outer_h)
+    unsigned* dbg_masks;       // debug export of the recomputed ReLU decisions + softmax weights (adfp_train_state.dbg_masks_att) or NULL
 };
 
 template <bool WGRAD, bool PGRAD>
@@ -603,6 +611,14 @@ __global__ __launch_bounds__(256) void k_attention_bwd(AttBwdArgs a) {
         const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
         const float den = e0 + e1;
         const float a0 = e0 / den, a1 = e1 / den;
+        if (a.dbg_masks && valid) {     // k_attention_h<TRAIN>'s layout: value v of a layer at bit 31 - v, counted over the layer's words
+            unsigned* mrow = a.dbg_masks + ((long long)idx * 2 + h) * 7;
+            mrow[0] = __brev(m0);
+            mrow[1] = (__brev(m1[0]) & 0xFFFF0000u) | (__brev(m1[1]) >> 16); mrow[2] = (__brev(m1[2]) & 0xFFFF0000u) | (__brev(m1[3]) >> 16);
+            mrow[3] = (__brev(m2[0]) & 0xFFFF0000u) | (__brev(m2[1]) >> 16); mrow[4] = (__brev(m2[2]) & 0xFFFF0000u) | (__brev(m2[3]) >> 16);
+            mrow[5] = (__brev(m3[0]) & 0xFFFF0000u) | (__brev(m3[1]) >> 16);
+            mrow[6] = __float_as_uint(h ? a1 : a0);
+        }
         // ---- backward: out = a0 occ + a1 u, w = a1
         const float g_out = valid ? a.g_raw[4ll * q + 3] : 0.f;
         const float g_w = (valid && a.g_weight && !(a.skip && *a.skip)) ? a.g_weight[q] : 0.f;

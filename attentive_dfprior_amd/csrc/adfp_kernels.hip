@@ -2100,7 +2100,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
     const bool fuse = stage != ADFP_STAGE_LOW;
     DecodeBwdArgs a;
     a.P = Pd; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
-    a.list = nullptr; a.count_ptr = nullptr; a.g_raw = bw.g_raw; a.att_g = nullptr; a.stage = nullptr;
+    a.list = nullptr; a.count_ptr = nullptr; a.g_raw = bw.g_raw; a.att_g = nullptr; a.stage = nullptr; a.dbg_masks = nullptr;
     a.g_pts = pgrad ? bw.g_pts : nullptr;
     if (pgrad) { e = zero_async(bw.g_pts, (size_t)P * 12, st); if (e != hipSuccess) return (int)e; }
     // a decoder takes the f16-split backward when its T image and the forward's masks are there and -- if its weight gradients
@@ -2186,7 +2186,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         t.packed = sc->w_att; t.list = state.list; t.count_ptr = state.counter; t.att_occ = state.att_occ;
         t.att_u = state.att_u; t.g_weight = g_weight; t.g_raw = bw.g_raw; t.att_g = bw.att_g; t.stage = bw.stage;
         t.P = Pd; t.nt = make_norm(sc->tsdf_bnds); t.t = make_tsdf(sc->tsdf); t.g_pts = a.g_pts;
-        t.gmax = nullptr; t.skip = state.counter ? state.counter + 8 : nullptr;
+        t.gmax = nullptr; t.skip = state.counter ? state.counter + 8 : nullptr; t.dbg_masks = state.dbg_masks_att;
         OuterArgs oa; attention_jobs(oa);
         if (go.flat_att) { rc = outer_begin(bw, AttLayout::F_TOTAL, st); if (rc) return rc; }
         for (int lo = 0; lo < P; lo += bw.stage_rows) {
@@ -2210,7 +2210,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         if (go.grid_high || go.flat_high || pgrad) {
             DecodeBwdArgs hgh = a;
             hgh.g0 = make_grid(sc->high); hgh.g1 = make_grid(sc->low); hgh.packed = sc->w_high;
-            hgh.list = state.list; hgh.count_ptr = state.counter; hgh.att_g = bw.att_g; hgh.g_grid = go.grid_high;
+            hgh.list = state.list; hgh.count_ptr = state.counter; hgh.att_g = bw.att_g; hgh.g_grid = go.grid_high; hgh.dbg_masks = state.dbg_masks_high;
             if (use_h(sc->ht_high, state.masks_high, state.act_high, go.flat_high, go.grid_high))
                 rc = run_decode_bwd_h<64, 1, ROLE_HIGH>(hgh, sc->ht_high, state.masks_high, state.act_high, sc->status, state.counter ? state.counter + 8 : nullptr, P, state.counter, go.flat_high, bw, bp, state.flags, options, st);
             else rc = sc->w_high ? run_decode_bwd<64, 1, ROLE_HIGH>(hgh, P, state.counter, go.flat_high, bw, st) : ADFP_E_ARG;
@@ -2219,7 +2219,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
     }
     if (go.grid_low || go.flat_low || pgrad) {
         DecodeBwdArgs lw = a;
-        lw.g0 = make_grid(sc->low); lw.g1 = lw.g0; lw.packed = sc->w_low; lw.g_grid = go.grid_low;
+        lw.g0 = make_grid(sc->low); lw.g1 = lw.g0; lw.packed = sc->w_low; lw.g_grid = go.grid_low; lw.dbg_masks = state.dbg_masks_low;
         if (use_h(sc->ht_low, state.masks_low, state.act_low, go.flat_low, go.grid_low))
             rc = run_decode_bwd_h<32, 1, ROLE_LOW>(lw, sc->ht_low, state.masks_low, state.act_low, sc->status, state.counter ? state.counter + 8 : nullptr, P, nullptr, go.flat_low, bw, bp, nullptr, options, st);
         else rc = sc->w_low ? run_decode_bwd<32, 1, ROLE_LOW>(lw, P, nullptr, go.flat_low, bw, st) : ADFP_E_ARG;
@@ -2227,7 +2227,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
     }
     if (stage == ADFP_STAGE_COLOR && (go.grid_color || go.flat_color || pgrad)) {
         DecodeBwdArgs cl = a;
-        cl.g0 = make_grid(sc->color); cl.g1 = cl.g0; cl.packed = sc->w_color; cl.g_grid = go.grid_color;
+        cl.g0 = make_grid(sc->color); cl.g1 = cl.g0; cl.packed = sc->w_color; cl.g_grid = go.grid_color; cl.dbg_masks = state.dbg_masks_color;
         if (use_h(sc->ht_color, state.masks_color, state.act_color, go.flat_color, go.grid_color))
             rc = run_decode_bwd_h<32, 4, ROLE_COLOR>(cl, sc->ht_color, state.masks_color, state.act_color, sc->status, state.counter ? state.counter + 8 : nullptr, P, nullptr, go.flat_color, bw, bp, nullptr, options, st);
         else rc = sc->w_color ? run_decode_bwd<32, 4, ROLE_COLOR>(cl, P, nullptr, go.flat_color, bw, st) : ADFP_E_ARG;

@@ -73,6 +73,9 @@ __global__ __launch_bounds__(256) void k_select_pixels(const long long* __restri
 // only the VALUE matters).  A rank count over all pairs -- the first version -- cost 47 us at 1 000 rays, VALU-bound on f64
 // compares; this is ~5 us.
 #define ADFP_TRACK_MAX_RAYS 8192
+// k_tracker_loss keeps the kept rays' 64-bit keys in LDS: 8192 x 8 B = 64 KB + a 4 KB histogram + scalars ~ 69 KB of static LDS.
+// That is a gfx950 budget (160 KB per workgroup); gfx90a / gfx942 stop at 64 KB -- this library targets gfx950 only (build.sh).
+static_assert(ADFP_TRACK_MAX_RAYS * 8 + 1024 * 4 + 16 * 4 + 16 * 8 + 64 <= 160 * 1024, "k_tracker_loss: static LDS beyond the gfx950 workgroup limit");
 struct TrackLossArgs {
     int n, handle_dynamic; float w_color;
     const double* depth; const double* unc; const float* color; const float* gd; const float* gc; const unsigned char* keep;

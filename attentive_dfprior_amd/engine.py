@@ -84,6 +84,9 @@ class Engine(object):
         # ADFP_BWD_* bits handed to the backward entries (adfp_backward_args.options).  ADFP_SCATTER=cache in the environment of
         # the HOST process selects the in-kernel scatter (kernel A/B runs); the library itself reads no environment.
         self.bwd_options = _lib.BWD_SCATTER_IN_KERNEL if os.environ.get('ADFP_SCATTER', '')[:1] == 'c' else 0
+        # Test / diagnostic switch: the training state also carries dbg_masks_* buffers, into which the EXACT backward kernels
+        # export the ReLU decisions they recomputed (adfp_train_state.dbg_masks_*; relu_masks() decodes them)
+        self.export_relu_masks = False
         self._ws = None          # forward scratch, grow-only (stream order makes the reuse safe)
         self._bws = None         # backward scratch, same
         self._grid_cache = {}    # key name -> (key, channels-last tensor)
@@ -253,6 +256,58 @@ class Engine(object):
         nbytes = saved['sizes'][name]
         t = saved['slab'][saved['offsets'][name]: saved['offsets'][name] + nbytes].view(dtype)
         return t if shape is None else t.view(shape)
+
+    @staticmethod
+    def relu_masks(saved, stage):
+        """Decodes the ReLU decisions the BACKWARD of a training call differentiated along (diagnostics / parity tests; needs
+        Engine.export_relu_masks for the networks that took the exact backward): {'low' / 'high' / 'color': bool [P, 5, 32] (layer,
+        unit; for 'high' only the in-band points are meaningful, 'high_valid' bool [P] marks them), 'att': [bool [P, 64], [P, 128],
+        [P, 128], [P, 64]] (rows of points outside the band are False), 'band': bool [P]}.  A network on the f16-split backward
+        used the masks its training forward left (masks_<net>); one on the exact backward exported what it recomputed
+        (dbg_masks_<net>, adfp_train_state)."""
+        P = saved['sizes']['flags']
+        dev = saved['slab'].device
+        ht = saved.get('ht_used', ())
+        count = int(Engine.state_tensor(saved, 'counter', torch.int32)[0]) if stage != 'low' else 0
+        lst = Engine.state_tensor(saved, 'list', torch.int32)[:count].long() if stage != 'low' else None
+        u = torch.arange(32, device=dev)
+        half, bit = (u >> 2) & 1, 15 - (4 * (u >> 3) + (u & 3))                   # unit -> lane half, bit of the 16-bit layer field
+        out = {}
+        for n in _STAGE_NETS[stage]:
+            src = ('masks_' if n in ht else 'dbg_masks_') + n
+            if src not in saved['sizes']:
+                raise RuntimeError(f'relu_masks: no {src} in the training state (set Engine.export_relu_masks before the forward)')
+            if n == 'att':
+                w = Engine.state_tensor(saved, src, torch.int32, (P, 2, 7))[:count].long() & 0xFFFFFFFF
+                layers = []
+                for first, units in ((0, 64), (1, 128), (3, 128), (5, 64)):
+                    uu = torch.arange(units, device=dev)
+                    hh = (uu >> 2) & 1
+                    v = 16 * (uu >> 5) + 4 * ((uu & 31) >> 3) + (uu & 3)          # value index inside the layer: 16 ob + r
+                    word, b = first + (v >> 5), 31 - (v & 31)
+                    m = ((w[:, hh, word] >> b) & 1).bool()                         # [count, units]
+                    full = torch.zeros((P, units), dtype=torch.bool, device=dev)
+                    full[lst] = m
+                    layers.append(full)
+                out['att'] = layers
+                out['att_softmax'] = w[:, :, 6]
+                continue
+            w = Engine.state_tensor(saved, src, torch.int32, (P, 2, 3)).long() & 0xFFFFFFFF
+            rows = w[:count] if n == 'high' else w
+            m = torch.stack([((rows[:, half, i >> 1] >> (16 * (i & 1) + bit)) & 1).bool() for i in range(5)], 1)     # [rows, 5, 32]
+            if n == 'high':
+                full = torch.zeros((P, 5, 32), dtype=torch.bool, device=dev)
+                full[lst] = m
+                valid = torch.zeros((P,), dtype=torch.bool, device=dev)
+                valid[lst] = True
+                out['high'], out['high_valid'] = full, valid
+            else:
+                out[n] = m
+        if stage != 'low':
+            band = torch.zeros((P,), dtype=torch.bool, device=dev)
+            band[lst] = True
+            out['band'] = band
+        return out
 
     @staticmethod
     def ht_nets(saved, need_flat, need_pos, need_grid=None):
@@ -514,7 +569,11 @@ class Engine(object):
             if train:
                 # buffers the backward reads after this call returns (never the shared workspace): one slab
                 P = N * S
-                aux = self.train_state(P, stage, dev, decoders, need_flat, extra=(('z_vals', 8 * P), ('raw', 16 * P)))
+                extra = (('z_vals', 8 * P), ('raw', 16 * P))
+                if self.export_relu_masks:
+                    extra += tuple(('dbg_masks_' + n, 4 * (_lib.TRAIN_ATT_MASK_WORDS if n == 'att' else _lib.TRAIN_MASK_WORDS) * P)
+                                   for n in _STAGE_NETS[stage])
+                aux = self.train_state(P, stage, dev, decoders, need_flat, extra=extra)
                 a.z_vals, a.raw = aux['ptrs']['z_vals'], aux['ptrs']['raw']
                 aux.update(rays_o=ro, rays_d=rd, S=S, N=N, keys=keys)
                 a.state = C.pointer(aux['_state'])
@@ -549,8 +608,9 @@ class Engine(object):
         f32 = torch.float32
         with _lib.device_guard(dev):
             N, S = ro.shape[0], saved['S']
-            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=True,
-                                  ht_nets=self.ht_nets(saved, need_flat, need_rays, need_grid), keys=saved.get('keys'))
+            ht = self.ht_nets(saved, need_flat, need_rays, need_grid)
+            saved['ht_used'] = ht
+            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=True, ht_nets=ht, keys=saved.get('keys'))
             a = _lib.AdfpBackwardArgs()
             a.stage = _lib.STAGE[stage]
             a.n_rays, a.S = N, S

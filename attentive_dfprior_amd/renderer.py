@@ -101,6 +101,18 @@ class Renderer(object):
             self.N_samples, self.N_surface, self.lindisp, self.perturb, t_rand, depth_max)
         return depth, unc, color, weight
 
+    def _fits_in_one_call(self, n, S, dev):
+        """ray_batch_size exists in the reference to BOUND memory (Renderer.py:294-313).  The one-call frame needs the forward
+        workspace for all n x S samples at once (~37 B per sample x 1.25) plus the [n, S] attention-weight output; it is taken
+        only when that fits in half of what the device has free (or the engine's workspace is that large already) -- otherwise
+        the frame is rendered batch by batch like the reference's."""
+        need_ws = int(_lib.lib().adfp_workspace_bytes(n * S))
+        ws = self._engine._ws
+        have = ws.numel() if ws is not None and ws.device == dev else 0
+        extra = (int(need_ws * 1.25) if have < need_ws else 0) + n * (4 * S + 28)
+        free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        return extra <= free // 2
+
     def render_img(self, c, decoders, c2w, device, tsdf_volume, tsdf_bnds, stage, gt_depth=None):
         """Full-frame render under no_grad in ``ray_batch_size`` batches -> depth [H,W] f64,
         uncertainty [H,W] f64, color [H,W,3] f32.  Each batch clamps ``far`` with ITS OWN max
@@ -114,7 +126,7 @@ class Renderer(object):
                 gt_depth = gt_depth.reshape(-1)
             n, S = rays_d.shape[0], self.N_samples + (self.N_surface if gt_depth is not None else 0)
             nseg = (n + self.ray_batch_size - 1) // self.ray_batch_size
-            if gt_depth is not None and self.perturb == 0 and 1 < nseg <= 48 and n * S < 2 ** 31:
+            if gt_depth is not None and self.perturb == 0 and 1 < nseg <= 48 and n * S < 2 ** 31 and self._fits_in_one_call(n, S, rays_d.device):
                 # The reference walks the frame in ray batches (memory), and the only thing a batch shares is max(gt_depth) for
                 # the far clamp -- carried per SEGMENT of ray_batch_size rays here (adfp_render_args.depth_max_segment), the whole
                 # frame is one kernel sequence with the batched loop's values bit for bit (tests: the golden image was rendered

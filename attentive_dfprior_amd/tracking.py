@@ -74,6 +74,12 @@ class TrackerIteration(object):
         self.derived = torch.empty((self.n_groups, 2), **f32)
         self.bound_dev = torch.as_tensor(renderer.bound).to(dev, torch.float64).contiguous()
         self._graphs, self._pick, self._pool = {}, {}, None
+        # The captured graphs read the grids through channels-last copies.  The iteration OWNS those copies (one per grid, re-used
+        # in place when a grid of the same shape is handed over) and registers them with the engine's layout cache before every
+        # eager pass and every replay: the cache has one slot per grid name and is shared with every other user of the same
+        # Renderer (a Mapper in the same process replaces or clears the slot), so a pointer baked into a graph must never be the
+        # cache's own buffer.
+        self._shadow, self._shadow_src = {}, {}
 
     # ---- per frame ----------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -163,8 +169,29 @@ class TrackerIteration(object):
     def gradient(self, batch_size, pick=None):
         """d loss / d camera tensor at the current pose without stepping (tests, diagnostics): (loss, g [7]) device tensors."""
         with torch.cuda.device(self.dev):
+            self._sync_shadows()
             self._sequence(self._draw(batch_size) if pick is None else pick.to(self.dev, torch.int64).contiguous(), adam=False)
         return self.loss.clone(), self.g_cam.clone()
+
+    def _sync_shadows(self):
+        """Every grid's channels-last shadow holds the grid as it stands (re-laid out here, outside any graph, when the grid was
+        replaced or written since) and is what Engine.scene() finds for it."""
+        eng = self.rend._engine
+        for k, g in self.c.items():
+            _lib.require_cuda(g, k)
+            src = (g.data_ptr(), g._version, g.shape, g.stride())
+            sh = self._shadow.get(k)
+            Z, Y, X = g.shape[2:]
+            if sh is None or sh.shape != (Z, Y, X, 32) or sh.device != g.device:
+                sh = self._shadow[k] = torch.empty((Z, Y, X, 32), dtype=torch.float32, device=g.device)
+                self._shadow_src[k] = None
+            if self._shadow_src[k] != src:
+                gc = g.detach()
+                if gc.dtype != torch.float32 or not gc.is_contiguous():
+                    gc = gc.float().contiguous()
+                check(lib().adfp_relayout_grid(ptr(gc), ptr(sh), 32, Z, Y, X, _lib.current_stream(g.device)), 'adfp_relayout_grid')
+                self._shadow_src[k] = src
+            eng.adopt_grid_cl(k, g, sh)
 
     def _draw(self, n):
         H0, H1, W0, W1 = self.window
@@ -180,6 +207,7 @@ class TrackerIteration(object):
             n = int(batch_size)
             if pick is None:
                 pick = self._draw(n)
+            self._sync_shadows()                            # before the eager sequence, the warm-up, the capture AND every replay
             if not self.use_graph:
                 self._sequence(pick.to(dev, torch.int64).contiguous())
                 return self.loss
@@ -220,10 +248,12 @@ class TrackerIteration(object):
             return self.loss
 
     def _scene_token(self):
-        """Identity + version of everything a captured graph has baked in (the grids' channels-last copies and the packed weight
-        images are made from these outside the graph): a graph is replayed only against the very tensors it was captured with."""
-        ts = list(self.c.values()) + list(self.dec.parameters()) + [self.tsdf]
-        return hash(tuple((t.data_ptr(), t._version) for t in ts))
+        """Identity of everything a captured graph has baked in: the iteration's own channels-last grid copies (their ADDRESSES --
+        the contents are refreshed in place by _sync_shadows, so new grids of the same shape replay the same graph), the decoder
+        parameters (identity + version: the packed weight images are made from them outside the graph, and re-made in place)
+        and the TSDF volume."""
+        ts = list(self.dec.parameters()) + [self.tsdf]
+        return hash((tuple(sh.data_ptr() for sh in self._shadow.values()), tuple((t.data_ptr(), t._version) for t in ts)))
 
     def update_para(self, decoders=None, c=None):
         """Tracker.update_para_from_mapping (src/Tracker.py:136-147) hands over fresh copies of the decoders and grids; graphs

@@ -576,7 +576,8 @@ def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, N
     else:
         # dominant kernel of the default mode: the fused low + colour launch (2 x 90 f16 MFMAs per 32-point tile)
         fl_color = 2.0 * (MAC_LOW + MAC_COLOR) * pts_per_launch
-        t_color_alone, t_color = t_color, t_lc
+        # a network latched to its exact image (f16-range event) has no fused launch: the stage is then the two decoders in turn
+        t_color_alone, t_color = t_color, (t_lc if t_lc else t_color + t_low)
         ach = fl_color / t_color / 1e12
         ex = 2.0 * F16X3_FLOP_COLOR * pts_per_launch / t_color / 1e12
         roof = {'kernel': 'k_decode_lc<768> (low + colour decoder in one launch, f16 MFMA with 3-product f32 operand split)',

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 119
+#define ADFP_VERSION 120
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -236,6 +236,15 @@ typedef struct adfp_train_state {
     float* act_color;
     unsigned* masks_att;      /* ADFP_TRAIN_ATT_MASK_WORDS words per point (in-band list entry): masks + softmax weights */
     float* act_att;           /* ADFP_TRAIN_ATT_ACT_FLOATS floats per point, only when g_flat_att will be requested */
+    /* Debug export, optional (NULL = none), written by the BACKWARD entries: the ReLU decisions the EXACT backward kernels
+     * recomputed for a network (they differentiate their own f32 forward, which decides a unit within rounding of zero on its
+     * own), in the layout of masks_* / masks_att.  A network that took the f16-split backward used the forward's masks_* and
+     * leaves its dbg buffer untouched.  With these a test differentiates the oracle along the SAME piecewise-linear function
+     * (oracle/adfp_oracle.py: relu_masks) and holds every gradient element to the forward tolerance. */
+    unsigned* dbg_masks_low;
+    unsigned* dbg_masks_high;
+    unsigned* dbg_masks_color;
+    unsigned* dbg_masks_att;
 } adfp_train_state;
 #define ADFP_TRAIN_ATT_MASK_WORDS 14
 #define ADFP_TRAIN_ATT_ACT_FLOATS 416

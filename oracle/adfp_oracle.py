@@ -193,8 +193,36 @@ def trilerp_explicit(vol, p, bound):
 # ----------------------------------------------------------------------------------
 # a8/a9: decoder MLP  (decoder.py:26-30, :177-203)
 # ----------------------------------------------------------------------------------
-def mlp_forward(sd, name, p, c_grid, bound):
-    """MLP.forward, decoder.py:177-203.  sd: state dict, name in DECODERS, p [P,3] f64/f32."""
+def _relu(h, forced=None, only=None):
+    """F.relu(h) -- or, test-only, the SAME piecewise-linear branch a kernel took: `forced` bool [..., units] says which units
+    pass (`only` bool [...]: rows the forced decisions apply to; the others keep relu's own).  A unit whose pre-activation lies
+    within rounding of zero is decided either way by two correct implementations, and its whole weight-gradient row moves with
+    the decision; forcing the kernel's decisions makes the oracle differentiate the function the kernels differentiated, so
+    that the comparison can be held to the forward tolerance (tests/test_gpu_grad.py)."""
+    if forced is None:
+        return F.relu(h)
+    if only is not None:
+        forced = torch.where(only.unsqueeze(-1), forced, h > 0)
+    flipped = forced != (h > 0)
+    RELU_FLIPS['units'] += forced.numel()
+    RELU_FLIPS['flipped'] += int(flipped.sum())
+    if flipped.any():
+        RELU_FLIPS['max_abs_preactivation'] = max(RELU_FLIPS['max_abs_preactivation'], float(h.detach()[flipped].abs().max()))
+    return torch.where(forced, h, torch.zeros_like(h))
+
+
+# what forcing cost (test-only bookkeeping of _relu): a forced decision that differs from relu's own must sit on a unit whose
+# pre-activation is within rounding of zero -- the tests assert it, so that forced masks cannot hide a wrong kernel
+RELU_FLIPS = {'units': 0, 'flipped': 0, 'max_abs_preactivation': 0.0}
+
+
+def reset_relu_flips():
+    RELU_FLIPS.update(units=0, flipped=0, max_abs_preactivation=0.0)
+
+
+def mlp_forward(sd, name, p, c_grid, bound, relu_mask=None, relu_rows=None):
+    """MLP.forward, decoder.py:177-203.  sd: state dict, name in DECODERS, p [P,3] f64/f32.
+    relu_mask (test-only, see _relu): bool [P, 5, 32]; relu_rows: bool [P] rows it applies to."""
     pre = f'{name}_decoder.'
     c = trilerp(c_grid['grid_' + name], p, bound).t()                       # decoder.py:179-180
     if name == 'high':                                                      # concat_feature, :182-187
@@ -206,7 +234,7 @@ def mlp_forward(sd, name, p, c_grid, bound):
     h = emb
     for i in range(5):
         h = F.linear(h, sd[pre + f'pts_linears.{i}.weight'], sd[pre + f'pts_linears.{i}.bias'])
-        h = F.relu(h)
+        h = _relu(h, None if relu_mask is None else relu_mask[:, i], relu_rows)
         h = h + F.linear(c, sd[pre + f'fc_c.{i}.weight'], sd[pre + f'fc_c.{i}.bias'])
         if i == 2:
             h = torch.cat([emb, h], -1)
@@ -224,13 +252,15 @@ def inv_tsdf(tsdf_val):
     return torch.clamp(u, -100.0, 100.0)
 
 
-def mlp_tsdf_forward(sd, occ, tsdf_val):
-    """mlp_tsdf.forward, decoder.py:240-258, given the TSDF value at the points."""
+def mlp_tsdf_forward(sd, occ, tsdf_val, relu_masks=None):
+    """mlp_tsdf.forward, decoder.py:240-258, given the TSDF value at the points.  relu_masks (test-only, see _relu): four bool
+    tensors [M, 64 / 128 / 128 / 64]."""
     u = inv_tsdf(tsdf_val)
     inp = torch.stack([occ, u], dim=1)
     h = inp
     for i in range(4):
-        h = F.relu(F.linear(h, sd[f'mlp.pts_linears.{i}.weight'], sd[f'mlp.pts_linears.{i}.bias']))
+        h = _relu(F.linear(h, sd[f'mlp.pts_linears.{i}.weight'], sd[f'mlp.pts_linears.{i}.bias']),
+                  None if relu_masks is None else relu_masks[i])
     a = torch.softmax(F.linear(h, sd['mlp.output_linear.weight'], sd['mlp.output_linear.bias']), dim=1)
     out = (a * inp).sum(dim=1)
     return out, a[:, 1]
@@ -239,25 +269,28 @@ def mlp_tsdf_forward(sd, occ, tsdf_val):
 # ----------------------------------------------------------------------------------
 # a12: DF.forward  (decoder.py:307-353)
 # ----------------------------------------------------------------------------------
-def df_forward(sd, p, c_grid, tsdf_volume, tsdf_bnds, bound, stage, return_aux=False):
-    """p [P,3] -> raw [P,4], w [P]."""
+def df_forward(sd, p, c_grid, tsdf_volume, tsdf_bnds, bound, stage, return_aux=False, relu_masks=None):
+    """p [P,3] -> raw [P,4], w [P].  relu_masks (test-only, see _relu): the dict Engine.relu_masks returns, on p's device."""
     P = p.shape[0]
-    low = mlp_forward(sd, 'low', p, c_grid, bound)
+    rm = relu_masks or {}
+    low = mlp_forward(sd, 'low', p, c_grid, bound, rm.get('low'))
     aux = {}
     if stage == 'low':
         raw = torch.zeros(P, 4, device=p.device)
         raw = torch.cat([raw[:, :3], low.unsqueeze(-1)], -1)
         w = torch.ones(P, device=p.device)
         return (raw, w, aux) if return_aux else (raw, w)
-    high = mlp_forward(sd, 'high', p, c_grid, bound)
+    high = mlp_forward(sd, 'high', p, c_grid, bound, rm.get('high'), rm.get('high_valid'))
     if stage == 'color':
-        rgb = mlp_forward(sd, 'color', p, c_grid, bound)[:, :3]
+        rgb = mlp_forward(sd, 'color', p, c_grid, bound, rm.get('color'))[:, :3]
     else:
         rgb = torch.zeros(P, 3, device=p.device)
     f_add = high + low                                                       # decoder.py:325/:342
     t = trilerp(tsdf_volume, p, tsdf_bnds).reshape(-1)
     mask = (t > -1.0 + 1e-4) & (t < 1.0 - 1e-4)                              # decoder.py:329/:346
-    fused, a1 = mlp_tsdf_forward(sd, f_add[mask], t[mask])
+    if 'band' in rm and not torch.equal(rm['band'], mask):
+        raise AssertionError('relu_masks: the kernels and the oracle disagree on which points are in the TSDF band')
+    fused, a1 = mlp_tsdf_forward(sd, f_add[mask], t[mask], [m[mask] for m in rm['att']] if 'att' in rm else None)
     occ = low.clone()
     occ[mask] = fused                                                        # unmasked keep LOW only
     w = torch.ones(P, device=p.device)
@@ -269,12 +302,12 @@ def df_forward(sd, p, c_grid, tsdf_volume, tsdf_bnds, bound, stage, return_aux=F
     return raw, w
 
 
-def eval_points(sd, p, c_grid, tsdf_volume, tsdf_bnds, bound, stage, return_aux=False):
+def eval_points(sd, p, c_grid, tsdf_volume, tsdf_bnds, bound, stage, return_aux=False, relu_masks=None):
     """Renderer.eval_points, src/utils/Renderer.py:27-71 (chunking is value-neutral)."""
     mask = ((p[:, 0] < bound[0][1]) & (p[:, 0] > bound[0][0]) &
             (p[:, 1] < bound[1][1]) & (p[:, 1] > bound[1][0]) &
             (p[:, 2] < bound[2][1]) & (p[:, 2] > bound[2][0]))
-    res = df_forward(sd, p, c_grid, tsdf_volume, tsdf_bnds, bound, stage, return_aux)
+    res = df_forward(sd, p, c_grid, tsdf_volume, tsdf_bnds, bound, stage, return_aux, relu_masks)
     raw, w = res[0], res[1]
     occ = torch.where(mask, raw[:, 3], torch.full_like(raw[:, 3], 100.0))  # Renderer.py:64
     raw = torch.cat([raw[:, :3], occ.unsqueeze(-1)], -1)
@@ -306,13 +339,13 @@ def raw2outputs(raw, z_vals):
 # ----------------------------------------------------------------------------------
 def render_batch_ray(sd, c_grid, rays_d, rays_o, tsdf_volume, tsdf_bnds, bound, stage, gt_depth,
                      N_samples, N_surface, lindisp=False, perturb=0.0, t_rand=None, return_aux=False,
-                     depth_max=None):
+                     depth_max=None, relu_masks=None):
     """Returns (depth f64 [N], uncertainty f64 [N], color f32 [N,3], weight f32 [N,S,1])."""
     N = rays_o.shape[0]
     z_vals = sample_z(rays_o, rays_d, gt_depth, bound, N_samples, N_surface, lindisp, perturb, t_rand, depth_max)
     S = z_vals.shape[1]
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z_vals[..., :, None]   # Renderer.py:223
-    res = eval_points(sd, pts.reshape(-1, 3), c_grid, tsdf_volume, tsdf_bnds, bound, stage, return_aux)
+    res = eval_points(sd, pts.reshape(-1, 3), c_grid, tsdf_volume, tsdf_bnds, bound, stage, return_aux, relu_masks)
     raw = res[0].reshape(N, S, 4)
     weight = res[1].reshape(N, S, 1)
     depth, var, color, cw = raw2outputs(raw, z_vals)

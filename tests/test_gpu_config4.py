@@ -76,7 +76,7 @@ def test_one_rank_shard_vs_oracle(scan):
     assert int(((w[pick].cpu() == 1) != (ow == 1)).sum()) == 0
     assert_close(d[pick], od, 1e-4, 'depth')
     assert_close(c[pick], oc, 1e-4, 'colour')
-    assert_close(u[pick], ou, 5e-4, 'uncertainty')
+    assert_close(u[pick], ou, 1e-4, 'uncertainty')
     assert_close(w[pick], ow, 1e-4, 'attention weight')
 
 

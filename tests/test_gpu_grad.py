@@ -8,7 +8,8 @@ import torch
 import attentive_dfprior_amd as A
 from attentive_dfprior_amd import synthetic
 from oracle import adfp_oracle as O
-from conftest import make_cfg, to_dev, assert_close_scale, assert_param_grad_close
+from conftest import (make_cfg, to_dev, assert_close_scale, assert_param_grad_close, assert_grad_tight, ReluCapture,
+                      assert_forced_decisions_are_boundary_units)
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -39,7 +40,8 @@ def grad_close(got, ref, what, tol=GTOL, mode=None):
         assert_close_scale(got.detach(), ref, tol, what, flip_frac=2e-3 if last.startswith('grid') else 0.0)
 
 
-def run(mini, stage, warm, sd=None, n_samples=None, n_surface=None, rays=None, bwd_options=None):
+def run(mini, stage, warm, sd=None, n_samples=None, n_surface=None, rays=None, bwd_options=None, capture=None):
+    """capture: a dict; the backward then exports its ReLU decisions and capture['relu_masks'] = Engine.relu_masks(...)."""
     sd = mini.sd if sd is None else sd
     dec = A.DF()
     dec.load_state_dict(sd)
@@ -51,6 +53,8 @@ def run(mini, stage, warm, sd=None, n_samples=None, n_surface=None, rays=None, b
                       None, mini)
     if bwd_options is not None:
         rend._engine.bwd_options = bwd_options
+    if capture is not None:
+        cap = ReluCapture(rend)
     c = {k: v.to(DEV).clone().requires_grad_(True) for k, v in mini.c.items()}
     ro, rd, gd, gc = rays if rays is not None else (mini.rays_o, mini.rays_d, mini.gt_depth, mini.gt_color)
     ro, rd, gd, gc = ro.to(DEV), rd.to(DEV), gd.to(DEV), gc.to(DEV)
@@ -58,7 +62,66 @@ def run(mini, stage, warm, sd=None, n_samples=None, n_surface=None, rays=None, b
                                          gt_depth=gd)
     loss = mapper_loss(d, col, w, gd, gc, stage, warm)
     loss.backward()
+    if capture is not None:
+        capture['relu_masks'] = cap.masks(stage)
     return loss, c, dec
+
+
+def oracle_grads(mini, sd, rays, stage, warm, n_samples, n_surface, relu_masks=None):
+    """The oracle's autograd under the Mapper loss -> (loss, {grid: grad}, {parameter: grad}); relu_masks: the kernels' ReLU
+    decisions, forced (oracle.adfp_oracle._relu)."""
+    c_or = {k: v.clone().requires_grad_(True) for k, v in mini.c.items()}
+    sd_or = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ro, rd, gd, gc = rays
+    d2, u2, col2, w2 = O.render_batch_ray(sd_or, c_or, rd, ro, mini.tsdf_volume, mini.tsdf_bnds, mini.bound, stage, gd, n_samples,
+                                          n_surface, relu_masks=relu_masks)
+    loss2 = O.mapper_loss(d2, col2, w2, gd, gc, stage, warm)
+    loss2.backward()
+    zero = lambda t: t.grad if t.grad is not None else torch.zeros_like(t)           # noqa: E731
+    return loss2, {k: zero(v) for k, v in c_or.items()}, {k: zero(v) for k, v in sd_or.items()}
+
+
+def check_tight(mini, stage, warm, mode, sd=None, n_samples=None, n_surface=None, rays=None, what=''):
+    """THE gradient criterion: kernels vs the oracle's autograd along the kernels' own ReLU decisions, every element of every
+    grid and parameter gradient within conftest.TIGHT_GRAD_TOL x the tensor's scale; and the forced decisions are legitimate --
+    they differ from relu's own only on units whose pre-activation is within rounding of zero."""
+    sd = mini.sd if sd is None else sd
+    ns = n_samples or mini.n_samples
+    nf = n_surface if n_surface is not None else mini.n_surface
+    rays = rays if rays is not None else (mini.rays_o, mini.rays_d, mini.gt_depth, mini.gt_color)
+    cap = {}
+    loss, c, dec = run(mini, stage, warm, sd=sd, n_samples=ns, n_surface=nf, rays=rays, capture=cap)
+    O.reset_relu_flips()
+    loss2, gc_or, gsd_or = oracle_grads(mini, sd, rays, stage, warm, ns, nf, relu_masks=cap['relu_masks'])
+    flips = dict(O.RELU_FLIPS)
+    assert_forced_decisions_are_boundary_units(flips)
+    assert abs(loss.item() - loss2.item()) <= 1e-5 * abs(loss2.item())
+    for k in c:
+        got = c[k].grad if c[k].grad is not None else torch.zeros_like(c[k])
+        assert_grad_tight(got, gc_or[k], f'{what}{stage} d/d {k}', mode)
+    for name, p in dec.named_parameters():
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert_grad_tight(got, gsd_or[name], f'{what}{stage} d/d {name}', mode)
+    return flips
+
+
+@pytest.mark.parametrize('mode', MODES)
+@pytest.mark.parametrize('stage', O.STAGES)
+@pytest.mark.parametrize('warm', [False, True])
+def test_mapper_gradients_along_the_kernels_relu_decisions(mini, stage, warm, mode, monkeypatch):
+    """The golden scene (the inputs of tests/golden/mini_<stage>.npz), all three stages, both loss variants, both math modes:
+    conftest.TIGHT_GRAD_TOL (5e-5, half the north-star tolerance) of each tensor's scale on EVERY element."""
+    monkeypatch.setenv('ADFP_MATH', mode)
+    check_tight(mini, stage, warm, mode, what='golden scene, ')
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_gradients_second_seed_64_samples_along_the_kernels_relu_decisions(mini, mode, monkeypatch):
+    """S = 64 (benchmark sampling), other weights, 300 rays of 3 poses (19 200 samples): the case whose unforced comparison shows
+    the largest ReLU-boundary deviations (profiles/r03_grad_stats.txt: 5.8e-4 x scale)."""
+    monkeypatch.setenv('ADFP_MATH', mode)
+    rays = synthetic.make_ray_batch(synthetic.mini_scene(), 300, seed=8, poses=3)
+    check_tight(mini, 'color', True, mode, sd=O.random_state_dict(seed=17), n_samples=48, n_surface=16, rays=rays, what='second seed, ')
 
 
 @pytest.mark.parametrize('mode', MODES)
@@ -211,6 +274,39 @@ def test_tracker_ray_gradients_vs_reference_golden(mini):
     assert abs(loss.item() - float(g['loss'])) <= 2e-5 * abs(float(g['loss']))
     grad_close(ro.grad, g['g_rays_o'], 'd/d rays_o', tol=5e-4)
     grad_close(rd.grad, g['g_rays_d'], 'd/d rays_d', tol=5e-4)
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_tracker_ray_gradients_along_the_kernels_relu_decisions(mini, mode, monkeypatch):
+    """The same ray gradients (d/d position through the trilinear coordinates of the grids and of the TSDF and through
+    sin(p @ B), reduced per ray) against the oracle's autograd along the kernels' ReLU decisions: every element within
+    conftest.TIGHT_GRAD_TOL x scale, on the f16-split PGRAD kernels and on the exact ones."""
+    monkeypatch.setenv('ADFP_MATH', mode)
+    dec = A.DF()
+    dec.load_state_dict(mini.sd)
+    dec.bound = mini.bound
+    dec = dec.to(DEV)
+    for p in dec.parameters():
+        p.requires_grad_(False)
+    rend = A.Renderer(make_cfg(mini.n_samples, mini.n_surface), None, mini)
+    cap = ReluCapture(rend)
+    c = to_dev(mini.c, DEV)
+    ro = mini.rays_o.to(DEV).clone().requires_grad_(True)
+    rd = mini.rays_d.to(DEV).clone().requires_grad_(True)
+    gd, gc = mini.gt_depth.to(DEV), mini.gt_color.to(DEV)
+    d, u, col, w = rend.render_batch_ray(c, dec, rd, ro, DEV, mini.tsdf_volume.to(DEV), mini.tsdf_bnds.to(DEV), 'color', gt_depth=gd)
+    loss = tracker_loss(d, u, col, gd, gc)
+    loss.backward()
+    ro_o, rd_o = mini.rays_o.clone().requires_grad_(True), mini.rays_d.clone().requires_grad_(True)
+    O.reset_relu_flips()
+    d2, u2, col2, w2 = O.render_batch_ray(mini.sd, mini.c, rd_o, ro_o, mini.tsdf_volume, mini.tsdf_bnds, mini.bound, 'color',
+                                          mini.gt_depth, mini.n_samples, mini.n_surface, relu_masks=cap.masks('color'))
+    assert_forced_decisions_are_boundary_units(dict(O.RELU_FLIPS))
+    loss2 = O.tracker_loss(d2, u2, col2, mini.gt_depth, mini.gt_color)
+    loss2.backward()
+    assert abs(loss.item() - loss2.item()) <= 2e-5 * abs(loss2.item())
+    assert_grad_tight(ro.grad, ro_o.grad, 'd/d rays_o', mode)
+    assert_grad_tight(rd.grad, rd_o.grad, 'd/d rays_d', mode)
 
 
 def test_pose_gradient_through_get_rays_from_uv(mini):

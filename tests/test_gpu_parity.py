@@ -59,7 +59,7 @@ def test_render_batch_ray_vs_reference_golden(mini, gm, stage):
     assert_close(d, g['depth'], TOL, f'{stage} depth')
     assert_close(c, g['color'], TOL, f'{stage} color') if stage == 'color' else None
     assert_close(w, g['weight'], TOL, f'{stage} weight')
-    assert_close(u, g['uncertainty'], 5 * TOL, f'{stage} uncertainty')
+    assert_close(u, g['uncertainty'], TOL, f'{stage} uncertainty')
 
 
 @pytest.mark.parametrize('stage', O.STAGES)
@@ -184,7 +184,7 @@ def test_second_seed_and_larger_scene_vs_oracle():
     assert flips <= 2, flips
     assert_close(d, od, TOL, 'depth')
     assert_close(c, oc, TOL, 'color')
-    assert_close(u, ou, 5 * TOL, 'uncertainty')
+    assert_close(u, ou, TOL, 'uncertainty')
 
 
 def test_composite_entry_vs_oracle(mini):

@@ -46,6 +46,27 @@ def test_camera_from_tensor_and_its_backward_match_torch_autograd():
         assert (d_g.cpu() - ref).abs().max() <= 1e-5 * max(1.0, ref.abs().max().item()), (d_g.cpu(), ref)
 
 
+def test_get_camera_from_tensor_on_the_gpu_is_one_kernel_each_way_with_the_torch_values():
+    """common.get_camera_from_tensor(cuda camera tensor) = adfp_camera_from_tensor under autograd: same [3,4] matrix and the same
+    gradient as the torch composition (quad2rotation, what a CPU tensor takes), through a further torch op like the Tracker's."""
+    g = torch.Generator().manual_seed(3)
+    for k in range(6):
+        cam = torch.randn(7, generator=g)
+        G = torch.randn(3, 4, generator=g)
+        ref_in = cam.clone().requires_grad_(True)
+        ref = common.get_camera_from_tensor(ref_in)
+        (ref * G).sum().backward()
+        dev_in = cam.to(DEV).requires_grad_(True)
+        got = common.get_camera_from_tensor(dev_in)
+        assert got.shape == (3, 4) and got.is_cuda and got.grad_fn is not None
+        (got * G.to(DEV)).sum().backward()
+        assert (got.detach().cpu() - ref.detach()).abs().max() <= 2e-6 * max(1.0, ref.detach().abs().max().item())
+        assert (dev_in.grad.cpu() - ref_in.grad).abs().max() <= 1e-5 * max(1.0, ref_in.grad.abs().max().item())
+    # a batch of camera tensors (bundle adjustment) keeps the torch composition
+    batch = torch.randn(3, 7, generator=g).to(DEV)
+    assert common.get_camera_from_tensor(batch).shape == (3, 3, 4)
+
+
 def test_camera_kernels_match_the_reference_golden():
     """adfp_camera_from_tensor and its backward against the reference's own get_camera_from_tensor + autograd
     (tests/golden/mini_pose.npz, made by tests/golden/make_pose_golden.py from src/common.py:139-178)."""
@@ -369,6 +390,21 @@ def test_graph_replay_equals_the_eager_sequence(tb):
     c2['grid_low'].mul_(1.02)
     la, lb = a.step(n, picks[2]), b.step(n, picks[2])
     assert abs(la.item() - lb.item()) <= 1e-9 * abs(la.item())
+    # Another user of the SAME Renderer with other grids in between (the reference shares slam.renderer between Tracker and
+    # Mapper): it takes the engine's one-slot-per-name layout cache, recycles the buffers, or clears it.  The graph reads the
+    # iteration's own channels-last copies, re-registered before every replay, so it still tracks against ITS map.
+    n_graphs = len(b._graphs)
+    other = {k: (v * 0.5).contiguous() for k, v in tb.sc.c.items()}
+    ro, rd, gd, _ = synthetic.make_ray_batch(tb.sc, 64, seed=2)
+    for clear in (False, True):
+        with torch.no_grad():
+            tb.rend.render_batch_ray(other, tb.dec, rd.to(DEV), ro.to(DEV), DEV, tb.sc.tsdf_volume, tb.tb, 'color', gt_depth=gd.to(DEV))
+        if clear:
+            tb.rend._engine._grid_cache.clear()
+        lb = b.step(n, picks[3 + clear])
+        la = a.step(n, picks[3 + clear])
+        assert abs(la.item() - lb.item()) <= 1e-9 * abs(la.item()) and len(b._graphs) == n_graphs
+        assert (a.camera_tensor - b.camera_tensor).abs().max().item() <= 1e-6
 
 
 def test_tracking_converges_towards_the_true_pose():

@@ -107,3 +107,26 @@ def test_synthetic_scene_shapes_follow_reference_formulas():
     assert sc.tsdf_volume.shape[:2] == (1, 1) and not sc.tsdf_volume.is_contiguous()
     assert sc.tsdf_volume.stride(2) == 1                           # Z fastest, as get_tsdf.py:95-97
     assert float(sc.tsdf_volume.min()) == -1.0 and float(sc.tsdf_volume.max()) == 1.0
+
+
+def test_get_tensor_from_camera_normalises_like_mathutils():
+    """The reference goes through mathutils' Matrix.to_quaternion (src/common.py:181-203), which normalises the matrix and returns a
+    UNIT quaternion.  The Tracker's constant-speed guess delta @ pre_c2w (src/Tracker.py:213-215) is orthonormal only up to float
+    error: the camera tensor made from it must still be a unit quaternion (Adam steps on the raw components), and the rotation
+    of a uniformly or per-axis scaled matrix is the rotation of the unscaled one."""
+    import torch
+    from attentive_dfprior_amd import common
+    g = torch.Generator().manual_seed(0)
+    for k in range(8):
+        cam = torch.randn(7, generator=g)
+        RT = common.get_camera_from_tensor(cam)
+        ref = common.get_tensor_from_camera(RT)
+        skew = RT.clone()
+        skew[:3, :3] *= torch.tensor([1.0 + 2e-3, 1.0 - 1e-3, 1.0 + 5e-4])          # per-column scale: unit axis vectors restore R
+        got = common.get_tensor_from_camera(skew)
+        assert abs(float(got[:4].norm()) - 1.0) < 1e-6
+        assert (got - ref).abs().max() < 1e-5, (got, ref)
+        noisy = RT.clone()
+        noisy[:3, :3] += 1e-4 * torch.randn(3, 3, generator=g)                     # accumulated float error: not exactly a rotation
+        q = common.get_tensor_from_camera(noisy)
+        assert abs(float(q[:4].norm()) - 1.0) < 1e-6 and (q - ref).abs().max() < 1e-3

@@ -219,3 +219,57 @@ def test_pose_utilities_match_the_reference():
         assert np.abs(t.grad.numpy() - g['g_cam'][k]).max() <= 2e-5 * max(1.0, np.abs(g['g_cam'][k]).max())
         back = common.get_camera_from_tensor(common.get_tensor_from_camera(torch.from_numpy(g['c2w'][k])))
         assert np.abs(back.numpy() - g['c2w'][k]).max() <= 1e-5 * max(1.0, np.abs(g['c2w'][k]).max())
+
+
+def _oracle_grads(mini, stage, warm, relu_masks=None):
+    c_or = {k: v.clone().requires_grad_(True) for k, v in mini.c.items()}
+    sd_or = {k: v.clone().requires_grad_(True) for k, v in mini.sd.items()}
+    d2, u2, col2, w2 = O.render_batch_ray(sd_or, c_or, mini.rays_d, mini.rays_o, mini.tsdf_volume, mini.tsdf_bnds, mini.bound, stage,
+                                          mini.gt_depth, mini.n_samples, mini.n_surface, relu_masks=relu_masks)
+    loss2 = O.mapper_loss(d2, col2, w2, mini.gt_depth, mini.gt_color, stage, warm)
+    loss2.backward()
+    zero = lambda t: t.grad if t.grad is not None else torch.zeros_like(t)           # noqa: E731
+    return loss2, {k: zero(v) for k, v in c_or.items()}, {k: zero(v) for k, v in sd_or.items()}
+
+
+def test_forced_relu_decisions_equal_to_relus_own_change_nothing(mini):
+    """The test-only oracle variant is the oracle: forcing the decisions relu itself takes reproduces its gradients bit for bit
+    (so the tight comparisons above are comparisons with the pinned oracle, moved only where a kernel decided a boundary unit
+    the other way)."""
+    loss, gc, gsd = _oracle_grads(mini, 'color', True)
+    # relu's own decisions, recorded from a plain forward
+    P = mini.rays_o.shape[0] * (mini.n_samples + mini.n_surface)
+    rec = {}
+    orig = O.F.relu
+
+    def recording(h):
+        rec.setdefault('calls', []).append(h.detach() > 0)
+        return orig(h)
+    O.F.relu = recording
+    try:
+        with torch.no_grad():
+            O.render_batch_ray(mini.sd, mini.c, mini.rays_d, mini.rays_o, mini.tsdf_volume, mini.tsdf_bnds, mini.bound, 'color',
+                               mini.gt_depth, mini.n_samples, mini.n_surface)
+    finally:
+        O.F.relu = orig
+    calls = rec['calls']                                  # low x5, high x5, color x5 (P rows each), att x4 (band rows)
+    assert len(calls) == 19 and all(m.shape[0] == P for m in calls[:15])
+    with torch.no_grad():
+        _, _, _, _, aux = O.render_batch_ray(mini.sd, mini.c, mini.rays_d, mini.rays_o, mini.tsdf_volume, mini.tsdf_bnds, mini.bound,
+                                             'color', mini.gt_depth, mini.n_samples, mini.n_surface, return_aux=True)
+    band = aux['band']
+    att = []
+    for m in calls[15:]:
+        full = torch.zeros((P, m.shape[1]), dtype=torch.bool)
+        full[band] = m
+        att.append(full)
+    rm = {'low': torch.stack(calls[0:5], 1), 'high': torch.stack(calls[5:10], 1), 'high_valid': torch.ones(P, dtype=torch.bool),
+          'color': torch.stack(calls[10:15], 1), 'att': att, 'band': band}
+    O.reset_relu_flips()
+    loss2, gc2, gsd2 = _oracle_grads(mini, 'color', True, relu_masks=rm)
+    assert O.RELU_FLIPS['flipped'] == 0 and O.RELU_FLIPS['units'] > 0
+    assert torch.equal(loss, loss2)
+    for k in gc:
+        assert torch.equal(gc[k], gc2[k]), k
+    for k in gsd:
+        assert torch.equal(gsd[k], gsd2[k]), k
