@@ -1,0 +1,289 @@
+// adfp_decode_g.h -- LOW + COLOR decoder in one launch (stage color, inference) on v_mfma_f32_16x16x32_f16.
+//
+// Same arithmetic as k_decode_lc (adfp_decode_h.h): every f32 operand split a = a_hi + a_lo into two f16, three MFMA products
+// per f32 product, f32 accumulation; same per-point work (f64 point, f64 normalisation, 8-corner gather, Fourier features with
+// exact turn reduction, 5 layers, VALU output layer).  What changes is the MFMA SHAPE: the 32 units x 32 points of a layer are
+// four 16 x 16 output blocks (2 out-blocks x 2 point-blocks), each fed K = 32 inputs per instruction, instead of one 32 x 32 block
+// fed K = 16.  Twice the instructions at half the pipe cycles each -- the same wave cycles per tile (43 200 against 43 000 in the
+// decoder-shaped loop of tools/micro/mfma_shape_ab.hip) -- but the chip HOLDS A HIGHER CLOCK on this shape under load (2.21 against
+// 2.09 GHz there; MI355X_MICROARCH.md "DVFS give-back" (7)): wall time -6.5 % in the microbenchmark.
+//
+// Lane roles.  lane l = (n = l & 15, g = l >> 4).  A tile is 32 consecutive points = two point-blocks of 16; lane (n, g) serves
+// point n of BOTH blocks with the 8 inputs / 8 outputs of K-group g:
+//   B operand of point-block pb: the lane's 8 values of point 16 pb + n, K-slot j <-> input unit16(8 g + j)
+//   D of (out-block ob, point-block pb): rows 4 g + r of the block = output units 16 ob + 4 g + r of point 16 pb + n
+// with unit16(k) = 16 ((k & 7) >> 2) + 4 (k >> 3) + (k & 3): the two D registers-quads of a point-block (ob = 0, 1) ARE the next
+// layer's B operand of that block -- as with the 32 x 32 shape there is no lane movement and no LDS round trip between layers.
+//
+// Front end.  The per-point work that does not factor over K-groups (f64 point, normalisation, trilinear set-up, the gather's
+// address arithmetic) is done ONCE per point like before: lanes 0-31 take the points of block 0, lanes 32-63 those of block 1
+// ("front point" 16 (g >> 1) + n, front half g & 1 = which 16 of the 32 channels the lane gathers, gather16's own split), and the
+// halves hand each other the eight values the other needs with v_permlane32_swap_b32 (one instruction per register pair, no
+// LDS): 8 swaps for the grid features, 3 for the position.  The Fourier features need no exchange: a lane computes its 24
+// features of BOTH its points from one read of each Fourier row (half the LDS reads of the 32 x 32 kernel).
+#pragma once
+#include "adfp_decode_h.h"
+
+__host__ __device__ constexpr int unit16(int k) { return 16 * ((k & 7) >> 2) + 4 * (k >> 3) + (k & 3); }
+
+// "G" image of one 32-channel decoder (words).  A K = 32 group of a [32 out x K in] block is 1024 words:
+// [out-block 0 | 1][hi | lo][g = 0..3][row i = 0..15][8 halves]: lane (n = i, g) reads its A operand (hi, lo) of an out-block with
+// two ds_read_b128 at word 4 l -- 64 lanes, 64 consecutive 16-byte pieces, conflict-free.  The same 4 reads per 32 inputs as the H
+// image's two k-steps.
+template <int NOUT>
+struct DecLayoutG {
+    using F = DecLayout<32, NOUT>;
+    static constexpr int KG_E = 3;                                    // K-groups of the 96 (93) Fourier features
+    __host__ __device__ static constexpr int kg(int i) { return i == 0 ? KG_E : (i == 3 ? KG_E + 1 : 1); }
+    static constexpr int P_BM = 0;                                    // [96 rows in K order][4] f32 = (bx, by, bz, 0)
+    __host__ __device__ static constexpr int layer_words(int i) { return kg(i) * 1024 + 32 + 1024 + 32; }
+    __host__ __device__ static constexpr int P_WP(int i) {
+        int o = 384;
+        for (int k = 0; k < i; ++k) o += layer_words(k);
+        return o;
+    }
+    __host__ __device__ static constexpr int P_BP(int i) { return P_WP(i) + kg(i) * 1024; }     // [32] f32, unit order
+    __host__ __device__ static constexpr int P_WC(int i) { return P_BP(i) + 32; }
+    __host__ __device__ static constexpr int P_BC(int i) { return P_WC(i) + 1024; }
+    static constexpr int P_WO = P_WP(5);                               // [NOUT][32] f32, unit order
+    static constexpr int P_BO = P_WO + NOUT * 32;
+    static constexpr int P_FLAG = P_BO + 4;                            // range flags, one word per pack block (see DecLayoutH)
+    static constexpr int NFLAG = (((P_FLAG + 511) / 256) + 3) & ~3;
+    static constexpr int P_TOTAL = P_FLAG + NFLAG;
+    static_assert((P_TOTAL + 255) / 256 <= NFLAG, "one flag word per pack block");
+};
+
+template <int NOUT>
+__device__ HSrc dec_g_src(int t) {
+    using L = DecLayoutG<NOUT>;
+    using F = DecLayout<32, NOUT>;
+    if (t < 384) {
+        const int row = t >> 2, c = t & 3;                            // row = 32 kg + k: feature 32 kg + unit16(k)
+        const int f = (row & ~31) + unit16(row & 31);
+        return HSrc{0, (f < 93 && c < 3) ? F::F_EB + c * 93 + f : -1, -1};
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        if (t < L::P_BP(i) || (t >= L::P_WC(i) && t < L::P_BC(i))) {
+            const bool fc = t >= L::P_WC(i);
+            const int u = t - (fc ? L::P_WC(i) : L::P_WP(i));
+            const int grp = u >> 10, ob = (u >> 9) & 1, part = (u >> 8) & 1, g = (u >> 6) & 3, row = 16 * ob + ((u >> 2) & 15), jp = (u & 3) * 2;
+            int src[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                int col = 32 * grp + unit16(8 * g + jp + e);            // input unit in the layer's own numbering: [features | hidden]
+                if (fc) src[e] = F::F_FC(i) + row * 32 + col;
+                else {
+                    if (i == 0) { if (col >= 93) col = -1; }
+                    else if (i == 3) { if (col < 96) { if (col >= 93) col = -1; } else col = 93 + (col - 96); }
+                    src[e] = col < 0 ? -1 : F::F_PL(i) + row * F::in_dim(i) + col;
+                }
+            }
+            return HSrc{1 + part, src[0], src[1]};
+        }
+        if (t < L::P_WC(i)) return HSrc{0, F::F_PL(i) + 32 * F::in_dim(i) + (t - L::P_BP(i)), -1};
+        if (t < L::P_BC(i) + 32) return HSrc{0, F::F_FC(i) + 32 * 32 + (t - L::P_BC(i)), -1};
+    }
+    if (t < L::P_BO) {
+        const int u = t - L::P_WO;
+        return HSrc{0, F::F_OW + u, -1};                              // [NOUT][32], the flat order
+    }
+    const int o = t - L::P_BO;
+    return HSrc{0, o < NOUT ? F::F_OB + o : -1, -1};
+}
+
+template <int NOUT>
+__global__ void k_pack_decoder_g(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status, int bit) {
+    using L = DecLayoutG<NOUT>;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    HSrc s{0, -1, -1};
+    float a = 0.f, b = 0.f;
+    if (t < L::P_FLAG) {
+        s = dec_g_src<NOUT>(t);
+        a = s.s0 < 0 ? 0.f : flat[s.s0]; b = s.s1 < 0 ? 0.f : flat[s.s1];
+    }
+    pack_block_flag(!(fmaxf(fabsf(a), fabsf(b)) < 65504.0f), packed + L::P_FLAG + blockIdx.x, status, bit);
+    if (t >= L::P_FLAG) return;
+    if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(a); return; }
+    a = f16_clamp(a); b = f16_clamp(b);
+    const float ah = f16_hi_part(a), bh = f16_hi_part(b);
+    _Float16 x, y;
+    if (s.kind == 1) { x = (_Float16)ah; y = (_Float16)bh; }
+    else { x = (_Float16)(a - ah); y = (_Float16)(b - bh); }
+    packed[t] = (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+
+// x (first operand): lanes 32-63 receive y of lane l - 32;  y: lanes 0-31 receive x of lane l + 32  (tools/micro/layout_probe_16x16x32.hip)
+ADFP_DEV void swap_halves(float& x, float& y) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(r[0]); y = __uint_as_float(r[1]);
+}
+
+// NG K-groups of a chain: acc[ob][pb] += W[out-block ob][group] * x[group][pb], 3-product split
+template <int NG>
+ADFP_DEV void mfma_chain_g(f32x4g acc[2][2], const unsigned* __restrict__ w, const f16x8 (*xh)[2], const f16x8 (*xl)[2]) {
+#pragma unroll
+    for (int kg = 0; kg < NG; ++kg) {
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, *(const u32x4*)(w + kg * 1024 + ob * 512));
+            const f16x8 al = __builtin_bit_cast(f16x8, *(const u32x4*)(w + kg * 1024 + ob * 512 + 256));
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                acc[ob][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[kg][pb], acc[ob][pb], 0, 0, 0);
+                acc[ob][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[kg][pb], acc[ob][pb], 0, 0, 0);
+                acc[ob][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[kg][pb], acc[ob][pb], 0, 0, 0);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting the next chain's LDS reads
+}
+
+// One network on a tile.  pn: the lane's FRONT point, normalised (gather); pf[pb]: the positions of the lane's two points (Fourier
+// features); out[pb][o]: the network's outputs for point 16 pb + n, valid on every lane.
+template <int NOUT>
+ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& grid, const float pn[3], const float (*pf)[3], int lane,
+                           float& amax, float (*out)[NOUT]) {
+    using L = DecLayoutG<NOUT>;
+    const int g = lane >> 4;
+    // every LDS access below is one of three lane-dependent bases plus an immediate: the weight rows (4 l), the unit-order rows
+    // (biases, output layer: 4 g) and the Fourier rows (32 g)
+    const unsigned* wl = ldsu + 4 * lane;
+    const float* b4 = (const float*)ldsu + 4 * g;
+    const float* brow = (const float*)ldsu + 32 * g;
+    f16x8 ch[1][2], cl[1][2];
+    {
+        float c[16];
+        gather16(grid, pn, g & 1, c);               // c[r] <-> channel kmapH(r, g & 1) of the front point: pieces g&1, +2, +4, +6 of the voxel line
+        // lower lanes (block 0) keep K-group g = c[0..3], c[8..11] and give K-group g + 2 = c[4..7], c[12..15]; upper lanes (block 1,
+        // g = 2, 3) keep c[4..7], c[12..15] and give c[0..3], c[8..11]: swap_halves(x, y) moves x.upper <-> y.lower
+        float x[8] = {c[0], c[1], c[2], c[3], c[8], c[9], c[10], c[11]};
+        float y[8] = {c[4], c[5], c[6], c[7], c[12], c[13], c[14], c[15]};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) swap_halves(x[s], y[s]);
+        split8(x, ch[0][0], cl[0][0], amax);        // block 0: channels unit16(8 g + j)
+        split8(y, ch[0][1], cl[0][1], amax);        // block 1
+    }
+    f16x8 eh[L::KG_E][2], el[L::KG_E][2];
+#pragma unroll
+    for (int kg = 0; kg < L::KG_E; ++kg) {
+        float e0[8], e1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 bm = *(const f32x4*)(brow + L::P_BM + (32 * kg + j) * 4);            // row 32 kg + 8 g + j
+            e0[j] = adfp_sinf(fmaf(pf[0][2], bm.z, fmaf(pf[0][1], bm.y, pf[0][0] * bm.x)));
+            e1[j] = adfp_sinf(fmaf(pf[1][2], bm.z, fmaf(pf[1][1], bm.y, pf[1][0] * bm.x)));
+        }
+        split8<false>(e0, eh[kg][0], el[kg][0], amax);
+        split8<false>(e1, eh[kg][1], el[kg][1], amax);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4g acc[2][2];
+    f16x8 hh[1][2], hl[1][2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) { const f32x4 t = *(const f32x4*)(b4 + L::P_BP(i) + 16 * ob); acc[ob][0] = t; acc[ob][1] = t; }
+        if (i == 0) mfma_chain_g<L::KG_E>(acc, wl + L::P_WP(0), eh, el);
+        else if (i == 3) {
+            mfma_chain_g<L::KG_E>(acc, wl + L::P_WP(3), eh, el);
+            mfma_chain_g<1>(acc, wl + L::P_WP(3) + L::KG_E * 1024, hh, hl);
+        } else mfma_chain_g<1>(acc, wl + L::P_WP(i), hh, hl);
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {               // relu, then the fc_c bias (the chain below adds Wc c)
+            const f32x4 t = *(const f32x4*)(b4 + L::P_BC(i) + 16 * ob);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ob][pb][r] = relu_f(acc[ob][pb][r]) + t[r];
+        }
+        mfma_chain_g<1>(acc, wl + L::P_WC(i), ch, cl);
+        if (i < 4) {
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const float t[8] = {acc[0][pb][0], acc[0][pb][1], acc[0][pb][2], acc[0][pb][3],
+                                    acc[1][pb][0], acc[1][pb][1], acc[1][pb][2], acc[1][pb][3]};
+                split8(t, hh[0][pb], hl[0][pb], amax);
+            }
+        }
+    }
+    // output_linear on the VALU in f32: the lane holds units 16 ob + 4 g + r of its two points; the four K-groups add up by two
+    // exchanges (lanes l ^ 16, l ^ 32)
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        const f32x4 w0 = *(const f32x4*)(b4 + L::P_WO + 32 * o), w1 = *(const f32x4*)(b4 + L::P_WO + 32 * o + 16);
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s = fmaf(acc[0][pb][r], w0[r], s);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s = fmaf(acc[1][pb][r], w1[r], s);
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            out[pb][o] = s + ((const float*)ldsu)[L::P_BO + o];
+        }
+    }
+}
+
+// DecodeLCArgs is k_decode_lc's; packed_low / packed_color point at the G images
+template <int NT>
+__global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16(DecodeLCArgs a) {
+    using LL = DecLayoutG<1>;
+    using LC = DecLayoutG<4>;
+    __shared__ __attribute__((aligned(16))) unsigned lds_all[LL::P_TOTAL + LC::P_TOTAL];      // the low image, then the colour image
+    __shared__ int s_next;
+    unsigned* lds_low = lds_all;
+    unsigned* lds_col = lds_all + LL::P_TOTAL;
+    for (int i = threadIdx.x; i < LL::P_TOTAL / 4; i += NT) ((u32x4*)lds_low)[i] = ((const u32x4*)a.packed_low)[i];
+    for (int i = threadIdx.x; i < LC::P_TOTAL / 4; i += NT) ((u32x4*)lds_col)[i] = ((const u32x4*)a.packed_color)[i];
+    if (threadIdx.x == 0) s_next = NT / 64;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int count = a.P.n;
+    const int ntiles = (count + 31) >> 5;
+    float amax_low = image_out_of_range<LL::P_FLAG, LL::NFLAG>(lds_low) ? INFINITY : 0.f;
+    float amax_col = image_out_of_range<LC::P_FLAG, LC::NFLAG>(lds_col) ? INFINITY : 0.f;
+    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<NT / 64>(j, &s_next, ntiles)) >= 0;) {
+        // front point: point n of block 0 on lanes 0-31 (both K-groups g = 0, 1 of the pair), of block 1 on lanes 32-63
+        const int idx = tile * 32 + 16 * (g >> 1) + n;
+        const bool valid = idx < count;
+        const int q = valid ? idx : 0;
+        float pn[3], pf[2][3];
+        bool pnan, keep_occ;                            // of the FRONT point: its lane with g & 1 == 0 stores the row
+        {
+            double pt[3];
+            load_point(a.P, q, pt);
+            normalize3(a.nb, pt, pn);
+            const float f0 = (float)pt[0], f1 = (float)pt[1], f2 = (float)pt[2];   // p.float() decoder.py:189
+            pnan = (pt[0] != pt[0]) | (pt[1] != pt[1]) | (pt[2] != pt[2]);
+            const unsigned f = a.flags ? a.flags[q] : 0u;
+            // in-band points keep the true low value for the HIGH pass; the attention pass overwrites them afterwards
+            keep_occ = (f & ADFP_F_BAND) || in_bound(pt, a.b) || !a.apply_bound;           // Renderer.py:64
+            pf[0][0] = f0; pf[0][1] = f1; pf[0][2] = f2; pf[1][0] = f0; pf[1][1] = f1; pf[1][2] = f2;
+        }
+        // both halves end up with block 0's position in pf[0] and block 1's in pf[1]
+#pragma unroll
+        for (int k = 0; k < 3; ++k) swap_halves(pf[0][k], pf[1][k]);
+        float occ[2][1], rgb[2][4];
+        int off_low = 0, off_col = LL::P_TOTAL;        // word offsets of the two images, opaque and per tile (see k_decode_lc)
+        asm volatile("" : "+v"(off_low), "+v"(off_col));
+        decode_net_g<1>(lds_all + off_low, a.g_low, pn, pf, lane, amax_low, occ);
+        asm volatile("" : "+v"(pn[0]), "+v"(pn[1]), "+v"(pn[2]), "+v"(occ[0][0]), "+v"(occ[1][0]));
+        __builtin_amdgcn_sched_barrier(0);
+        decode_net_g<4>(lds_all + off_col, a.g_color, pn, pf, lane, amax_col, rgb);
+        // the front point's lane with g & 1 == 0 stores its row: lanes 0-15 block 0, lanes 32-47 block 1
+        if (valid && (g & 1) == 0) {
+            const int pb = g >> 1;
+            const float nanv = __builtin_nanf("");     // a NaN position renders NaN like the reference's (nan_point_outputs)
+            const float o = pnan ? nanv : (keep_occ ? (pb ? occ[1][0] : occ[0][0]) : 100.f);
+            const f32x4 c4 = pb ? f32x4{rgb[1][0], rgb[1][1], rgb[1][2], o} : f32x4{rgb[0][0], rgb[0][1], rgb[0][2], o};
+            *(f32x4*)(a.raw + 4ll * q) = pnan ? f32x4{nanv, nanv, nanv, o} : c4;
+            if (a.write_w) a.w[q] = 1.f;
+        }
+    }
+    report_range(a.status, amax_low, ADFP_STATUS_F16_RANGE_LOW, a.call_flag);
+    report_range(a.status, amax_col, ADFP_STATUS_F16_RANGE_COLOR, a.call_flag);
+}

@@ -958,6 +958,7 @@ extern "C" int adfp_debug_phases_fused(unsigned long long* host_out, int reset) 
 #include "adfp_mapping.h"
 #include "adfp_mapper_iter.h"
 #include "adfp_tracker_iter.h"
+#include "adfp_decode_g.h"
 
 // =====================================================================================
 // host side: C ABI
@@ -1084,11 +1085,13 @@ int adfp_pack_decoder(int kind, const float* flat, float* packed, void* stream) 
     ADFP_CHECK_LAUNCH();
     return 0;
 }
+// The split image of a 32-channel decoder is TWO images back to back: the "H" image (32x32x16 operand order: the training forward,
+// the single-network kernels) and the "G" image (16x16x32 operand order, adfp_decode_g.h: the fused low + colour inference launch).
 long long adfp_decoder_packed_h_words(int kind) {
     switch (kind) {
-        case ADFP_DEC_LOW: return DecLayoutH<32, 1>::P_TOTAL;
+        case ADFP_DEC_LOW: return DecLayoutH<32, 1>::P_TOTAL + DecLayoutG<1>::P_TOTAL;
         case ADFP_DEC_HIGH: return DecLayoutH<64, 1>::P_TOTAL;
-        case ADFP_DEC_COLOR: return DecLayoutH<32, 4>::P_TOTAL;
+        case ADFP_DEC_COLOR: return DecLayoutH<32, 4>::P_TOTAL + DecLayoutG<4>::P_TOTAL;
     }
     return ADFP_E_ARG;
 }
@@ -1099,12 +1102,14 @@ int adfp_pack_decoder_h(int kind, const float* flat, void* packed, int* status, 
     switch (kind) {
         case ADFP_DEC_LOW:
             hipLaunchKernelGGL((k_pack_decoder_h<32, 1>), dim3(DecLayoutH<32, 1>::NFLAG), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_LOW);
+            hipLaunchKernelGGL((k_pack_decoder_g<1>), dim3(DecLayoutG<1>::NFLAG), dim3(256), 0, st, flat, out + DecLayoutH<32, 1>::P_TOTAL, status, ADFP_STATUS_F16_RANGE_LOW);
             break;
         case ADFP_DEC_HIGH:
             hipLaunchKernelGGL((k_pack_decoder_h<64, 1>), dim3(DecLayoutH<64, 1>::NFLAG), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_HIGH);
             break;
         case ADFP_DEC_COLOR:
             hipLaunchKernelGGL((k_pack_decoder_h<32, 4>), dim3(DecLayoutH<32, 4>::NFLAG), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_COLOR);
+            hipLaunchKernelGGL((k_pack_decoder_g<4>), dim3(DecLayoutG<4>::NFLAG), dim3(256), 0, st, flat, out + DecLayoutH<32, 4>::P_TOTAL, status, ADFP_STATUS_F16_RANGE_COLOR);
             break;
         default: return ADFP_E_ARG;
     }
@@ -1339,7 +1344,12 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         f.g_low = make_grid(sc->low); f.g_color = make_grid(sc->color);
         f.packed_low = (const unsigned*)sc->h_low; f.packed_color = (const unsigned*)sc->h_color;
         f.flags = a.flags; f.raw = raw; f.w = w; f.write_w = 1; f.apply_bound = apply_bound; f.status = sc->status; f.call_flag = call_flag;
+#ifdef ADFP_LC_32X32          // A/B build: the 32x32x16 form of the fused launch (adfp_decode_h.h)
         hipLaunchKernelGGL((k_decode_lc<ADFP_LC_NT>), dim3(decode_grid(ntiles, ADFP_LC_NT / 64, 1)), dim3(ADFP_LC_NT), 0, st, f);
+#else
+        f.packed_low += DecLayoutH<32, 1>::P_TOTAL; f.packed_color += DecLayoutH<32, 4>::P_TOTAL;       // the G images
+        hipLaunchKernelGGL((k_decode_lc16<ADFP_LC_NT>), dim3(decode_grid(ntiles, ADFP_LC_NT / 64, 1)), dim3(ADFP_LC_NT), 0, st, f);
+#endif
         ADFP_CHECK_LAUNCH();
     }
     // LOW on every point
@@ -1437,7 +1447,12 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
         f.g_low = make_grid(sc->low); f.g_color = make_grid(sc->color);
         f.packed_low = (const unsigned*)sc->h_low; f.packed_color = (const unsigned*)sc->h_color;
         f.flags = nullptr; f.raw = raw; f.w = w; f.write_w = 1; f.apply_bound = 1; f.status = sc->status; f.call_flag = nullptr;
+#ifdef ADFP_LC_32X32
         hipLaunchKernelGGL((k_decode_lc<ADFP_LC_NT>), dim3(decode_grid((P.n + 31) / 32, ADFP_LC_NT / 64, 1)), dim3(ADFP_LC_NT), 0, (hipStream_t)stream, f);
+#else
+        f.packed_low += DecLayoutH<32, 1>::P_TOTAL; f.packed_color += DecLayoutH<32, 4>::P_TOTAL;       // the G images
+        hipLaunchKernelGGL((k_decode_lc16<ADFP_LC_NT>), dim3(decode_grid((P.n + 31) / 32, ADFP_LC_NT / 64, 1)), dim3(ADFP_LC_NT), 0, (hipStream_t)stream, f);
+#endif
         ADFP_CHECK_LAUNCH();
         return 0;
     }
