@@ -81,10 +81,13 @@ class _RenderFn(torch.autograd.Function):
             off += len(idx)
         if g_weight is not None:
             g_weight = g_weight.reshape(g_weight.shape[0], -1)
-        if ctx.saved is None:                                 # zero rays
-            return (None,) * len(needs)
-        grids, flats, g_rays = engine.render_backward(decoders, ctx.c, tsdf_volume, tsdf_bnds, bound, stage, ctx.saved,
-                                                      g_depth, g_unc, g_color, g_weight, need_grid, need_flat, need_rays)
+        if ctx.saved is None:                                 # zero rays (an empty shard): zero gradients in the usual bucket layout
+            dev = ctx.c['grid_low'].device
+            grids, flats = engine.zero_grad_bucket(ctx.c, need_grid, need_flat, dev)
+            g_rays = (torch.zeros((0, 3), device=dev), torch.zeros((0, 3), device=dev))
+        else:
+            grids, flats, g_rays = engine.render_backward(decoders, ctx.c, tsdf_volume, tsdf_bnds, bound, stage, ctx.saved,
+                                                          g_depth, g_unc, g_color, g_weight, need_grid, need_flat, need_rays)
         out = [None, g_rays[0] if needs[1] else None, g_rays[1] if needs[2] else None]
         for k, (name, key) in enumerate(_GRIDS):
             g = grids.get(name)

@@ -960,6 +960,24 @@ extern "C" int adfp_debug_phases_fused(unsigned long long* host_out, int reset) 
 #include "adfp_tracker_iter.h"
 #include "adfp_decode_g.h"
 
+// The two sides of a sharded render's ONE all-gather (adfp.h: adfp_gather_pack / adfp_gather_unpack): several per-ray arrays <->
+// one interleaved row buffer.  blockIdx.y = rank (unpack), a thread moves one 4-byte word.
+struct GatherJobs { unsigned* arr[ADFP_GATHER_MAX]; int words[ADFP_GATHER_MAX]; int woff[ADFP_GATHER_MAX + 1]; int n, world; long long pad; long long prefix[ADFP_GATHER_MAX_RANKS + 1]; };
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_gather_rows(GatherJobs j, unsigned* __restrict__ buf) {
+    const int W = j.woff[j.n];
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int rank = blockIdx.y;
+    const long long row = t / W;
+    const int word = (int)(t - row * W);
+    if (row >= j.prefix[rank + 1] - j.prefix[rank]) return;
+    int a = 0;
+    while (a + 1 < j.n && word >= j.woff[a + 1]) ++a;
+    unsigned* arr = j.arr[a] + (j.prefix[rank] + row) * j.words[a] + (word - j.woff[a]);
+    unsigned* slot = buf + ((long long)rank * j.pad + row) * W + word;
+    if (PACK) *slot = *arr; else *arr = *slot;
+}
+
 // =====================================================================================
 // host side: C ABI
 // =====================================================================================
@@ -1748,6 +1766,41 @@ int adfp_tracker_loss(const adfp_track_loss_args* l, void* stream) {
     a.depth = l->depth; a.unc = l->uncertainty; a.color = l->color; a.gd = l->gt_depth; a.gc = l->gt_color; a.keep = l->keep;
     a.loss = l->loss; a.g_depth = l->g_depth; a.g_color = l->g_color;
     hipLaunchKernelGGL(k_tracker_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
+int adfp_gather_pack(int n_arrays, const void* const* src, const int* words, long long rows, void* dst, void* stream) {
+    if (n_arrays < 1 || n_arrays > ADFP_GATHER_MAX || !src || !words || !dst || rows < 0) return ADFP_E_ARG;
+    GatherJobs j; j.n = n_arrays; j.world = 1; j.pad = rows; j.prefix[0] = 0; j.prefix[1] = rows; j.woff[0] = 0;
+    for (int a = 0; a < n_arrays; ++a) {
+        if (!src[a] || words[a] <= 0) return ADFP_E_ARG;
+        j.arr[a] = (unsigned*)src[a]; j.words[a] = words[a]; j.woff[a + 1] = j.woff[a] + words[a];
+    }
+    const long long total = rows * j.woff[n_arrays];
+    if (total == 0) return 0;
+    if (total > 0x7fffffffll * 256) return ADFP_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_gather_rows<true>, dim3((unsigned)((total + 255) / 256), 1), dim3(256), 0, (hipStream_t)stream, j, (unsigned*)dst);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+int adfp_gather_unpack(int n_arrays, void* const* dst, const int* words, int world, long long pad, const long long* rows_per_rank,
+                       const void* gathered, void* stream) {
+    if (n_arrays < 1 || n_arrays > ADFP_GATHER_MAX || !dst || !words || !rows_per_rank || !gathered || world < 1 || world > ADFP_GATHER_MAX_RANKS || pad < 0)
+        return ADFP_E_ARG;
+    GatherJobs j; j.n = n_arrays; j.world = world; j.pad = pad; j.prefix[0] = 0; j.woff[0] = 0;
+    for (int r = 0; r < world; ++r) {
+        if (rows_per_rank[r] < 0 || rows_per_rank[r] > pad) return ADFP_E_ARG;
+        j.prefix[r + 1] = j.prefix[r] + rows_per_rank[r];
+    }
+    for (int a = 0; a < n_arrays; ++a) {
+        if (!dst[a] || words[a] <= 0) return ADFP_E_ARG;
+        j.arr[a] = (unsigned*)dst[a]; j.words[a] = words[a]; j.woff[a + 1] = j.woff[a] + words[a];
+    }
+    const long long per_rank = pad * j.woff[n_arrays];
+    if (per_rank == 0) return 0;
+    if (per_rank > 0x7fffffffll * 256) return ADFP_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_gather_rows<false>, dim3((unsigned)((per_rank + 255) / 256), (unsigned)world), dim3(256), 0, (hipStream_t)stream, j, (unsigned*)gathered);
     ADFP_CHECK_LAUNCH();
     return 0;
 }

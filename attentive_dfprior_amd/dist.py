@@ -39,12 +39,34 @@ def _all_gather_rows(x, sizes, group):
 
 def _all_gather_packed(outs, sizes, group):
     """ONE collective for several per-ray outputs: every rank packs its rows (depth f64, uncertainty f64, colour 3 x f32 ... =
-    28 B per ray for a render) into one byte buffer padded to the largest shard, all_gather_into_tensor, unpack.  A frame's
-    outputs are ~1 MB per rank at 8 GPUs: the collective is latency bound, so one launch instead of one per output."""
+    28 B per ray for a render) into one row buffer padded to the largest shard, all_gather_into_tensor, unpack.  A frame's
+    outputs are ~1 MB per rank at 8 GPUs: the collective is latency bound, so one launch instead of one per output.  On the GPU
+    the two sides are ONE kernel each (adfp_gather_pack straight into the send buffer, adfp_gather_unpack out of the gathered
+    one; no zero fill, no per-output slice copies, no torch.cat); host tensors (the gloo tests) take the torch composition."""
     world, pad = len(sizes), max(sizes)
     rows = [o.contiguous().reshape(o.shape[0], -1) for o in outs]
     widths = [r.shape[1] * r.element_size() for r in rows]
     dev = outs[0].device
+    if dev.type == 'cuda' and all(wd % 4 == 0 for wd in widths) and len(outs) <= 8 and world <= 64:
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        W = sum(widths)
+        n = len(outs)
+        words = (C.c_int * n)(*[wd // 4 for wd in widths])
+        with _lib.device_guard(dev):
+            st = _lib.current_stream(dev)
+            send = torch.empty((pad, W), dtype=torch.uint8, device=dev)        # rows beyond the shard: never read by unpack
+            gathered = torch.empty((world * pad, W), dtype=torch.uint8, device=dev)
+            src = (C.c_void_p * n)(*[r.data_ptr() for r in rows])
+            _lib.check(L.adfp_gather_pack(n, src, words, rows[0].shape[0], _lib.ptr(send), st), 'adfp_gather_pack')
+            dist.all_gather_into_tensor(gathered, send, group=group)
+            total = sum(sizes)
+            res = [torch.empty((total,) + tuple(o.shape[1:]), dtype=o.dtype, device=dev) for o in outs]
+            dst = (C.c_void_p * n)(*[r.data_ptr() for r in res])
+            per = (C.c_longlong * world)(*sizes)
+            _lib.check(L.adfp_gather_unpack(n, dst, words, world, pad, per, _lib.ptr(gathered), st), 'adfp_gather_unpack')
+        return tuple(res)
     buf = torch.zeros((pad, sum(widths)), dtype=torch.uint8, device=dev)
     off = 0
     for r, wd in zip(rows, widths):
@@ -86,6 +108,23 @@ def render_rays_sharded(render_fn, rays_o, rays_d, gt_depth, group=None, gather=
     return _all_gather_packed(tuple(outs), sizes, group)
 
 
+def _common_bucket(grads):
+    """If every gradient is a contiguous float32 view of ONE storage and together they cover (almost all of) one span of it, that
+    span as a flat tensor; otherwise None.  Elements of the span that belong to no listed gradient (frozen parameters of a network
+    whose flat gradient was produced anyway) are summed too, harmlessly."""
+    if not grads or any(g is None or g.dtype != torch.float32 or not g.is_contiguous() for g in grads):
+        return None
+    st = grads[0].untyped_storage()
+    base = st.data_ptr()
+    if any(g.untyped_storage().data_ptr() != base for g in grads):
+        return None
+    lo = min(g.storage_offset() for g in grads)
+    hi = max(g.storage_offset() + g.numel() for g in grads)
+    if hi - lo > 1.25 * sum(g.numel() for g in grads) + 64:
+        return None
+    return grads[0].new_empty(0).set_(st, lo, (hi - lo,))
+
+
 def allreduce_grads(tensors, group=None, skip_single=True):
     """One flat-bucket all-reduce (SUM, fp32) of the gradients of `tensors` (parameters or grids).
     Tensors without a gradient contribute zeros so that every rank issues the same collective.
@@ -96,6 +135,13 @@ def allreduce_grads(tensors, group=None, skip_single=True):
     tensors = [t for t in tensors if t.requires_grad]
     if not tensors:
         return 0
+    span = _common_bucket([t.grad for t in tensors])
+    if span is not None:
+        # The backward of Renderer.render_batch_ray hands autograd views of ONE buffer (engine.render_backward), and autograd
+        # keeps them as the .grad tensors: the bucket is contiguous as it stands -- all-reduce it in place, no packing copies
+        # (48.6 MB each way for room0's dense grids).
+        dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group)
+        return span.numel() * 4
     flats = []
     for t in tensors:
         g = t.grad if t.grad is not None else torch.zeros_like(t)

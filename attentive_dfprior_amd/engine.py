@@ -60,12 +60,13 @@ class _PrivateWorkspaces(object):
         self.e = engine
 
     def __enter__(self):
-        self.saved = (self.e._ws, self.e._bws)
+        self.saved = (self.e._ws, self.e._bws, self.e._gcl)
         self.e._ws = self.e._bws = None
+        self.e._gcl = {}
         return self
 
     def __exit__(self, *exc):
-        self.e._ws, self.e._bws = self.saved
+        self.e._ws, self.e._bws, self.e._gcl = self.saved
         return False
 
 
@@ -89,6 +90,7 @@ class Engine(object):
         self.export_relu_masks = False
         self._ws = None          # forward scratch, grow-only (stream order makes the reuse safe)
         self._bws = None         # backward scratch, same
+        self._gcl = {}           # channels-last gradient scratch per grid (render_backward)
         self._grid_cache = {}    # key name -> (key, channels-last tensor)
         self._bound_cache = {}   # id -> (key, host list)
 
@@ -106,6 +108,32 @@ class Engine(object):
         if self._bws is None or self._bws.numel() < need or self._bws.device != device:
             self._bws = torch.empty(int(need * 1.25) + 1024, dtype=torch.uint8, device=device)
         return self._bws
+
+    @staticmethod
+    def zero_grad_bucket(c, need_grid, need_flat, dev):
+        """The gradient outputs of render_backward for a batch of ZERO rays: the same single-allocation layout (grids first, then
+        the flat parameter gradients), zero-filled -- a rank whose ray shard is empty then contributes to dist.allreduce_grads
+        through the same in-place path as every other rank."""
+        sizes = [('g' + n, c[k].numel()) for n, k in (('low', 'grid_low'), ('high', 'grid_high'), ('color', 'grid_color')) if need_grid.get(n)]
+        sizes += [('f' + n, _flat_floats(n)) for n in ('low', 'high', 'color', 'att') if need_flat.get(n)]
+        bucket = torch.zeros((sum(v for _, v in sizes),), dtype=torch.float32, device=dev)
+        grids, flats, off = {}, {}, 0
+        for tag, nfl in sizes:
+            if tag[0] == 'g':
+                key = 'grid_' + tag[1:]
+                grids[tag[1:]] = bucket[off:off + nfl].view(c[key].shape)
+            else:
+                flats[tag[1:]] = bucket[off:off + nfl]
+            off += nfl
+        return grids, flats
+
+    def _cl_scratch(self, name, shape, device):
+        """Channels-last scratch the backward scatters a grid's gradient into before it is re-laid out for autograd (a temporary of
+        the call, kept across calls like the workspaces)."""
+        t = self._gcl.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.device != device:
+            t = self._gcl[name] = torch.empty(shape, dtype=torch.float32, device=device)
+        return t
 
     def private_workspaces(self):
         """`with engine.private_workspaces():` -- a HIP-graph capture gets workspaces of its OWN (allocated from the graph's pool
@@ -632,6 +660,23 @@ class Engine(object):
                 a.ray_keep = ray_keep.data_ptr()
             grids_cl, flats = {}, {}
             direct = {}
+            # Gradient outputs the caller did not provide come out of ONE allocation (the three grids first: their channel-major
+            # copies are written with 16-byte stores; then the flat parameter gradients): one torch.empty instead of five, and
+            # dist.allreduce_grads finds the whole bucket contiguous -- the .grad tensors autograd keeps are views of it -- and
+            # all-reduces it in place, with no packing copy either way.
+            own_grid = [(name, key) for name, key in (('low', 'grid_low'), ('high', 'grid_high'), ('color', 'grid_color'))
+                        if need_grid.get(name) and not (out_grids_cl and name in out_grids_cl) and not (out_grids and name in out_grids)]
+            own_flat = [name for name in ('low', 'high', 'color', 'att') if need_flat.get(name) and not (out_flats and name in out_flats)]
+            bucket, boff = None, {}
+            if own_grid or own_flat:
+                off = 0
+                for name, key in own_grid:
+                    boff['g' + name] = off
+                    off += c[key].numel()
+                for name in own_flat:
+                    boff['f' + name] = off
+                    off += _flat_floats(name)
+                bucket = torch.empty((off,), dtype=f32, device=dev)
             for name, key in (('low', 'grid_low'), ('high', 'grid_high'), ('color', 'grid_color')):
                 if need_grid.get(name):
                     Z, Y, X = c[key].shape[2:]
@@ -639,12 +684,15 @@ class Engine(object):
                         direct[name] = out_grids_cl[name]
                         setattr(a, 'g_grid_' + name, direct[name].data_ptr())
                         continue
-                    grids_cl[name] = torch.empty((Z, Y, X, 32), dtype=f32, device=dev)
+                    grids_cl[name] = self._cl_scratch(name, (Z, Y, X, 32), dev)
                     setattr(a, 'g_grid_' + name, grids_cl[name].data_ptr())
             for name in ('low', 'high', 'color', 'att'):
                 if need_flat.get(name):
-                    flats[name] = out_flats[name] if out_flats and name in out_flats else \
-                        torch.empty((_flat_floats(name),), dtype=f32, device=dev)
+                    if out_flats and name in out_flats:
+                        flats[name] = out_flats[name]
+                    else:
+                        o = boff['f' + name]
+                        flats[name] = bucket[o:o + _flat_floats(name)]
                     setattr(a, 'g_flat_' + name, flats[name].data_ptr())
             g_ro = g_rd = None
             if need_rays:
@@ -659,7 +707,11 @@ class Engine(object):
             grids = dict(direct)
             for name, g in grids_cl.items():
                 Z, Y, X = g.shape[:3]
-                out = out_grids[name] if out_grids and name in out_grids else torch.empty((1, 32, Z, Y, X), dtype=f32, device=dev)
+                if out_grids and name in out_grids:
+                    out = out_grids[name]
+                else:
+                    o = boff['g' + name]
+                    out = bucket[o:o + 32 * Z * Y * X].view(1, 32, Z, Y, X)
                 check(L.adfp_relayout_grid_back(ptr(g), ptr(out), 32, Z, Y, X, stream), 'adfp_relayout_grid_back')
                 grids[name] = out
         return grids, flats, (g_ro, g_rd)

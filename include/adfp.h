@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 120
+#define ADFP_VERSION 121
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -496,6 +496,18 @@ int adfp_track_keep_best(const double* loss, const float* cam, double* best_loss
 size_t adfp_sort_workspace_bytes(long long n);
 int adfp_sort_pairs(int* key, int* val, int* key_tmp, int* val_tmp, long long n, int key_bits, void* workspace, size_t workspace_bytes,
                     void* stream);
+
+/* ---- multi-GPU render (new functionality; the reference has no distributed code): the send / receive side of ONE all-gather ----
+ * A sharded render returns several per-ray arrays (depth f64, uncertainty f64, colour 3 x f32 ... = 28 B per ray).  pack writes
+ * the rank's `rows` rows of all of them interleaved into dst [rows][sum words] (the send buffer: the rank's slot of the gather
+ * buffer, or a buffer padded to the largest shard); unpack reads the gathered [world][pad][sum words] buffer and writes every
+ * array contiguous in ray order, rank r contributing rows_per_rank[r] <= pad rows.  Row widths in 4-byte words; at most
+ * ADFP_GATHER_MAX arrays and ADFP_GATHER_MAX_RANKS ranks; src / dst / words / rows_per_rank are HOST arrays. */
+#define ADFP_GATHER_MAX 8
+#define ADFP_GATHER_MAX_RANKS 64
+int adfp_gather_pack(int n_arrays, const void* const* src, const int* words, long long rows, void* dst, void* stream);
+int adfp_gather_unpack(int n_arrays, void* const* dst, const int* words, int world, long long pad, const long long* rows_per_rank,
+                       const void* gathered, void* stream);
 
 /* Per-stage timing hook for bench.py: runs ONLY the TSDF trilerp + band-mask kernel (a10).
  * w may be NULL (that is the render path's launch: there the LOW decoder writes w = 1). */
