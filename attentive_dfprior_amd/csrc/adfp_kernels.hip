@@ -1027,15 +1027,17 @@ struct Workspace {
     size_t bytes;
 };
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+// (offsets are formed as integers: the size queries carve a NULL base, and pointer arithmetic on NULL is undefined)
+template <typename T> static T* at(void* base, size_t o) { return (T*)((uintptr_t)base + o); }
 static Workspace carve(void* base, long long P) {
-    Workspace w; size_t o = 0; char* b = (char*)base;
-    w.counter = (int*)(b + o); o += 256;
-    w.z = (double*)(b + o); o += align256((size_t)P * 8);
-    w.raw = (float*)(b + o); o += align256((size_t)P * 16);
-    w.list = (int*)(b + o); o += align256((size_t)P * 4);
-    w.att_occ = (float*)(b + o); o += align256((size_t)P * 4);
-    w.att_u = (float*)(b + o); o += align256((size_t)P * 4);
-    w.flags = (unsigned char*)(b + o); o += align256((size_t)P);
+    Workspace w; size_t o = 0;
+    w.counter = at<int>(base, o); o += 256;
+    w.z = at<double>(base, o); o += align256((size_t)P * 8);
+    w.raw = at<float>(base, o); o += align256((size_t)P * 16);
+    w.list = at<int>(base, o); o += align256((size_t)P * 4);
+    w.att_occ = at<float>(base, o); o += align256((size_t)P * 4);
+    w.att_u = at<float>(base, o); o += align256((size_t)P * 4);
+    w.flags = at<unsigned char>(base, o); o += align256((size_t)P);
     w.bytes = o;
     return w;
 }
@@ -1716,7 +1718,7 @@ int adfp_prefilter_mask(const float* rays_o, const float* rays_d, const float* g
     return 0;
 }
 int adfp_mapper_loss(const adfp_loss_args* l, void* stream) {
-    if (!l || !l->depth || !l->gt_depth || !l->g_depth || l->n_rays < 0 || l->S <= 0) return ADFP_E_ARG;
+    if (!l || !l->depth || !l->gt_depth || !l->g_depth || !l->loss || l->n_rays < 0 || l->S <= 0) return ADFP_E_ARG;
     if (l->stage < ADFP_STAGE_LOW || l->stage > ADFP_STAGE_COLOR) return ADFP_E_ARG;
     if (l->stage == ADFP_STAGE_COLOR && (!l->color || !l->gt_color || !l->g_color)) return ADFP_E_ARG;
     if (l->warmup && (!l->weight || !l->g_weight)) return ADFP_E_ARG;
@@ -1759,7 +1761,7 @@ int adfp_track_keep_best(const double* loss, const float* cam, double* best_loss
     return 0;
 }
 int adfp_tracker_loss(const adfp_track_loss_args* l, void* stream) {
-    if (!l || !l->depth || !l->uncertainty || !l->color || !l->gt_depth || !l->gt_color || !l->g_depth || !l->g_color || l->n_rays < 0) return ADFP_E_ARG;
+    if (!l || !l->depth || !l->uncertainty || !l->color || !l->gt_depth || !l->gt_color || !l->g_depth || !l->g_color || !l->loss || l->n_rays < 0) return ADFP_E_ARG;
     if (l->n_rays > ADFP_TRACK_MAX_RAYS) return ADFP_E_UNSUPPORTED;
     TrackLossArgs a;
     a.n = l->n_rays; a.handle_dynamic = l->handle_dynamic; a.w_color = l->w_color_loss;
@@ -1826,6 +1828,9 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
     if (S > ADFP_MAX_SAMPLES) return ADFP_E_UNSUPPORTED;
     const long long Pn = (long long)r->n_rays * S;
     if (Pn > 0x7fffffffll) return ADFP_E_UNSUPPORTED;
+    // per-segment far clamp: the maxima live in 48 words of the workspace head (refused here, before anything is launched)
+    if (r->gt_depth && !r->depth_max && r->depth_max_segment > 0 && ((long long)r->n_rays + r->depth_max_segment - 1) / r->depth_max_segment > 48)
+        return ADFP_E_UNSUPPORTED;
     Workspace ws = carve(r->workspace, Pn);
     if (r->workspace_bytes < ws.bytes) return ADFP_E_WORKSPACE;
     if (r->n_rays == 0) return 0;
@@ -1858,28 +1863,28 @@ struct BwdWorkspace { float* g_raw; float* att_g; float* g_pts; float* stage; in
                       float* gc; int* bin_key; int* bin_val; int* bin_key_sorted; int* bin_perm; int* sort_table;
                       size_t bytes; };
 static BwdWorkspace carve_bwd(void* base, long long P) {
-    BwdWorkspace w; size_t o = 0; char* b = (char*)base;
-    w.g_raw = (float*)(b + o); o += align256((size_t)P * 16);
-    w.att_g = (float*)(b + o); o += align256((size_t)P * 4);
-    w.g_pts = (float*)(b + o); o += align256((size_t)P * 12);
+    BwdWorkspace w; size_t o = 0;
+    w.g_raw = at<float>(base, o); o += align256((size_t)P * 16);
+    w.att_g = at<float>(base, o); o += align256((size_t)P * 4);
+    w.g_pts = at<float>(base, o); o += align256((size_t)P * 12);
     w.stage_rows = (int)(P < STG_ROWS_MAX ? P : STG_ROWS_MAX);
     if (w.stage_rows < 32) w.stage_rows = 32;
-    w.stage = (float*)(b + o); o += align256((size_t)w.stage_rows * AttStage::NCOLS * 4);
+    w.stage = at<float>(base, o); o += align256((size_t)w.stage_rows * AttStage::NCOLS * 4);
     int fmax = DecLayout<32, 1>::F_TOTAL;
     if (DecLayout<64, 1>::F_TOTAL > fmax) fmax = DecLayout<64, 1>::F_TOTAL;
     if (DecLayout<32, 4>::F_TOTAL > fmax) fmax = DecLayout<32, 4>::F_TOTAL;
     if (AttLayout::F_TOTAL > fmax) fmax = AttLayout::F_TOTAL;
     w.part_stride = (fmax + 63) / 64 * 64;
-    w.partial = (float*)(b + o); o += align256((size_t)OUTER_NSLOT * w.part_stride * 4);
-    w.gmax = (float*)(b + o); o += 256;            // largest |cotangent of raw| of the call (grad_scale)
-    w.gmax_parts = (float*)(b + o); o += align256((size_t)P * 4);     // ... per ray / per workgroup, before k_max_reduce
+    w.partial = at<float>(base, o); o += align256((size_t)OUTER_NSLOT * w.part_stride * 4);
+    w.gmax = at<float>(base, o); o += 256;            // largest |cotangent of raw| of the call (grad_scale)
+    w.gmax_parts = at<float>(base, o); o += align256((size_t)P * 4);     // ... per ray / per workgroup, before k_max_reduce
     // spatially ordered grid-gradient scatter of the f16-split backward (k_scatter_sorted): d/d c rows, sort keys, sorted order
-    w.gc = (float*)(b + o); o += align256((size_t)P * 128);
-    w.bin_key = (int*)(b + o); o += align256((size_t)P * 4);
-    w.bin_val = (int*)(b + o); o += align256((size_t)P * 4);
-    w.bin_key_sorted = (int*)(b + o); o += align256((size_t)P * 4);
-    w.bin_perm = (int*)(b + o); o += align256((size_t)P * 4);
-    w.sort_table = (int*)(b + o); o += align256((((size_t)P + ADFP_RS_TILE - 1) / ADFP_RS_TILE) * 256 * 4 + 1024);     // [256 digits][tiles] + [256] totals
+    w.gc = at<float>(base, o); o += align256((size_t)P * 128);
+    w.bin_key = at<int>(base, o); o += align256((size_t)P * 4);
+    w.bin_val = at<int>(base, o); o += align256((size_t)P * 4);
+    w.bin_key_sorted = at<int>(base, o); o += align256((size_t)P * 4);
+    w.bin_perm = at<int>(base, o); o += align256((size_t)P * 4);
+    w.sort_table = at<int>(base, o); o += align256((((size_t)P + ADFP_RS_TILE - 1) / ADFP_RS_TILE) * 256 * 4 + 1024);     // [256 digits][tiles] + [256] totals
     w.bytes = o;
     return w;
 }
