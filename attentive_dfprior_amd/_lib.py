@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ADFP_LIB_PATH', os.path.join(_HERE, 'libadfp.so'))   # override: kernel A/B builds
 
-ABI_VERSION = 121                 # ADFP_VERSION of include/adfp.h this binding was written against
+ABI_VERSION = 123                 # ADFP_VERSION of include/adfp.h this binding was written against
 STATUS_F16_RANGE = 31              # ADFP_STATUS_F16_RANGE: any of the bits below
 STATUS_RANGE_BITS = {'low': 1, 'high': 2, 'color': 4, 'att': 8, 'bwd': 16}      # ADFP_STATUS_F16_RANGE_<net>
 BWD_SCATTER_IN_KERNEL = 1        # ADFP_BWD_SCATTER_IN_KERNEL
@@ -181,6 +181,8 @@ SYMBOLS = [
     ('adfp_track_keep_best', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_sort_workspace_bytes', C.c_size_t, [C.c_longlong]),
     ('adfp_sort_pairs', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ('adfp_ray_sort_keys', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Bound), C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_ray_order_probe', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     ('adfp_gather_pack', C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_longlong, C.c_void_p, C.c_void_p]),
     ('adfp_gather_unpack', C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_longlong, C.POINTER(C.c_longlong), C.c_void_p, C.c_void_p]),
     ('adfp_tsdf_stage', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_void_p, C.c_void_p,

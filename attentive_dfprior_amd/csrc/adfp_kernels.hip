@@ -960,6 +960,58 @@ extern "C" int adfp_debug_phases_fused(unsigned long long* host_out, int reset) 
 #include "adfp_tracker_iter.h"
 #include "adfp_decode_g.h"
 
+// adfp_ray_sort_keys (adfp.h): Morton keys of (origin cell, surface-point cell) per ray
+__device__ __forceinline__ unsigned morton3(unsigned x, unsigned y, unsigned z, int bits) {
+    unsigned k = 0;
+    for (int b = 0; b < bits; ++b) k |= (((x >> b) & 1u) << (3 * b)) | (((y >> b) & 1u) << (3 * b + 1)) | (((z >> b) & 1u) << (3 * b + 2));
+    return k;
+}
+struct RayKeyArgs { const float* ro; const float* rd; const float* gd; int n; float lo[3], inv[3]; int* key; int* val; };
+__global__ __launch_bounds__(256) void k_ray_sort_keys(RayKeyArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    float t = a.gd ? a.gd[i] : 1.f;
+    if (!(t > 0.f) || !(t < 3.0e38f)) t = 1.f;
+    unsigned co[3], cs[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float o = a.ro[3 * i + k], p = fmaf(a.rd[3 * i + k], t, o);
+        const float uo = (o - a.lo[k]) * a.inv[k], us = (p - a.lo[k]) * a.inv[k];
+        co[k] = (unsigned)fminf(fmaxf(uo * 4.f, 0.f), 3.f);           // NaN -> 0
+        cs[k] = (unsigned)fminf(fmaxf(us * 256.f, 0.f), 255.f);
+    }
+    a.key[i] = (int)((morton3(co[0], co[1], co[2], 2) << 24) | morton3(cs[0], cs[1], cs[2], 8));
+    a.val[i] = i;
+}
+
+// adfp_ray_order_probe (adfp.h): one workgroup, 2048 pairs of consecutive rays
+__global__ __launch_bounds__(256) void k_ray_order_probe(const float* __restrict__ ro, const float* __restrict__ rd, const float* __restrict__ gd, int n,
+                                                         float far2, int* __restrict__ verdict) {
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int pairs = n - 1 < 2048 ? n - 1 : 2048;
+    const int stride = pairs > 0 ? (n - 1) / pairs : 1;
+    int far = 0;
+    for (int k = threadIdx.x; k < pairs; k += 256) {
+        const int i = k * stride;
+        float p[2][3];
+        for (int e = 0; e < 2; ++e) {
+            float t = gd ? gd[i + e] : 1.f;
+            if (!(t > 0.f) || !(t < 3.0e38f)) t = 1.f;
+            for (int c = 0; c < 3; ++c) p[e][c] = fmaf(rd[3 * (i + e) + c], t, ro[3 * (i + e) + c]);
+        }
+        const float dx = p[1][0] - p[0][0], dy = p[1][1] - p[0][1], dz = p[1][2] - p[0][2];
+        far += (dx * dx + dy * dy + dz * dz > far2) ? 1 : 0;
+    }
+    atomicAdd(&s_cnt, far);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(verdict + 1, pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(verdict, s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // The two sides of a sharded render's ONE all-gather (adfp.h: adfp_gather_pack / adfp_gather_unpack): several per-ray arrays <->
 // one interleaved row buffer.  blockIdx.y = rank (unpack), a thread moves one 4-byte word.
 struct GatherJobs { unsigned* arr[ADFP_GATHER_MAX]; int words[ADFP_GATHER_MAX]; int woff[ADFP_GATHER_MAX + 1]; int n, world; long long pad; long long prefix[ADFP_GATHER_MAX_RANKS + 1]; };
@@ -1772,6 +1824,25 @@ int adfp_tracker_loss(const adfp_track_loss_args* l, void* stream) {
     return 0;
 }
 
+int adfp_ray_sort_keys(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double tsdf_bnds[3][2], int* key, int* val,
+                       void* stream) {
+    if (!rays_o || !rays_d || !tsdf_bnds || !key || !val || n_rays < 0) return ADFP_E_ARG;
+    if (n_rays == 0) return 0;
+    RayKeyArgs a; a.ro = rays_o; a.rd = rays_d; a.gd = gt_depth; a.n = n_rays; a.key = key; a.val = val;
+    for (int k = 0; k < 3; ++k) {
+        if (!(tsdf_bnds[k][1] > tsdf_bnds[k][0])) return ADFP_E_ARG;
+        a.lo[k] = (float)tsdf_bnds[k][0]; a.inv[k] = (float)(1.0 / (tsdf_bnds[k][1] - tsdf_bnds[k][0]));
+    }
+    hipLaunchKernelGGL(k_ray_sort_keys, dim3((n_rays + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+int adfp_ray_order_probe(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, float far_distance, int* verdict, void* stream) {
+    if (!rays_o || !rays_d || !verdict || n_rays < 0 || !(far_distance > 0.f)) return ADFP_E_ARG;
+    hipLaunchKernelGGL(k_ray_order_probe, dim3(1), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, gt_depth, n_rays, far_distance * far_distance, verdict);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
 int adfp_gather_pack(int n_arrays, const void* const* src, const int* words, long long rows, void* dst, void* stream) {
     if (n_arrays < 1 || n_arrays > ADFP_GATHER_MAX || !src || !words || !dst || rows < 0) return ADFP_E_ARG;
     GatherJobs j; j.n = n_arrays; j.world = 1; j.pad = rows; j.prefix[0] = 0; j.prefix[1] = rows; j.woff[0] = 0;

@@ -42,6 +42,10 @@ class Renderer(object):
             raise NotImplementedError('occupancy=False (density compositing) is not used by the reference '
                                       'configs (configs/df_prior.yaml:4); not supported')
         self.need_param_grad = True          # see render_batch_ray
+        # Not in the reference: a large inference batch whose rays arrive in INCOHERENT order (e.g. a random subset of several
+        # images' pixels) is rendered in a spatially sorted order and handed back in the caller's (see _coherent_order).
+        self.sort_rays_min = 65536           # batches below this are not looked at (0 / None: never sort)
+        self._order_verdict = {}             # batch size -> pinned verdict words of adfp_ray_order_probe
         self._engine = Engine()
 
     def check_overflow(self, device=None, decoders=None):
@@ -96,22 +100,84 @@ class Renderer(object):
             return render_with_grad(self._engine, decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds,
                                     self.bound, stage, self.N_samples, self.N_surface, self.lindisp, self.perturb,
                                     t_rand, depth_max, need_param_grad)
+        perm = None
+        if self.sort_rays_min and N >= self.sort_rays_min and stage != 'low' and gt_depth is not None and t_rand is None:
+            perm = self._coherent_order(rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds)
+        if perm is not None:
+            # rays are independent units: the far clamp's batch maximum (Renderer.py:159, :195) is order-free, everything else is
+            # per ray -- the sorted render returns the same values, restored to the caller's order
+            if depth_max is None:
+                depth_max = gt_depth.detach().reshape(-1).float().max().reshape(1)
+            d, u, col, w, _ = self._engine.render_forward(
+                decoders, c, rays_o.detach().index_select(0, perm), rays_d.detach().index_select(0, perm),
+                gt_depth.detach().reshape(-1).index_select(0, perm), tsdf_volume, tsdf_bnds, self.bound, stage,
+                self.N_samples, self.N_surface, self.lindisp, self.perturb, None, depth_max)
+            depth, unc, color, weight = torch.empty_like(d), torch.empty_like(u), torch.empty_like(col), torch.empty_like(w)
+            depth.index_copy_(0, perm, d)
+            unc.index_copy_(0, perm, u)
+            color.index_copy_(0, perm, col)
+            weight.index_copy_(0, perm, w)
+            return depth, unc, color, weight
         depth, unc, color, weight, _ = self._engine.render_forward(
             decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, self.bound, stage,
             self.N_samples, self.N_surface, self.lindisp, self.perturb, t_rand, depth_max)
         return depth, unc, color, weight
 
-    def _fits_in_one_call(self, n, S, dev):
-        """ray_batch_size exists in the reference to BOUND memory (Renderer.py:294-313).  The one-call frame needs the forward
-        workspace for all n x S samples at once (~37 B per sample x 1.25) plus the [n, S] attention-weight output; it is taken
-        only when that fits in half of what the device has free (or the engine's workspace is that large already) -- otherwise
-        the frame is rendered batch by batch like the reference's."""
-        need_ws = int(_lib.lib().adfp_workspace_bytes(n * S))
-        ws = self._engine._ws
-        have = ws.numel() if ws is not None and ws.device == dev else 0
-        extra = (int(need_ws * 1.25) if have < need_ws else 0) + n * (4 * S + 28)
-        free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-        return extra <= free // 2
+    def _coherent_order(self, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, wait=False):
+        """None if the batch is to be rendered as it stands, otherwise the permutation (int64 [N]) that sorts its rays by (cell of
+        the origin, cell of the surface point) -- adfp_ray_sort_keys + the library's radix sort.
+
+        Why: the TSDF lookup fetches four 8-byte column pieces per sample.  In pixel order a wave's 64 lanes (the same sample of 64
+        neighbouring rays) find them in a few cache lines; with unrelated neighbours every piece is its own 64-byte sector and its
+        own page (1024^3 volume, 131 072 random rays x 128 samples: 175 B fetched per sample against 9 B in pixel order,
+        profiles/r04_pmc_hbm_config5_random.csv).  A 5 % random sample of an image stays sparser than the image after sorting, but
+        the rays a workgroup walks together are millimetres to centimetres apart again.
+
+        Whether a batch is coherent is measured by ONE tiny kernel (adfp_ray_order_probe: do consecutive rays land within a few
+        voxels of each other?) that writes its verdict to pinned host memory; nothing waits for it -- the verdict of a call steers
+        the NEXT call of the same batch size (callers send streams of like batches: frames in pixel order, or random draws).
+        `wait=True` (tests) waits for this batch's own verdict."""
+        import ctypes as C
+        dev = rays_o.device
+        N = rays_o.shape[0]
+        L = _lib.lib()
+        ro = rays_o.detach()
+        if ro.dtype != torch.float32 or not ro.is_contiguous():
+            ro = ro.float().contiguous()
+        rd = rays_d.detach()
+        if rd.dtype != torch.float32 or not rd.is_contiguous():
+            rd = rd.float().contiguous()
+        gd = gt_depth.detach().reshape(-1)
+        if gd.dtype != torch.float32 or not gd.is_contiguous():
+            gd = gd.float().contiguous()
+        slot = self._order_verdict.get(N)
+        if slot is None:
+            ext = self._engine.host_bound(tsdf_bnds, 'tsdf_bnds')
+            Z, Y, X = tsdf_volume.shape[2:]
+            voxel = max((ext[0][1] - ext[0][0]) / X, (ext[1][1] - ext[1][0]) / Y, (ext[2][1] - ext[2][0]) / Z)
+            word = torch.zeros(2, dtype=torch.int32).pin_memory()
+            slot = self._order_verdict[N] = (word, C.c_int.from_address(word.data_ptr()), C.c_int.from_address(word.data_ptr() + 4), 8.0 * voxel)
+        word, far, pairs, far_distance = slot
+        with _lib.device_guard(dev):
+            st = _lib.current_stream(dev)
+            if not wait:
+                incoherent = pairs.value > 0 and 2 * far.value > pairs.value          # the PREVIOUS like batch's verdict
+            _lib.check(L.adfp_ray_order_probe(_lib.ptr(ro), _lib.ptr(rd), _lib.ptr(gd), N, far_distance, C.c_void_p(word.data_ptr()), st),
+                       'adfp_ray_order_probe')
+            if wait:
+                torch.cuda.synchronize(dev)
+                incoherent = 2 * far.value > pairs.value
+            if not incoherent:
+                return None
+            key, val = torch.empty((N,), dtype=torch.int32, device=dev), torch.empty((N,), dtype=torch.int32, device=dev)
+            kt, vt = torch.empty_like(key), torch.empty_like(val)
+            b = _lib.Bound()
+            _lib.fill_bound(b, self._engine.host_bound(tsdf_bnds, 'tsdf_bnds'))
+            _lib.check(L.adfp_ray_sort_keys(_lib.ptr(ro), _lib.ptr(rd), _lib.ptr(gd), N, C.byref(b), _lib.ptr(key), _lib.ptr(val), st), 'adfp_ray_sort_keys')
+            nb = int(L.adfp_sort_workspace_bytes(N))
+            ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+            _lib.check(L.adfp_sort_pairs(_lib.ptr(key), _lib.ptr(val), _lib.ptr(kt), _lib.ptr(vt), N, 30, _lib.ptr(ws), nb, st), 'adfp_sort_pairs')
+        return val.long()
 
     def render_img(self, c, decoders, c2w, device, tsdf_volume, tsdf_bnds, stage, gt_depth=None):
         """Full-frame render under no_grad in ``ray_batch_size`` batches -> depth [H,W] f64,

@@ -142,7 +142,7 @@ def pmc_traffic(kernel_prefix, samples_per_launch, fname='r03_pmc_hbm_traffic.cs
     is the PROFILED bytes/sample x this run's samples per launch.  Returns (bytes or None, provenance dict); the csv's
     header carries the source hash of the build it was taken from and `stale` says whether that is this build."""
     import csv
-    for name in (fname, fname.replace('r03_', 'r02_'), fname.replace('r03_', 'r01_')):
+    for name in (fname.replace('r03_', 'r04_'), fname, fname.replace('r03_', 'r02_'), fname.replace('r03_', 'r01_')):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             break
@@ -679,9 +679,31 @@ def config5_leg(A, synthetic, _lib, L, dev, n_rays=131072, NS=96, NF=32):
         t_all = ev_time(whole, 5)
         t_tsdf = ev_time(lambda: _lib.check(L.adfp_tsdf_stage(C.byref(scn), C.byref(ap), _lib.ptr(flags), _lib.ptr(lst), _lib.ptr(attu),
                                                               None, _lib.ptr(cnt), st), 'tsdf'), 10)
-        return t_all, t_tsdf, float((w != 1).float().mean())
-    t_all, t_tsdf, band = measure('pixel')
-    t_all_r, t_tsdf_r, band_r = measure('random')
+        extra = None
+        if order == 'random':
+            # what Renderer.render_batch_ray does with such a batch: the order probe's verdict makes it render in sorted order
+            # (Renderer._coherent_order) -- the whole call incl. keys, radix sort, gathers and the outputs' way back, and the TSDF
+            # stage alone on the sorted rays
+            def auto():
+                with torch.no_grad():
+                    return rend.render_batch_ray(sc.c, dec, rd, ro, dev, sc.tsdf_volume, tb, 'color', gt_depth=gd)
+            for _ in range(3):
+                auto()
+                torch.cuda.synchronize(dev)
+            t_auto = ev_time(auto, 5)
+            perm = rend._coherent_order(ro, rd, gd, sc.tsdf_volume, tb, wait=True)
+            ro_s, rd_s, gd_s = ro.index_select(0, perm).contiguous(), rd.index_select(0, perm).contiguous(), gd.index_select(0, perm).contiguous()
+            with torch.no_grad():
+                aux_s = eng.render_forward(dec, sc.c, ro_s, rd_s, gd_s, sc.tsdf_volume, tb, sc.bound, 'color', NS, NF, want_aux=True)[4]
+            ap_s = _lib.AdfpPoints()
+            ap_s.mode, ap_s.n_points = _lib.PTS_RAYS, P
+            ap_s.rays_o, ap_s.rays_d, ap_s.z_vals, ap_s.S = ro_s.data_ptr(), rd_s.data_ptr(), aux_s['z_vals'].data_ptr(), S
+            t_tsdf_s = ev_time(lambda: _lib.check(L.adfp_tsdf_stage(C.byref(scn), C.byref(ap_s), _lib.ptr(flags), _lib.ptr(lst), _lib.ptr(attu),
+                                                                    None, _lib.ptr(cnt), st), 'tsdf'), 10)
+            extra = (t_auto, t_tsdf_s)
+        return t_all, t_tsdf, float((w != 1).float().mean()), extra
+    t_all, t_tsdf, band, _ = measure('pixel')
+    t_all_r, t_tsdf_r, band_r, (t_auto_r, t_tsdf_sorted) = measure('random')
     by = float(TSDF_BYTES_PER_SAMPLE) * P
     traffic, prov = pmc_traffic('k_tsdf', P, 'r03_pmc_hbm_config5.csv')
     return {'workload': '16 m cube, 1024^3 TSDF (4.29 GB), 128 samples/ray (96 + 32), 131 072 rays = 8 poses x 16 384 consecutive pixels '
@@ -691,10 +713,18 @@ def config5_leg(A, synthetic, _lib, L, dev, n_rays=131072, NS=96, NF=32):
                               'frac': by / t_tsdf / 1e9 / PEAK_HBM_GBPS, 'traffic': traffic,
                               'real_hbm_gbps': (traffic / t_tsdf / 1e9) if traffic else None,
                               'traffic_source': prov, 'bytes_per_launch': by, 'avg_launch_ms': t_tsdf * 1e3},
-            'random_ray_order': {'value': n_rays / t_all_r, 'unit': 'rays/s', 'ms_per_batch': t_all_r * 1e3, 'in_band_fraction': band_r,
-                                 'tsdf_algorithmic_gbps': by / t_tsdf_r / 1e9, 'tsdf_avg_launch_ms': t_tsdf_r * 1e3,
-                                 'note': 'the same volume and sample count with each pose\'s rays drawn at random from its image: consecutive '
-                                         'rays share no cache lines, every 8-corner lookup costs 4 HBM sectors'}}
+            'random_ray_order': {'value': n_rays / t_auto_r, 'unit': 'rays/s', 'ms_per_batch': t_auto_r * 1e3, 'in_band_fraction': band_r,
+                                 'tsdf_algorithmic_gbps': by / t_tsdf_sorted / 1e9, 'tsdf_avg_launch_ms': t_tsdf_sorted * 1e3,
+                                 'tsdf_frac_of_hbm_peak': by / t_tsdf_sorted / 1e9 / PEAK_HBM_GBPS,
+                                 'as_given': {'value': n_rays / t_all_r, 'ms_per_batch': t_all_r * 1e3, 'tsdf_algorithmic_gbps': by / t_tsdf_r / 1e9,
+                                              'tsdf_avg_launch_ms': t_tsdf_r * 1e3,
+                                              'tsdf_counter_bytes_per_sample': pmc_traffic('k_tsdf', 1, 'r04_pmc_hbm_config5_random.csv')[0]},
+                                 'note': 'the same volume and sample count with each pose\'s rays drawn at random from its image.  Rendered AS GIVEN '
+                                         '(`as_given`) consecutive rays share no cache lines: every 8-corner lookup costs four 64-byte sectors '
+                                         '(tsdf_counter_bytes_per_sample, rocprofv3 FETCH + WRITE, against 32 algorithmic bytes).  '
+                                         'Renderer.render_batch_ray notices the incoherent order of such a batch (adfp_ray_order_probe, no sync) '
+                                         'and renders it sorted by (origin cell, surface cell): `value` / `ms_per_batch` = the whole call incl. keys, '
+                                         'radix sort, gathers and the outputs\' way back; tsdf_* = the TSDF stage alone on the sorted rays'}}
 
 
 def torch_gpu_leg(rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF, n=100000):

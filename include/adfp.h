@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 121
+#define ADFP_VERSION 123
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -496,6 +496,21 @@ int adfp_track_keep_best(const double* loss, const float* cam, double* best_loss
 size_t adfp_sort_workspace_bytes(long long n);
 int adfp_sort_pairs(int* key, int* val, int* key_tmp, int* val_tmp, long long n, int key_bits, void* workspace, size_t workspace_bytes,
                     void* stream);
+
+/* Sort keys that bring a large batch of rays in INCOHERENT order (a random subset of several images' pixels) into a spatially
+ * coherent one before it is rendered: key[i] = (Morton code of the ray origin's cell, 2 bits per axis) << 24 | Morton code of the
+ * cell of the ray's surface point o + d * gt_depth (gt_depth <= 0 / NULL: depth 1), 8 bits per axis, both inside tsdf_bnds; val[i]
+ * = i.  Sorted with adfp_sort_pairs (30 key bits) the rays of one camera that look at one 1/256 cell of the scene become
+ * neighbours, and the TSDF stage's wave-wide loads and the decoders' grid gathers find their lines and pages shared again
+ * (1024^3 volume, 131 072 random rays x 128 samples: 5.49 -> 4.93 ms per batch; rays are independent units, so the rendered values
+ * do not depend on the order).  tsdf_bnds is a HOST array. */
+int adfp_ray_sort_keys(const float* rays_o, const float* rays_d, const float* gt_depth /*or NULL*/, int n_rays, const double tsdf_bnds[3][2],
+                       int* key, int* val, void* stream);
+/* Is a batch in a coherent order?  Looks at up to 2048 evenly spread pairs of CONSECUTIVE rays and writes to verdict[0] how many
+ * of them have surface points further apart than `far_distance` (a few TSDF voxels), and to verdict[1] the number of pairs
+ * looked at.  verdict: two ints in device-visible memory (pinned host memory: the host reads it later without a sync). */
+int adfp_ray_order_probe(const float* rays_o, const float* rays_d, const float* gt_depth /*or NULL*/, int n_rays, float far_distance,
+                         int* verdict, void* stream);
 
 /* ---- multi-GPU render (new functionality; the reference has no distributed code): the send / receive side of ONE all-gather ----
  * A sharded render returns several per-ray arrays (depth f64, uncertainty f64, colour 3 x f32 ... = 28 B per ray).  pack writes

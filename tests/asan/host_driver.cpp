@@ -250,6 +250,14 @@ int main() {
     EXPECT_REACHES_LAUNCH(adfp_tsdf_integrate(dev<float>(5), dev<float>(1), nullptr, 61, 64, 63, origin, 0.02f, intr, c2w, nullptr, dev<float>(4), 48, 64, 0.1f, 1.f, st));   // ragged dims, no colour
     EXPECT_REACHES_LAUNCH(adfp_tsdf_integrate(dev<float>(5), dev<float>(1), dev<float>(2), 64, 64, 64, origin, 0.02f, intr, c2w, dev<float>(3), dev<float>(4), 48, 64, 0.1f, 1.f, st));
 
+    EXPECT_NEG(adfp_ray_sort_keys(dev<float>(1), nullptr, dev<float>(2), 100, bound, dev<int>(3), dev<int>(4), st));
+    { const double flat[3][2] = {{0, 1}, {2, 2}, {0, 1}}; EXPECT_NEG(adfp_ray_sort_keys(dev<float>(1), dev<float>(5), dev<float>(2), 100, flat, dev<int>(3), dev<int>(4), st)); }
+    EXPECT_REACHES_LAUNCH(adfp_ray_sort_keys(dev<float>(1), dev<float>(5), nullptr, 131072, bound, dev<int>(3), dev<int>(4), st));
+
+    EXPECT_NEG(adfp_ray_order_probe(dev<float>(1), dev<float>(5), nullptr, 1000, 0.f, dev<int>(3), st));
+    EXPECT_NEG(adfp_ray_order_probe(dev<float>(1), dev<float>(5), nullptr, 1000, 0.1f, nullptr, st));
+    EXPECT_REACHES_LAUNCH(adfp_ray_order_probe(dev<float>(1), dev<float>(5), dev<float>(2), 131072, 0.1f, dev<int>(3), st));
+
     // ---- the sharded render's gather
     const void* src[3] = {dev<void>(1), dev<void>(2), dev<void>(3)}; void* dst[3] = {dev<void>(4), dev<void>(5), dev<void>(6)};
     const int words[3] = {2, 2, 3}; const long long per[8] = {35650, 35650, 35650, 35650, 35650, 35650, 35650, 35649};

@@ -39,9 +39,24 @@ def test_1024_cubed_tsdf_128_samples_vs_oracle():
         gds.append(gd.reshape(-1)[pick])
     ro, rd, gd = torch.cat(ros), torch.cat(rds), torch.cat(gds)
     with torch.no_grad():
-        d, u, c, w = rend.render_batch_ray(sc.c, dec, rd, ro, dev, sc.tsdf_volume, tsdf_bnds, 'color', gt_depth=gd)
+        for _ in range(2):                                         # the second call of a like batch acts on the first one's verdict
+            d, u, c, w = rend.render_batch_ray(sc.c, dec, rd, ro, dev, sc.tsdf_volume, tsdf_bnds, 'color', gt_depth=gd)
+            torch.cuda.synchronize()
     assert torch.isfinite(d).all() and torch.isfinite(c).all() and torch.isfinite(u).all()
     assert 0.02 < float((w != 1).float().mean()) < 0.9          # the band is hit, and not everywhere
+    # These rays are a random subset of every pose's pixels: the renderer took the SORTED path (Renderer._coherent_order: a batch of
+    # >= 65 536 rays whose neighbours are unrelated is rendered in spatial order and handed back in the caller's).  Rays are
+    # independent units, so the values must be the unsorted render's bit for bit; a batch in pixel order is left alone.
+    assert rend._coherent_order(ro, rd, gd, sc.tsdf_volume, tsdf_bnds, wait=True) is not None
+    rend.sort_rays_min = 0
+    with torch.no_grad():
+        d0, u0, c0, w0 = rend.render_batch_ray(sc.c, dec, rd, ro, dev, sc.tsdf_volume, tsdf_bnds, 'color', gt_depth=gd)
+    rend.sort_rays_min = 65536
+    assert torch.equal(d, d0) and torch.equal(u, u0) and torch.equal(c, c0) and torch.equal(w, w0)
+    c2w = sc.default_c2w(yaw=0.7, pitch=-0.2)
+    rp, dp = get_rays(sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2w, dev)
+    assert rend._coherent_order(rp.reshape(-1, 3)[:100000].contiguous(), dp.reshape(-1, 3)[:100000].contiguous(),
+                                sc.depth_image(c2w).reshape(-1)[:100000].contiguous(), sc.tsdf_volume, tsdf_bnds, wait=True) is None
     idx = torch.arange(0, n_rays, n_rays // check, device=dev)[:check]
     idx[0] = int(torch.argmax(gd))                               # keeps the batch-global far clamp of the subset equal
     cpu = {k: v.cpu() for k, v in sc.c.items()}
