@@ -30,13 +30,14 @@ __host__ __device__ constexpr int unit16(int k) { return 16 * ((k & 7) >> 2) + 4
 // [out-block 0 | 1][hi | lo][g = 0..3][row i = 0..15][8 halves]: lane (n = i, g) reads its A operand (hi, lo) of an out-block with
 // two ds_read_b128 at word 4 l -- 64 lanes, 64 consecutive 16-byte pieces, conflict-free.  The same 4 reads per 32 inputs as the H
 // image's two k-steps.
-template <int NOUT>
+template <int CDIM, int NOUT>
 struct DecLayoutG {
-    using F = DecLayout<32, NOUT>;
+    using F = DecLayout<CDIM, NOUT>;
     static constexpr int KG_E = 3;                                    // K-groups of the 96 (93) Fourier features
+    static constexpr int KG_C = CDIM / 32;                            // K-groups of the grid features (high decoder: own grid, then the low grid)
     __host__ __device__ static constexpr int kg(int i) { return i == 0 ? KG_E : (i == 3 ? KG_E + 1 : 1); }
     static constexpr int P_BM = 0;                                    // [96 rows in K order][4] f32 = (bx, by, bz, 0)
-    __host__ __device__ static constexpr int layer_words(int i) { return kg(i) * 1024 + 32 + 1024 + 32; }
+    __host__ __device__ static constexpr int layer_words(int i) { return kg(i) * 1024 + 32 + KG_C * 1024 + 32; }
     __host__ __device__ static constexpr int P_WP(int i) {
         int o = 384;
         for (int k = 0; k < i; ++k) o += layer_words(k);
@@ -44,7 +45,7 @@ struct DecLayoutG {
     }
     __host__ __device__ static constexpr int P_BP(int i) { return P_WP(i) + kg(i) * 1024; }     // [32] f32, unit order
     __host__ __device__ static constexpr int P_WC(int i) { return P_BP(i) + 32; }
-    __host__ __device__ static constexpr int P_BC(int i) { return P_WC(i) + 1024; }
+    __host__ __device__ static constexpr int P_BC(int i) { return P_WC(i) + KG_C * 1024; }
     static constexpr int P_WO = P_WP(5);                               // [NOUT][32] f32, unit order
     static constexpr int P_BO = P_WO + NOUT * 32;
     static constexpr int P_FLAG = P_BO + 4;                            // range flags, one word per pack block (see DecLayoutH)
@@ -53,10 +54,10 @@ struct DecLayoutG {
     static_assert((P_TOTAL + 255) / 256 <= NFLAG, "one flag word per pack block");
 };
 
-template <int NOUT>
+template <int CDIM, int NOUT>
 __device__ HSrc dec_g_src(int t) {
-    using L = DecLayoutG<NOUT>;
-    using F = DecLayout<32, NOUT>;
+    using L = DecLayoutG<CDIM, NOUT>;
+    using F = DecLayout<CDIM, NOUT>;
     if (t < 384) {
         const int row = t >> 2, c = t & 3;                            // row = 32 kg + k: feature 32 kg + unit16(k)
         const int f = (row & ~31) + unit16(row & 31);
@@ -72,7 +73,7 @@ __device__ HSrc dec_g_src(int t) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 int col = 32 * grp + unit16(8 * g + jp + e);            // input unit in the layer's own numbering: [features | hidden]
-                if (fc) src[e] = F::F_FC(i) + row * 32 + col;
+                if (fc) src[e] = F::F_FC(i) + row * CDIM + col;
                 else {
                     if (i == 0) { if (col >= 93) col = -1; }
                     else if (i == 3) { if (col < 96) { if (col >= 93) col = -1; } else col = 93 + (col - 96); }
@@ -82,7 +83,7 @@ __device__ HSrc dec_g_src(int t) {
             return HSrc{1 + part, src[0], src[1]};
         }
         if (t < L::P_WC(i)) return HSrc{0, F::F_PL(i) + 32 * F::in_dim(i) + (t - L::P_BP(i)), -1};
-        if (t < L::P_BC(i) + 32) return HSrc{0, F::F_FC(i) + 32 * 32 + (t - L::P_BC(i)), -1};
+        if (t < L::P_BC(i) + 32) return HSrc{0, F::F_FC(i) + 32 * CDIM + (t - L::P_BC(i)), -1};
     }
     if (t < L::P_BO) {
         const int u = t - L::P_WO;
@@ -92,14 +93,14 @@ __device__ HSrc dec_g_src(int t) {
     return HSrc{0, o < NOUT ? F::F_OB + o : -1, -1};
 }
 
-template <int NOUT>
+template <int CDIM, int NOUT>
 __global__ void k_pack_decoder_g(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status, int bit) {
-    using L = DecLayoutG<NOUT>;
+    using L = DecLayoutG<CDIM, NOUT>;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     HSrc s{0, -1, -1};
     float a = 0.f, b = 0.f;
     if (t < L::P_FLAG) {
-        s = dec_g_src<NOUT>(t);
+        s = dec_g_src<CDIM, NOUT>(t);
         a = s.s0 < 0 ? 0.f : flat[s.s0]; b = s.s1 < 0 ? 0.f : flat[s.s1];
     }
     pack_block_flag(!(fmaxf(fabsf(a), fabsf(b)) < 65504.0f), packed + L::P_FLAG + blockIdx.x, status, bit);
@@ -143,28 +144,29 @@ ADFP_DEV void mfma_chain_g(f32x4g acc[2][2], const unsigned* __restrict__ w, con
 
 // One network on a tile.  pn: the lane's FRONT point, normalised (gather); pf[pb]: the positions of the lane's two points (Fourier
 // features); out[pb][o]: the network's outputs for point 16 pb + n, valid on every lane.
-template <int NOUT>
-ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& grid, const float pn[3], const float (*pf)[3], int lane,
-                           float& amax, float (*out)[NOUT]) {
-    using L = DecLayoutG<NOUT>;
+template <int CDIM, int NOUT>
+ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& grid, const GridDev& grid1, const float pn[3], const float (*pf)[3],
+                           int lane, float& amax, float (*out)[NOUT]) {
+    using L = DecLayoutG<CDIM, NOUT>;
     const int g = lane >> 4;
     // every LDS access below is one of three lane-dependent bases plus an immediate: the weight rows (4 l), the unit-order rows
     // (biases, output layer: 4 g) and the Fourier rows (32 g)
     const unsigned* wl = ldsu + 4 * lane;
     const float* b4 = (const float*)ldsu + 4 * g;
     const float* brow = (const float*)ldsu + 32 * g;
-    f16x8 ch[1][2], cl[1][2];
-    {
+    f16x8 ch[L::KG_C][2], cl[L::KG_C][2];
+#pragma unroll
+    for (int kc = 0; kc < L::KG_C; ++kc) {          // high decoder: K-group 0 = its own grid, K-group 1 = the low grid (decoder.py:182-187)
         float c[16];
-        gather16(grid, pn, g & 1, c);               // c[r] <-> channel kmapH(r, g & 1) of the front point: pieces g&1, +2, +4, +6 of the voxel line
+        gather16(kc == 0 ? grid : grid1, pn, g & 1, c);   // c[r] <-> channel kmapH(r, g & 1) of the front point: pieces g&1, +2, +4, +6 of the voxel line
         // lower lanes (block 0) keep K-group g = c[0..3], c[8..11] and give K-group g + 2 = c[4..7], c[12..15]; upper lanes (block 1,
         // g = 2, 3) keep c[4..7], c[12..15] and give c[0..3], c[8..11]: swap_halves(x, y) moves x.upper <-> y.lower
         float x[8] = {c[0], c[1], c[2], c[3], c[8], c[9], c[10], c[11]};
         float y[8] = {c[4], c[5], c[6], c[7], c[12], c[13], c[14], c[15]};
 #pragma unroll
         for (int s = 0; s < 8; ++s) swap_halves(x[s], y[s]);
-        split8(x, ch[0][0], cl[0][0], amax);        // block 0: channels unit16(8 g + j)
-        split8(y, ch[0][1], cl[0][1], amax);        // block 1
+        split8(x, ch[kc][0], cl[kc][0], amax);      // block 0: channels unit16(8 g + j)
+        split8(y, ch[kc][1], cl[kc][1], amax);      // block 1
     }
     f16x8 eh[L::KG_E][2], el[L::KG_E][2];
 #pragma unroll
@@ -199,7 +201,7 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[ob][pb][r] = relu_f(acc[ob][pb][r]) + t[r];
         }
-        mfma_chain_g<1>(acc, wl + L::P_WC(i), ch, cl);
+        mfma_chain_g<L::KG_C>(acc, wl + L::P_WC(i), ch, cl);
         if (i < 4) {
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb) {
@@ -231,8 +233,8 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
 // DecodeLCArgs is k_decode_lc's; packed_low / packed_color point at the G images
 template <int NT>
 __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16(DecodeLCArgs a) {
-    using LL = DecLayoutG<1>;
-    using LC = DecLayoutG<4>;
+    using LL = DecLayoutG<32, 1>;
+    using LC = DecLayoutG<32, 4>;
     __shared__ __attribute__((aligned(16))) unsigned lds_all[LL::P_TOTAL + LC::P_TOTAL];      // the low image, then the colour image
     __shared__ int s_next;
     unsigned* lds_low = lds_all;
@@ -270,10 +272,10 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16(DecodeLCArgs a) {
         float occ[2][1], rgb[2][4];
         int off_low = 0, off_col = LL::P_TOTAL;        // word offsets of the two images, opaque and per tile (see k_decode_lc)
         asm volatile("" : "+v"(off_low), "+v"(off_col));
-        decode_net_g<1>(lds_all + off_low, a.g_low, pn, pf, lane, amax_low, occ);
+        decode_net_g<32, 1>(lds_all + off_low, a.g_low, a.g_low, pn, pf, lane, amax_low, occ);
         asm volatile("" : "+v"(pn[0]), "+v"(pn[1]), "+v"(pn[2]), "+v"(occ[0][0]), "+v"(occ[1][0]));
         __builtin_amdgcn_sched_barrier(0);
-        decode_net_g<4>(lds_all + off_col, a.g_color, pn, pf, lane, amax_col, rgb);
+        decode_net_g<32, 4>(lds_all + off_col, a.g_color, a.g_color, pn, pf, lane, amax_col, rgb);
         // the front point's lane with g & 1 == 0 stores its row: lanes 0-15 block 0, lanes 32-47 block 1
         if (valid && (g & 1) == 0) {
             const int pb = g >> 1;
@@ -286,4 +288,226 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16(DecodeLCArgs a) {
     }
     report_range(a.status, amax_low, ADFP_STATUS_F16_RANGE_LOW, a.call_flag);
     report_range(a.status, amax_col, ADFP_STATUS_F16_RANGE_COLOR, a.call_flag);
+}
+
+// =============================================================================================
+// The HIGH decoder on the in-band list (inference) in the G layout: DecodeArgs is k_decode_h's, a.packed points at the G image.
+// A tile is 32 consecutive LIST entries; the front point of a lane is entry 16 (g >> 1) + n of its tile.
+// =============================================================================================
+template <int NT>
+__global__ __launch_bounds__(NT, NT / 256) void k_decode_high_g(DecodeArgs a) {
+    using L = DecLayoutG<64, 1>;
+    __shared__ __attribute__((aligned(16))) unsigned ldsu[L::P_TOTAL];
+    __shared__ int s_next;
+    for (int i = threadIdx.x; i < L::P_TOTAL / 4; i += NT) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed)[i];
+    if (threadIdx.x == 0) s_next = NT / 64;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int count = *a.count_ptr;
+    const int ntiles = (count + 31) >> 5;
+    float amax = image_out_of_range<L::P_FLAG, L::NFLAG>(ldsu) ? INFINITY : 0.f;
+    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<NT / 64>(j, &s_next, ntiles)) >= 0;) {
+        const int idx = tile * 32 + 16 * (g >> 1) + n;
+        const bool valid = idx < count;
+        const int q = a.list[valid ? idx : 0];
+        float pn[3], pf[2][3];
+        bool pnan;
+        {
+            double pt[3];
+            load_point(a.P, q, pt);
+            normalize3(a.nb, pt, pn);
+            const float f0 = (float)pt[0], f1 = (float)pt[1], f2 = (float)pt[2];
+            pnan = (pt[0] != pt[0]) | (pt[1] != pt[1]) | (pt[2] != pt[2]);
+            pf[0][0] = f0; pf[0][1] = f1; pf[0][2] = f2; pf[1][0] = f0; pf[1][1] = f1; pf[1][2] = f2;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) swap_halves(pf[0][k], pf[1][k]);
+        float out[2][1];
+        decode_net_g<64, 1>(ldsu, a.g0, a.g1, pn, pf, lane, amax, out);
+        if (valid && (g & 1) == 0) {
+            const float o = g >> 1 ? out[1][0] : out[0][0];
+            const float v = pnan ? __builtin_nanf("") : o;
+            a.att_occ[idx] = a.single ? v : v + a.raw[4ll * q + 3];    // high + low, decoder.py:342
+        }
+    }
+    report_range(a.status, amax, ADFP_STATUS_F16_RANGE_HIGH, a.call_flag);
+}
+
+// =============================================================================================
+// attention fusion mlp_tsdf (a11), inference, in the G layout: 2 -> 64 -> 128 -> 128 -> 64 -> 2, softmax, convex blend.
+// A layer's 32-unit out-blocks are the next layer's K = 32 groups (unit 32 b + unit16(8 g + j) in K-slot j of group b).
+// =============================================================================================
+struct AttLayoutG {
+    using F = AttLayout;
+    static constexpr int P_A0 = 0;                               // [64 rows in K order][4] f32 = (w0, w1, b, 0)
+    static constexpr int P_W1 = 256;                             // 4 out-blocks x 2 K-groups
+    static constexpr int P_B1 = P_W1 + 4 * 2 * 1024;             // [128] f32, unit order
+    static constexpr int P_W2 = P_B1 + 128;                      // 4 out-blocks x 4 K-groups
+    static constexpr int P_B2 = P_W2 + 4 * 4 * 1024;
+    static constexpr int P_W3 = P_B2 + 128;                      // 2 out-blocks x 4 K-groups
+    static constexpr int P_B3 = P_W3 + 2 * 4 * 1024;
+    static constexpr int P_WO = P_B3 + 64;                       // [2 outputs][64] f32, unit order
+    static constexpr int P_BO = P_WO + 128;
+    static constexpr int P_FLAG = P_BO + 4;
+    static constexpr int NFLAG = (((P_FLAG + 511) / 256) + 3) & ~3;
+    static constexpr int P_TOTAL = P_FLAG + NFLAG;
+    static_assert((P_TOTAL + 255) / 256 <= NFLAG, "one flag word per pack block");
+};
+
+__device__ HSrc att_g_src(int t) {
+    using L = AttLayoutG;
+    using F = AttLayout;
+    if (t < L::P_W1) {
+        const int row = t >> 2, c = t & 3;                       // row = 32 b + k: unit 32 b + unit16(k)
+        const int u = (row & ~31) + unit16(row & 31);
+        return HSrc{0, c < 2 ? F::F_W0 + u * 2 + c : (c == 2 ? F::F_B0 + u : -1), -1};
+    }
+    auto chain = [](int u, int ngrp, int base, int ld) {
+        const int blk = u / (ngrp * 1024), v = u % (ngrp * 1024);
+        const int grp = v >> 10, ob = (v >> 9) & 1, part = (v >> 8) & 1, g = (v >> 6) & 3, row = 32 * blk + 16 * ob + ((v >> 2) & 15), jp = (v & 3) * 2;
+        return HSrc{1 + part, base + row * ld + 32 * grp + unit16(8 * g + jp), base + row * ld + 32 * grp + unit16(8 * g + jp + 1)};
+    };
+    if (t < L::P_B1) return chain(t - L::P_W1, 2, F::F_W1, 64);
+    if (t < L::P_W2) return HSrc{0, F::F_B1 + (t - L::P_B1), -1};
+    if (t < L::P_B2) return chain(t - L::P_W2, 4, F::F_W2, 128);
+    if (t < L::P_W3) return HSrc{0, F::F_B2 + (t - L::P_B2), -1};
+    if (t < L::P_B3) return chain(t - L::P_W3, 4, F::F_W3, 128);
+    if (t < L::P_WO) return HSrc{0, F::F_B3 + (t - L::P_B3), -1};
+    if (t < L::P_BO) return HSrc{0, F::F_WO + (t - L::P_WO), -1};
+    const int o = t - L::P_BO;
+    return HSrc{0, o < 2 ? F::F_BO + o : -1, -1};
+}
+
+__global__ void k_pack_attention_g(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status) {
+    using L = AttLayoutG;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    HSrc s{0, -1, -1};
+    float a = 0.f, b = 0.f;
+    if (t < L::P_FLAG) {
+        s = att_g_src(t);
+        a = s.s0 < 0 ? 0.f : flat[s.s0]; b = s.s1 < 0 ? 0.f : flat[s.s1];
+    }
+    pack_block_flag(!(fmaxf(fabsf(a), fabsf(b)) < 65504.0f), packed + L::P_FLAG + blockIdx.x, status, ADFP_STATUS_F16_RANGE_ATT);
+    if (t >= L::P_FLAG) return;
+    if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(a); return; }
+    a = f16_clamp(a); b = f16_clamp(b);
+    const float ah = f16_hi_part(a), bh = f16_hi_part(b);
+    _Float16 x, y;
+    if (s.kind == 1) { x = (_Float16)ah; y = (_Float16)bh; }
+    else { x = (_Float16)(a - ah); y = (_Float16)(b - bh); }
+    packed[t] = (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+
+// AttArgs is k_attention_h's; a.packed points at the G image
+template <int NT>
+__global__ __launch_bounds__(NT) void k_attention_g(AttArgs a) {
+    using A = AttLayoutG;
+    __shared__ __attribute__((aligned(16))) unsigned ldsu[A::P_TOTAL];
+    __shared__ int s_next;
+    for (int i = threadIdx.x; i < A::P_TOTAL / 4; i += NT) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed)[i];
+    if (threadIdx.x == 0) s_next = NT / 64;
+    __syncthreads();
+    const float* lds = (const float*)ldsu;
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const unsigned* wl = ldsu + 4 * lane;
+    const float* b4 = lds + 4 * g;
+    const float* arow = lds + 32 * g;
+    const int count = a.count_ptr ? *a.count_ptr : a.n_rows;
+    const int ntiles = (count + 31) >> 5;
+    float amax = image_out_of_range<A::P_FLAG, A::NFLAG>(ldsu) ? INFINITY : 0.f;
+    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<NT / 64>(j, &s_next, ntiles)) >= 0;) {
+        int idx[2]; bool valid[2]; float occ[2], u[2];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            idx[pb] = tile * 32 + 16 * pb + n;
+            valid[pb] = idx[pb] < count;
+            const int ii = valid[pb] ? idx[pb] : 0;
+            occ[pb] = a.att_occ[ii]; u[pb] = a.att_u[ii];
+        }
+        // layer 0 (2 -> 64) on the VALU: the lane's 8 units of each of the two K-groups, for both its rows
+        f16x8 xh[4][2], xl[4][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float t0[8], t1[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const f32x4 t = *(const f32x4*)(arow + A::P_A0 + (32 * b + k) * 4);            // row 32 b + 8 g + k
+                t0[k] = relu_f(fmaf(u[0], t.y, fmaf(occ[0], t.x, t.z)));
+                t1[k] = relu_f(fmaf(u[1], t.y, fmaf(occ[1], t.x, t.z)));
+            }
+            split8(t0, xh[b][0], xl[b][0], amax);
+            split8(t1, xh[b][1], xl[b][1], amax);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // layer 1: 64 -> 128
+        f16x8 yh[4][2], yl[4][2];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            f32x4g acc[2][2];
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) { const f32x4 t = *(const f32x4*)(b4 + A::P_B1 + 32 * blk + 16 * ob); acc[ob][0] = t; acc[ob][1] = t; }
+            mfma_chain_g<2>(acc, wl + A::P_W1 + blk * 2 * 1024, xh, xl);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const float t[8] = {relu_f(acc[0][pb][0]), relu_f(acc[0][pb][1]), relu_f(acc[0][pb][2]), relu_f(acc[0][pb][3]),
+                                    relu_f(acc[1][pb][0]), relu_f(acc[1][pb][1]), relu_f(acc[1][pb][2]), relu_f(acc[1][pb][3])};
+                split8(t, yh[blk][pb], yl[blk][pb], amax);
+            }
+        }
+        // layer 2: 128 -> 128
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            f32x4g acc[2][2];
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) { const f32x4 t = *(const f32x4*)(b4 + A::P_B2 + 32 * blk + 16 * ob); acc[ob][0] = t; acc[ob][1] = t; }
+            mfma_chain_g<4>(acc, wl + A::P_W2 + blk * 4 * 1024, yh, yl);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const float t[8] = {relu_f(acc[0][pb][0]), relu_f(acc[0][pb][1]), relu_f(acc[0][pb][2]), relu_f(acc[0][pb][3]),
+                                    relu_f(acc[1][pb][0]), relu_f(acc[1][pb][1]), relu_f(acc[1][pb][2]), relu_f(acc[1][pb][3])};
+                split8(t, xh[blk][pb], xl[blk][pb], amax);
+            }
+        }
+        // layer 3: 128 -> 64, output 64 -> 2 on the VALU in f32
+        float l0[2] = {0.f, 0.f}, l1[2] = {0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            f32x4g acc[2][2];
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) { const f32x4 t = *(const f32x4*)(b4 + A::P_B3 + 32 * blk + 16 * ob); acc[ob][0] = t; acc[ob][1] = t; }
+            mfma_chain_g<4>(acc, wl + A::P_W3 + blk * 4 * 1024, xh, xl);
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+                const f32x4 w0 = *(const f32x4*)(b4 + A::P_WO + 32 * blk + 16 * ob), w1 = *(const f32x4*)(b4 + A::P_WO + 64 + 32 * blk + 16 * ob);
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = relu_f(acc[ob][pb][r]);
+                        l0[pb] = fmaf(v, w0[r], l0[pb]);
+                        l1[pb] = fmaf(v, w1[r], l1[pb]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            l0[pb] += __shfl_xor(l0[pb], 16); l0[pb] += __shfl_xor(l0[pb], 32);
+            l1[pb] += __shfl_xor(l1[pb], 16); l1[pb] += __shfl_xor(l1[pb], 32);
+        }
+        // softmax over 2, convex blend (decoder.py:255-258): lanes g = 0 finish block 0's row, lanes g = 1 block 1's
+        if (g < 2 && valid[g]) {
+            const float a0l = l0[g] + lds[A::P_BO], a1l = l1[g] + lds[A::P_BO + 1];
+            const float m = fmaxf(a0l, a1l);
+            const float e0 = expf(a0l - m), e1 = expf(a1l - m);
+            const float den = e0 + e1;
+            const float a0 = e0 / den, a1 = e1 / den;
+            const float fused = a0 * occ[g] + a1 * u[g];
+            const int ii = idx[g];
+            const int q = a.list ? a.list[ii] : ii;              // list == NULL: mlp_tsdf.forward on explicit (occ, u) rows
+            const bool inb = !a.flags || (a.flags[q] & ADFP_F_INBOUND) != 0;
+            a.raw[4ll * q + 3] = (inb || !a.apply_bound) ? fused : 100.f;   // Renderer.py:64
+            a.w[q] = a1;
+        }
+    }
+    report_range(a.status, amax, ADFP_STATUS_F16_RANGE_ATT, a.call_flag);
 }

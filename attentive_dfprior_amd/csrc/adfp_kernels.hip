@@ -1161,9 +1161,9 @@ int adfp_pack_decoder(int kind, const float* flat, float* packed, void* stream) 
 // the single-network kernels) and the "G" image (16x16x32 operand order, adfp_decode_g.h: the fused low + colour inference launch).
 long long adfp_decoder_packed_h_words(int kind) {
     switch (kind) {
-        case ADFP_DEC_LOW: return DecLayoutH<32, 1>::P_TOTAL + DecLayoutG<1>::P_TOTAL;
-        case ADFP_DEC_HIGH: return DecLayoutH<64, 1>::P_TOTAL;
-        case ADFP_DEC_COLOR: return DecLayoutH<32, 4>::P_TOTAL + DecLayoutG<4>::P_TOTAL;
+        case ADFP_DEC_LOW: return DecLayoutH<32, 1>::P_TOTAL + DecLayoutG<32, 1>::P_TOTAL;
+        case ADFP_DEC_HIGH: return DecLayoutH<64, 1>::P_TOTAL + DecLayoutG<64, 1>::P_TOTAL;
+        case ADFP_DEC_COLOR: return DecLayoutH<32, 4>::P_TOTAL + DecLayoutG<32, 4>::P_TOTAL;
     }
     return ADFP_E_ARG;
 }
@@ -1174,14 +1174,15 @@ int adfp_pack_decoder_h(int kind, const float* flat, void* packed, int* status, 
     switch (kind) {
         case ADFP_DEC_LOW:
             hipLaunchKernelGGL((k_pack_decoder_h<32, 1>), dim3(DecLayoutH<32, 1>::NFLAG), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_LOW);
-            hipLaunchKernelGGL((k_pack_decoder_g<1>), dim3(DecLayoutG<1>::NFLAG), dim3(256), 0, st, flat, out + DecLayoutH<32, 1>::P_TOTAL, status, ADFP_STATUS_F16_RANGE_LOW);
+            hipLaunchKernelGGL((k_pack_decoder_g<32, 1>), dim3(DecLayoutG<32, 1>::NFLAG), dim3(256), 0, st, flat, out + DecLayoutH<32, 1>::P_TOTAL, status, ADFP_STATUS_F16_RANGE_LOW);
             break;
         case ADFP_DEC_HIGH:
             hipLaunchKernelGGL((k_pack_decoder_h<64, 1>), dim3(DecLayoutH<64, 1>::NFLAG), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_HIGH);
+            hipLaunchKernelGGL((k_pack_decoder_g<64, 1>), dim3(DecLayoutG<64, 1>::NFLAG), dim3(256), 0, st, flat, out + DecLayoutH<64, 1>::P_TOTAL, status, ADFP_STATUS_F16_RANGE_HIGH);
             break;
         case ADFP_DEC_COLOR:
             hipLaunchKernelGGL((k_pack_decoder_h<32, 4>), dim3(DecLayoutH<32, 4>::NFLAG), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_COLOR);
-            hipLaunchKernelGGL((k_pack_decoder_g<4>), dim3(DecLayoutG<4>::NFLAG), dim3(256), 0, st, flat, out + DecLayoutH<32, 4>::P_TOTAL, status, ADFP_STATUS_F16_RANGE_COLOR);
+            hipLaunchKernelGGL((k_pack_decoder_g<32, 4>), dim3(DecLayoutG<32, 4>::NFLAG), dim3(256), 0, st, flat, out + DecLayoutH<32, 4>::P_TOTAL, status, ADFP_STATUS_F16_RANGE_COLOR);
             break;
         default: return ADFP_E_ARG;
     }
@@ -1222,10 +1223,11 @@ long long adfp_train_act_floats(int kind) {
     }
     return ADFP_E_ARG;
 }
-long long adfp_attention_packed_h_words(void) { return AttLayoutH::P_TOTAL; }
+long long adfp_attention_packed_h_words(void) { return AttLayoutH::P_TOTAL + AttLayoutG::P_TOTAL; }      // H image, then G image (see adfp_decoder_packed_h_words)
 int adfp_pack_attention_h(const float* flat, void* packed, int* status, void* stream) {
     if (!flat || !packed) return ADFP_E_ARG;
     hipLaunchKernelGGL(k_pack_attention_h, dim3(AttLayoutH::NFLAG), dim3(256), 0, (hipStream_t)stream, flat, (unsigned*)packed, status);
+    hipLaunchKernelGGL(k_pack_attention_g, dim3(AttLayoutG::NFLAG), dim3(256), 0, (hipStream_t)stream, flat, (unsigned*)packed + AttLayoutH::P_TOTAL, status);
     ADFP_CHECK_LAUNCH();
     return 0;
 }
@@ -1465,8 +1467,13 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
             else hipLaunchKernelGGL((k_decode_h<64, 1, ROLE_HIGH, 512, 1>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
             a.masks = nullptr; a.act = nullptr;
         } else if (sc->h_high) {
+#ifdef ADFP_LC_32X32
             a.packed = (const float*)sc->h_high;
             hipLaunchKernelGGL((k_decode_h<64, 1, ROLE_HIGH, ADFP_HIGH_NT>), dim3(decode_grid(ntiles, ADFP_HIGH_NT / 64, 1)), dim3(ADFP_HIGH_NT), 0, st, a);
+#else
+            a.packed = (const float*)((const unsigned*)sc->h_high + DecLayoutH<64, 1>::P_TOTAL);          // the G image
+            hipLaunchKernelGGL((k_decode_high_g<ADFP_HIGH_NT>), dim3(decode_grid(ntiles, ADFP_HIGH_NT / 64, 1)), dim3(ADFP_HIGH_NT), 0, st, a);
+#endif
         } else {
             a.packed = sc->w_high;
             hipLaunchKernelGGL((k_decode<64, 1, ROLE_HIGH, 512>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
@@ -1480,8 +1487,13 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
             t.packed = (const float*)sc->h_att; t.masks = state->masks_att; t.act = state->act_att;
             hipLaunchKernelGGL((k_attention_h<1, 256>), dim3(decode_grid(ntiles, 4, 1)), dim3(256), 0, st, t);
         } else if (sc->h_att) {
+#ifdef ADFP_LC_32X32
             t.packed = (const float*)sc->h_att;
             hipLaunchKernelGGL(k_attention_h<0>, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
+#else
+            t.packed = (const float*)((const unsigned*)sc->h_att + AttLayoutH::P_TOTAL);                 // the G image
+            hipLaunchKernelGGL(k_attention_g<512>, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
+#endif
         } else {
             t.packed = sc->w_att;
             hipLaunchKernelGGL(k_attention, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);

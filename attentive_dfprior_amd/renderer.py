@@ -179,6 +179,18 @@ class Renderer(object):
             _lib.check(L.adfp_sort_pairs(_lib.ptr(key), _lib.ptr(val), _lib.ptr(kt), _lib.ptr(vt), N, 30, _lib.ptr(ws), nb, st), 'adfp_sort_pairs')
         return val.long()
 
+    def _fits_in_one_call(self, n, S, dev):
+        """ray_batch_size exists in the reference to BOUND memory (Renderer.py:294-313).  The one-call frame needs the forward
+        workspace for all n x S samples at once (~37 B per sample x 1.25) plus the [n, S] attention-weight output; it is taken
+        only when that fits in half of what the device has free (or the engine's workspace is that large already) -- otherwise
+        the frame is rendered batch by batch like the reference's."""
+        need_ws = int(_lib.lib().adfp_workspace_bytes(n * S))
+        ws = self._engine._ws
+        have = ws.numel() if ws is not None and ws.device == dev else 0
+        extra = (int(need_ws * 1.25) if have < need_ws else 0) + n * (4 * S + 28)
+        free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        return extra <= free // 2
+
     def render_img(self, c, decoders, c2w, device, tsdf_volume, tsdf_bnds, stage, gt_depth=None):
         """Full-frame render under no_grad in ``ray_batch_size`` batches -> depth [H,W] f64,
         uncertainty [H,W] f64, color [H,W,3] f32.  Each batch clamps ``far`` with ITS OWN max

@@ -189,7 +189,7 @@ def test_tracker_loss_edge_cases():
     assert ref.item() == 0 and loss.item() == 0 and not g_d.any()
     la = _lib.AdfpTrackLossArgs()
     la.n_rays = 8193
-    la.depth = la.uncertainty = la.color = la.gt_depth = la.gt_color = la.g_depth = la.g_color = 8
+    la.depth = la.uncertainty = la.color = la.gt_depth = la.gt_color = la.g_depth = la.g_color = la.loss = 8
     assert lib().adfp_tracker_loss(C.byref(la), stream()) == -2
 
 
