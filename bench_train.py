@@ -89,7 +89,27 @@ def main():
                     itf.step(ro, rd, gd, gc, 'color')
                 torch.cuda.synchronize()
                 res[mode] = (time.perf_counter() - t0) / args.iters * 1e3
+            # the floor the CALLER's own torch code sets (tools/host_breakdown.py: render_batch_ray replaced by an allocation-only stub wired
+            # into autograd like the real function): zero_grad, the loss ops with their boolean-index syncs, one AccumulateGrad per
+            # parameter, torch.optim.Adam over the same 36 tensors -- what an unchanged Mapper.py pays whatever the renderer costs
+            import os, sys
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
+            from host_breakdown import stub_render_batch_ray
+            real = rend.render_batch_ray
+            rend.render_batch_ray = stub_render_batch_ray(rend, dec)
+            try:
+                for _ in range(5):
+                    it()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.iters):
+                    it()
+                torch.cuda.synchronize()
+                floor = (time.perf_counter() - t0) / args.iters
+            finally:
+                rend.render_batch_ray = real
             print(json.dumps({'metric': 'mapper iteration (render fwd + loss + bwd + Adam), stage color', 'rays': n_rays,
+                              'ms_per_iter_torch_floor': floor * 1e3, 'ms_per_iter_above_floor': (dt - floor) * 1e3,
                               'samples_per_ray': ns + nf, 'ms_per_iter': dt * 1e3, 'rays_per_s_fwd_bwd': n_rays / dt,
                               'ms_forward_only': df * 1e3, 'loss': float(loss),
                               'ms_per_iter_fused_eager': res['fused_eager'], 'ms_per_iter_fused_graph': res['fused_graph']}))
