@@ -103,3 +103,29 @@ int main(void) {
     G, T = _lib.AdfpAdamGroup, _lib.AdfpTrainState
     assert list(map(int, out[6].split())) == [ctypes.sizeof(G), G.mask.offset, G.channels.offset, G.derived.offset, S.ht_low.offset,
                                               T.masks_low.offset, T.act_color.offset]
+
+
+def test_reference_fusion_kernel_builds_as_a_checker():
+    """oracle/_ref: the reference's CUDA C kernel string (src/fusion.py:69-142) compiled by hipcc from where it lies, in the
+    as-written and the contracted variant; both export the launcher tests/test_gpu_fusion.py calls on the GPU box."""
+    import ctypes
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists('/root/reference/src/fusion.py'):
+        pytest.skip('/root/reference is not present (GPU box): the prebuilt oracle/_ref files are used as they are')
+    sys.path.insert(0, os.path.join(root, 'oracle'))
+    try:
+        import build_ref_fusion
+        assert 'SourceModule' not in build_ref_fusion.kernel_string() and '__global__ void integrate' in build_ref_fusion.kernel_string()
+        assert build_ref_fusion.build()
+    finally:
+        sys.path.pop(0)
+    for name in ('libref_fusion_exact.so', 'libref_fusion_contract.so'):
+        lib = ctypes.CDLL(os.path.join(root, 'oracle', '_ref', name))
+        assert hasattr(lib, 'ref_fusion_integrate')
+    # nothing of the reference's text is kept in the repository
+    for dirpath, _, files in os.walk(os.path.join(root, 'oracle')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.cu', '.txt')):
+                assert 'float voxel_x = floorf' not in open(os.path.join(dirpath, f), errors='ignore').read(), f

@@ -1,9 +1,12 @@
-"""GPU: TSDF fusion kernel.  PARITY UNPINNED, stated: the reference's fusion needs pycuda + a CUDA
-device (its CPU path numba) and cannot run in the build container, and the reference ships no vectors for it.  Two checks stand
-in: (1) bit for bit against the numpy restatement of the reference's kernel string (oracle.tsdf_integrate_np, float32 operation by
-operation, including the float index decomposition); (2) against an INDEPENDENT float64 fusion written from the method, not from
-the kernel (integer lattice coordinates, float64 projection): away from pixel-rounding ties and the truncation edge the two must
-agree to float32 rounding."""
+"""GPU: TSDF fusion kernel.  PINNED since round 4 against the REFERENCE'S OWN KERNEL: the CUDA C string
+of src/fusion.py:69-142 is plain CUDA C; oracle/build_ref_fusion.py compiles it with hipcc from where it lies under /root/reference
+into oracle/_ref/ (twice: -ffp-contract=off = every operation rounded as written, and the compiler's default contraction like
+nvcc's -fmad under PyCUDA) and test_integrate_matches_the_reference_kernel runs it on the MI355X beside adfp_tsdf_integrate, with
+the launch geometry of src/fusion.py:146-154 / :226-251 -- bit for bit against the as-written build, float32 rounding against the
+contracted one; the numpy restatement (oracle.tsdf_integrate_np) is held to the same kernel there.  Two further checks: (1) bit
+for bit against that numpy restatement; (2) against an INDEPENDENT float64 fusion written from the method, not from the kernel
+(integer lattice coordinates, float64 projection): away from pixel-rounding ties and the truncation edge the two must agree to
+float32 rounding."""
 import numpy as np
 import pytest
 import torch
@@ -49,6 +52,77 @@ def test_integrate_matches_cuda_kernel_restatement(voxel):
     assert not bad.any(), (int(bad.sum()), float(np.abs(gt - t).max()), gt[bad][:5], t[bad][:5], w[bad][:5])
     assert np.array_equal(gc, c)
     assert gt.min() >= -1.0 and gt.max() <= 1.0
+
+
+def _ref_lib(name):
+    import ctypes as C
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', '_ref', name)
+    if not os.path.exists(path):
+        pytest.skip(f'{path} has not been built (oracle/build_ref_fusion.py needs /root/reference)')
+    lib = C.CDLL(path)
+    lib.ref_fusion_integrate.restype = C.c_int
+    lib.ref_fusion_integrate.argtypes = [C.c_void_p] * 10 + [C.c_int] * 5 + [C.c_void_p]
+    return lib
+
+
+def _reference_launch_geometry(n_vox, threads=1024, max_grid=(2147483647, 65535, 65535)):
+    """src/fusion.py:146-154 (gpu_dev.MAX_THREADS_PER_BLOCK = 1024; MAX_GRID_DIM_* as HIP reports them for gfx950)"""
+    n_blocks = int(np.ceil(float(n_vox) / float(threads)))
+    gx = min(max_grid[0], int(np.floor(np.cbrt(n_blocks))))
+    gy = min(max_grid[1], int(np.floor(np.sqrt(n_blocks / gx))))
+    gz = min(max_grid[2], int(np.ceil(float(n_blocks) / float(gx * gy))))
+    loops = int(np.ceil(float(n_vox) / float(gx * gy * gz * threads)))
+    return gx, gy, gz, loops
+
+
+@pytest.mark.parametrize('voxel', [0.04, 0.0062])       # 40x40x32 and 259x259x207 = 13.9 M voxels (> 2^23: the float index decomposition rounds)
+def test_integrate_matches_the_reference_kernel(voxel):
+    """adfp_tsdf_integrate (and the numpy restatement) against the reference's CUDA kernel string compiled by hipcc and launched
+    like PyCUDA launches it: three frames into one volume; tsdf, weight and packed-colour volumes bit for bit."""
+    from attentive_dfprior_amd import _lib
+    exact, contract = _ref_lib('libref_fusion_exact.so'), _ref_lib('libref_fusion_contract.so')
+    sc = synthetic.mini_scene(device=DEV)
+    vol = TSDFVolume(sc.bound.numpy(), voxel, device=DEV)
+    dims = tuple(int(v) for v in vol._vol_dim)
+    n = int(np.prod(dims))
+    gx, gy, gz, loops = _reference_launch_geometry(n)
+
+    def fresh():      # + 1 element: the reference's bound check is `voxel_idx > N`, so thread N writes one element past the volume
+        t = torch.full((n + 1,), -1.0, device=DEV)
+        return t, torch.zeros(n + 1, device=DEV), torch.zeros(n + 1, device=DEV)
+    state = {'exact': fresh(), 'contract': fresh()}
+    t_np = np.full(dims, -1.0, np.float32)
+    w_np, c_np = np.zeros_like(t_np), np.zeros_like(t_np)
+    st = _lib.current_stream(torch.device(DEV))
+    for color, depth, K, pose in frames(sc, 3):
+        vol.integrate(color, depth, K, pose, obs_weight=1.0)
+        packed = np.floor(color[..., 2].astype(np.float32) * 65536 + color[..., 1].astype(np.float32) * 256 + color[..., 0].astype(np.float32))
+        t_np, w_np, c_np = O.tsdf_integrate_np(t_np, w_np, c_np, vol._vol_origin, vol._voxel_size, K, pose, packed, depth, vol._trunc_margin, 1.0)
+        im_h, im_w = depth.shape
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32).reshape(-1)).to(DEV)            # noqa: E731
+        args = [dev(vol._vol_dim.astype(np.float32)), dev(vol._vol_origin), dev(K), dev(pose),
+                dev(np.array([[k, vol._voxel_size, im_h, im_w, vol._trunc_margin, 1.0] for k in range(loops)], np.float32)), dev(packed), dev(depth)]
+        for name, lib in (('exact', exact), ('contract', contract)):
+            t, w, c = state[name]
+            rc = lib.ref_fusion_integrate(t.data_ptr(), w.data_ptr(), c.data_ptr(), *[a.data_ptr() for a in args], loops, gx, gy, gz, 1024, st)
+            assert rc == 0
+        torch.cuda.synchronize()
+    ours_t, ours_c, _ = vol.get_volume()
+    ours_w = vol._weight.cpu().numpy()
+    rt, rw, rc_ = (x[:n].cpu().numpy().reshape(dims) for x in state['exact'])
+    assert (rw > 0).mean() > 0.05
+    # as written (no contraction): the product kernel and the numpy restatement ARE the reference's arithmetic
+    assert np.array_equal(ours_w, rw) and np.array_equal(ours_t, rt) and np.array_equal(ours_c, rc_)
+    assert np.array_equal(w_np, rw) and np.array_equal(t_np, rt) and np.array_equal(c_np, rc_)
+    # with the compiler free to contract mul + add into fma (what nvcc does under PyCUDA by default): the projection moves by an
+    # ulp, so a voxel whose pixel centre or truncation edge sits on a rounding tie may take the other branch; everywhere else the
+    # two agree to float32 rounding
+    ct, cw, cc = (x[:n].cpu().numpy().reshape(dims) for x in state['contract'])
+    same = cw == rw
+    assert same.mean() > 0.999, same.mean()
+    assert np.abs(ct[same] - rt[same]).max() <= 2e-5          # one ulp of the camera-space depth (~2.4e-7 at 3 m) over the truncation margin (0.031 m)
+    assert (cc[same] == rc_[same]).mean() > 0.999
 
 
 def fuse_f64(tsdf, weight, origin, voxel, K, pose, depth, trunc, obs_w=1.0):
