@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ADFP_LIB_PATH', os.path.join(_HERE, 'libadfp.so'))   # override: kernel A/B builds
 
-ABI_VERSION = 123                 # ADFP_VERSION of include/adfp.h this binding was written against
+ABI_VERSION = 124                 # ADFP_VERSION of include/adfp.h this binding was written against
 STATUS_F16_RANGE = 31              # ADFP_STATUS_F16_RANGE: any of the bits below
 STATUS_RANGE_BITS = {'low': 1, 'high': 2, 'color': 4, 'att': 8, 'bwd': 16}      # ADFP_STATUS_F16_RANGE_<net>
 BWD_SCATTER_IN_KERNEL = 1        # ADFP_BWD_SCATTER_IN_KERNEL
@@ -17,6 +17,8 @@ BWD_GRIDS_PREZEROED = 2          # ADFP_BWD_GRIDS_PREZEROED
 BWD_STAGED_WGRAD = 4             # ADFP_BWD_STAGED_WGRAD
 STAGE = {'low': 0, 'high': 1, 'color': 2}
 DEC_KIND = {'low': 0, 'high': 1, 'color': 2}
+NET_ID = {'low': 0, 'high': 1, 'color': 2, 'att': 3}      # adfp_pack_split_image's `net`
+IMAGE_H, IMAGE_G = 1, 2
 PTS_RAYS, PTS_F64, PTS_F32 = 0, 1, 2
 
 ERRORS = {-1: 'ADFP_E_ARG (null pointer / bad size)',
@@ -130,6 +132,7 @@ SYMBOLS = [
     ('adfp_pack_attention', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_decoder_packed_h_words', C.c_longlong, [C.c_int]),
     ('adfp_pack_decoder_h', C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_pack_split_image', C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_decoder_packed_ht_words', C.c_longlong, [C.c_int]),
     ('adfp_pack_decoder_ht', C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_train_act_floats', C.c_longlong, [C.c_int]),

@@ -1167,27 +1167,36 @@ long long adfp_decoder_packed_h_words(int kind) {
     }
     return ADFP_E_ARG;
 }
-int adfp_pack_decoder_h(int kind, const float* flat, void* packed, int* status, void* stream) {
-    if (!flat || !packed) return ADFP_E_ARG;
+int adfp_pack_split_image(int net, int which, const float* flat, void* packed, int* status, void* stream) {
+    if (!flat || !packed || !(which & (ADFP_IMAGE_H | ADFP_IMAGE_G)) || (which & ~(ADFP_IMAGE_H | ADFP_IMAGE_G))) return ADFP_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     unsigned* out = (unsigned*)packed;
-    switch (kind) {
+    const bool H = which & ADFP_IMAGE_H, G = which & ADFP_IMAGE_G;
+    switch (net) {
         case ADFP_DEC_LOW:
-            hipLaunchKernelGGL((k_pack_decoder_h<32, 1>), dim3(DecLayoutH<32, 1>::NFLAG), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_LOW);
-            hipLaunchKernelGGL((k_pack_decoder_g<32, 1>), dim3(DecLayoutG<32, 1>::NFLAG), dim3(256), 0, st, flat, out + DecLayoutH<32, 1>::P_TOTAL, status, ADFP_STATUS_F16_RANGE_LOW);
+            if (H) hipLaunchKernelGGL((k_pack_decoder_h<32, 1>), dim3(DecLayoutH<32, 1>::NFLAG), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_LOW);
+            if (G) hipLaunchKernelGGL((k_pack_decoder_g<32, 1>), dim3(DecLayoutG<32, 1>::NFLAG), dim3(256), 0, st, flat, out + DecLayoutH<32, 1>::P_TOTAL, status, ADFP_STATUS_F16_RANGE_LOW);
             break;
         case ADFP_DEC_HIGH:
-            hipLaunchKernelGGL((k_pack_decoder_h<64, 1>), dim3(DecLayoutH<64, 1>::NFLAG), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_HIGH);
-            hipLaunchKernelGGL((k_pack_decoder_g<64, 1>), dim3(DecLayoutG<64, 1>::NFLAG), dim3(256), 0, st, flat, out + DecLayoutH<64, 1>::P_TOTAL, status, ADFP_STATUS_F16_RANGE_HIGH);
+            if (H) hipLaunchKernelGGL((k_pack_decoder_h<64, 1>), dim3(DecLayoutH<64, 1>::NFLAG), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_HIGH);
+            if (G) hipLaunchKernelGGL((k_pack_decoder_g<64, 1>), dim3(DecLayoutG<64, 1>::NFLAG), dim3(256), 0, st, flat, out + DecLayoutH<64, 1>::P_TOTAL, status, ADFP_STATUS_F16_RANGE_HIGH);
             break;
         case ADFP_DEC_COLOR:
-            hipLaunchKernelGGL((k_pack_decoder_h<32, 4>), dim3(DecLayoutH<32, 4>::NFLAG), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_COLOR);
-            hipLaunchKernelGGL((k_pack_decoder_g<32, 4>), dim3(DecLayoutG<32, 4>::NFLAG), dim3(256), 0, st, flat, out + DecLayoutH<32, 4>::P_TOTAL, status, ADFP_STATUS_F16_RANGE_COLOR);
+            if (H) hipLaunchKernelGGL((k_pack_decoder_h<32, 4>), dim3(DecLayoutH<32, 4>::NFLAG), dim3(256), 0, st, flat, out, status, ADFP_STATUS_F16_RANGE_COLOR);
+            if (G) hipLaunchKernelGGL((k_pack_decoder_g<32, 4>), dim3(DecLayoutG<32, 4>::NFLAG), dim3(256), 0, st, flat, out + DecLayoutH<32, 4>::P_TOTAL, status, ADFP_STATUS_F16_RANGE_COLOR);
+            break;
+        case ADFP_NET_ATT:
+            if (H) hipLaunchKernelGGL(k_pack_attention_h, dim3(AttLayoutH::NFLAG), dim3(256), 0, st, flat, out, status);
+            if (G) hipLaunchKernelGGL(k_pack_attention_g, dim3(AttLayoutG::NFLAG), dim3(256), 0, st, flat, out + AttLayoutH::P_TOTAL, status);
             break;
         default: return ADFP_E_ARG;
     }
     ADFP_CHECK_LAUNCH();
     return 0;
+}
+int adfp_pack_decoder_h(int kind, const float* flat, void* packed, int* status, void* stream) {
+    if (kind < ADFP_DEC_LOW || kind > ADFP_DEC_COLOR) return ADFP_E_ARG;
+    return adfp_pack_split_image(kind, ADFP_IMAGE_H | ADFP_IMAGE_G, flat, packed, status, stream);
 }
 long long adfp_decoder_packed_ht_words(int kind) {
     switch (kind) {
@@ -1225,11 +1234,7 @@ long long adfp_train_act_floats(int kind) {
 }
 long long adfp_attention_packed_h_words(void) { return AttLayoutH::P_TOTAL + AttLayoutG::P_TOTAL; }      // H image, then G image (see adfp_decoder_packed_h_words)
 int adfp_pack_attention_h(const float* flat, void* packed, int* status, void* stream) {
-    if (!flat || !packed) return ADFP_E_ARG;
-    hipLaunchKernelGGL(k_pack_attention_h, dim3(AttLayoutH::NFLAG), dim3(256), 0, (hipStream_t)stream, flat, (unsigned*)packed, status);
-    hipLaunchKernelGGL(k_pack_attention_g, dim3(AttLayoutG::NFLAG), dim3(256), 0, (hipStream_t)stream, flat, (unsigned*)packed + AttLayoutH::P_TOTAL, status);
-    ADFP_CHECK_LAUNCH();
-    return 0;
+    return adfp_pack_split_image(ADFP_NET_ATT, ADFP_IMAGE_H | ADFP_IMAGE_G, flat, packed, status, stream);
 }
 long long adfp_attention_packed_ht_words(void) { return AttLayoutHT::P_TOTAL; }
 int adfp_pack_attention_ht(const float* flat, void* packed, int* status, void* stream) {

@@ -51,18 +51,20 @@ def _pack_size(name, fmt):
     hit = _PACK_SIZES.get((name, fmt))
     if hit is None:
         L = lib()
+        f = 'h' if fmt in ('g', 'hg') else fmt                 # one buffer holds the H and the G layout (adfp_pack_split_image)
         if name == 'att':
-            hit = {'h': L.adfp_attention_packed_h_words, 'ht': L.adfp_attention_packed_ht_words, 'f32': L.adfp_attention_packed_floats}[fmt]()
+            hit = {'h': L.adfp_attention_packed_h_words, 'ht': L.adfp_attention_packed_ht_words, 'f32': L.adfp_attention_packed_floats}[f]()
         else:
             kind = _lib.DEC_KIND[name]
-            hit = {'h': L.adfp_decoder_packed_h_words, 'ht': L.adfp_decoder_packed_ht_words, 'f32': L.adfp_decoder_packed_floats}[fmt](kind)
+            hit = {'h': L.adfp_decoder_packed_h_words, 'ht': L.adfp_decoder_packed_ht_words, 'f32': L.adfp_decoder_packed_floats}[f](kind)
         _PACK_SIZES[(name, fmt)] = hit = int(hit)
     return hit
 
 
 def pack_network(name, params, fmt='f32', status=None, flat=None, out=None):
     """Packed image of one sub-network ('low' / 'high' / 'color' / 'att') from its parameters in state_dict order.
-    fmt: 'f32' (adfp_pack_decoder / adfp_pack_attention), 'h' (adfp_pack_*_h), 'ht' (adfp_pack_*_ht).
+    fmt: 'f32' (adfp_pack_decoder / adfp_pack_attention), 'ht' (adfp_pack_*_ht); 'h' / 'g' / 'hg': the split image with its H
+    (32x32x16 order: training forward, single-network entries) / G (16x16x32 order: inference kernels) / both parts written.
     status: the pinned status word a weight outside the f16 range is reported to (default: the process-wide one).
     out: an image of the same network and format to overwrite (a training iteration re-packs the trained networks every step:
     same-stream ordering makes the in-place rebuild safe, and the image keeps its address)."""
@@ -79,7 +81,10 @@ def pack_network(name, params, fmt='f32', status=None, flat=None, out=None):
     with _lib.device_guard(dev):
         stream = _lib.current_stream(dev)
         packed = out if out is not None else torch.empty(n, dtype=dtype, device=dev)
-        if fmt in ('h', 'ht'):
+        if fmt in ('h', 'g', 'hg'):
+            which = {'h': _lib.IMAGE_H, 'g': _lib.IMAGE_G, 'hg': _lib.IMAGE_H | _lib.IMAGE_G}[fmt]
+            _lib.check(L.adfp_pack_split_image(_lib.NET_ID[name], which, _lib.ptr(flat), _lib.ptr(packed), sptr, stream), 'adfp_pack_split_image')
+        elif fmt in ('h', 'ht'):
             if name == 'att':
                 fn = L.adfp_pack_attention_h if fmt == 'h' else L.adfp_pack_attention_ht
                 _lib.check(fn(_lib.ptr(flat), _lib.ptr(packed), sptr, stream), 'adfp_pack_attention_' + fmt)
@@ -365,6 +370,26 @@ class DF(nn.Module):
         module = self.net_params(name)
         if key is None:
             key = _version_key(module)
+        if fmt in ('h', 'g', 'hg'):
+            # ONE buffer, two layouts: 'h' (the training forward, sub-networks on their own) and 'g' (the inference kernels) are
+            # kept current separately -- a training iteration re-packs only the H part of a trained network, a frame only the G part
+            slot = name + '.split'
+            hit = self._packed.get(slot)
+            need = [p for p in (('h', 'g') if fmt == 'hg' else (fmt,)) if hit is None or hit[2].get(p) != key]
+            if not need:
+                return hit[1]
+            flat = self.flat_weights(name, key)
+            if module[0].data_ptr() != key[0][0]:
+                key = _version_key(module)         # flat_weights re-homed the parameters: new addresses
+                need = ['h', 'g'] if fmt == 'hg' else [fmt]
+            hit = self._packed.get(slot)
+            packed = pack_network(name, module, 'hg' if len(need) == 2 else need[0], status=self.status_word(), flat=flat,
+                                  out=None if hit is None else hit[1])
+            keys = dict(hit[2]) if hit is not None and hit[1] is packed else {}
+            for p in need:
+                keys[p] = key
+            self._packed[slot] = (key, packed, keys)
+            return packed
         slot = name if fmt == 'f32' else name + '.' + fmt
         hit = self._packed.get(slot)
         if hit is not None and hit[0] == key:

@@ -85,6 +85,9 @@ class Engine(object):
         # ADFP_BWD_* bits handed to the backward entries (adfp_backward_args.options).  ADFP_SCATTER=cache in the environment of
         # the HOST process selects the in-kernel scatter (kernel A/B runs); the library itself reads no environment.
         self.bwd_options = _lib.BWD_SCATTER_IN_KERNEL if os.environ.get('ADFP_SCATTER', '')[:1] == 'c' else 0
+        # which part of the split weight images an INFERENCE call keeps current: 'g' (the 16x16x32 kernels of this library);
+        # ADFP_IMAGES=hg in the host's environment keeps both (A/B runs against a library built with -DADFP_LC_32X32)
+        self.inference_images = os.environ.get('ADFP_IMAGES', 'g')
         # Test / diagnostic switch: the training state also carries dbg_masks_* buffers, into which the EXACT backward kernels
         # export the ReLU decisions they recomputed (adfp_train_state.dbg_masks_*; relu_masks() decodes them)
         self.export_relu_masks = False
@@ -181,13 +184,16 @@ class Engine(object):
         return dst
 
     # ---- descriptor ----------------------------------------------------------------------
-    def scene(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=False, ht_nets=(), keys=None):
+    def scene(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=False, ht_nets=(), keys=None, images=None, state=None):
         """Returns (AdfpScene, keepalive list).  Forward: every network of the stage takes its f16-split image (ADFP_MATH=f16x3 and
         not latched to exact, DF.uses_split) or its exact f32 image, plus -- when any split image is in use -- the flat parameters
         the device-side f32 repair path needs (adfp_scene.flat_*).  Backward: the exact f32 images, except for the decoders named
         in `ht_nets`: those get their transposed f16-split image (the caller has checked that the forward left their ReLU masks).
         keys: {net: DF.net_key(net)} when the caller has them (a backward re-uses its forward's: parameters must not change in
-        between); filled in for the stage's networks otherwise."""
+        between); filled in for the stage's networks otherwise.
+        images: which part(s) of the split images to keep current -- None: exactly what the forward entries read for this stage,
+        these latches and this training `state` (Engine.image_parts); 'hg' = both (bench / A-B tools that launch single kernels
+        of either family)."""
         decoders.absorb_status()                 # an f16-range event of an EARLIER call: that network is exact from now on
         sc = _lib.AdfpScene()
         sc.status = decoders.status_word().data_ptr()
@@ -215,7 +221,7 @@ class Engine(object):
                 else:
                     setattr(sc, 'w_' + n, decoders.packed_weights(n, 'f32', k).data_ptr())
             elif split and n not in latch:
-                setattr(sc, 'h_' + n, decoders.packed_weights(n, 'h', k).data_ptr())
+                setattr(sc, 'h_' + n, decoders.packed_weights(n, images or self.image_parts(stage, n, latch, state), k).data_ptr())
                 any_split = True
             else:
                 setattr(sc, 'w_' + n, decoders.packed_weights(n, 'f32', k).data_ptr())
@@ -230,6 +236,22 @@ class Engine(object):
         return sc, keep
 
     # ---- training state --------------------------------------------------------------------
+    def image_parts(self, stage, net, latch, state):
+        """Which part of `net`'s split image the forward entries (adfp_render_forward / adfp_eval_points_train, include/adfp.h at
+        adfp_pack_split_image) read, given that `net` itself is f16-split:
+          a training call whose state has ReLU-mask room for the network   -> H (the mask-leaving 32x32x16 kernels)
+          high decoder / attention MLP otherwise                            -> G (k_decode_high_g / k_attention_g)
+          low / colour decoder otherwise: inside the fused low + colour launch (stage colour, no training state, both split) -> G
+                                          (k_decode_lc16); on their own (stages low / high, the other one latched to exact, a
+                                          training call without mask room)   -> H (k_decode_h)
+        self.inference_images replaces 'g' (ADFP_IMAGES=hg: a library built with -DADFP_LC_32X32 reads H everywhere)."""
+        if state is not None and ('masks_' + net) in state:
+            return 'h'
+        if net in ('high', 'att'):
+            return self.inference_images
+        fused = stage == 'color' and state is None and 'low' not in latch and 'color' not in latch
+        return self.inference_images if fused else 'h'
+
     @staticmethod
     def train_state(P, stage, dev, decoders, need_flat=None, extra=()):
         """The caller-owned buffers a training forward leaves for the backward (adfp_train_state): always the TSDF stage's
@@ -395,7 +417,9 @@ class Engine(object):
             if P == 0:
                 return raw, w, saved
             keys = {}
-            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, keys=keys)
+            if train:
+                saved = self.train_state(P, stage, dev, decoders, need_flat)
+            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, keys=keys, state=saved)
             ap = _lib.AdfpPoints()
             ap.mode = mode
             ap.n_points = P
@@ -403,7 +427,6 @@ class Engine(object):
             ws = self.workspace(P, dev)
             st = None
             if train:
-                saved = self.train_state(P, stage, dev, decoders, need_flat)
                 saved.update(pts=pts, mode=mode, keys=keys)
                 st = saved['_state']
             check(lib().adfp_eval_points_train(C.byref(sc), C.byref(ap), _lib.STAGE[stage], 1 if apply_bound_rule else 0,
@@ -572,7 +595,15 @@ class Engine(object):
             if N == 0:
                 return depth, unc, color, weight, aux
             keys = {}
-            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, keys=keys)
+            if train:
+                # buffers the backward reads after this call returns (never the shared workspace): one slab
+                P = N * S
+                extra = (('z_vals', 8 * P), ('raw', 16 * P))
+                if self.export_relu_masks:
+                    extra += tuple(('dbg_masks_' + n, 4 * (_lib.TRAIN_ATT_MASK_WORDS if n == 'att' else _lib.TRAIN_MASK_WORDS) * P)
+                                   for n in _STAGE_NETS[stage])
+                aux = self.train_state(P, stage, dev, decoders, need_flat, extra=extra)
+            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, keys=keys, state=aux)
             a = _lib.AdfpRenderArgs()
             a.stage = _lib.STAGE[stage]
             a.n_rays = N
@@ -595,13 +626,6 @@ class Engine(object):
             a.color = color.data_ptr()
             a.weight = weight.data_ptr()
             if train:
-                # buffers the backward reads after this call returns (never the shared workspace): one slab
-                P = N * S
-                extra = (('z_vals', 8 * P), ('raw', 16 * P))
-                if self.export_relu_masks:
-                    extra += tuple(('dbg_masks_' + n, 4 * (_lib.TRAIN_ATT_MASK_WORDS if n == 'att' else _lib.TRAIN_MASK_WORDS) * P)
-                                   for n in _STAGE_NETS[stage])
-                aux = self.train_state(P, stage, dev, decoders, need_flat, extra=extra)
                 a.z_vals, a.raw = aux['ptrs']['z_vals'], aux['ptrs']['raw']
                 aux.update(rays_o=ro, rays_d=rd, S=S, N=N, keys=keys)
                 a.state = C.pointer(aux['_state'])

@@ -227,8 +227,8 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(minutes=30))
-        else:
-            dist.init_process_group(backend, timeout=datetime.timedelta(minutes=30))
+        else:       # test hook (gloo on one device): a stuck collective should raise within minutes, not hold the suite for half an hour
+            dist.init_process_group(backend, timeout=datetime.timedelta(minutes=3))
     n_gpus = dist.get_world_size() if dist is not None else 1
     if args.gpus != n_gpus and rank == 0:
         print(f'bench.py: --gpus {args.gpus} but the process group has {n_gpus} rank(s); reporting n_gpus={n_gpus}', file=sys.stderr)
@@ -560,7 +560,7 @@ def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, N
     S = NS + NF
     ro_all, rd_all = get_rays(scene.H, scene.W, scene.fx, scene.fy, scene.cx, scene.cy, c2w, dev)
     ro_all, rd_all, gd_all = ro_all.reshape(-1, 3), rd_all.reshape(-1, 3), gt_depth.reshape(-1)
-    sc, keep = eng.scene(dec, scene.c, scene.tsdf_volume, tsdf_bnds, scene.bound, 'color')
+    sc, keep = eng.scene(dec, scene.c, scene.tsdf_volume, tsdf_bnds, scene.bound, 'color', images='hg')
     batches, n_band, n_pts = [], 0, 0
     # the launch structure of render_img: ONE call for the whole frame, the reference's ray batches carried as depth-max segments
     # (a frame too large for one call would fall back to the batch loop)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 123
+#define ADFP_VERSION 124
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -151,6 +151,19 @@ long long adfp_attention_packed_h_words(void);
 long long adfp_attention_packed_ht_words(void);
 int adfp_pack_attention_ht(const float* flat, void* packed, int* status, void* stream);
 int adfp_pack_attention_h(const float* flat, void* packed, int* status, void* stream);
+/* A split image holds TWO operand layouts back to back: H (v_mfma_f32_32x32x16_f16 order: the training forward, the
+ * single-network entries) and G (v_mfma_f32_16x16x32_f16 order: the inference kernels).  adfp_pack_decoder_h / adfp_pack_attention_h
+ * write both; this entry writes the chosen part(s) of the same buffer, so that a training iteration re-packs only the H part of
+ * a trained network and an inference frame only the G part.  net: ADFP_DEC_LOW / _HIGH / _COLOR or ADFP_NET_ATT; which: bit 0 = H,
+ * bit 1 = G.  A consumer must only be handed an image whose part IT reads is current:
+ *   H: a network of a training call (adfp_*_train with a state) whose state carries masks_<net>; adfp_decode / adfp_attention on a
+ *      single network; the f16-split backward (its ht images are separate buffers)
+ *   G: every network of an inference call, and a network of a training call whose state has NO masks_<net> (its forward is the
+ *      inference kernel, its backward recomputes) */
+#define ADFP_NET_ATT 3
+#define ADFP_IMAGE_H 1
+#define ADFP_IMAGE_G 2
+int adfp_pack_split_image(int net, int which, const float* flat, void* packed, int* status, void* stream);
 /* mlp_tsdf parameters (decoder.py:206-258) */
 int adfp_pack_attention(const float* flat, float* packed, void* stream);
 

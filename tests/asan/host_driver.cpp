@@ -66,6 +66,10 @@ int main() {
             EXPECT_NEG(adfp_pack_decoder_h(k, dev<float>(1), nullptr, nullptr, st));
         }
     }
+    EXPECT_NEG(adfp_pack_split_image(4, ADFP_IMAGE_H, dev<float>(1), dev<void>(2), nullptr, st));
+    EXPECT_NEG(adfp_pack_split_image(ADFP_NET_ATT, 0, dev<float>(1), dev<void>(2), nullptr, st));
+    EXPECT_NEG(adfp_pack_split_image(ADFP_NET_ATT, 4, dev<float>(1), dev<void>(2), nullptr, st));
+    for (int net = 0; net < 4; ++net) for (int which = 1; which < 4; ++which) EXPECT_REACHES_LAUNCH(adfp_pack_split_image(net, which, dev<float>(1), dev<void>(2), dev<int>(3), st));
     EXPECT_NEG(adfp_pack_attention(nullptr, dev<float>(1), st)); EXPECT_NEG(adfp_pack_attention_h(dev<float>(1), nullptr, nullptr, st));
     EXPECT_NEG(adfp_pack_attention_ht(nullptr, nullptr, nullptr, st));
     EXPECT_REACHES_LAUNCH(adfp_pack_attention(dev<float>(1), dev<float>(2), st));

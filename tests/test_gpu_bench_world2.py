@@ -17,8 +17,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_self_launches_two_ranks_and_reports_them():
     env = dict(os.environ, ADFP_BENCH_TEST_SAME_DEVICE='1', ADFP_BENCH_TEST_BACKEND='gloo')
     env.pop('WORLD_SIZE', None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--cpu-rays', '0'],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--cpu-rays', '0']
+    # The run takes ~10 s.  Once in ~25 leases the two-process gloo rendezvous / first collective on a fresh box did not complete
+    # (observed once in round 4, not reproducible in 12 consecutive runs on another box): a run that exceeds 5 minutes is started
+    # again ONCE; a wrong result or a non-zero exit is never retried.
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    except subprocess.TimeoutExpired as e:
+        print('bench.py --gpus 2 timed out once; stderr tail:', (e.stderr or b'').decode(errors='replace')[-1500:])
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
     assert len(lines) == 1, p.stdout.decode()[-2000:]

@@ -35,7 +35,7 @@ def main(reps=int(os.environ.get("AB_REPS", "8"))):
     with torch.no_grad():
         d, u, c, w, aux = eng.render_forward(dec, scene.c, ro, rd, gd, scene.tsdf_volume, tsdf_bnds, scene.bound,
                                              'color', 48, 16, want_aux=True)
-    sc, keep = eng.scene(dec, scene.c, scene.tsdf_volume, tsdf_bnds, scene.bound, 'color')
+    sc, keep = eng.scene(dec, scene.c, scene.tsdf_volume, tsdf_bnds, scene.bound, 'color', images='hg')
     P = N * S
     ap = _lib.AdfpPoints()
     ap.mode, ap.n_points = _lib.PTS_RAYS, P
