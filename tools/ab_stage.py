@@ -30,7 +30,7 @@ def main(reps=int(os.environ.get("AB_REPS", "8"))):
     c2w = scene.default_c2w()
     gd_img = scene.depth_image(c2w)
     ro, rd = get_rays(scene.H, scene.W, scene.fx, scene.fy, scene.cx, scene.cy, c2w, dev)
-    N, S = 100000, 64
+    N, S = int(os.environ.get('AB_RAYS', '100000')), 64
     ro, rd, gd = ro.reshape(-1, 3)[:N].contiguous(), rd.reshape(-1, 3)[:N].contiguous(), gd_img.reshape(-1)[:N].contiguous()
     with torch.no_grad():
         d, u, c, w, aux = eng.render_forward(dec, scene.c, ro, rd, gd, scene.tsdf_volume, tsdf_bnds, scene.bound,
@@ -59,7 +59,7 @@ def main(reps=int(os.environ.get("AB_REPS", "8"))):
             ts.append(e0.elapsed_time(e1))
         ts.sort()
         return ts[len(ts) // 2], ts[0]
-    res = {'lib': os.path.basename(_lib.LIB_PATH)}
+    res = {'lib': os.path.basename(_lib.LIB_PATH), 'checksum': [d.double().sum().item(), u.double().sum().item(), c.double().sum().item()]}
     res['color_ms'] = timed(lambda: L.adfp_decode_stage(C.byref(sc), C.byref(ap), 2, _lib.ptr(raw), _lib.ptr(wb), st))
     res['low_ms'] = timed(lambda: L.adfp_decode_stage(C.byref(sc), C.byref(ap), 0, _lib.ptr(raw), _lib.ptr(wb), st))
     if L.adfp_decode_stage(C.byref(sc), C.byref(ap), 3, _lib.ptr(raw), _lib.ptr(wb), st) == 0:      # the fused low + colour launch
@@ -69,6 +69,7 @@ def main(reps=int(os.environ.get("AB_REPS", "8"))):
     res['batch_ms'] = timed(lambda: eng.render_forward(dec, scene.c, ro, rd, gd, scene.tsdf_volume, tsdf_bnds, scene.bound, 'color', 48, 16))
     res['color_tflops'] = 2.0 * 15575 * P / (res['color_ms'][0] * 1e-3) / 1e12
     res['tsdf_gbps'] = 32.0 * P / (res['tsdf_ms'][0] * 1e-3) / 1e9
+    res['in_band_points'] = int(cnt[0].item())
     print(json.dumps(res))
     if hasattr(L, 'adfp_debug_stamps') or os.environ.get('ADFP_STAMPS'):
         # debug build (-DADFP_STAMPS): per-wave start/end wall clock of the last k_decode_h launch
