@@ -144,11 +144,35 @@ ADFP_DEV void mfma_chain_g(f32x4g acc[2][2], const unsigned* __restrict__ w, con
 
 // One network on a tile.  pn: the lane's FRONT point, normalised (gather); pf[pb]: the positions of the lane's two points (Fourier
 // features); out[pb][o]: the network's outputs for point 16 pb + n, valid on every lane.
-template <int CDIM, int NOUT>
+//
+// TRAIN (the training forward of the fused low + colour launch): the network also leaves what the f16-split backward reads -- in
+// the formats of k_decode_h<..., TRAIN> (adfp_decode_h.h), so that the backward kernels do not know which forward ran:
+//   mw[k], k = 0..2: the ReLU-mask words of the lane's FRONT point 16 (g >> 1) + n, lane half g & 1 (adfp_train_state.masks_*:
+//        [row][half][3] words, 16-bit field of layer i, bit 15 - r <-> unit kmapH(r, half)).  The lane holds units 16 ob + 4 g + r of
+//        its two points = bits 15 - 8 ob - 4 (g >> 1) - r of the field of half g & 1: half of a field; the other half sits in lane
+//        l ^ 32, and ONE v_permlane32_swap per word brings the two halves of point-block 0 together on the lower lanes and those
+//        of point-block 1 on the upper lanes -- each lane ends up with the complete words of its front point.
+//   srow0 / rowbits: the X piece of point 16 pb + n's staging row (DecStage: [x, y, z, 1, 0 ...] | c | h_0..h_4, natural unit
+//        order).  The lane's units 16 ob + 4 g .. + 3 are one 16-byte piece: head pieces g and g + 4, 2 pieces of c and of every h_i
+//        per point -- the same 28 stores per lane and tile as the 32 x 32 kernel.
+template <int CDIM, int NOUT, int TRAIN = 0>
 ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& grid, const GridDev& grid1, const float pn[3], const float (*pf)[3],
-                           int lane, float& amax, float (*out)[NOUT]) {
+                           int lane, float& amax, float (*out)[NOUT], unsigned* __restrict__ mw = nullptr, float* srow0 = nullptr, unsigned rowbits = 0u) {
     using L = DecLayoutG<CDIM, NOUT>;
+    using ST = DecStage<CDIM>;
     const int g = lane >> 4;
+    // TRAIN: srow0 = the row of point n (point-block 0), the row of point 16 + n lies 16 rows on; rowbits bit pb = that row exists
+    float* srow[2] = {nullptr, nullptr};
+    if constexpr (TRAIN) {
+        srow[0] = (rowbits & 1u) ? srow0 : nullptr;
+        srow[1] = (rowbits & 2u) ? srow0 + 16 * ST::NXM : nullptr;
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) if (srow[pb]) {
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            *(f32x4*)(srow[pb] + ST::xm(ST::SX) + 4 * g) = g == 0 ? f32x4{pf[pb][0], pf[pb][1], pf[pb][2], 1.f} : z4;
+            *(f32x4*)(srow[pb] + ST::xm(ST::SX) + 16 + 4 * g) = z4;
+        }
+    }
     // every LDS access below is one of three lane-dependent bases plus an immediate: the weight rows (4 l), the unit-order rows
     // (biases, output layer: 4 g) and the Fourier rows (32 g)
     const unsigned* wl = ldsu + 4 * lane;
@@ -165,6 +189,11 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
         float y[8] = {c[4], c[5], c[6], c[7], c[12], c[13], c[14], c[15]};
 #pragma unroll
         for (int s = 0; s < 8; ++s) swap_halves(x[s], y[s]);
+        if constexpr (TRAIN) {
+            static_assert(!TRAIN || CDIM == 32, "training rows: 32-channel decoders");
+            if (srow[0]) { *(f32x4*)(srow[0] + ST::xm(ST::SC) + 4 * g) = f32x4{x[0], x[1], x[2], x[3]}; *(f32x4*)(srow[0] + ST::xm(ST::SC) + 16 + 4 * g) = f32x4{x[4], x[5], x[6], x[7]}; }
+            if (srow[1]) { *(f32x4*)(srow[1] + ST::xm(ST::SC) + 4 * g) = f32x4{y[0], y[1], y[2], y[3]}; *(f32x4*)(srow[1] + ST::xm(ST::SC) + 16 + 4 * g) = f32x4{y[4], y[5], y[6], y[7]}; }
+        }
         split8(x, ch[kc][0], cl[kc][0], amax);      // block 0: channels unit16(8 g + j)
         split8(y, ch[kc][1], cl[kc][1], amax);      // block 1
     }
@@ -184,6 +213,7 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
     __builtin_amdgcn_sched_barrier(0);
     f32x4g acc[2][2];
     f16x8 hh[1][2], hl[1][2];
+    unsigned mk[3] = {0u, 0u, 0u};      // TRAIN: 16 bits per layer, two layers per register, pushed in the order ob, pb, r: [ob0 pb0 | ob0 pb1 | ob1 pb0 | ob1 pb1] nibbles
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
 #pragma unroll
@@ -199,9 +229,20 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[ob][pb][r] = relu_f(acc[ob][pb][r]) + t[r];
+                for (int r = 0; r < 4; ++r) {
+                    const float v = relu_f(acc[ob][pb][r]);
+                    if constexpr (TRAIN) mk[i >> 1] = __builtin_amdgcn_alignbit(mk[i >> 1], 0u - __float_as_uint(v), 31);   // relu_bias_mask's predicate
+                    acc[ob][pb][r] = v + t[r];
+                }
         }
         mfma_chain_g<L::KG_C>(acc, wl + L::P_WC(i), ch, cl);
+        if constexpr (TRAIN) {
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) if (srow[pb]) {
+                *(f32x4*)(srow[pb] + ST::xm(ST::SH(i)) + 4 * g) = f32x4{acc[0][pb][0], acc[0][pb][1], acc[0][pb][2], acc[0][pb][3]};
+                *(f32x4*)(srow[pb] + ST::xm(ST::SH(i)) + 16 + 4 * g) = f32x4{acc[1][pb][0], acc[1][pb][1], acc[1][pb][2], acc[1][pb][3]};
+            }
+        }
         if (i < 4) {
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb) {
@@ -226,6 +267,27 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
             s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
             out[pb][o] = s + ((const float*)ldsu)[L::P_BO + o];
+        }
+    }
+    if constexpr (TRAIN) {
+        // layer i's 16 bits: the low half of its register for i = 1, 3, 4, the high half for i = 0, 2; nibbles [ob0 pb0][ob0 pb1][ob1 pb0][ob1 pb1]
+        const int sh = 4 * (g >> 1);
+        unsigned wpb[2][3];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            unsigned f[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const unsigned m16 = (i == 4 || (i & 1)) ? (mk[i >> 1] & 0xFFFFu) : (mk[i >> 1] >> 16);
+                const unsigned n0 = (m16 >> (12 - 4 * pb)) & 0xFu, n1 = (m16 >> (4 - 4 * pb)) & 0xFu;       // ob 0, ob 1 of this point-block
+                f[i] = (n0 << (12 - sh)) | (n1 << (4 - sh));
+            }
+            wpb[pb][0] = f[0] | (f[1] << 16); wpb[pb][1] = f[2] | (f[3] << 16); wpb[pb][2] = f[4];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const auto r = __builtin_amdgcn_permlane32_swap(wpb[0][k], wpb[1][k], false, false);   // lower lanes: (own pb 0, partner's pb 0); upper: (partner's pb 1, own pb 1)
+            mw[k] = r[0] | r[1];
         }
     }
 }
@@ -280,6 +342,80 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16(DecodeLCArgs a) {
         if (valid && (g & 1) == 0) {
             const int pb = g >> 1;
             const float nanv = __builtin_nanf("");     // a NaN position renders NaN like the reference's (nan_point_outputs)
+            const float o = pnan ? nanv : (keep_occ ? (pb ? occ[1][0] : occ[0][0]) : 100.f);
+            const f32x4 c4 = pb ? f32x4{rgb[1][0], rgb[1][1], rgb[1][2], o} : f32x4{rgb[0][0], rgb[0][1], rgb[0][2], o};
+            *(f32x4*)(a.raw + 4ll * q) = pnan ? f32x4{nanv, nanv, nanv, o} : c4;
+            if (a.write_w) a.w[q] = 1.f;
+        }
+    }
+    report_range(a.status, amax_low, ADFP_STATUS_F16_RANGE_LOW, a.call_flag);
+    report_range(a.status, amax_col, ADFP_STATUS_F16_RANGE_COLOR, a.call_flag);
+}
+
+// =============================================================================================
+// The TRAINING forward of the fused launch (stage color, both networks f16-split, adfp_train_state with masks_low and masks_color):
+// k_decode_lc16 plus the ReLU masks of both networks and, for a network whose weight gradients are wanted (act_* != NULL), its
+// layer inputs.  A NaN position (a ray the Mapper's pre-filter drops) is decoded at the origin, as in k_decode_h<..., TRAIN>.
+// Replaces k_decode_h<32, 1, LOW, 512, TRAIN> + k_decode_h<32, 4, COLOR, 512, TRAIN> of the training iteration.
+// =============================================================================================
+struct DecodeLCTrainArgs {
+    DecodeLCArgs f;
+    unsigned* masks_low; unsigned* masks_color;
+    float* act_low; float* act_color;              // or NULL
+};
+template <int NT>
+__global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16_train(DecodeLCTrainArgs t) {
+    const DecodeLCArgs& a = t.f;
+    using LL = DecLayoutG<32, 1>;
+    using LC = DecLayoutG<32, 4>;
+    using ST = DecStage<32>;
+    __shared__ __attribute__((aligned(16))) unsigned lds_all[LL::P_TOTAL + LC::P_TOTAL];
+    __shared__ int s_next;
+    unsigned* lds_low = lds_all;
+    unsigned* lds_col = lds_all + LL::P_TOTAL;
+    for (int i = threadIdx.x; i < LL::P_TOTAL / 4; i += NT) ((u32x4*)lds_low)[i] = ((const u32x4*)a.packed_low)[i];
+    for (int i = threadIdx.x; i < LC::P_TOTAL / 4; i += NT) ((u32x4*)lds_col)[i] = ((const u32x4*)a.packed_color)[i];
+    if (threadIdx.x == 0) s_next = NT / 64;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    const int count = a.P.n;
+    const int ntiles = (count + 31) >> 5;
+    float amax_low = image_out_of_range<LL::P_FLAG, LL::NFLAG>(lds_low) ? INFINITY : 0.f;
+    float amax_col = image_out_of_range<LC::P_FLAG, LC::NFLAG>(lds_col) ? INFINITY : 0.f;
+    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<NT / 64>(j, &s_next, ntiles)) >= 0;) {
+        const int idx = tile * 32 + 16 * (g >> 1) + n;
+        const bool valid = idx < count;
+        const int q = valid ? idx : 0;
+        float pn[3], pf[2][3];
+        bool pnan, keep_occ;
+        {
+            double pt[3];
+            load_point(a.P, q, pt);
+            normalize3(a.nb, pt, pn);
+            pnan = (pt[0] != pt[0]) | (pt[1] != pt[1]) | (pt[2] != pt[2]);
+            const float f0 = pnan ? 0.f : (float)pt[0], f1 = pnan ? 0.f : (float)pt[1], f2 = pnan ? 0.f : (float)pt[2];
+            const unsigned f = a.flags ? a.flags[q] : 0u;
+            keep_occ = (f & ADFP_F_BAND) || in_bound(pt, a.b) || !a.apply_bound;
+            pf[0][0] = f0; pf[0][1] = f1; pf[0][2] = f2; pf[1][0] = f0; pf[1][1] = f1; pf[1][2] = f2;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) swap_halves(pf[0][k], pf[1][k]);
+        // the rows of the lane's two points (point 16 pb + n of the tile): row of point-block 0 + which of the two exist
+        const int i0 = tile * 32 + n;
+        const unsigned rowbits = (i0 < count ? 1u : 0u) | (i0 + 16 < count ? 2u : 0u);
+        float occ[2][1], rgb[2][4];
+        unsigned mw[3];
+        int off_low = 0, off_col = LL::P_TOTAL;
+        asm volatile("" : "+v"(off_low), "+v"(off_col));
+        decode_net_g<32, 1, 1>(lds_all + off_low, a.g_low, a.g_low, pn, pf, lane, amax_low, occ, mw, t.act_low + (long long)i0 * ST::NXM, t.act_low ? rowbits : 0u);
+        if (valid) { unsigned* mrow = t.masks_low + ((long long)q * 2 + (g & 1)) * 3; mrow[0] = mw[0]; mrow[1] = mw[1]; mrow[2] = mw[2]; }
+        asm volatile("" : "+v"(pn[0]), "+v"(pn[1]), "+v"(pn[2]), "+v"(occ[0][0]), "+v"(occ[1][0]));
+        __builtin_amdgcn_sched_barrier(0);
+        decode_net_g<32, 4, 1>(lds_all + off_col, a.g_color, a.g_color, pn, pf, lane, amax_col, rgb, mw, t.act_color + (long long)i0 * ST::NXM, t.act_color ? rowbits : 0u);
+        if (valid) { unsigned* mrow = t.masks_color + ((long long)q * 2 + (g & 1)) * 3; mrow[0] = mw[0]; mrow[1] = mw[1]; mrow[2] = mw[2]; }
+        if (valid && (g & 1) == 0) {
+            const int pb = g >> 1;
+            const float nanv = __builtin_nanf("");
             const float o = pnan ? nanv : (keep_occ ? (pb ? occ[1][0] : occ[0][0]) : 100.f);
             const f32x4 c4 = pb ? f32x4{rgb[1][0], rgb[1][1], rgb[1][2], o} : f32x4{rgb[0][0], rgb[0][1], rgb[0][2], o};
             *(f32x4*)(a.raw + 4ll * q) = pnan ? f32x4{nanv, nanv, nanv, o} : c4;

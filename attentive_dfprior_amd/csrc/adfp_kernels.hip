@@ -818,6 +818,9 @@ struct AttArgs {
 #define ADFP_HIGH_NT 512
 #endif
 #define ADFP_LC_NT ADFP_DECH_NT
+#ifndef ADFP_LCT_NT
+#define ADFP_LCT_NT 512          // the training forward of the fused low + colour launch: 212 VGPRs (at 768 threads 64 spilled)
+#endif
 #include "adfp_decode_h.h"
 #include "adfp_fallback.h"
 
@@ -1431,9 +1434,26 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
 #endif
         ADFP_CHECK_LAUNCH();
     }
+    // stage color, TRAINING, both networks f16-split with mask room: the same ONE launch, leaving masks (+ layer inputs)
+#ifdef ADFP_LC_32X32
+    const bool fused_lc_train = false;
+#else
+    const bool fused_lc_train = stage == ADFP_STAGE_COLOR && state && sc->h_low && sc->h_color && state->masks_low && state->masks_color;
+    if (fused_lc_train) {
+        DecodeLCTrainArgs t;
+        DecodeLCArgs& f = t.f;
+        f.P = P; f.nb = a.nb; fill_bound(f.b, sc->bound);
+        f.g_low = make_grid(sc->low); f.g_color = make_grid(sc->color);
+        f.packed_low = (const unsigned*)sc->h_low + DecLayoutH<32, 1>::P_TOTAL; f.packed_color = (const unsigned*)sc->h_color + DecLayoutH<32, 4>::P_TOTAL;   // the G images
+        f.flags = a.flags; f.raw = raw; f.w = w; f.write_w = 1; f.apply_bound = apply_bound; f.status = sc->status; f.call_flag = call_flag;
+        t.masks_low = state->masks_low; t.masks_color = state->masks_color; t.act_low = state->act_low; t.act_color = state->act_color;
+        hipLaunchKernelGGL((k_decode_lc16_train<ADFP_LCT_NT>), dim3(decode_grid(ntiles, ADFP_LCT_NT / 64, 1)), dim3(ADFP_LCT_NT), 0, st, t);
+        ADFP_CHECK_LAUNCH();
+    }
+#endif
     // LOW on every point
     a.g0 = make_grid(sc->low); a.g1 = a.g0;
-    if (fused_lc) {
+    if (fused_lc || fused_lc_train) {
     } else if (sc->h_low && state && state->masks_low) {              // training forward: leaves the ReLU masks (+ layer inputs)
         a.packed = (const float*)sc->h_low; a.masks = state->masks_low; a.act = state->act_low;
         if (a.act) hipLaunchKernelGGL((k_decode_h<32, 1, ROLE_LOW, 512, 2>), dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, a);
@@ -1447,7 +1467,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         hipLaunchKernelGGL((k_decode<32, 1, ROLE_LOW, 256>), dim3(decode_grid(ntiles, 4, 2)), dim3(256), 0, st, a);
     }
     ADFP_CHECK_LAUNCH();
-    if (stage == ADFP_STAGE_COLOR && !fused_lc) {
+    if (stage == ADFP_STAGE_COLOR && !fused_lc && !fused_lc_train) {
         a.g0 = make_grid(sc->color); a.g1 = a.g0;
         if (sc->h_color && state && state->masks_color) {
             a.packed = (const float*)sc->h_color; a.masks = state->masks_color; a.act = state->act_color;

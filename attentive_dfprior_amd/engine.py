@@ -85,6 +85,8 @@ class Engine(object):
         # ADFP_BWD_* bits handed to the backward entries (adfp_backward_args.options).  ADFP_SCATTER=cache in the environment of
         # the HOST process selects the in-kernel scatter (kernel A/B runs); the library itself reads no environment.
         self.bwd_options = _lib.BWD_SCATTER_IN_KERNEL if os.environ.get('ADFP_SCATTER', '')[:1] == 'c' else 0
+        if os.environ.get('ADFP_WGRAD', '')[:1] == 's':          # weight gradients through the staged two-kernel path (A/B runs)
+            self.bwd_options |= _lib.BWD_STAGED_WGRAD
         # which part of the split weight images an INFERENCE call keeps current: 'g' (the 16x16x32 kernels of this library);
         # ADFP_IMAGES=hg in the host's environment keeps both (A/B runs against a library built with -DADFP_LC_32X32)
         self.inference_images = os.environ.get('ADFP_IMAGES', 'g')
@@ -239,17 +241,17 @@ class Engine(object):
     def image_parts(self, stage, net, latch, state):
         """Which part of `net`'s split image the forward entries (adfp_render_forward / adfp_eval_points_train, include/adfp.h at
         adfp_pack_split_image) read, given that `net` itself is f16-split:
-          a training call whose state has ReLU-mask room for the network   -> H (the mask-leaving 32x32x16 kernels)
-          high decoder / attention MLP otherwise                            -> G (k_decode_high_g / k_attention_g)
-          low / colour decoder otherwise: inside the fused low + colour launch (stage colour, no training state, both split) -> G
-                                          (k_decode_lc16); on their own (stages low / high, the other one latched to exact, a
-                                          training call without mask room)   -> H (k_decode_h)
+          high decoder / attention MLP: a training call whose state has ReLU-mask room for the network -> H (the mask-leaving
+                  32x32x16 kernels), otherwise -> G (k_decode_high_g / k_attention_g)
+          low / colour decoder: inside the fused low + colour launch -- stage colour, both split, and either no training state
+                  (k_decode_lc16) or mask room for BOTH (k_decode_lc16_train) -> G; on their own (stages low / high, the other
+                  one latched to exact, a training call with mask room for one of them only) -> H (k_decode_h)
         self.inference_images replaces 'g' (ADFP_IMAGES=hg: a library built with -DADFP_LC_32X32 reads H everywhere)."""
-        if state is not None and ('masks_' + net) in state:
-            return 'h'
+        has = (lambda n: ('masks_' + n) in state) if state is not None else (lambda n: False)
         if net in ('high', 'att'):
-            return self.inference_images
-        fused = stage == 'color' and state is None and 'low' not in latch and 'color' not in latch
+            return 'h' if has(net) else self.inference_images
+        fused = stage == 'color' and 'low' not in latch and 'color' not in latch and \
+            (state is None or (has('low') and has('color')))
         return self.inference_images if fused else 'h'
 
     @staticmethod

@@ -156,10 +156,13 @@ int adfp_pack_attention_h(const float* flat, void* packed, int* status, void* st
  * write both; this entry writes the chosen part(s) of the same buffer, so that a training iteration re-packs only the H part of
  * a trained network and an inference frame only the G part.  net: ADFP_DEC_LOW / _HIGH / _COLOR or ADFP_NET_ATT; which: bit 0 = H,
  * bit 1 = G.  A consumer must only be handed an image whose part IT reads is current:
- *   H: a network of a training call (adfp_*_train with a state) whose state carries masks_<net>; adfp_decode / adfp_attention on a
- *      single network; the f16-split backward (its ht images are separate buffers)
- *   G: every network of an inference call, and a network of a training call whose state has NO masks_<net> (its forward is the
- *      inference kernel, its backward recomputes) */
+ *   H: the high decoder / attention MLP of a training call (adfp_*_train with a state) whose state carries masks_<net>; the low or
+ *      the colour decoder whenever it does NOT run inside the fused low + colour launch (stages low / high; the other one on its
+ *      exact image; a training state with masks for one of the two only); adfp_decode_single / adfp_attention_rows; (the f16-split
+ *      backward reads the separate ht images)
+ *   G: the fused low + colour launch = stage colour with both networks on split images, inference or a training state that
+ *      carries masks_low AND masks_color; the high decoder / attention MLP of an inference call or of a training call without
+ *      masks_<net> (forward = the inference kernel, backward recomputes) */
 #define ADFP_NET_ATT 3
 #define ADFP_IMAGE_H 1
 #define ADFP_IMAGE_G 2

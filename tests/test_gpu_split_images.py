@@ -30,8 +30,9 @@ def test_every_consumer_sees_the_current_weights(monkeypatch):
     o, d, z = (t.to(DEV) for t in synthetic.make_ray_batch(sc, 200, seed=5)[:3])
     dec = _fresh(synthetic.seeded_state_dict(3), sc)
     rend = A.Renderer(make_cfg(32, 16), None, sc)
-    opt = torch.optim.SGD(dec.parameters(), lr=1e-3)
+    opt = torch.optim.SGD(dec.parameters(), lr=1e-7)          # sum losses: large gradients; the weights must move, not explode
     stages = ('low', 'high', 'color')
+    last = {}
     # (stage of the training step, then the stages rendered without grad) in every order that matters: the step leaves H parts
     # current, the renders need G for the fused low + colour launch / high / attention and H for a lone low decoder
     for k, (train_stage, order) in enumerate(itertools.product(stages, itertools.permutations(stages))):
@@ -41,12 +42,17 @@ def test_every_consumer_sees_the_current_weights(monkeypatch):
         (out[0].float().sum() + out[2].sum()).backward()
         opt.step()
         twin = _fresh(dec.state_dict(), sc)
+        assert all(torch.isfinite(p).all() for p in dec.parameters()) and not dec._exact_latch
         with torch.no_grad():
             for stage in order:
                 got = rend.render_batch_ray(sc.c, dec, d, o, DEV, sc.tsdf_volume, bnds, stage, gt_depth=z)
                 want = A.Renderer(make_cfg(32, 16), None, sc).render_batch_ray(sc.c, twin, d, o, DEV, sc.tsdf_volume, bnds, stage, gt_depth=z)
                 for a, b in zip(got, want):
+                    assert torch.isfinite(a).all()
                     assert torch.equal(a, b), f'step {k}: stage {stage} after a {train_stage} step rendered stale weights'
+                # the step moved the weights enough to show: a stale image would reproduce the previous render
+                assert stage not in last or not torch.equal(last[stage], got[0])
+                last[stage] = got[0].clone()
         # and the NEXT training forward (H parts) after those renders equals the twin's
         a = rend.render_batch_ray(c, dec, d, o, DEV, sc.tsdf_volume, bnds, train_stage, gt_depth=z)
         b = A.Renderer(make_cfg(32, 16), None, sc).render_batch_ray(c, twin, d, o, DEV, sc.tsdf_volume, bnds, train_stage, gt_depth=z)
@@ -59,10 +65,13 @@ def test_image_parts_rule():
     eng = Engine()
     eng.inference_images = 'g'
     masks = {'masks_low': True, 'masks_high': True, 'masks_att': True, 'masks_color': True}
-    for n in ('low', 'high', 'att', 'color'):
-        assert eng.image_parts('color', n, set(), masks) == 'h'
-        assert eng.image_parts('color', n, set(), None) == 'g'
-    assert eng.image_parts('high', 'low', set(), None) == 'h' and eng.image_parts('low', 'low', set(), None) == 'h'
-    assert eng.image_parts('high', 'high', set(), None) == 'g' and eng.image_parts('high', 'att', set(), None) == 'g'
+    for n in ('low', 'color'):                                   # the fused low + colour launch, inference and training
+        assert eng.image_parts('color', n, set(), masks) == 'g' and eng.image_parts('color', n, set(), None) == 'g'
+    for n in ('high', 'att'):
+        assert eng.image_parts('color', n, set(), masks) == 'h' and eng.image_parts('color', n, set(), None) == 'g'
+        assert eng.image_parts('high', n, set(), masks) == 'h' and eng.image_parts('high', n, set(), None) == 'g'
+        assert eng.image_parts('color', n, set(), {}) == 'g'     # a training state without mask room: the inference kernel
+    for st in ('low', 'high'):                                   # the low decoder on its own
+        assert eng.image_parts(st, 'low', set(), None) == 'h' and eng.image_parts(st, 'low', set(), masks) == 'h'
     assert eng.image_parts('color', 'low', {'color'}, None) == 'h' and eng.image_parts('color', 'color', {'low'}, None) == 'h'
-    assert eng.image_parts('color', 'low', set(), {}) == 'h' and eng.image_parts('color', 'high', set(), {}) == 'g'
+    assert eng.image_parts('color', 'low', set(), {}) == 'h' and eng.image_parts('color', 'low', set(), {'masks_low': True}) == 'h'

@@ -426,6 +426,8 @@ def test_tracking_converges_towards_the_true_pose():
         first = l.item() if first is None else first
     err0, err1 = (start[4:] - true[4:]).norm().item(), (it.best_camera_tensor[4:] - true[4:]).norm().item()
     assert it.best_loss.item() < first
-    # measured: 0.0439 m -> 0.025 - 0.027 m after 40 iterations of 1 000 random pixels (the draw sequence and 1e-7-level changes of the
-    # rendered target move the Adam trajectory by a few per cent)
-    assert err1 < 0.7 * err0, (err0, err1)
+    # The pose kept is the one of the LOWEST LOSS SEEN (src/Tracker.py:128-131), and the loss of an iteration is that of ITS 1 000 random
+    # pixels: which iteration wins is a draw, not the end of the trajectory.  Measured over 3 seeds x {f16x3 on either MFMA shape, f32}
+    # (tools/experiments/track_convergence.txt): 0.0439 m -> 0.013 - 0.016 m at iteration 20, and a kept pose between 0.019 and 0.031 m
+    # after 40 - 120 iterations in every mode, the exact f32 one included.  The bound is what all of them meet.
+    assert err1 < 0.85 * err0, (err0, err1)
