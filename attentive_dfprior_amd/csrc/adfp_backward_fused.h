@@ -49,7 +49,7 @@ struct DecodeBwdFArgs {
     float* gc_out;             // [P][32] d/d c rows for k_scatter_sorted, or NULL (no grid gradient wanted)
     int total;                 // points
     int* status; const float* gmax; const int* skip;
-    float* partial; int part_stride;          // one private copy of the flat gradient per workgroup (zeroed by outer_begin)
+    float* partial; int part_stride;          // one private copy of the flat gradient per workgroup (slot blockIdx.x, overwritten; the host reduces gridDim.x slots)
 };
 
 // slots (columns) of the narrow-product accumulator
@@ -451,5 +451,5 @@ __global__ __launch_bounds__(256) void k_decode_bwd_fused(DecodeBwdFArgs a) {
         __syncthreads();
     }
     float* part = a.partial + (long long)blockIdx.x * a.part_stride;
-    for (int i = threadIdx.x; i < F::F_TOTAL; i += 256) part[i] += s_red[i];
+    for (int i = threadIdx.x; i < F::F_TOTAL; i += 256) part[i] = s_red[i];       // the slot is this workgroup's alone and written whole: no zero fill before the launch
 }

@@ -431,46 +431,68 @@ struct RaySampler {
     }
 };
 
-// One wave per ray.  Lane e computes merged-list element e (uniform e < ns, surface otherwise),
-// stages it in LDS, and finds its rank in the sorted union by counting (only the values
-// matter: torch.sort, Renderer.py:220).
+// One wave per ADFP_SAMPLE_RPW consecutive rays.  Lane e computes merged-list element e of the current ray (uniform e < ns, surface
+// otherwise), stages it in the wave's LDS row, and finds its rank in the sorted union by counting (only the values matter:
+// torch.sort, Renderer.py:220).
+// Round 4: a wave used to take ONE ray -- origin / direction / depth loaded, one f64 division, 64 values, a binary search, one row
+// written -- and the launch was bound by that chain's latency (160 us per 640 x 480 frame = 1 TB/s of z_vals written, 37 rounds of
+// 32 waves per CU at ~4 us each).  Now the wave's first instruction loads the inputs of ALL its rays (16 lanes per ray: lane 16 r +
+// sel takes axis sel >> 1, side sel & 1 of ray r), the one f64 division per lane serves four rays at once, and the rays are then
+// worked off in turn out of registers (v_readlane with constant lane numbers) while the previous rows' stores drain.
+#ifndef ADFP_SAMPLE_RPW
+#define ADFP_SAMPLE_RPW 4
+#endif
 __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
+    constexpr int RPW = ADFP_SAMPLE_RPW;
+    static_assert(RPW == 1 || RPW == 2 || RPW == 4, "16 lanes per ray");
     __shared__ double sv[4][ADFP_MAX_SAMPLES];
     const int lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const bool active = ray < a.n_rays;
+    const int ray0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (ray0 >= a.n_rays) return;                      // wave-uniform; no block-wide barrier below
     double* v = sv[threadIdx.x >> 6];
+    const bool has_depth = a.depth != nullptr;
+    // ---- the inputs of the wave's rays, one load each, all in flight together
+    const int myr = lane >> 4;                         // the ray (of the wave's RPW) this lane loads for
+    const int lray = (myr < RPW && ray0 + myr < a.n_rays) ? ray0 + myr : ray0;
+    float dep_l = 0.f, dmax_l = 0.f;
+    double tmk_l;
+    {
+        const int sel = lane & 7, ax = sel < 6 ? sel >> 1 : 0, side = sel & 1;
+        const double o = (double)a.ro[3 * lray + ax], d = (double)a.rd[3 * lray + ax];
+        if (has_depth) {
+            dep_l = a.depth[lray];
+            const int sg = a.dmax_seg > 0 ? lray / a.dmax_seg : 0;
+            dmax_l = a.dmax_f ? a.dmax_f[sg] : ord2f(a.dmax_ord[sg]);
+        }
+        // far_bb = min_axis max_side (bound - o)/d + 0.01   (Renderer.py:151-156), f64: ONE division per lane -- lane (ray, axis, side)
+        // (an f64 division is ~40 instructions; six of them in every lane were most of this kernel's VALU work).
+        const double bk = ax == 0 ? (side ? a.b[1] : a.b[0]) : (ax == 1 ? (side ? a.b[3] : a.b[2]) : (side ? a.b[5] : a.b[4]));
+        const double t = (bk - o) / d;
+        const double tp = dpp_f64<0xB1>(t);              // lane ^ 1
+        const double t0 = side ? tp : t, t1 = side ? t : tp;
+        // torch.max / torch.min propagate NaN (0/0: a zero direction component with the origin on that bound
+        // plane; inf/inf), and so does torch.clamp below -- the whole ray then samples NaN like the reference's
+        tmk_l = (t0 != t0 || t1 != t1) ? (double)NAN : (t0 > t1 ? t0 : t1);
+    }
     RaySampler rs;
     rs.ns = a.n_samples; rs.lindisp = a.lindisp != 0; rs.perturb = a.perturb > 0.f;
-    rs.has_depth = a.depth != nullptr;
-    rs.nf = rs.has_depth ? a.n_surface : 0;
+    rs.has_depth = has_depth;
+    rs.nf = has_depth ? a.n_surface : 0;
     const int S = rs.ns + rs.nf;
-    if (active) {
-        rs.trand = a.t_rand ? a.t_rand + (long long)ray * a.n_samples : nullptr;
-        float dmaxf = 0.f;
-        if (rs.has_depth) { const int sg = a.dmax_seg > 0 ? ray / a.dmax_seg : 0; dmaxf = a.dmax_f ? a.dmax_f[sg] : ord2f(a.dmax_ord[sg]); }
-        rs.dmax = (double)dmaxf;
-        rs.dep = rs.has_depth ? a.depth[ray] : 0.f;
-        rs.nearf = __fmul_rn(rs.dep, 0.01f);
-        // far_bb = min_axis max_side (bound - o)/d + 0.01   (Renderer.py:151-156), f64
-        // The six plane distances are ONE f64 division per wave: lane l (mod 8) < 6 takes axis l >> 1, side l & 1
-        // (an f64 division is ~40 instructions; six of them in every lane were most of this kernel's VALU work).
-        double far_bb = INFINITY;
-        {
-            const int sel = lane & 7, ax = sel < 6 ? sel >> 1 : 0, side = sel & 1;
-            const double o = (double)a.ro[3 * ray + ax], d = (double)a.rd[3 * ray + ax];
-            const double bk = ax == 0 ? (side ? a.b[1] : a.b[0]) : (ax == 1 ? (side ? a.b[3] : a.b[2]) : (side ? a.b[5] : a.b[4]));
-            const double t = (bk - o) / d;
-            const double tp = dpp_f64<0xB1>(t);              // lane ^ 1
-            const double t0 = side ? tp : t, t1 = side ? t : tp;
-            // torch.max / torch.min propagate NaN (0/0: a zero direction component with the origin on that bound
-            // plane; inf/inf), and so does torch.clamp below -- the whole ray then samples NaN like the reference's
-            const double tmk = (t0 != t0 || t1 != t1) ? (double)NAN : (t0 > t1 ? t0 : t1);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double tm = readlane_f64(tmk, 2 * k);
-                far_bb = (tm != tm || far_bb != far_bb) ? (double)NAN : (tm < far_bb ? tm : far_bb);
-            }
+    for (int r = 0; r < RPW; ++r) {
+        const int ray = ray0 + r;
+        if (ray >= a.n_rays) break;                    // wave-uniform
+        rs.trand = a.t_rand ? a.t_rand + (long long)ray * a.n_samples : nullptr;
+        const float dmaxf = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dmax_l), 16 * r));
+        rs.dmax = (double)dmaxf;
+        rs.dep = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dep_l), 16 * r));
+        rs.nearf = __fmul_rn(rs.dep, 0.01f);
+        double far_bb = INFINITY;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double tm = readlane_f64(tmk_l, 16 * r + 2 * k);
+            far_bb = (tm != tm || far_bb != far_bb) ? (double)NAN : (tm < far_bb ? tm : far_bb);
         }
         far_bb += 0.01;
         if (rs.has_depth) {
@@ -478,53 +500,54 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
             double f = far_bb < 0.0 ? 0.0 : far_bb;       // clamp(far_bb, 0, max(gt_depth*1.2))
             rs.far = f > hi ? hi : f;
         } else rs.far = far_bb;
+        // the row is the wave's own: LDS executes a wave's accesses in order, the fences keep the compiler from moving them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int e = lane; e < S; e += 64) v[e] = e < rs.ns ? rs.zu(e) : rs.zs(e - rs.ns);
-    }
-    __syncthreads();
-    if (!active) return;
-    double* zrow = a.z + (long long)ray * S;
-    if (rs.nf == 0) {                                  // no sort in the reference either
-        for (int e = lane; e < S; e += 64) zrow[e] = v[e];
-        return;
-    }
-    // Both lists are monotone (uniform samples run near -> far, surface samples 0.95 d -> 1.05 d), so
-    // the rank of an element is its own index plus a binary-search count in the OTHER list (ties:
-    // uniform first, like a stable sort of the concatenation).  The O(S^2) count is kept for the
-    // degenerate cases: descending lists (far < near when the ray leaves the bound at once) and NaN samples
-    // (NaN far plane; lindisp with a zero sensor depth gives inf * 0 in the last uniform sample), which
-    // torch.sort orders after every number.
-    bool any_nan = false;
-    for (int e0 = 0; e0 < S; e0 += 64) { const int e = e0 + lane; any_nan |= __ballot(e < S && v[e] != v[e]) != 0ull; }
-    const bool ascending = !any_nan && (v[0] <= v[rs.ns - 1]) && (v[rs.ns] <= v[S - 1]);
-    if (ascending) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double* zrow = a.z + (long long)ray * S;
+        if (rs.nf == 0) {                                  // no sort in the reference either
+            for (int e = lane; e < S; e += 64) zrow[e] = v[e];
+            continue;
+        }
+        // Both lists are monotone (uniform samples run near -> far, surface samples 0.95 d -> 1.05 d), so
+        // the rank of an element is its own index plus a binary-search count in the OTHER list (ties:
+        // uniform first, like a stable sort of the concatenation).  The O(S^2) count is kept for the
+        // degenerate cases: descending lists (far < near when the ray leaves the bound at once) and NaN samples
+        // (NaN far plane; lindisp with a zero sensor depth gives inf * 0 in the last uniform sample), which
+        // torch.sort orders after every number.
+        bool any_nan = false;
+        for (int e0 = 0; e0 < S; e0 += 64) { const int e = e0 + lane; any_nan |= __ballot(e < S && v[e] != v[e]) != 0ull; }
+        const bool ascending = !any_nan && (v[0] <= v[rs.ns - 1]) && (v[rs.ns] <= v[S - 1]);
+        if (ascending) {
+            for (int e = lane; e < S; e += 64) {
+                const double val = v[e];
+                const bool uni = e < rs.ns;
+                // uniform element: count surface elements <  val;  surface element: count uniform elements <= val
+                int lo = uni ? rs.ns : 0, hi = uni ? S : rs.ns;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const double o = v[mid];
+                    const bool before = uni ? (o < val) : (o <= val);
+                    if (before) lo = mid + 1; else hi = mid;
+                }
+                const int rank = uni ? e + (lo - rs.ns) : (e - rs.ns) + lo;
+                zrow[rank] = val;
+            }
+            continue;
+        }
         for (int e = lane; e < S; e += 64) {
             const double val = v[e];
-            const bool uni = e < rs.ns;
-            // uniform element: count surface elements <  val;  surface element: count uniform elements <= val
-            int lo = uni ? rs.ns : 0, hi = uni ? S : rs.ns;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                const double o = v[mid];
-                const bool before = uni ? (o < val) : (o <= val);
-                if (before) lo = mid + 1; else hi = mid;
+            const bool vn = val != val;
+            int rank = 0;
+            for (int k = 0; k < S; ++k) {
+                const double o = v[k];
+                const bool on = o != o;
+                const bool less = vn ? !on : (o < val);                  // every number sorts before a NaN
+                const bool same = vn ? on : (o == val);
+                rank += less || (same && k < e);
             }
-            const int rank = uni ? e + (lo - rs.ns) : (e - rs.ns) + lo;
             zrow[rank] = val;
         }
-        return;
-    }
-    for (int e = lane; e < S; e += 64) {
-        const double val = v[e];
-        const bool vn = val != val;
-        int rank = 0;
-        for (int k = 0; k < S; ++k) {
-            const double o = v[k];
-            const bool on = o != o;
-            const bool less = vn ? !on : (o < val);                  // every number sorts before a NaN
-            const bool same = vn ? on : (o == val);
-            rank += less || (same && k < e);
-        }
-        zrow[rank] = val;
     }
 }
 
@@ -1325,7 +1348,7 @@ static int sample_rays_impl(const float* rays_o, const float* rays_d, const floa
         ADFP_CHECK_LAUNCH();
         a.dmax_ord = (const unsigned*)scratch;
     }
-    hipLaunchKernelGGL(k_sample, dim3((n_rays + 3) / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_sample, dim3((n_rays + 4 * ADFP_SAMPLE_RPW - 1) / (4 * ADFP_SAMPLE_RPW)), dim3(256), 0, st, a);
     ADFP_CHECK_LAUNCH();
     return 0;
 }
@@ -2201,13 +2224,13 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
             f.P = o.P; f.nb = o.nb; f.packed_t = (const unsigned*)t; f.g_raw = o.g_raw; f.masks = masks; f.act = act;
             f.gc_out = binned ? bw.gc : nullptr; f.total = total; f.status = status; f.gmax = bw.gmax; f.skip = skip;
             f.partial = bw.partial; f.part_stride = bw.part_stride;
-            int rc = outer_begin(bw, DecLayout<CDIM, NOUT>::F_TOTAL, st);
-            if (rc) return rc;
-            const int ntiles = (total + 31) / 32, nwg = (ntiles + 3) / 4;
-            hipLaunchKernelGGL((k_decode_bwd_fused<NOUT, ROLE>), dim3(nwg < OUTER_NSLOT ? nwg : OUTER_NSLOT), dim3(256), 0, st, f);
+            // every workgroup OVERWRITES its slot of bw.partial (no 20 MB zero fill per network), and the reduction reads the slots in use
+            const int ntiles = (total + 31) / 32, nwg = (ntiles + 3) / 4, nslot = nwg < OUTER_NSLOT ? nwg : OUTER_NSLOT;
+            hipLaunchKernelGGL((k_decode_bwd_fused<NOUT, ROLE>), dim3(nslot), dim3(256), 0, st, f);
             ADFP_CHECK_LAUNCH();
-            rc = outer_end_scaled(bw, DecLayout<CDIM, NOUT>::F_TOTAL, flat, st);
-            if (rc) return rc;
+            hipLaunchKernelGGL(k_reduce_partials_scaled, dim3((DecLayout<CDIM, NOUT>::F_TOTAL + 31) / 32), dim3(256), 0, st, bw.partial, nslot, bw.part_stride,
+                               DecLayout<CDIM, NOUT>::F_TOTAL, flat, bw.gmax);
+            ADFP_CHECK_LAUNCH();
             return binned ? scatter_bins(bp, o, bw, flags, st) : 0;
         }
     }
