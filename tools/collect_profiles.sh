@@ -29,7 +29,7 @@ python tools/pmc_traffic.py $O/pmc_${R}_train_fetch $O/pmc_${R}_train_write 3200
 python tools/diag_bwd.py > $O/${R}_diag_backward_modes.txt 2>/dev/null
 python bench_train.py > $O/${R}_bench_train.json 2>/dev/null
 ADFP_MATH=f32 python bench_train.py --rays 5000 2>/dev/null | sed 's/^{/{"math": "f32 (exact forward + backward)", /' >> $O/${R}_bench_train.json
-ADFP_HOST_TIMING=1 python tools/host_breakdown.py --rays 1000 5000 > $O/${R}_host_breakdown.txt 2>&1
+ADFP_HOST_TIMING=1 python tools/host_breakdown.py --rays 1000 5000 > $O/${R}_host_breakdown_box2.txt 2>&1   # (r04_host_breakdown.txt = the lease DESIGN section 4.6 quotes)
 python tools/mapping_loop.py --frames 200 --every-frame 5 2>/dev/null | tail -1 > $O/${R}_mapping_loop.json
 python tools/mapping_loop.py --frames 200 --every-frame 5 --fused 2>/dev/null | tail -1 >> $O/${R}_mapping_loop.json
 python tools/stress_config5.py pixel 2>/dev/null | tail -1 > $O/${R}_config5.json
