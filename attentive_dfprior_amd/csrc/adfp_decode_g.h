@@ -116,6 +116,21 @@ __global__ void k_pack_decoder_g(const float* __restrict__ flat, unsigned* __res
 
 typedef float f32x4g __attribute__((ext_vector_type(4)));
 
+// debug build (-DADFP_STAMPS_G, tools/phase_g.sh): wave-cycles per phase of a tile, summed over waves.  Slots: [0..7] k_decode_high_g,
+// [8..15] / [16..23] the low / colour network of k_decode_lc16; phase 0 = tile claim + point, 1 = gather + exchange + split,
+// 2 = Fourier features, 3 = the five layers, 4 = output layer, 5 = stores
+#ifdef ADFP_STAMPS_G
+__device__ unsigned long long g_phase_g[24];
+#define ADFP_PHG_PARAMS , unsigned long long* ph_, unsigned long long& last_
+#define ADFP_PHG_ARGS(base) , ph_ + (base), last_
+#define ADFP_PHG(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = clock64(); \
+                         __builtin_amdgcn_sched_barrier(0); ph_[k] += now_ - last_; last_ = now_; } while (0)
+#else
+#define ADFP_PHG_PARAMS
+#define ADFP_PHG_ARGS(base)
+#define ADFP_PHG(k) do {} while (0)
+#endif
+
 // x (first operand): lanes 32-63 receive y of lane l - 32;  y: lanes 0-31 receive x of lane l + 32  (tools/micro/layout_probe_16x16x32.hip)
 ADFP_DEV void swap_halves(float& x, float& y) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
@@ -157,7 +172,7 @@ ADFP_DEV void mfma_chain_g(f32x4g acc[2][2], const unsigned* __restrict__ w, con
 //        per point -- the same 28 stores per lane and tile as the 32 x 32 kernel.
 template <int CDIM, int NOUT, int TRAIN = 0>
 ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& grid, const GridDev& grid1, const float pn[3], const float (*pf)[3],
-                           int lane, float& amax, float (*out)[NOUT], unsigned* __restrict__ mw = nullptr, float* srow0 = nullptr, unsigned rowbits = 0u) {
+                           int lane, float& amax, float (*out)[NOUT], unsigned* __restrict__ mw, float* srow0, unsigned rowbits ADFP_PHG_PARAMS) {
     using L = DecLayoutG<CDIM, NOUT>;
     using ST = DecStage<CDIM>;
     const int g = lane >> 4;
@@ -182,7 +197,13 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
 #pragma unroll
     for (int kc = 0; kc < L::KG_C; ++kc) {          // high decoder: K-group 0 = its own grid, K-group 1 = the low grid (decoder.py:182-187)
         float c[16];
+#if defined(ADFP_EXP_NOGATHER)     // timing experiments (tools/ab_high.sh): no gather at all / no second gather
+        for (int r = 0; r < 16; ++r) c[r] = pn[r % 3] * (float)(r + 1 + 16 * kc);
+#elif defined(ADFP_EXP_NOGATHER1)
+        if (kc == 0) gather16(grid, pn, g & 1, c); else for (int r = 0; r < 16; ++r) c[r] = pn[r % 3] * (float)(r + 1);
+#else
         gather16(kc == 0 ? grid : grid1, pn, g & 1, c);   // c[r] <-> channel kmapH(r, g & 1) of the front point: pieces g&1, +2, +4, +6 of the voxel line
+#endif
         // lower lanes (block 0) keep K-group g = c[0..3], c[8..11] and give K-group g + 2 = c[4..7], c[12..15]; upper lanes (block 1,
         // g = 2, 3) keep c[4..7], c[12..15] and give c[0..3], c[8..11]: swap_halves(x, y) moves x.upper <-> y.lower
         float x[8] = {c[0], c[1], c[2], c[3], c[8], c[9], c[10], c[11]};
@@ -197,6 +218,7 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
         split8(x, ch[kc][0], cl[kc][0], amax);      // block 0: channels unit16(8 g + j)
         split8(y, ch[kc][1], cl[kc][1], amax);      // block 1
     }
+    ADFP_PHG(1);
     f16x8 eh[L::KG_E][2], el[L::KG_E][2];
 #pragma unroll
     for (int kg = 0; kg < L::KG_E; ++kg) {
@@ -210,6 +232,7 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
         split8<false>(e0, eh[kg][0], el[kg][0], amax);
         split8<false>(e1, eh[kg][1], el[kg][1], amax);
     }
+    ADFP_PHG(2);
     __builtin_amdgcn_sched_barrier(0);
     f32x4g acc[2][2];
     f16x8 hh[1][2], hl[1][2];
@@ -252,6 +275,7 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
             }
         }
     }
+    ADFP_PHG(3);
     // output_linear on the VALU in f32: the lane holds units 16 ob + 4 g + r of its two points; the four K-groups add up by two
     // exchanges (lanes l ^ 16, l ^ 32)
 #pragma unroll
@@ -269,6 +293,7 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
             out[pb][o] = s + ((const float*)ldsu)[L::P_BO + o];
         }
     }
+    ADFP_PHG(4);
     if constexpr (TRAIN) {
         // layer i's 16 bits: the low half of its register for i = 1, 3, 4, the high half for i = 0, 2; nibbles [ob0 pb0][ob0 pb1][ob1 pb0][ob1 pb1]
         const int sh = 4 * (g >> 1);
@@ -310,6 +335,9 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16(DecodeLCArgs a) {
     const int ntiles = (count + 31) >> 5;
     float amax_low = image_out_of_range<LL::P_FLAG, LL::NFLAG>(lds_low) ? INFINITY : 0.f;
     float amax_col = image_out_of_range<LC::P_FLAG, LC::NFLAG>(lds_col) ? INFINITY : 0.f;
+#ifdef ADFP_STAMPS_G
+    unsigned long long ph_[24] = {}, last_ = clock64();
+#endif
     for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<NT / 64>(j, &s_next, ntiles)) >= 0;) {
         // front point: point n of block 0 on lanes 0-31 (both K-groups g = 0, 1 of the pair), of block 1 on lanes 32-63
         const int idx = tile * 32 + 16 * (g >> 1) + n;
@@ -334,10 +362,11 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16(DecodeLCArgs a) {
         float occ[2][1], rgb[2][4];
         int off_low = 0, off_col = LL::P_TOTAL;        // word offsets of the two images, opaque and per tile (see k_decode_lc)
         asm volatile("" : "+v"(off_low), "+v"(off_col));
-        decode_net_g<32, 1>(lds_all + off_low, a.g_low, a.g_low, pn, pf, lane, amax_low, occ);
+        ADFP_PHG(8);
+        decode_net_g<32, 1>(lds_all + off_low, a.g_low, a.g_low, pn, pf, lane, amax_low, occ, nullptr, nullptr, 0u ADFP_PHG_ARGS(8));
         asm volatile("" : "+v"(pn[0]), "+v"(pn[1]), "+v"(pn[2]), "+v"(occ[0][0]), "+v"(occ[1][0]));
         __builtin_amdgcn_sched_barrier(0);
-        decode_net_g<32, 4>(lds_all + off_col, a.g_color, a.g_color, pn, pf, lane, amax_col, rgb);
+        decode_net_g<32, 4>(lds_all + off_col, a.g_color, a.g_color, pn, pf, lane, amax_col, rgb, nullptr, nullptr, 0u ADFP_PHG_ARGS(16));
         // the front point's lane with g & 1 == 0 stores its row: lanes 0-15 block 0, lanes 32-47 block 1
         if (valid && (g & 1) == 0) {
             const int pb = g >> 1;
@@ -347,7 +376,11 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16(DecodeLCArgs a) {
             *(f32x4*)(a.raw + 4ll * q) = pnan ? f32x4{nanv, nanv, nanv, o} : c4;
             if (a.write_w) a.w[q] = 1.f;
         }
+        ADFP_PHG(21);
     }
+#ifdef ADFP_STAMPS_G
+    if (lane == 0) for (int k = 8; k < 24; ++k) atomicAdd(&g_phase_g[k], ph_[k]);
+#endif
     report_range(a.status, amax_low, ADFP_STATUS_F16_RANGE_LOW, a.call_flag);
     report_range(a.status, amax_col, ADFP_STATUS_F16_RANGE_COLOR, a.call_flag);
 }
@@ -403,15 +436,18 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16_train(DecodeLCTrai
         // the rows of the lane's two points (point 16 pb + n of the tile): row of point-block 0 + which of the two exist
         const int i0 = tile * 32 + n;
         const unsigned rowbits = (i0 < count ? 1u : 0u) | (i0 + 16 < count ? 2u : 0u);
+#ifdef ADFP_STAMPS_G
+        unsigned long long ph_[24] = {}, last_ = 0;      // not collected for the training kernel
+#endif
         float occ[2][1], rgb[2][4];
         unsigned mw[3];
         int off_low = 0, off_col = LL::P_TOTAL;
         asm volatile("" : "+v"(off_low), "+v"(off_col));
-        decode_net_g<32, 1, 1>(lds_all + off_low, a.g_low, a.g_low, pn, pf, lane, amax_low, occ, mw, t.act_low + (long long)i0 * ST::NXM, t.act_low ? rowbits : 0u);
+        decode_net_g<32, 1, 1>(lds_all + off_low, a.g_low, a.g_low, pn, pf, lane, amax_low, occ, mw, t.act_low + (long long)i0 * ST::NXM, t.act_low ? rowbits : 0u ADFP_PHG_ARGS(8));
         if (valid) { unsigned* mrow = t.masks_low + ((long long)q * 2 + (g & 1)) * 3; mrow[0] = mw[0]; mrow[1] = mw[1]; mrow[2] = mw[2]; }
         asm volatile("" : "+v"(pn[0]), "+v"(pn[1]), "+v"(pn[2]), "+v"(occ[0][0]), "+v"(occ[1][0]));
         __builtin_amdgcn_sched_barrier(0);
-        decode_net_g<32, 4, 1>(lds_all + off_col, a.g_color, a.g_color, pn, pf, lane, amax_col, rgb, mw, t.act_color + (long long)i0 * ST::NXM, t.act_color ? rowbits : 0u);
+        decode_net_g<32, 4, 1>(lds_all + off_col, a.g_color, a.g_color, pn, pf, lane, amax_col, rgb, mw, t.act_color + (long long)i0 * ST::NXM, t.act_color ? rowbits : 0u ADFP_PHG_ARGS(16));
         if (valid) { unsigned* mrow = t.masks_color + ((long long)q * 2 + (g & 1)) * 3; mrow[0] = mw[0]; mrow[1] = mw[1]; mrow[2] = mw[2]; }
         if (valid && (g & 1) == 0) {
             const int pb = g >> 1;
@@ -442,12 +478,22 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_high_g(DecodeArgs a) {
     const int count = *a.count_ptr;
     const int ntiles = (count + 31) >> 5;
     float amax = image_out_of_range<L::P_FLAG, L::NFLAG>(ldsu) ? INFINITY : 0.f;
+#ifdef ADFP_STAMPS_G
+    unsigned long long ph_[8] = {}, last_ = clock64();
+#endif
     for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<NT / 64>(j, &s_next, ntiles)) >= 0;) {
         const int idx = tile * 32 + 16 * (g >> 1) + n;
         const bool valid = idx < count;
+#ifdef ADFP_HIGH_IDENTITY      // timing experiment: the same number of tiles over CONTIGUOUS points (no list indirection; results are not the network's)
+        const int q = valid ? idx : 0;
+#else
         const int q = a.list[valid ? idx : 0];
+#endif
         float pn[3], pf[2][3];
         bool pnan;
+        // the point's low-decoder value (added to the output at the end of the tile): requested NOW -- waited for after the network
+        // it was a full memory latency per tile with nothing in flight (13 % of the wave's tile time, tools/phase_g.py)
+        const float low_occ = (a.single || !valid) ? 0.f : a.raw[4ll * q + 3];
         {
             double pt[3];
             load_point(a.P, q, pt);
@@ -459,13 +505,18 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_high_g(DecodeArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) swap_halves(pf[0][k], pf[1][k]);
         float out[2][1];
-        decode_net_g<64, 1>(ldsu, a.g0, a.g1, pn, pf, lane, amax, out);
+        ADFP_PHG(0);
+        decode_net_g<64, 1>(ldsu, a.g0, a.g1, pn, pf, lane, amax, out, nullptr, nullptr, 0u ADFP_PHG_ARGS(0));
         if (valid && (g & 1) == 0) {
             const float o = g >> 1 ? out[1][0] : out[0][0];
             const float v = pnan ? __builtin_nanf("") : o;
-            a.att_occ[idx] = a.single ? v : v + a.raw[4ll * q + 3];    // high + low, decoder.py:342
+            a.att_occ[idx] = a.single ? v : v + low_occ;    // high + low, decoder.py:342
         }
+        ADFP_PHG(5);
     }
+#ifdef ADFP_STAMPS_G
+    if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_phase_g[k], ph_[k]);
+#endif
     report_range(a.status, amax, ADFP_STATUS_F16_RANGE_HIGH, a.call_flag);
 }
 

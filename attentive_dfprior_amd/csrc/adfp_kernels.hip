@@ -985,6 +985,13 @@ extern "C" int adfp_debug_phases_fused(unsigned long long* host_out, int reset) 
 #include "adfp_mapper_iter.h"
 #include "adfp_tracker_iter.h"
 #include "adfp_decode_g.h"
+#ifdef ADFP_STAMPS_G
+extern "C" int adfp_debug_phases_g(unsigned long long* host_out, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_g), 192);
+    if (!rc && reset) { unsigned long long z[24] = {}; rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_g), z, 192); }
+    return rc;
+}
+#endif
 
 // adfp_ray_sort_keys (adfp.h): Morton keys of (origin cell, surface-point cell) per ray
 __device__ __forceinline__ unsigned morton3(unsigned x, unsigned y, unsigned z, int bits) {
