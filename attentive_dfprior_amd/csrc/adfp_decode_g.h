@@ -362,6 +362,9 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16(DecodeLCArgs a) {
         float occ[2][1], rgb[2][4];
         int off_low = 0, off_col = LL::P_TOTAL;        // word offsets of the two images, opaque and per tile (see k_decode_lc)
         asm volatile("" : "+v"(off_low), "+v"(off_col));
+#ifdef ADFP_STAMPS_G
+        ph_[14] += 1;
+#endif
         ADFP_PHG(8);
         decode_net_g<32, 1>(lds_all + off_low, a.g_low, a.g_low, pn, pf, lane, amax_low, occ, nullptr, nullptr, 0u ADFP_PHG_ARGS(8));
         asm volatile("" : "+v"(pn[0]), "+v"(pn[1]), "+v"(pn[2]), "+v"(occ[0][0]), "+v"(occ[1][0]));
@@ -505,6 +508,9 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_high_g(DecodeArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) swap_halves(pf[0][k], pf[1][k]);
         float out[2][1];
+#ifdef ADFP_STAMPS_G
+        ph_[6] += 1;
+#endif
         ADFP_PHG(0);
         decode_net_g<64, 1>(ldsu, a.g0, a.g1, pn, pf, lane, amax, out, nullptr, nullptr, 0u ADFP_PHG_ARGS(0));
         if (valid && (g & 1) == 0) {

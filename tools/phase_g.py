@@ -42,6 +42,7 @@ names = ['claim + point', 'gather + exchange + split c', 'Fourier', 'five layers
 tiles_lc = N * S / 32
 tiles_hi = band * N * S / 32
 print('in-band fraction %.4f' % band)
+print('tiles processed: k_decode_high_g', ph[6], 'expected', int(band * N * S) // 32 + 1, '| k_decode_lc16', ph[14], 'expected', N * S // 32)
 print('k_decode_high_g  wave-cycles per tile:', {n: round(ph[k] / tiles_hi) for k, n in enumerate(names)}, 'sum', round(sum(ph[:6]) / tiles_hi))
 print('k_decode_lc16 low    :', {n: round(ph[8 + k] / tiles_lc) for k, n in enumerate(names[:5])}, 'sum', round(sum(ph[8:13]) / tiles_lc))
 print('k_decode_lc16 colour :', {n: round(ph[16 + k] / tiles_lc) for k, n in enumerate(names)}, 'sum', round(sum(ph[16:22]) / tiles_lc))
