@@ -195,7 +195,6 @@ ADFP_DEV void gather16(const GridDev& g, const float pn[3], int h, float* __rest
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const f32x4 t = src[2 * v];
-
                     c[4 * v + 0] = fmaf(t.x, w, c[4 * v + 0]);
                     c[4 * v + 1] = fmaf(t.y, w, c[4 * v + 1]);
                     c[4 * v + 2] = fmaf(t.z, w, c[4 * v + 2]);
