@@ -121,6 +121,7 @@ typedef float f32x4g __attribute__((ext_vector_type(4)));
 // 2 = Fourier features, 3 = the five layers, 4 = output layer, 5 = stores
 #ifdef ADFP_STAMPS_G
 __device__ unsigned long long g_phase_g[24];
+__device__ unsigned long long g_wave_span_g[2 * 4096];      // k_decode_lc16: per wave (wall-clock start, end), 100 MHz
 #define ADFP_PHG_PARAMS , unsigned long long* ph_, unsigned long long& last_
 #define ADFP_PHG_ARGS(base) , ph_ + (base), last_
 #define ADFP_PHG(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = clock64(); \
@@ -324,21 +325,25 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16(DecodeLCArgs a) {
     using LC = DecLayoutG<32, 4>;
     __shared__ __attribute__((aligned(16))) unsigned lds_all[LL::P_TOTAL + LC::P_TOTAL];      // the low image, then the colour image
     __shared__ int s_next;
+    __shared__ unsigned long long s_ring[ADFP_POOL_RING];
     unsigned* lds_low = lds_all;
     unsigned* lds_col = lds_all + LL::P_TOTAL;
     for (int i = threadIdx.x; i < LL::P_TOTAL / 4; i += NT) ((u32x4*)lds_low)[i] = ((const u32x4*)a.packed_low)[i];
     for (int i = threadIdx.x; i < LC::P_TOTAL / 4; i += NT) ((u32x4*)lds_col)[i] = ((const u32x4*)a.packed_color)[i];
     if (threadIdx.x == 0) s_next = NT / 64;
+    if (threadIdx.x < ADFP_POOL_RING) s_ring[threadIdx.x] = 0ull;
     __syncthreads();
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const int count = a.P.n;
     const int ntiles = (count + 31) >> 5;
+    const TilePlan plan = tile_plan(ntiles, (int)gridDim.x, NT / 64, a.pool != nullptr);
     float amax_low = image_out_of_range<LL::P_FLAG, LL::NFLAG>(lds_low) ? INFINITY : 0.f;
     float amax_col = image_out_of_range<LC::P_FLAG, LC::NFLAG>(lds_col) ? INFINITY : 0.f;
 #ifdef ADFP_STAMPS_G
     unsigned long long ph_[24] = {}, last_ = clock64();
+    const unsigned long long wstart_ = wall_clock64();
 #endif
-    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<NT / 64>(j, &s_next, ntiles)) >= 0;) {
+    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile_pool<NT / 64>(j, &s_next, s_ring, plan, ntiles, a.pool)) >= 0;) {
         // front point: point n of block 0 on lanes 0-31 (both K-groups g = 0, 1 of the pair), of block 1 on lanes 32-63
         const int idx = tile * 32 + 16 * (g >> 1) + n;
         const bool valid = idx < count;
@@ -382,7 +387,11 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16(DecodeLCArgs a) {
         ADFP_PHG(21);
     }
 #ifdef ADFP_STAMPS_G
+    { const unsigned long long wend_ = wall_clock64();       // before the phase atomics below (3 072 waves x 16 atomics on 16 addresses)
+      const int wv_ = blockIdx.x * (NT / 64) + (threadIdx.x >> 6); if (lane == 0 && wv_ < 4096) { g_wave_span_g[2 * wv_] = wstart_ | (ph_[14] << 48); g_wave_span_g[2 * wv_ + 1] = wend_; } }
+#if ADFP_STAMPS_G != 2      // (= 2: spans only -- the 49 000 atomics below queue up in L2 in front of the still running waves' gathers and fake a tail)
     if (lane == 0) for (int k = 8; k < 24; ++k) atomicAdd(&g_phase_g[k], ph_[k]);
+#endif
 #endif
     report_range(a.status, amax_low, ADFP_STATUS_F16_RANGE_LOW, a.call_flag);
     report_range(a.status, amax_col, ADFP_STATUS_F16_RANGE_COLOR, a.call_flag);
@@ -474,17 +483,20 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_high_g(DecodeArgs a) {
     using L = DecLayoutG<64, 1>;
     __shared__ __attribute__((aligned(16))) unsigned ldsu[L::P_TOTAL];
     __shared__ int s_next;
+    __shared__ unsigned long long s_ring[ADFP_POOL_RING];
     for (int i = threadIdx.x; i < L::P_TOTAL / 4; i += NT) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed)[i];
     if (threadIdx.x == 0) s_next = NT / 64;
+    if (threadIdx.x < ADFP_POOL_RING) s_ring[threadIdx.x] = 0ull;
     __syncthreads();
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
     const int count = *a.count_ptr;
     const int ntiles = (count + 31) >> 5;
+    const TilePlan plan = tile_plan(ntiles, (int)gridDim.x, NT / 64, a.pool != nullptr);
     float amax = image_out_of_range<L::P_FLAG, L::NFLAG>(ldsu) ? INFINITY : 0.f;
 #ifdef ADFP_STAMPS_G
     unsigned long long ph_[8] = {}, last_ = clock64();
 #endif
-    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<NT / 64>(j, &s_next, ntiles)) >= 0;) {
+    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile_pool<NT / 64>(j, &s_next, s_ring, plan, ntiles, a.pool)) >= 0;) {
         const int idx = tile * 32 + 16 * (g >> 1) + n;
         const bool valid = idx < count;
 #ifdef ADFP_HIGH_IDENTITY      // timing experiment: the same number of tiles over CONTIGUOUS points (no list indirection; results are not the network's)
@@ -521,7 +533,9 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_high_g(DecodeArgs a) {
         ADFP_PHG(5);
     }
 #ifdef ADFP_STAMPS_G
+#if ADFP_STAMPS_G != 2
     if (lane == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_phase_g[k], ph_[k]);
+#endif
 #endif
     report_range(a.status, amax, ADFP_STATUS_F16_RANGE_HIGH, a.call_flag);
 }
@@ -597,8 +611,10 @@ __global__ __launch_bounds__(NT) void k_attention_g(AttArgs a) {
     using A = AttLayoutG;
     __shared__ __attribute__((aligned(16))) unsigned ldsu[A::P_TOTAL];
     __shared__ int s_next;
+    __shared__ unsigned long long s_ring[ADFP_POOL_RING];
     for (int i = threadIdx.x; i < A::P_TOTAL / 4; i += NT) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed)[i];
     if (threadIdx.x == 0) s_next = NT / 64;
+    if (threadIdx.x < ADFP_POOL_RING) s_ring[threadIdx.x] = 0ull;
     __syncthreads();
     const float* lds = (const float*)ldsu;
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
@@ -607,8 +623,9 @@ __global__ __launch_bounds__(NT) void k_attention_g(AttArgs a) {
     const float* arow = lds + 32 * g;
     const int count = a.count_ptr ? *a.count_ptr : a.n_rows;
     const int ntiles = (count + 31) >> 5;
+    const TilePlan plan = tile_plan(ntiles, (int)gridDim.x, NT / 64, a.pool != nullptr);
     float amax = image_out_of_range<A::P_FLAG, A::NFLAG>(ldsu) ? INFINITY : 0.f;
-    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<NT / 64>(j, &s_next, ntiles)) >= 0;) {
+    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile_pool<NT / 64>(j, &s_next, s_ring, plan, ntiles, a.pool)) >= 0;) {
         int idx[2]; bool valid[2]; float occ[2], u[2];
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {

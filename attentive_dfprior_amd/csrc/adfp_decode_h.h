@@ -469,6 +469,7 @@ struct DecodeLCArgs {
     float* raw; float* w;
     int write_w, apply_bound;
     int* status; int* call_flag;
+    int* pool;                 // k_decode_lc16: device counter of the chip-wide tile tail (claim_tile_pool), zero at launch, or NULL
 };
 template <int NT>
 __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc(DecodeLCArgs a) {

@@ -516,6 +516,53 @@ ADFP_DEV float wave_scan_mul(float v, int lane, float& total) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Tile hand-out with a CHIP-WIDE tail (round 4).  Per-wave end stamps of the fused decoder launch (tools/phase_g.py, spans-only
+// build) showed the waves of a workgroup ending within 23 us of each other but the WORKGROUPS 1 352 ... 1 444 us after the start
+// (one XCD 3.4 % behind the others): with every workgroup owning the same number of tiles the launch waits for its slowest CU
+// while the others idle -- 4.9 % of the launch.  So a workgroup owns only its first `j_static` slots (whole rows of the fixed
+// split); the tiles behind them (from `pool_base` on) are handed out in CHUNKS of NWW consecutive tiles from ONE device counter,
+// one global atomic per chunk -- issued by the wave that DRAWS the chunk's first slot, a tile ahead of its use, and published to
+// the workgroup through a small LDS ring -- so a fast CU takes more chunks.  (Round 2 handed the last eighth out tile by tile:
+// 25 000 returning atomics on one address made the launch 18 % slower; this is 1 in 12 of that.)
+// `pool` == NULL: the fixed split (bench hooks without a workspace).  *pool must be zero at launch.
+// ---------------------------------------------------------------------------------------------
+#define ADFP_POOL_RING 16
+struct TilePlan { int j_static, pool_base; };
+__host__ __device__ inline TilePlan tile_plan(int ntiles, int nwg, int nww, bool pooled) {
+    const int per_row = nwg * nww, rows = (ntiles + per_row - 1) / per_row;
+    int keep = rows;
+    if (pooled && rows >= 6) { int tail = rows / 10; if (tail < 2) tail = 2; keep = rows - tail; }
+    TilePlan p; p.j_static = keep * nww; p.pool_base = keep * per_row;
+    if (!pooled || rows < 6) { p.j_static = 0x7fffffff; p.pool_base = 0; }
+    return p;
+}
+template <int NWW>
+ADFP_DEV int claim_tile_pool(int& j, int* s_next, unsigned long long* s_ring, const TilePlan plan, int ntiles, int* pool) {
+    int tile;
+    if (j < plan.j_static) tile = blockIdx.x * NWW + (j % NWW) + (j / NWW) * (gridDim.x * NWW);
+    else {
+        const int d = j - plan.j_static, c = d / NWW, slot = d - c * NWW;
+        unsigned long long e;
+        do { e = __hip_atomic_load(s_ring + (c & (ADFP_POOL_RING - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while ((int)(e >> 32) != c + 1);
+        tile = plan.pool_base + (int)(unsigned)e + slot;
+    }
+    if (tile >= ntiles) return -1;
+    int jn = 0;
+    if ((threadIdx.x & 63) == 0) {
+        jn = atomicAdd(s_next, 1);
+        if (jn >= plan.j_static) {
+            const int d = jn - plan.j_static, c = d / NWW;
+            if (d - c * NWW == 0) {                      // this draw opens chunk c: fetch its tiles now, a tile before anyone needs them
+                const int base = atomicAdd(pool, NWW);
+                __hip_atomic_store(s_ring + (c & (ADFP_POOL_RING - 1)), ((unsigned long long)(unsigned)(c + 1) << 32) | (unsigned)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    j = __builtin_amdgcn_readfirstlane(jn);
+    return tile;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Tile hand-out inside a workgroup.  A workgroup of NWW waves owns the tiles
 //   wg_tile(j) = blockIdx.x * NWW + (j % NWW) + (j / NWW) * (gridDim.x * NWW),   j = 0, 1, 2, ...
 // (the same set a fixed wave-strided split would give it) and its waves take slots j from an LDS

@@ -728,6 +728,7 @@ struct DecodeArgs {
     float* act;                // training forward: X part of the staging rows, [rows][DecStage::NX], or NULL
     int single;                // adfp_decode_single: one decoder alone (COLOR writes its 4th output, HIGH does not add `low`)
     int* call_flag;            // f16x3 kernels: the call's range flag (device memory, arms k_fallback_points) or NULL
+    int* pool = nullptr;       // k_decode_high_g: counter of the chip-wide tile tail (claim_tile_pool), zero at launch, or NULL
 };
 
 template <int CDIM, int NOUT, int ROLE, int NT>
@@ -829,6 +830,7 @@ struct AttArgs {
     int* call_flag;            // as DecodeArgs.call_flag
     unsigned* masks;           // training forward (k_attention_h<1>): ReLU masks + softmax weights, [rows][2][ATT_MASK_WORDS / 2]
     float* act;                // training forward: X piece of the staging rows ([rows][416]: inputs, h_0..h_3), or NULL
+    int* pool = nullptr;       // k_attention_g: counter of the chip-wide tile tail (claim_tile_pool), zero at launch, or NULL
 };
 
 // workgroup shape of the dense f16x3 decoder kernels: 256 threads x 2 workgroups per CU, or one
@@ -990,6 +992,9 @@ extern "C" int adfp_debug_phases_g(unsigned long long* host_out, int reset) {
     int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_g), 192);
     if (!rc && reset) { unsigned long long z[24] = {}; rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_g), z, 192); }
     return rc;
+}
+extern "C" int adfp_debug_wave_span_g(unsigned long long* host_out, int n_waves) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wave_span_g), (size_t)n_waves * 16);
 }
 #endif
 
@@ -1456,6 +1461,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         f.g_low = make_grid(sc->low); f.g_color = make_grid(sc->color);
         f.packed_low = (const unsigned*)sc->h_low; f.packed_color = (const unsigned*)sc->h_color;
         f.flags = a.flags; f.raw = raw; f.w = w; f.write_w = 1; f.apply_bound = apply_bound; f.status = sc->status; f.call_flag = call_flag;
+        f.pool = ws.counter ? ws.counter + 10 : nullptr;            // zero: this call's 64-byte counter block was cleared above (or by the caller)
 #ifdef ADFP_LC_32X32          // A/B build: the 32x32x16 form of the fused launch (adfp_decode_h.h)
         hipLaunchKernelGGL((k_decode_lc<ADFP_LC_NT>), dim3(decode_grid(ntiles, ADFP_LC_NT / 64, 1)), dim3(ADFP_LC_NT), 0, st, f);
 #else
@@ -1475,7 +1481,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         f.P = P; f.nb = a.nb; fill_bound(f.b, sc->bound);
         f.g_low = make_grid(sc->low); f.g_color = make_grid(sc->color);
         f.packed_low = (const unsigned*)sc->h_low + DecLayoutH<32, 1>::P_TOTAL; f.packed_color = (const unsigned*)sc->h_color + DecLayoutH<32, 4>::P_TOTAL;   // the G images
-        f.flags = a.flags; f.raw = raw; f.w = w; f.write_w = 1; f.apply_bound = apply_bound; f.status = sc->status; f.call_flag = call_flag;
+        f.flags = a.flags; f.raw = raw; f.w = w; f.write_w = 1; f.apply_bound = apply_bound; f.status = sc->status; f.call_flag = call_flag; f.pool = nullptr;
         t.masks_low = state->masks_low; t.masks_color = state->masks_color; t.act_low = state->act_low; t.act_color = state->act_color;
         hipLaunchKernelGGL((k_decode_lc16_train<ADFP_LCT_NT>), dim3(decode_grid(ntiles, ADFP_LCT_NT / 64, 1)), dim3(ADFP_LCT_NT), 0, st, t);
         ADFP_CHECK_LAUNCH();
@@ -1527,6 +1533,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
             hipLaunchKernelGGL((k_decode_h<64, 1, ROLE_HIGH, ADFP_HIGH_NT>), dim3(decode_grid(ntiles, ADFP_HIGH_NT / 64, 1)), dim3(ADFP_HIGH_NT), 0, st, a);
 #else
             a.packed = (const float*)((const unsigned*)sc->h_high + DecLayoutH<64, 1>::P_TOTAL);          // the G image
+            a.pool = ws.counter ? ws.counter + 11 : nullptr;
             hipLaunchKernelGGL((k_decode_high_g<ADFP_HIGH_NT>), dim3(decode_grid(ntiles, ADFP_HIGH_NT / 64, 1)), dim3(ADFP_HIGH_NT), 0, st, a);
 #endif
         } else {
@@ -1547,6 +1554,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
             hipLaunchKernelGGL(k_attention_h<0>, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
 #else
             t.packed = (const float*)((const unsigned*)sc->h_att + AttLayoutH::P_TOTAL);                 // the G image
+            t.pool = ws.counter ? ws.counter + 12 : nullptr;
             hipLaunchKernelGGL(k_attention_g<512>, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
 #endif
         } else {
@@ -1585,7 +1593,7 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
         f.P = P; f.nb = make_norm(sc->bound); fill_bound(f.b, sc->bound);
         f.g_low = make_grid(sc->low); f.g_color = make_grid(sc->color);
         f.packed_low = (const unsigned*)sc->h_low; f.packed_color = (const unsigned*)sc->h_color;
-        f.flags = nullptr; f.raw = raw; f.w = w; f.write_w = 1; f.apply_bound = 1; f.status = sc->status; f.call_flag = nullptr;
+        f.flags = nullptr; f.raw = raw; f.w = w; f.write_w = 1; f.apply_bound = 1; f.status = sc->status; f.call_flag = nullptr; f.pool = nullptr;
 #ifdef ADFP_LC_32X32
         hipLaunchKernelGGL((k_decode_lc<ADFP_LC_NT>), dim3(decode_grid((P.n + 31) / 32, ADFP_LC_NT / 64, 1)), dim3(ADFP_LC_NT), 0, (hipStream_t)stream, f);
 #else

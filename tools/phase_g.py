@@ -46,3 +46,24 @@ print('tiles processed: k_decode_high_g', ph[6], 'expected', int(band * N * S) /
 print('k_decode_high_g  wave-cycles per tile:', {n: round(ph[k] / tiles_hi) for k, n in enumerate(names)}, 'sum', round(sum(ph[:6]) / tiles_hi))
 print('k_decode_lc16 low    :', {n: round(ph[8 + k] / tiles_lc) for k, n in enumerate(names[:5])}, 'sum', round(sum(ph[8:13]) / tiles_lc))
 print('k_decode_lc16 colour :', {n: round(ph[16 + k] / tiles_lc) for k, n in enumerate(names)}, 'sum', round(sum(ph[16:22]) / tiles_lc))
+
+# per-wave wall-clock span of the last k_decode_lc16 launch (256 workgroups x 12 waves)
+import numpy as np
+nw = 256 * 12
+buf = (C.c_ulonglong * (2 * nw))()
+L.adfp_debug_wave_span_g.argtypes = [C.c_void_p, C.c_int]
+assert L.adfp_debug_wave_span_g(buf, nw) == 0
+raw_ = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 2)
+ntile_ = (raw_[:, 0] >> np.uint64(48)).astype(np.int64)
+a = np.stack([(raw_[:, 0] & np.uint64((1 << 48) - 1)).astype(np.int64), raw_[:, 1].astype(np.int64)], 1)
+t0 = a[:, 0].min()
+st, en = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0          # us
+wg = en.reshape(256, 12).max(1)
+print('k_decode_lc16 waves: start us min %.1f max %.1f | end us min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f' % (
+    st.min(), st.max(), en.min(), np.percentile(en, 10), np.median(en), np.percentile(en, 90), en.max()))
+print('per-workgroup end us: min %.1f p50 %.1f max %.1f; mean idle tail per wave %.1f us = %.2f %% of the launch' % (
+    wg.min(), np.median(wg), wg.max(), (en.max() - en).mean(), 100 * (en.max() - en).mean() / en.max()))
+print('per-XCD mean workgroup end us:', wg.reshape(32, 8).mean(0).round(1).tolist())
+for b in (0, 100, 255):
+    print('workgroup', b, 'wave ends us:', en.reshape(256, 12)[b].round(0).tolist(), 'tiles per wave:', ntile_.reshape(256, 12)[b].tolist())
+print('within-workgroup spread (max - min of wave ends) us: mean %.1f max %.1f' % ((en.reshape(256, 12).max(1) - en.reshape(256, 12).min(1)).mean(), (en.reshape(256, 12).max(1) - en.reshape(256, 12).min(1)).max()))
