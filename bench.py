@@ -167,7 +167,7 @@ def pmc_traffic(kernel_prefix, samples_per_launch, fname='r03_pmc_hbm_traffic.cs
 # scale for parity).  Named in config.workload and config.grid_init.
 GRID_STD_SCALE, GRID_HIGH_EXTRA = 20.0, 100.0
 # instruction counts of one 32-point tile of k_decode_lc16 (both networks), from the compiled kernel (tools/isa_mix.py)
-LC16_MFMA_PER_TILE, LC16_VALU_PER_TILE, LC16_LDS_PER_TILE = 360, 2377, 247
+LC16_MFMA_PER_TILE, LC16_VALU_PER_TILE, LC16_LDS_PER_TILE = 360, 2415, 250      # static counts; ~35 of the VALU are the other branch of the tile hand-out
 
 
 def pmc_sq(kernel_prefix, fname='r04_pmc_sq_forward.txt'):
