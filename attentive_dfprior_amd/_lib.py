@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ADFP_LIB_PATH', os.path.join(_HERE, 'libadfp.so'))   # override: kernel A/B builds
 
-ABI_VERSION = 124                 # ADFP_VERSION of include/adfp.h this binding was written against
+ABI_VERSION = 125                 # ADFP_VERSION of include/adfp.h this binding was written against
 STATUS_F16_RANGE = 31              # ADFP_STATUS_F16_RANGE: any of the bits below
 STATUS_RANGE_BITS = {'low': 1, 'high': 2, 'color': 4, 'att': 8, 'bwd': 16}      # ADFP_STATUS_F16_RANGE_<net>
 BWD_SCATTER_IN_KERNEL = 1        # ADFP_BWD_SCATTER_IN_KERNEL
@@ -193,7 +193,7 @@ SYMBOLS = [
     ('adfp_backward_workspace_bytes', C.c_size_t, [C.c_longlong]),
     ('adfp_render_backward', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpBackwardArgs), C.c_void_p]),
     ('adfp_decode_stage', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_int, C.c_void_p, C.c_void_p,
-                                    C.c_void_p]),
+                                    C.c_void_p, C.c_void_p]),
     ('adfp_decode_single', C.c_int, [C.POINTER(AdfpScene), C.POINTER(AdfpPoints), C.c_int, C.c_void_p, C.c_void_p]),
     ('adfp_attention_rows', C.c_int, [C.POINTER(AdfpScene), C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),

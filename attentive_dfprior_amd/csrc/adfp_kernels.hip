@@ -1581,7 +1581,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
 }
 
 // bench hook: ONE decoder kernel (LOW or COLOR) over every point, nothing else.
-extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, int kind, float* raw, float* w, void* stream) {
+extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, int kind, float* raw, float* w, int* tile_counter, void* stream) {
     if (!sc || !pts || !raw || !w) return ADFP_E_ARG;
     if (kind != ADFP_DEC_LOW && kind != ADFP_DEC_COLOR && kind != ADFP_DEC_LOW_COLOR) return ADFP_E_UNSUPPORTED;
     if (grid_too_big(sc->low) || grid_too_big(sc->color)) return ADFP_E_UNSUPPORTED;
@@ -1593,7 +1593,8 @@ extern "C" int adfp_decode_stage(const adfp_scene* sc, const adfp_points* pts, i
         f.P = P; f.nb = make_norm(sc->bound); fill_bound(f.b, sc->bound);
         f.g_low = make_grid(sc->low); f.g_color = make_grid(sc->color);
         f.packed_low = (const unsigned*)sc->h_low; f.packed_color = (const unsigned*)sc->h_color;
-        f.flags = nullptr; f.raw = raw; f.w = w; f.write_w = 1; f.apply_bound = 1; f.status = sc->status; f.call_flag = nullptr; f.pool = nullptr;
+        f.flags = nullptr; f.raw = raw; f.w = w; f.write_w = 1; f.apply_bound = 1; f.status = sc->status; f.call_flag = nullptr; f.pool = tile_counter;
+        if (tile_counter) { hipError_t e = zero_async(tile_counter, 4, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
 #ifdef ADFP_LC_32X32
         hipLaunchKernelGGL((k_decode_lc<ADFP_LC_NT>), dim3(decode_grid((P.n + 31) / 32, ADFP_LC_NT / 64, 1)), dim3(ADFP_LC_NT), 0, (hipStream_t)stream, f);
 #else

@@ -590,6 +590,7 @@ def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, N
     lst = torch.empty((Pmax,), dtype=torch.int32, device=dev)
     attu = torch.empty((Pmax,), dtype=torch.float32, device=dev)
     cnt = torch.zeros((4,), dtype=torch.int32, device=dev)
+    tile_cnt = torch.zeros((1,), dtype=torch.int32, device=dev)      # the fused launch's chip-wide tile counter (in the frame: a word of the workspace)
     st = _lib.current_stream(dev)
     band_frac = n_band / n_pts
     nl = len(batches)
@@ -608,10 +609,10 @@ def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, N
         torch.cuda.synchronize(dev)
         return e0.elapsed_time(e1) / (reps * nl) * 1e-3
 
-    t_color = timed(lambda b: _lib.check(L.adfp_decode_stage(C.byref(sc), C.byref(b[0]), 2, _lib.ptr(raw), _lib.ptr(wbuf), st), 'decode'))
-    t_low = timed(lambda b: _lib.check(L.adfp_decode_stage(C.byref(sc), C.byref(b[0]), 0, _lib.ptr(raw), _lib.ptr(wbuf), st), 'decode'))
+    t_color = timed(lambda b: _lib.check(L.adfp_decode_stage(C.byref(sc), C.byref(b[0]), 2, _lib.ptr(raw), _lib.ptr(wbuf), _lib.ptr(tile_cnt), st), 'decode'))
+    t_low = timed(lambda b: _lib.check(L.adfp_decode_stage(C.byref(sc), C.byref(b[0]), 0, _lib.ptr(raw), _lib.ptr(wbuf), _lib.ptr(tile_cnt), st), 'decode'))
     # the launch stage color actually uses in the default mode: low + colour decoder fused (k_decode_lc)
-    t_lc = timed(lambda b: _lib.check(L.adfp_decode_stage(C.byref(sc), C.byref(b[0]), 3, _lib.ptr(raw), _lib.ptr(wbuf), st), 'decode')) \
+    t_lc = timed(lambda b: _lib.check(L.adfp_decode_stage(C.byref(sc), C.byref(b[0]), 3, _lib.ptr(raw), _lib.ptr(wbuf), _lib.ptr(tile_cnt), st), 'decode')) \
         if sc.h_low and sc.h_color else None
     t_tsdf = timed(lambda b: _lib.check(L.adfp_tsdf_stage(C.byref(sc), C.byref(b[0]), _lib.ptr(flags), _lib.ptr(lst), _lib.ptr(attu),
                                                           None, _lib.ptr(cnt), st), 'tsdf'))

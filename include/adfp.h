@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 124
+#define ADFP_VERSION 125
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -547,9 +547,10 @@ int adfp_tsdf_stage(const adfp_scene* scene, const adfp_points* pts, unsigned ch
 
 /* Per-stage timing hook for bench.py: runs ONLY one decoder kernel (kind = ADFP_DEC_LOW or ADFP_DEC_COLOR, or
  * ADFP_DEC_LOW_COLOR = the fused low + colour launch that stage color uses with f16-split images) over every point and
- * writes its output channel(s) of raw. */
+ * writes its output channel(s) of raw.  tile_counter: one device int the fused launch may use for its chip-wide tile tail (as it
+ * does inside adfp_render_forward, where the word lives in the workspace; zeroed here before the launch), or NULL = fixed split. */
 #define ADFP_DEC_LOW_COLOR 3
-int adfp_decode_stage(const adfp_scene* scene, const adfp_points* pts, int kind, float* raw, float* w, void* stream);
+int adfp_decode_stage(const adfp_scene* scene, const adfp_points* pts, int kind, float* raw, float* w, int* tile_counter, void* stream);
 
 /* ---- one sub-network alone (reference: the public modules `decoders.low_decoder / high_decoder / color_decoder / mlp`) ---- */
 /* MLP.forward(p, c_grid) of src/conv_onet/models/decoder.py:177-203 for one decoder kind, no bound rule, no band logic.

@@ -132,9 +132,9 @@ int main() {
     EXPECT_NEG(adfp_tsdf_stage(&sc, &pts, dev<unsigned char>(4), dev<int>(1), nullptr, nullptr, dev<int>(3), st));       // a list without its att_u
     EXPECT_REACHES_LAUNCH(adfp_tsdf_stage(&sc, &pts, nullptr, nullptr, nullptr, dev<float>(2), nullptr, st));               // flags / list are optional
     EXPECT_REACHES_LAUNCH(adfp_tsdf_stage(&sc, &pts, dev<unsigned char>(4), dev<int>(1), dev<float>(2), nullptr, dev<int>(3), st));
-    EXPECT_CODE(adfp_decode_stage(&sc, &pts, 5, dev<float>(10), dev<float>(11), st), ADFP_E_UNSUPPORTED);
-    EXPECT_NEG(adfp_decode_stage(&sc, &pts, ADFP_DEC_LOW_COLOR, dev<float>(10), dev<float>(11), st));       // the fused launch needs the split images
-    EXPECT_REACHES_LAUNCH(adfp_decode_stage(&sc, &pts, ADFP_DEC_LOW, dev<float>(10), dev<float>(11), st));
+    EXPECT_CODE(adfp_decode_stage(&sc, &pts, 5, dev<float>(10), dev<float>(11), nullptr, st), ADFP_E_UNSUPPORTED);
+    EXPECT_NEG(adfp_decode_stage(&sc, &pts, ADFP_DEC_LOW_COLOR, dev<float>(10), dev<float>(11), nullptr, st));       // the fused launch needs the split images
+    EXPECT_REACHES_LAUNCH(adfp_decode_stage(&sc, &pts, ADFP_DEC_LOW, dev<float>(10), dev<float>(11), nullptr, st));
     EXPECT_NEG(adfp_decode_single(&sc, &pts, 4, dev<float>(10), st));
     EXPECT_NEG(adfp_decode_single(&sc, &pts, ADFP_DEC_HIGH, nullptr, st));
     for (int k = 0; k < 3; ++k) EXPECT_REACHES_LAUNCH(adfp_decode_single(&sc, &pts, k, dev<float>(10), st));

@@ -60,10 +60,10 @@ def main(reps=int(os.environ.get("AB_REPS", "8"))):
         ts.sort()
         return ts[len(ts) // 2], ts[0]
     res = {'lib': os.path.basename(_lib.LIB_PATH), 'checksum': [d.double().sum().item(), u.double().sum().item(), c.double().sum().item()]}
-    res['color_ms'] = timed(lambda: L.adfp_decode_stage(C.byref(sc), C.byref(ap), 2, _lib.ptr(raw), _lib.ptr(wb), st))
-    res['low_ms'] = timed(lambda: L.adfp_decode_stage(C.byref(sc), C.byref(ap), 0, _lib.ptr(raw), _lib.ptr(wb), st))
-    if L.adfp_decode_stage(C.byref(sc), C.byref(ap), 3, _lib.ptr(raw), _lib.ptr(wb), st) == 0:      # the fused low + colour launch
-        res['low_color_ms'] = timed(lambda: L.adfp_decode_stage(C.byref(sc), C.byref(ap), 3, _lib.ptr(raw), _lib.ptr(wb), st))
+    res['color_ms'] = timed(lambda: L.adfp_decode_stage(C.byref(sc), C.byref(ap), 2, _lib.ptr(raw), _lib.ptr(wb), _lib.ptr(cnt[1:]), st))
+    res['low_ms'] = timed(lambda: L.adfp_decode_stage(C.byref(sc), C.byref(ap), 0, _lib.ptr(raw), _lib.ptr(wb), _lib.ptr(cnt[1:]), st))
+    if L.adfp_decode_stage(C.byref(sc), C.byref(ap), 3, _lib.ptr(raw), _lib.ptr(wb), _lib.ptr(cnt[1:]), st) == 0:      # the fused low + colour launch
+        res['low_color_ms'] = timed(lambda: L.adfp_decode_stage(C.byref(sc), C.byref(ap), 3, _lib.ptr(raw), _lib.ptr(wb), _lib.ptr(cnt[1:]), st))
     res['tsdf_ms'] = timed(lambda: L.adfp_tsdf_stage(C.byref(sc), C.byref(ap), _lib.ptr(flags), _lib.ptr(lst), _lib.ptr(attu),
                                                      None, _lib.ptr(cnt), st))
     res['batch_ms'] = timed(lambda: eng.render_forward(dec, scene.c, ro, rd, gd, scene.tsdf_volume, tsdf_bnds, scene.bound, 'color', 48, 16))
@@ -74,7 +74,7 @@ def main(reps=int(os.environ.get("AB_REPS", "8"))):
     if hasattr(L, 'adfp_debug_stamps') or os.environ.get('ADFP_STAMPS'):
         # debug build (-DADFP_STAMPS): per-wave start/end wall clock of the last k_decode_h launch
         import numpy as np
-        L.adfp_decode_stage(C.byref(sc), C.byref(ap), 2, _lib.ptr(raw), _lib.ptr(wb), st)
+        L.adfp_decode_stage(C.byref(sc), C.byref(ap), 2, _lib.ptr(raw), _lib.ptr(wb), _lib.ptr(cnt[1:]), st)
         torch.cuda.synchronize()
         nw = 256 * 12
         buf = (C.c_ulonglong * (2 * nw))()
@@ -95,7 +95,7 @@ def main(reps=int(os.environ.get("AB_REPS", "8"))):
         ph = (C.c_ulonglong * 8)()
         L.adfp_debug_phases.argtypes = [C.c_void_p, C.c_int]
         L.adfp_debug_phases(ph, 1)
-        L.adfp_decode_stage(C.byref(sc), C.byref(ap), 2, _lib.ptr(raw), _lib.ptr(wb), st)
+        L.adfp_decode_stage(C.byref(sc), C.byref(ap), 2, _lib.ptr(raw), _lib.ptr(wb), _lib.ptr(cnt[1:]), st)
         torch.cuda.synchronize()
         L.adfp_debug_phases(ph, 1)
         tot = float(sum(ph[:5]))
