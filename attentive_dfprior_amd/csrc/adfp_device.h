@@ -526,7 +526,9 @@ ADFP_DEV float wave_scan_mul(float v, int lane, float& total) {
 // 25 000 returning atomics on one address made the launch 18 % slower; this is 1 in 12 of that.)
 // `pool` == NULL: the fixed split (bench hooks without a workspace).  *pool must be zero at launch.
 // ---------------------------------------------------------------------------------------------
-#define ADFP_POOL_RING 16
+// ring size: an entry is overwritten ADFP_POOL_RING chunks later; a wave uses the slot it drew one tile earlier, and in one tile of the
+// slowest wave (the arbiter starves the youngest wave of a SIMD to ~0.45 x the oldest one's rate) the workgroup draws < 3 chunks
+#define ADFP_POOL_RING 64
 struct TilePlan { int j_static, pool_base; };
 __host__ __device__ inline TilePlan tile_plan(int ntiles, int nwg, int nww, bool pooled) {
     const int per_row = nwg * nww, rows = (ntiles + per_row - 1) / per_row;
