@@ -232,9 +232,7 @@ int adfp_composite(const float* raw /*[N,S,4]*/, const double* z_vals /*[N,S]*/,
 /* Buffers the backward needs from the forward (training only).  Caller-owned, sized for P points:
  * flags P bytes, list P ints, counter >= 64 bytes (int[0] = length of the in-band list, int[8] = the forward call's f16-range
  * flag: non-zero = the forward was repaired by the f32 fallback, the ReLU masks / layer inputs it left are not valid, and the
- * backward entries then return ZERO gradients for that call -- see adfp_scene.flat_*; int[10..12] = the tile counters of the
- * chip-wide launch tail of the inference kernels, used when the same block is a workspace's; the library zeroes the block itself),
- * att_occ / att_u P floats.
+ * backward entries then return ZERO gradients for that call -- see adfp_scene.flat_*), att_occ / att_u P floats.
  * Optional, for the f16-split backward (scene->h_* and ->ht_* set; any of them may be NULL = exact backward for that
  * decoder): masks_* = ADFP_TRAIN_MASK_WORDS 32-bit words per point, the ReLU masks of the decoder's five layers;
  * act_* = adfp_train_act_floats(kind) floats per point, the inputs of every layer (position, Fourier features, grid
