@@ -104,7 +104,20 @@ def pack_network(name, params, fmt='f32', status=None, flat=None, out=None):
 
 class _SingleNet(object):
     """Mixin of MLP / mlp_tsdf: the packed image of THIS module alone, for direct calls of a sub-network
-    (``decoders.low_decoder(p, c_grid)``, reference decoder.py:177).  The cache is dropped by deepcopy / pickling."""
+    (``decoders.low_decoder(p, c_grid)``, reference decoder.py:177).  The cache is dropped by deepcopy / pickling.
+
+    WHERE the parameters live.  The kernels want a network's parameters as one flat float32 buffer in state_dict order.  They
+    are put there at the moments the storage is replaced ANYWAY and nobody can hold the old one yet: ``.to(device)`` /
+    ``.cuda()`` / ``.float()`` (``_apply``) and ``copy.deepcopy`` -- never lazily inside a render call.  The reference shares
+    the decoders between its Mapper and Tracker processes through CUDA IPC after ``.to(device)`` (src/DF_Prior.py:50-51,
+    :108-110, :305-307): the flat buffer then IS the exported storage, every nn.Parameter a view of it on both sides, and an
+    in-place optimiser step in the Mapper process is what the Tracker process reads.  Parameters that are not in one buffer
+    (somebody assigned ``p.data``) are served from a copy cached on their versions (DF.flat_weights)."""
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        home_parameters(self)
+        return out
 
     def _single_packed(self, name, fmt):
         params = tuple(self.parameters())
@@ -254,6 +267,19 @@ def _home_in_one_buffer(params):
     return flat
 
 
+def home_parameters(module):
+    """Puts the float32 CUDA parameters of one sub-network into one buffer (see _SingleNet) unless they are there already.
+    Only for a module whose parameter storage is private at this moment (just converted / just copied).  Returns the flat
+    view, or None when the parameters are not all float32 on one GPU."""
+    params = tuple(module.parameters())
+    if not params or not all(p.is_cuda and p.dtype == torch.float32 and p.device == params[0].device for p in params):
+        return None
+    flat = _flat_params(params)
+    if flat.untyped_storage().data_ptr() == params[0].untyped_storage().data_ptr():
+        return flat
+    return _home_in_one_buffer(params)
+
+
 _NET_ATTR = {'low': 'low_decoder', 'high': 'high_decoder', 'color': 'color_decoder', 'att': 'mlp'}
 
 
@@ -337,9 +363,10 @@ class DF(nn.Module):
         return out
 
     def flat_weights(self, name, key=None):
-        """The network's parameters as one flat float32 buffer in state_dict order.  Float32 parameters on the GPU are re-homed
-        in one buffer on first use (_home_in_one_buffer), after which this is a VIEW of the live parameters (cached on their
-        addresses); anything else (half / double parameters) is a copy cached on the parameters' versions."""
+        """The network's parameters as one flat float32 buffer in state_dict order: a VIEW of the live parameters when they lie
+        in one buffer (home_parameters put them there at .to(device) / deepcopy, cached on their addresses), otherwise a copy
+        cached on the parameters' versions.  Never moves a parameter: another process may hold the storage through CUDA IPC
+        (src/DF_Prior.py:108-110)."""
         module = self.net_params(name)
         if key is None:
             key = _version_key(module)
@@ -348,11 +375,6 @@ class DF(nn.Module):
             return hit[1]
         flat = _flat_params(module)
         is_view = flat.untyped_storage().data_ptr() == module[0].untyped_storage().data_ptr()
-        if not is_view and all(p.is_cuda and p.dtype == torch.float32 for p in module):
-            flat = _home_in_one_buffer(module)
-            is_view = True
-            key = _version_key(module)
-            self._packed = {k: v for k, v in self._packed.items() if k.split('.')[0] != name}    # images keyed on the old addresses
         self._packed[name + '.flat'] = (key[0], flat, is_view, key[1])
         return flat
 
@@ -379,10 +401,6 @@ class DF(nn.Module):
             if not need:
                 return hit[1]
             flat = self.flat_weights(name, key)
-            if module[0].data_ptr() != key[0][0]:
-                key = _version_key(module)         # flat_weights re-homed the parameters: new addresses
-                need = ['h', 'g'] if fmt == 'hg' else [fmt]
-            hit = self._packed.get(slot)
             packed = pack_network(name, module, 'hg' if len(need) == 2 else need[0], status=self.status_word(), flat=flat,
                                   out=None if hit is None else hit[1])
             keys = dict(hit[2]) if hit is not None and hit[1] is packed else {}
@@ -395,9 +413,6 @@ class DF(nn.Module):
         if hit is not None and hit[0] == key:
             return hit[1]
         flat = self.flat_weights(name, key)
-        if module[0].data_ptr() != key[0][0]:
-            key = _version_key(module)             # flat_weights re-homed the parameters: new addresses
-        hit = self._packed.get(slot)
         packed = pack_network(name, module, fmt, status=self.status_word(), flat=flat, out=None if hit is None else hit[1])
         self._packed[slot] = (key, packed)
         return packed
@@ -416,6 +431,8 @@ class DF(nn.Module):
         new._plists = {}
         new._engine = None
         new._status = None
+        for attr in _NET_ATTR.values():            # Parameter.__deepcopy__ clones each tensor on its own; the copy is private here
+            home_parameters(getattr(new, attr))
         return new
 
     def __getstate__(self):

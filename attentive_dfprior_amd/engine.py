@@ -196,8 +196,9 @@ class Engine(object):
         images: which part(s) of the split images to keep current -- None: exactly what the forward entries read for this stage,
         these latches and this training `state` (Engine.image_parts); 'hg' = both (bench / A-B tools that launch single kernels
         of either family)."""
-        decoders.absorb_status()                 # an f16-range event of an EARLIER call: that network is exact from now on
-        sc = _lib.AdfpScene()
+        if state is None:                        # (a training forward absorbed BEFORE it laid its state out: the latch that chose the
+            decoders.absorb_status()             # state's regions must be the latch that picks the images below)
+        sc = _lib.AdfpScene()                    # an f16-range event of an EARLIER call: that network is exact from now on
         sc.status = decoders.status_word().data_ptr()
         keep = []
         _lib.fill_bound(sc.bound, self.host_bound(bound, 'bound'))
@@ -227,8 +228,6 @@ class Engine(object):
                 any_split = True
             else:
                 setattr(sc, 'w_' + n, decoders.packed_weights(n, 'f32', k).data_ptr())
-            if decoders.net_params(n)[0].data_ptr() != k[0][0]:
-                keys[n] = decoders.net_key(n)    # first use re-homed the parameters in one buffer (DF.flat_weights)
         if any_split:
             for n in nets:
                 setattr(sc, 'flat_' + n, decoders.flat_weights(n, keys[n]).data_ptr())
@@ -300,6 +299,7 @@ class Engine(object):
         bufs = dict(present)                              # presence flags (Engine.ht_nets asks for 'masks_<net>' / 'act_<net>')
         bufs['slab'], bufs['offsets'], bufs['ptrs'], bufs['sizes'] = slab, offsets, ptrs, sizes
         bufs['counter_ptr'], bufs['bwd_exact'], bufs['_state'] = ptrs['counter'], 'bwd' in latch, st
+        bufs['exact_nets'] = frozenset(latch)             # networks whose forward runs on the exact kernels: they leave no masks
         return bufs
 
     @staticmethod
@@ -370,8 +370,10 @@ class Engine(object):
             return ()
         need_grid = need_grid or {}
 
+        exact = saved.get('exact_nets', ())
+
         def ok(n):
-            if ('masks_' + n) not in saved or (need_flat.get(n) and ('act_' + n) not in saved):
+            if n in exact or ('masks_' + n) not in saved or (need_flat.get(n) and ('act_' + n) not in saved):
                 return False
             return not (need_pos and (need_flat.get(n) or need_grid.get(n)))
         return tuple(n for n in ('low', 'high', 'color', 'att') if ok(n))
@@ -420,6 +422,7 @@ class Engine(object):
                 return raw, w, saved
             keys = {}
             if train:
+                decoders.absorb_status()          # BEFORE the state is laid out: a network that latches to exact now gets no mask room
                 saved = self.train_state(P, stage, dev, decoders, need_flat)
             sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, keys=keys, state=saved)
             ap = _lib.AdfpPoints()
@@ -604,6 +607,7 @@ class Engine(object):
                 if self.export_relu_masks:
                     extra += tuple(('dbg_masks_' + n, 4 * (_lib.TRAIN_ATT_MASK_WORDS if n == 'att' else _lib.TRAIN_MASK_WORDS) * P)
                                    for n in _STAGE_NETS[stage])
+                decoders.absorb_status()          # BEFORE the state is laid out (see eval_points_forward)
                 aux = self.train_state(P, stage, dev, decoders, need_flat, extra=extra)
             sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, keys=keys, state=aux)
             a = _lib.AdfpRenderArgs()

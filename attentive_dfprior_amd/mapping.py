@@ -122,6 +122,10 @@ def flatten_parameters(module):
     """Re-home the parameters of `module` in ONE contiguous float32 buffer (state_dict order); every nn.Parameter keeps its
     identity and becomes a view of the buffer.  Returns the buffer."""
     params = list(module.parameters())
+    from .decoder import _flat_params
+    flat = _flat_params(tuple(params))
+    if flat.untyped_storage().data_ptr() == params[0].untyped_storage().data_ptr():
+        return flat                              # already one buffer (MLP._apply put them there at .to(device))
     flat = torch.cat([p.detach().reshape(-1).float() for p in params])
     off = 0
     for p in params:

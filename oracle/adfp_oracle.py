@@ -541,28 +541,81 @@ def remap_linear_np(img, u, v):
     return np.where(gone, np.float32(0), out).astype(np.float32)
 
 
-def frustum_mask_np(c2w, val_shape, depth_np, bound, H, W, fx, fy, cx, cy):
-    """Mapper.get_mask_from_c2w; returns the bool mask in the grid tensor's [Z, Y, X] order
-    (= the reference's [X, Y, Z] result after the permute(2, 1, 0) of src/Mapper.py:345)."""
-    import numpy as np
+def _frustum_points(val_shape, bound):
     Z, Y, X = val_shape
     gx, gy, gz = torch.meshgrid(torch.linspace(bound[0][0], bound[0][1], X), torch.linspace(bound[1][0], bound[1][1], Y),
                                 torch.linspace(bound[2][0], bound[2][1], Z), indexing='ij')      # Mapper.py:105-107
-    pts = torch.stack([gx, gy, gz], -1).reshape(-1, 3)
-    c2w = c2w.cpu().numpy()
-    w2c = np.linalg.inv(c2w)
-    homo = np.concatenate([pts.numpy(), np.ones((pts.shape[0], 1), np.float32)], 1).reshape(-1, 4, 1)
-    cam = (w2c @ homo)[:, :3]                                               # :116-117
+    return torch.stack([gx, gy, gz], -1).reshape(-1, 3)
+
+
+def _frustum_decide(cam, pts, c2w, depth_np, H, W, fx, fy, cx, cy, dmax=None, dist2=None):
+    """Mapper.py:118-153 from the camera-space coordinates on: returns (mask, max of the looked-up depths)."""
+    import numpy as np
     K = np.array([[fx, .0, cx], [.0, fy, cy], [.0, .0, 1.0]])
+    cam = cam.copy()
     cam[:, 0] *= -1
     uv = K @ cam                                                            # f64 from here, :120
     z = uv[:, -1:] + 1e-5
     uv = (uv[:, :2] / z).astype(np.float32)
     depths = remap_linear_np(depth_np, uv[:, 0, 0], uv[:, 1, 0]).reshape(-1, 1)
     mask = (uv[:, 0] < W) * (uv[:, 0] > 0) * (uv[:, 1] < H) * (uv[:, 1] > 0)
-    depths[depths == 0] = np.max(depths)                                    # :138-140
+    top = np.max(depths)
+    depths[depths == 0] = top if dmax is None else dmax                     # :138-140
     mask = mask & (0 <= -z[:, :, 0]) & (-z[:, :, 0] <= depths + 0.5)
     mask = mask.reshape(-1)
-    dist = pts - torch.from_numpy(c2w[:3, 3]).unsqueeze(0)                  # :146-151
-    mask = mask | (torch.sum(dist * dist, 1) < 0.5 * 0.5).numpy()
+    if dist2 is None:
+        dist = pts - torch.from_numpy(c2w[:3, 3]).unsqueeze(0)              # :146-151
+        dist2 = torch.sum(dist * dist, 1).numpy()
+    mask = mask | (dist2 < 0.5 * 0.5)
+    return mask, top
+
+
+def frustum_mask_np(c2w, val_shape, depth_np, bound, H, W, fx, fy, cx, cy):
+    """Mapper.get_mask_from_c2w; returns the bool mask in the grid tensor's [Z, Y, X] order
+    (= the reference's [X, Y, Z] result after the permute(2, 1, 0) of src/Mapper.py:345)."""
+    import numpy as np
+    Z, Y, X = val_shape
+    pts = _frustum_points(val_shape, bound)
+    c2w = c2w.cpu().numpy()
+    w2c = np.linalg.inv(c2w)
+    homo = np.concatenate([pts.numpy(), np.ones((pts.shape[0], 1), np.float32)], 1).reshape(-1, 4, 1)
+    cam = (w2c @ homo)[:, :3]                                               # :116-117
+    mask, _ = _frustum_decide(cam, pts, c2w, depth_np, H, W, fx, fy, cx, cy)
     return np.ascontiguousarray(mask.reshape(X, Y, Z).transpose(2, 1, 0))
+
+
+def frustum_boundary_points_np(c2w, val_shape, depth_np, bound, H, W, fx, fy, cx, cy):
+    """Test support for the frustum mask (tests/test_gpu_mapping.py): WHICH grid points may legitimately come out differently
+    in two correct float32 implementations of src/Mapper.py:111-153, as an explicit set.
+
+    The one place where the reference leaves the evaluation order open is the float32 transform `w2c @ homo` (:116-117: numpy's
+    batched matmul; the kernel sums left to right): two orders of a four-term float32 sum differ by at most
+    6 x 2^-24 x sum |terms| per camera coordinate (each order is within 3 roundings of the exact sum).  Everything after it is
+    float64 or a single rounding.  A grid point is a BOUNDARY point when its decision changes somewhere in that box -- i.e. its
+    pixel coordinates sit on the image border, its 1/32-pixel map rounding sits on a tie that changes the looked-up depth across
+    the depth test, its camera depth sits on 0 or on depth + 0.5 -- or when its squared distance to the camera centre is within
+    float32 summation noise of 0.25.  Returns (boundary [Z, Y, X] bool, mask [Z, Y, X] bool)."""
+    import numpy as np
+    Z, Y, X = val_shape
+    pts = _frustum_points(val_shape, bound)
+    c2w = c2w.cpu().numpy()
+    w2c = np.linalg.inv(c2w)
+    P = pts.numpy().astype(np.float32)
+    homo = np.concatenate([P, np.ones((P.shape[0], 1), np.float32)], 1)
+    cam = (w2c @ homo.reshape(-1, 4, 1))[:, :3]
+    mag = (np.abs(w2c[:3, :].astype(np.float64))[None] * np.abs(homo.astype(np.float64))[:, None, :]).sum(-1)   # [n, 3] sum of |terms|
+    tol = (6.0 * 2.0 ** -24 * mag).astype(np.float32).reshape(-1, 3, 1)
+    dist = pts - torch.from_numpy(c2w[:3, 3]).unsqueeze(0)
+    d2 = torch.sum(dist * dist, 1).numpy()
+    base, top = _frustum_decide(cam, pts, c2w, depth_np, H, W, fx, fy, cx, cy)
+    differs = np.zeros_like(base)
+    for sx in (-1.0, 1.0):
+        for sy in (-1.0, 1.0):
+            for sz in (-1.0, 1.0):
+                sgn = np.array([sx, sy, sz], np.float32).reshape(1, 3, 1)
+                for s2 in (-1.0, 1.0):
+                    m, _ = _frustum_decide(cam + sgn * tol, pts, c2w, depth_np, H, W, fx, fy, cx, cy, dmax=top,
+                                           dist2=d2 * (1.0 + s2 * 6.0 * 2.0 ** -24))
+                    differs |= m != base
+    to_grid = lambda a: np.ascontiguousarray(a.reshape(X, Y, Z).transpose(2, 1, 0))
+    return to_grid(differs), to_grid(base)

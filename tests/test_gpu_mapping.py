@@ -1,6 +1,11 @@
 """GPU: the Mapper bookkeeping kernels -- frustum feature mask against the numpy
-restatement of Mapper.get_mask_from_c2w (parity unpinned: cv2 is absent, see oracle header) and the masked
-in-place Adam against torch.optim.Adam on the compact copy the reference optimises."""
+restatement of Mapper.get_mask_from_c2w (pinned by the reference's own lines with cv2.remap substituted: cv2 is absent,
+see oracle header) and the masked in-place Adam against torch.optim.Adam on the compact copy the reference optimises.
+
+A grid point whose mask differs from the oracle's is accepted ONLY when it is in the oracle's explicit boundary set
+(oracle.frustum_boundary_points_np: its decision changes when its camera-space coordinates move within the float32
+summation-order bound of `w2c @ homo`, the one operation whose order src/Mapper.py:116-117 leaves to numpy) -- rounds 3-4 tolerated
+a COUNT of flips ("<= 2") without saying which points may flip."""
 import pytest
 import torch
 
@@ -13,6 +18,18 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
+def assert_only_boundary_points_differ(got, ref, boundary, what):
+    """Every grid point outside the oracle's boundary set must agree; the set itself must stay a sliver of the grid (a criterion
+    that excuses 1 % of the points would excuse a wrong kernel)."""
+    import numpy as np
+    flips = got != ref
+    assert boundary.sum() <= max(2, ref.size // 2000), f'{what}: {int(boundary.sum())} of {ref.size} grid points are boundary points'
+    stray = flips & ~boundary
+    assert not stray.any(), (f'{what}: {int(stray.sum())} grid points differ from the oracle away from every decision boundary, '
+                             f'first at [z, y, x] = {np.argwhere(stray)[0].tolist()} ({int(flips.sum())} differ in all, '
+                             f'{int(boundary.sum())} boundary points)')
+
+
 @pytest.mark.parametrize('scene_name,pose', [('mini', dict()), ('mini', dict(offset=(0.3, -0.2, 0.1), yaw=2.1, pitch=0.4)),
                                              ('room0', dict(yaw=1.0, pitch=-0.2))])
 def test_frustum_mask_vs_oracle(scene_name, pose):
@@ -22,12 +39,11 @@ def test_frustum_mask_vs_oracle(scene_name, pose):
     for key, val in sc.c.items():
         shp = tuple(val.shape[2:])
         ref = O.frustum_mask_np(c2w, shp, depth.numpy(), sc.bound, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy)
+        boundary, again = O.frustum_boundary_points_np(c2w, shp, depth.numpy(), sc.bound, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy)
+        assert (again == ref).all()
         got = mapping.frustum_mask(c2w, shp, depth.to(DEV), sc.bound, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy)
         assert got.dtype == torch.bool and tuple(got.shape) == shp
-        diff = int((got.cpu().numpy() != ref).sum())
-        # the 4x4 inverse and the projection are float32 on both sides but numpy's batched matmul and the
-        # kernel sum in different orders: points exactly on a frustum / depth boundary may flip
-        assert diff <= max(1, ref.size // 2000), f'{key}: {diff} of {ref.size} grid points differ'
+        assert_only_boundary_points_differ(got.cpu().numpy(), ref, boundary, key)
         assert 0 < ref.sum() < ref.size
 
 
@@ -133,13 +149,12 @@ def test_frustum_mask_vs_reference_lines():
     g = np.load(os.path.join(GOLDEN, 'mapper_frustum.npz'))
     H, W, fx, fy, cx, cy = g['intrinsics'].tolist()
     bound = torch.from_numpy(g['bound'])
-    total = diff = 0
     for k in range(3):
         c2w = torch.from_numpy(g[f'pose{k}.c2w'])
-        depth = torch.from_numpy(g[f'pose{k}.depth']).to(DEV)
+        depth = torch.from_numpy(g[f'pose{k}.depth'])
         for key in ('grid_low', 'grid_high', 'grid_color'):
             ref = g[f'pose{k}.{key}'].transpose(2, 1, 0)                      # [X,Y,Z] -> the grid tensor's [Z,Y,X]
-            got = mapping.frustum_mask(c2w, ref.shape, depth, bound, int(H), int(W), fx, fy, cx, cy)
-            diff += int((got.cpu().numpy() != ref).sum())
-            total += ref.size
-    assert diff <= 2, f'{diff} of {total} grid points differ from the reference-executed masks'
+            boundary, again = O.frustum_boundary_points_np(c2w, ref.shape, depth.numpy(), bound, int(H), int(W), fx, fy, cx, cy)
+            assert (again == ref).all()                                       # the oracle IS the reference-executed mask
+            got = mapping.frustum_mask(c2w, ref.shape, depth.to(DEV), bound, int(H), int(W), fx, fy, cx, cy)
+            assert_only_boundary_points_differ(got.cpu().numpy(), ref, boundary, f'pose {k} {key}')

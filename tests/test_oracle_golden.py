@@ -185,6 +185,27 @@ def test_frustum_mask_vs_reference_lines():
             assert 0 < ref_xyz.sum() < ref_xyz.size
 
 
+def test_frustum_boundary_set_names_the_points_on_a_decision_boundary():
+    """oracle.frustum_boundary_points_np (the explicit list of grid points two correct float32 implementations may decide
+    differently, tests/test_gpu_mapping.py): empty on a generic pose, and it does name a point that sits exactly on a boundary --
+    a grid point at distance 0.5 from the camera centre (the ball of src/Mapper.py:146-151) and one at camera depth 0."""
+    bound = torch.tensor([[0.0, 1.0], [0.0, 1.0], [0.0, 1.0]], dtype=torch.float64)
+    depth = np.full((8, 8), 0.25, np.float32)
+    c2w = torch.eye(4)                                                      # camera at the origin looking down -z
+    boundary, mask = O.frustum_boundary_points_np(c2w, (3, 3, 3), depth, bound, 8, 8, 4.0, 4.0, 3.5, 3.5)
+    assert (mask == O.frustum_mask_np(c2w, (3, 3, 3), depth, bound, 8, 8, 4.0, 4.0, 3.5, 3.5)).all()
+    # grid points (x, y, z) in {0, 0.5, 1}^3, mask indexed [z, y, x]: (0.5, 0, 0), (0, 0.5, 0), (0, 0, 0.5) have dist^2 == 0.25
+    for z, y, x in ((0, 0, 1), (0, 1, 0), (1, 0, 0)):
+        assert boundary[z, y, x] and not mask[z, y, x]
+    assert mask[0, 0, 0] and not boundary[0, 0, 0]                          # the camera centre itself: inside the ball, no doubt
+    assert not boundary[2, 2, 2]
+    g = _mapper_golden('mapper_frustum.npz')                                # the committed poses are generic: nothing may flip there
+    H, W, fx, fy, cx, cy = g['intrinsics'].tolist()
+    b, m = O.frustum_boundary_points_np(torch.from_numpy(g['pose0.c2w']), g['pose0.grid_high'].shape[::-1], g['pose0.depth'],
+                                        torch.from_numpy(g['bound']), int(H), int(W), fx, fy, cx, cy)
+    assert not b.any() and (m == g['pose0.grid_high'].transpose(2, 1, 0)).all()
+
+
 def test_oracle_subnetworks_vs_reference_golden(mini):
     """mlp_forward / mlp_tsdf_forward against the REFERENCE's sub-modules called on their own
     (tests/golden/make_subnet_golden.py -> mini_subnets.npz; decoder.py:177-203, :240-258)."""
