@@ -20,10 +20,12 @@
 // early; reproduced on purpose, an integer decomposition would give a different volume), every product and sum is rounded
 // separately, roundf is C's.  What is NOT reproduced: the reference's bound test `index > N` (:89), which lets thread N
 // read and write one element past the volume.
-// PARITY UNPINNED: the reference kernel needs pycuda + a CUDA device (and its CPU path needs numba), neither exists in the
-// build container; oracle.tsdf_integrate_np restates the kernel string, tests/test_gpu_fusion.py holds this kernel to it bit for
-// bit and, independently, to a float64 fusion of the same frames away from pixel-rounding ties.  nvcc's default -fmad=true may
-// contract some of the reference's mul+add pairs, which moves a projection by <= 1 ulp before the pixel rounding.
+// PARITY PINNED (since round 4) against the reference's own kernel: the CUDA C string of src/fusion.py:69-142 is compiled by hipcc
+// from where it lies (oracle/build_ref_fusion.py -> oracle/_ref/, once as written and once with the compiler's default
+// contraction, which is what nvcc's -fmad=true under PyCUDA does) and tests/test_gpu_fusion.py holds this kernel AND the numpy
+// restatement oracle.tsdf_integrate_np to the as-written build bit for bit (tsdf, weight and packed-colour volumes), to the
+// contracted build within one ulp of the camera-space depth over the truncation margin, and -- independently -- to a float64
+// fusion of the same frames away from pixel-rounding ties.
 #pragma once
 #include "adfp_device.h"
 

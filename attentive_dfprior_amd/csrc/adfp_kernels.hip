@@ -1071,15 +1071,12 @@ __global__ __launch_bounds__(256) void k_gather_rows(GatherJobs j, unsigned* __r
 // =====================================================================================
 // host side: C ABI
 // =====================================================================================
-static int g_num_cu = 0;
+// compute units of the CURRENT device (launch geometry of the persistent kernels).  Asked per call: the library keeps no global
+// mutable state, and a process may drive GPUs of different sizes.  hipDeviceGetAttribute is a table lookup (no device round trip).
 static int num_cu() {
-    if (g_num_cu == 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            g_num_cu = prop.multiProcessorCount;
-        if (g_num_cu <= 0) g_num_cu = 256;
-    }
-    return g_num_cu;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
 }
 
 static NormDev make_norm(const double b[3][2]) {

@@ -17,15 +17,22 @@ from ._lib import lib, ptr, check
 
 class TSDFVolume(object):
     def __init__(self, vol_bnds, voxel_size, device='cuda:0'):
-        vol_bnds = np.asarray(vol_bnds, dtype=np.float64).copy()
-        assert vol_bnds.shape == (3, 2), '[!] `vol_bnds` should be of shape (3, 2).'
-        self._vol_bnds = vol_bnds
-        self._voxel_size = float(voxel_size)
-        self._trunc_margin = 5 * self._voxel_size                       # src/fusion.py:38
+        # Volume geometry as src/fusion.py:32-44 defines it: the voxel count per axis is the extent divided by the voxel edge, rounded
+        # up; the upper bounds then move out to the last voxel's far face; the origin is the lower corner in float32 (it is a kernel
+        # argument).  Attribute names are the reference's (get_tsdf.py and the mesh code read them).
+        bnds = np.array(vol_bnds, dtype=np.float64)
+        if bnds.shape != (3, 2):
+            raise AssertionError('[!] `vol_bnds` should be of shape (3, 2).')
+        edge = float(voxel_size)
+        lower = bnds[:, 0]
+        counts = np.ceil((bnds[:, 1] - lower) / edge).astype(int)
+        bnds[:, 1] = lower + counts * edge
+        self._vol_bnds = bnds
+        self._voxel_size = edge
+        self._trunc_margin = 5 * edge                                   # src/fusion.py:38
         self._color_const = 256 * 256
-        self._vol_dim = np.ceil((vol_bnds[:, 1] - vol_bnds[:, 0]) / self._voxel_size).copy(order='C').astype(int)
-        self._vol_bnds[:, 1] = self._vol_bnds[:, 0] + self._vol_dim * self._voxel_size
-        self._vol_origin = self._vol_bnds[:, 0].copy(order='C').astype(np.float32)
+        self._vol_dim = np.ascontiguousarray(counts)
+        self._vol_origin = np.ascontiguousarray(lower, dtype=np.float32)
         self.device = torch.device(device)
         dims = tuple(int(v) for v in self._vol_dim)
         self._tsdf = torch.full(dims, -1.0, dtype=torch.float32, device=self.device)      # unobserved = -1 (:52)

@@ -125,14 +125,41 @@ def launch_workers(args):
 
 
 # ----------------------------------------------------------------------------------------------------------
+def strip_c_comments(text):
+    """C / C++ source without its comments and with white space collapsed: what the compiler sees of it, near enough.  The stamp
+    below is taken over THIS, so that correcting a comment does not mark every committed profile stale (round 4 left a wrong
+    'PARITY UNPINNED' comment in place for that reason)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        ch = text[i]
+        if ch == '/' and i + 1 < n and text[i + 1] == '/':
+            j = text.find('\n', i)
+            i = n if j < 0 else j
+        elif ch == '/' and i + 1 < n and text[i + 1] == '*':
+            j = text.find('*/', i + 2)
+            i = n if j < 0 else j + 2
+            out.append(' ')
+        elif ch in '"\'':
+            j = i + 1
+            while j < n and text[j] != ch:
+                j += 2 if text[j] == '\\' else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        else:
+            out.append(ch)
+            i += 1
+    return ' '.join(''.join(out).split())
+
+
 def source_hash():
-    """sha256 of the kernel sources + C header: stamps profile-derived numbers with the build they belong to."""
+    """sha256 of the kernel sources + C header, comments and white space stripped: stamps profile-derived numbers with the build
+    they belong to."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, 'attentive_dfprior_amd', 'csrc')
     for f in sorted(os.listdir(d)) + ['../../include/adfp.h']:
         p = os.path.join(d, f)
         if os.path.isfile(p) and p.endswith(('.h', '.hip')):
-            h.update(open(p, 'rb').read())
+            h.update(strip_c_comments(open(p, 'r', errors='replace').read()).encode())
     return h.hexdigest()[:16]
 
 

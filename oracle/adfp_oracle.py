@@ -20,9 +20,10 @@ Mapper-side restatements (src.Mapper needs cv2 / colorama and cannot be imported
 of optimize_map; get_mask_from_c2w as a method of a stub object) -- ``tests/test_oracle_golden.py`` checks both
 exactly.  In get_mask_from_c2w one name is substituted: ``cv2.remap`` (opencv-python==4.5.5.64,
 environment.yaml:194, absent here) resolves to ``remap_linear_np`` below, a restatement of OpenCV's documented
-bilinear remap; that one function stays PARITY UNPINNED, as does ``tsdf_integrate_np`` (the CUDA kernel string of
-src/fusion.py:69-142: pycuda / numba / skimage are absent and the reference ships no vectors).  Each says so at its
-definition; everything on the render path proper (rows a1-a15) is pinned as above.
+bilinear remap; that ONE function stays PARITY UNPINNED and says so at its definition.  ``tsdf_integrate_np`` (the CUDA
+kernel string of src/fusion.py:69-142) is pinned since round 4: ``oracle/build_ref_fusion.py`` compiles the reference's own
+kernel string with hipcc from where it lies and ``tests/test_gpu_fusion.py`` holds the restatement to it bit for bit on the
+MI355X.  Everything on the render path proper (rows a1-a15) is pinned as above.
 
 Every function cites the reference file:line it follows (paths relative to the
 reference checkout).  Decoder weights are passed as a flat ``dict`` keyed exactly like
@@ -456,9 +457,10 @@ def random_state_dict(seed=0, bias_scale=0.05, occ_bias=-0.5, out_scale=0.15):
 
 # ----------------------------------------------------------------------------------
 # TSDF fusion: numpy restatement of the reference's CUDA kernel
-# src/fusion.py:69-142 in float32, statement by statement.  PARITY UNPINNED for this function: neither
-# pycuda nor numba exists in the build container, so the reference's fusion cannot be executed here and
-# it ships no vectors; the restatement is checked only by reading.
+# src/fusion.py:69-142 in float32, statement by statement.  PINNED (round 4): the reference's kernel string itself is
+# compiled with hipcc by oracle/build_ref_fusion.py (neither pycuda nor numba exists in the build container, but the
+# string is plain CUDA C) and tests/test_gpu_fusion.py::test_integrate_matches_the_reference_kernel holds this function
+# to that build bit for bit (tsdf, weight, packed colour; 13.9 M voxels, three frames) on the MI355X.
 # ----------------------------------------------------------------------------------
 def tsdf_integrate_np(tsdf, weight, color, origin, voxel, cam_intr, cam_pose, color_im_packed, depth_im, trunc, obs_w):
     import numpy as np

@@ -31,10 +31,10 @@ def run(mode, sc, sd, rays, stage='color'):
     os.environ['ADFP_MATH'] = 'f32' if mode == 'f32' else 'f16x3'
     orig = engine.Engine.train_state
     if mode.startswith('mix'):
-        def no_masks(P, stage, dev, decoders, need_flat=None):
+        def no_masks(*args, **kwargs):            # (whatever Engine.train_state takes: round 4 added `extra` and this tool broke silently)
             os.environ['ADFP_MATH'] = 'f32'
             try:
-                return orig(P, stage, dev, decoders, need_flat)
+                return orig(*args, **kwargs)
             finally:
                 os.environ['ADFP_MATH'] = 'f16x3'
         engine.Engine.train_state = staticmethod(no_masks)
