@@ -381,7 +381,8 @@ __global__ __launch_bounds__(256) void k_depth_max_seg(const float* __restrict__
 struct SampleArgs {
     const float* ro; const float* rd; const float* depth; const float* t_rand;
     const float* dmax_f;        // device float(s) (caller-provided or k_depth_max_seg) or NULL
-    int dmax_seg;               // > 0: dmax_f[ray / dmax_seg] (one maximum per segment of rays), 0: dmax_f[0]
+    int dmax_seg;               // > 0: dmax_f[(dmax_first + ray) / dmax_seg] (one maximum per segment of rays), 0: dmax_f[0]
+    int dmax_first;             // the call's first ray in the segmented batch (a ray shard of a frame), else 0
     const unsigned* dmax_ord;   // ordered-uint reduction result or NULL
     double b[6];                // bound lo/hi per axis
     int n_rays, n_samples, n_surface, lindisp;
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
         const double o = (double)a.ro[3 * lray + ax], d = (double)a.rd[3 * lray + ax];
         if (has_depth) {
             dep_l = a.depth[lray];
-            const int sg = a.dmax_seg > 0 ? lray / a.dmax_seg : 0;
+            const int sg = a.dmax_seg > 0 ? (a.dmax_first + lray) / a.dmax_seg : 0;
             dmax_l = a.dmax_f ? a.dmax_f[sg] : ord2f(a.dmax_ord[sg]);
         }
         // far_bb = min_axis max_side (bound - o)/d + 0.01   (Renderer.py:151-156), f64: ONE division per lane -- lane (ray, axis, side)
@@ -1320,7 +1321,7 @@ int adfp_prefilter_rays(const float* rays_o, const float* rays_d, const float* g
 
 static int sample_rays_impl(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double bound[3][2],
                             int n_samples, int n_surface, int lindisp, float perturb, const float* t_rand, const float* depth_max,
-                            double* z_vals, void* scratch, void* stream, bool scratch_is_zero, int segment = 0);
+                            double* z_vals, void* scratch, void* stream, bool scratch_is_zero, int segment = 0, int first_ray = 0);
 int adfp_sample_rays(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double bound[3][2],
                      int n_samples, int n_surface, int lindisp, float perturb, const float* t_rand, const float* depth_max,
                      double* z_vals, void* scratch, void* stream) {
@@ -1329,15 +1330,16 @@ int adfp_sample_rays(const float* rays_o, const float* rays_d, const float* gt_d
 }
 static int sample_rays_impl(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double bound[3][2],
                             int n_samples, int n_surface, int lindisp, float perturb, const float* t_rand, const float* depth_max,
-                            double* z_vals, void* scratch, void* stream, bool scratch_is_zero, int segment) {
+                            double* z_vals, void* scratch, void* stream, bool scratch_is_zero, int segment, int first_ray) {
     if (!rays_o || !rays_d || !z_vals || !bound || n_rays < 0 || n_samples <= 0 || n_surface < 0) return ADFP_E_ARG;
+    if (first_ray < 0 || (first_ray > 0 && (!depth_max || segment <= 0))) return ADFP_E_ARG;
     if (perturb > 0.f && !t_rand) return ADFP_E_ARG;
     if (n_samples + n_surface > ADFP_MAX_SAMPLES) return ADFP_E_UNSUPPORTED;
     if (n_rays == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     SampleArgs a;
     a.ro = rays_o; a.rd = rays_d; a.depth = gt_depth; a.t_rand = perturb > 0.f ? t_rand : nullptr;
-    a.dmax_f = depth_max; a.dmax_ord = nullptr; a.dmax_seg = segment > 0 ? segment : 0;
+    a.dmax_f = depth_max; a.dmax_ord = nullptr; a.dmax_seg = segment > 0 ? segment : 0; a.dmax_first = first_ray;
     fill_bound(a.b, bound);
     a.n_rays = n_rays; a.n_samples = n_samples; a.n_surface = n_surface; a.lindisp = lindisp; a.perturb = perturb; a.z = z_vals;
     if (gt_depth && !depth_max && segment > 0) {        // one maximum per segment, into the scratch (48 floats of room)
@@ -1966,6 +1968,7 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
     int rc = check_scene(scene, r->stage); if (rc) return rc;
     if (!r->rays_o || !r->rays_d || !r->depth || !r->uncertainty || !r->color || !r->weight || !r->workspace) return ADFP_E_ARG;
     if (r->n_rays < 0 || r->n_samples <= 0 || r->n_surface < 0 || r->depth_max_segment < 0) return ADFP_E_ARG;
+    if (r->depth_max_first_ray < 0 || (r->depth_max_first_ray > 0 && (!r->depth_max || r->depth_max_segment <= 0 || !r->gt_depth))) return ADFP_E_ARG;
     if (r->state && r->stage != ADFP_STAGE_LOW &&
         (!r->state->flags || !r->state->list || !r->state->counter || !r->state->att_occ || !r->state->att_u)) return ADFP_E_ARG;
     const int S = r->n_samples + (r->gt_depth ? r->n_surface : 0);
@@ -1985,7 +1988,7 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
     // reduction's scratch (bytes 64-255: up to 48 per-segment maxima) share the first 256 bytes of the workspace
     { hipError_t e = zero_async(ws.counter, 256, st); if (e != hipSuccess) return (int)e; }
     rc = sample_rays_impl(r->rays_o, r->rays_d, r->gt_depth, r->n_rays, scene->bound, r->n_samples, r->n_surface, r->lindisp,
-                          r->perturb, r->t_rand, r->depth_max, z, (char*)ws.counter + 64, stream, true, r->depth_max_segment);
+                          r->perturb, r->t_rand, r->depth_max, z, (char*)ws.counter + 64, stream, true, r->depth_max_segment, r->depth_max_first_ray);
     if (rc) return rc;
     PtsDev P;
     P.mode = ADFP_PTS_RAYS; P.S = S; P.n = (int)Pn; P.pts = nullptr; P.ro = r->rays_o; P.rd = r->rays_d; P.z = z;

@@ -108,6 +108,26 @@ def render_rays_sharded(render_fn, rays_o, rays_d, gt_depth, group=None, gather=
     return _all_gather_packed(tuple(outs), sizes, group)
 
 
+def render_img_sharded(renderer, c, decoders, c2w, device, tsdf_volume, tsdf_bnds, stage, gt_depth, group=None, gather=True):
+    """Renderer.render_img with the frame's rays sharded over the ranks: rank r renders the contiguous pixel
+    range shard_range(H W, r, world) with the far clamp of the reference's ray batches taken over the whole frame
+    (Renderer.render_img_shard), and ONE packed all-gather (28 B per ray) hands every rank the frame -- the images render_img
+    returns, bit for bit.  gather=False: the rank's flat shard only."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    H, W = renderer.H, renderer.W
+    n = H * W
+    lo, hi = shard_range(n, rank, world)
+    outs = renderer.render_img_shard(c, decoders, c2w, device, tsdf_volume, tsdf_bnds, stage, gt_depth, lo, hi)
+    if not gather:
+        return outs
+    if world > 1:
+        sizes = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+        outs = _all_gather_packed(tuple(outs), sizes, group)
+    depth, unc, color = outs
+    return depth.reshape(H, W), unc.reshape(H, W), color.reshape(H, W, 3)
+
+
 def _common_bucket(grads):
     """If every gradient is a contiguous float32 view of ONE storage and together they cover (almost all of) one span of it, that
     span as a flat tensor; otherwise None.  Elements of the span that belong to no listed gradient (frozen parameters of a network

@@ -574,7 +574,7 @@ class Engine(object):
     # ---- a4..a13 ---------------------------------------------------------------------------
     def render_forward(self, decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage,
                        n_samples, n_surface, lindisp=False, perturb=0.0, t_rand=None, depth_max=None,
-                       want_aux=False, train=False, need_flat=None, depth_max_segment=0):
+                       want_aux=False, train=False, need_flat=None, depth_max_segment=0, depth_max_first_ray=0):
         _lib.require_cuda(rays_o, 'rays_o')
         dev = rays_o.device
         f32 = torch.float32
@@ -624,6 +624,7 @@ class Engine(object):
                 t_rand = t_rand.to(dev, f32).contiguous()
                 a.t_rand = t_rand.data_ptr()
             a.depth_max_segment = int(depth_max_segment)
+            a.depth_max_first_ray = int(depth_max_first_ray)
             if depth_max is not None:
                 depth_max = depth_max.to(dev, f32).reshape(-1).contiguous()
                 a.depth_max = depth_max.data_ptr()

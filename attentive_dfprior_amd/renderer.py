@@ -191,6 +191,39 @@ class Renderer(object):
         free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
         return extra <= free // 2
 
+    def segment_depth_max(self, gt_depth):
+        """max(gt_depth) of every ray_batch_size segment of a frame (float32 [nseg]): what each of render_img's batches clamps `far`
+        with (src/utils/Renderer.py:294-313 with :159, :195)."""
+        gd = gt_depth.detach().reshape(-1).float()
+        n, B = gd.shape[0], self.ray_batch_size
+        nseg = (n + B - 1) // B
+        if nseg * B != n:
+            gd = torch.nn.functional.pad(gd, (0, nseg * B - n), value=float('-inf'))
+        return gd.view(nseg, B).amax(dim=1).contiguous()
+
+    def render_img_shard(self, c, decoders, c2w, device, tsdf_volume, tsdf_bnds, stage, gt_depth, lo, hi):
+        """Not in the reference: pixels [lo, hi) (row-major) of the frame render_img returns, as flat (depth [hi-lo] f64,
+        uncertainty [hi-lo] f64, colour [hi-lo,3] f32) -- one GPU's contiguous share of a ray-sharded frame (SURVEY.md section 8e,
+        dist.render_img_sharded).  Bit for bit the values of render_img: a ray sees its batch only through the max(gt_depth) of its
+        ray_batch_size segment, and those maxima are taken over the WHOLE frame here (adfp_render_args.depth_max_first_ray)."""
+        if gt_depth is None or self.perturb > 0:
+            raise NotImplementedError('render_img_shard: a frame with sensor depth and perturb = 0 (what render_img is called with)')
+        with torch.no_grad():
+            H, W = self.H, self.W
+            lo, hi = int(lo), int(hi)
+            if not (0 <= lo <= hi <= H * W):
+                raise ValueError(f'render_img_shard: [{lo}, {hi}) is not a pixel range of a {H}x{W} frame')
+            rays_o, rays_d = get_rays(H, W, self.fx, self.fy, self.cx, self.cy, c2w, device)
+            gd = gt_depth.reshape(-1)
+            seg_max = self.segment_depth_max(gd)
+            if seg_max.shape[0] > 48:
+                raise NotImplementedError('render_img_shard: more than 48 ray batches per frame')
+            depth, unc, color, _, _ = self._engine.render_forward(
+                decoders, c, rays_o.reshape(-1, 3)[lo:hi], rays_d.reshape(-1, 3)[lo:hi], gd[lo:hi], tsdf_volume, tsdf_bnds, self.bound,
+                stage, self.N_samples, self.N_surface, self.lindisp, self.perturb, None, seg_max,
+                depth_max_segment=self.ray_batch_size, depth_max_first_ray=lo)
+            return depth, unc, color
+
     def render_img(self, c, decoders, c2w, device, tsdf_volume, tsdf_bnds, stage, gt_depth=None):
         """Full-frame render under no_grad in ``ray_batch_size`` batches -> depth [H,W] f64,
         uncertainty [H,W] f64, color [H,W,3] f32.  Each batch clamps ``far`` with ITS OWN max

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 125
+#define ADFP_VERSION 126
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -293,6 +293,11 @@ typedef struct adfp_render_args {
      * depth_max, when given, then holds one float per segment; otherwise the maxima are reduced here (at most 48 segments).
      * 0: one maximum for the whole call (render_batch_ray). */
     int depth_max_segment;
+    /* With depth_max_segment > 0 and depth_max given: the index, in the segmented batch, of this call's FIRST ray -- the call is a
+     * ray shard [first, first + n_rays) of a frame (one GPU's share, attentive_dfprior_amd.dist.render_img_sharded), ray i belongs
+     * to segment (first + i) / depth_max_segment, and depth_max holds the maxima of the WHOLE frame's segments.  0 otherwise
+     * (non-zero without depth_max is ADFP_E_ARG: the call cannot know the maxima of rays it does not hold). */
+    int depth_max_first_ray;
 } adfp_render_args;
 
 int adfp_render_forward(const adfp_scene* scene /*host*/, const adfp_render_args* args /*host*/, void* stream);

@@ -165,7 +165,12 @@ int main() {
       r2 = ra; r2.n_rays = 60000000; r2.workspace_bytes = (size_t)1 << 44; EXPECT_CODE(adfp_render_forward(&sc, &r2, st), ADFP_E_UNSUPPORTED); }     // 2.9e9 points
     EXPECT_REACHES_LAUNCH(adfp_render_forward(&sc, &ra, st));
     { adfp_render_args r2 = ra; r2.depth_max_segment = 100; r2.n_rays = 4800; r2.workspace_bytes = adfp_workspace_bytes(4800 * 48); EXPECT_REACHES_LAUNCH(adfp_render_forward(&sc, &r2, st));
-      r2.depth_max_segment = 10; EXPECT_CODE(adfp_render_forward(&sc, &r2, st), ADFP_E_UNSUPPORTED); }                                                      // 480 segments > 48
+      r2.depth_max_segment = 10; EXPECT_CODE(adfp_render_forward(&sc, &r2, st), ADFP_E_UNSUPPORTED);                                                        // 480 segments > 48
+      // a ray shard of a segmented frame: needs the frame's maxima from the caller
+      r2.depth_max_segment = 100; r2.depth_max_first_ray = 250; EXPECT_NEG(adfp_render_forward(&sc, &r2, st));
+      r2.depth_max = dev<float>(21); EXPECT_REACHES_LAUNCH(adfp_render_forward(&sc, &r2, st));
+      r2.depth_max_first_ray = -1; EXPECT_NEG(adfp_render_forward(&sc, &r2, st));
+      r2.depth_max_first_ray = 250; r2.depth_max_segment = 0; EXPECT_NEG(adfp_render_forward(&sc, &r2, st)); }
     adfp_backward_args ba; memset(&ba, 0, sizeof(ba));
     ba.stage = ADFP_STAGE_COLOR; ba.n_rays = 500; ba.S = 48; ba.rays_o = dev<float>(1); ba.rays_d = dev<float>(2); ba.z_vals = dev<double>(3); ba.raw = dev<float>(4);
     ba.state = ts; ba.g_depth = dev<double>(5); ba.g_color = dev<float>(6);

@@ -30,7 +30,15 @@ def test_bench_self_launches_two_ranks_and_reports_them():
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
     assert len(lines) == 1, p.stdout.decode()[-2000:]
     r = json.loads(lines[0])
-    assert r['n_gpus'] == 2 and r['scaling'] == 'weak' and r['value'] > 0
+    # the headline at N > 1 is the RAY-SHARDED frame (strong scaling, the all-gather inside the timed region): one 640x480 frame per
+    # step for the whole job, whatever N is -- not one frame per rank
+    assert r['n_gpus'] == 2 and r['scaling'] == 'strong' and r['value'] > 0
+    assert r['config']['rays_per_step'] == 640 * 480 and r['config']['rays_per_step_per_gpu'] == 640 * 480 // 2
+    assert abs(r['value'] - 640 * 480 / (r['ms_per_step'] * 1e-3)) <= 1e-6 * r['value']
+    assert 'ray-sharded over the 2 GPUs' in r['config']['workload']
+    # ... and the old headline (one whole frame per rank, no collective) is kept beside it under its own name
+    assert r['weak']['scaling'] == 'weak' and r['weak']['n_gpus'] == 2 and r['weak']['value'] > 0
+    assert abs(r['weak']['value'] - 2 * 640 * 480 / (r['weak']['ms_per_step'] * 1e-3)) <= 1e-6 * r['weak']['value']
     assert 'dist_legs_error' not in r, r.get('dist_legs_error')
     assert r['rccl']['world_size'] == 2 and r['rccl']['allreduce_of_ones'] == 2.0
     assert r['strong']['n_gpus'] == 2 and r['strong']['value'] > 0
@@ -39,3 +47,25 @@ def test_bench_self_launches_two_ranks_and_reports_them():
     for leg in ('dense', 'frustum_masked', 'fused_dense', 'fused_frustum_masked'):
         assert t[leg]['ms_per_iteration'] > 0
     assert t['fused_frustum_masked']['bucket_bytes'] < t['fused_dense']['bucket_bytes']
+
+
+def test_bench_one_gpu_line_carries_the_shard_model():
+    """N = 1: `config.shard_model` times a 1/2, 1/4 and 1/8 shard of the headline frame (per-step fixed costs included) and states the
+    efficiency bound they imply -- the north star's >= 6x at 8 GPUs bounded from one GPU."""
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--cpu-rays', '0', '--no-extra', '--no-stage-timing']
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 1 and r['scaling'] == 'strong' and 'weak' not in r
+    m = r['config']['shard_model']
+    assert 'error' not in m, m
+    assert m['k1']['ms'] > 0
+    for k in (2, 4, 8):
+        e = m[f'k{k}']
+        assert 0 < e['ms_fastest_shard'] <= e['ms_slowest_shard'] < m['k1']['ms'] * 1.05
+        assert abs(e['efficiency_bound'] - m['k1']['ms'] / (k * e['ms_slowest_shard'])) < 1e-9 and 0 < e['efficiency_bound'] <= 1.2
+    assert m['k8']['ms_slowest_shard'] >= m['fixed_cost_ms'] > 0

@@ -12,7 +12,7 @@ import attentive_dfprior_amd as A
 from attentive_dfprior_amd import synthetic, dist as adist
 from attentive_dfprior_amd.common import get_rays
 from oracle import adfp_oracle as O
-from conftest import make_cfg, assert_close
+from conftest import make_cfg, assert_close, assert_close_scale
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda:0')
@@ -113,7 +113,7 @@ def test_shard_gradients_sum_to_the_unsharded_gradient(scan):
     bucket_bytes = sum(t.numel() for t in full) * 4
     assert 6.0e6 < bucket_bytes < 8.0e6                                        # scene0050 ~ 6.8 MB
     for a, b in zip(acc, full):
-        assert_close(a, b, 2e-5, 'sum of shard gradients vs unsharded gradient')
+        assert_close_scale(a, b, 2e-5, 'sum of shard gradients vs unsharded gradient')      # sums in a different order: held to the tensor's scale
     for p in dec.parameters():
         p.grad = None
         p.requires_grad_(True)

@@ -19,7 +19,7 @@ import tempfile
 import pytest
 import torch
 
-from conftest import assert_close
+from conftest import assert_close_scale      # sums over shards in a different order: held to each tensor's scale
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -60,6 +60,16 @@ with torch.no_grad():
         outs = adist.render_rays_sharded(render_fn, ro[:n], rd[:n], gd[:n], gather=True)
         if rank == 0:
             res[name] = [t.cpu() for t in outs]
+
+# ---- Renderer.render_img, ray-sharded: the reference's 100 000-ray batches (their far clamps) cut across the 35 650-ray shards
+rend_b = A.Renderer(make_cfg(48, 16), None, sc)
+assert rend_b.ray_batch_size == 100000
+with torch.no_grad():
+    imgs = adist.render_img_sharded(rend_b, sc.c, dec, c2w, DEV, sc.tsdf_volume, tb, 'color', sc.depth_image(c2w))
+    if rank == 0:
+        res['img'] = [t.cpu() for t in imgs]
+        if world == 1:
+            res['img_ref'] = [t.cpu() for t in rend_b.render_img(sc.c, dec, c2w, DEV, sc.tsdf_volume, tb, 'color', gt_depth=sc.depth_image(c2w))]
 
 # ---- the Mapper's 5 000 rays: every rank differentiates ITS shard, the gradients are summed over the ranks
 for p in list(dec.low_decoder.parameters()) + list(dec.high_decoder.parameters()):
@@ -133,6 +143,18 @@ def test_eight_ranks_gather_the_single_process_render(runs):
             assert torch.equal(eight[name][k], one[name][k]), f'{name}: gathered {what} differs from the single-process render'
 
 
+def test_eight_ranks_render_img_sharded_equals_render_img(runs):
+    """dist.render_img_sharded (the bench's N > 1 headline): eight contiguous pixel ranges, the far clamp of every 100 000-ray batch
+    taken over the whole frame, ONE packed all-gather -- the images Renderer.render_img returns, bit for bit."""
+    one, eight = runs
+    for k, what in enumerate(('depth', 'uncertainty', 'colour')):
+        ref = one['img_ref'][k]
+        assert ref.shape[:2] == (460, 620)
+        assert one['img'][k].dtype == ref.dtype and eight['img'][k].dtype == ref.dtype
+        assert torch.equal(one['img'][k], ref), f'{what}: one rank, shard = the whole frame'
+        assert torch.equal(eight['img'][k], ref), f'{what}: eight ranks gathered'
+
+
 def test_eight_ranks_sum_to_the_single_process_gradient(runs):
     one, eight = runs
     assert eight['dense']['zero_copy'] is True              # autograd's .grad tensors are views of ONE buffer: all-reduced in place
@@ -144,6 +166,6 @@ def test_eight_ranks_sum_to_the_single_process_gradient(runs):
             if mode == 'masked':
                 m = one['masked']['masks'][k]
                 ref = torch.where(m.reshape((1, 1) + tuple(m.shape)), one['dense']['grids'][k], torch.zeros_like(ref))
-            assert_close(eight[mode]['grids'][k], ref, 2e-5, f'{mode}: sum of 8 shard gradients of {k}')
+            assert_close_scale(eight[mode]['grids'][k], ref, 2e-5, f'{mode}: sum of 8 shard gradients of {k}')
         for a, b in zip(eight[mode]['params'], one['dense']['params']):
-            assert_close(a, b, 2e-5, f'{mode}: sum of 8 shard parameter gradients')
+            assert_close_scale(a, b, 2e-5, f'{mode}: sum of 8 shard parameter gradients')
