@@ -453,6 +453,7 @@ def main():
                           ('tracker_iteration', lambda: BX.tracker_leg(A, synthetic, scene, sd, dec, dev)),
                           ('mesher_query', lambda: BX.mesher_leg(A, synthetic, scene, sd, dec, dev)),
                           ('tsdf_fusion', lambda: BX.fusion_leg(synthetic, scene, dev)),
+                          ('replica_native_frame', lambda: BX.replica_native_leg(A, synthetic, scene, dec, dev)),
                           ('config3', lambda: BX.config3_leg(dev)),
                           ('allreduce_model', lambda: BX.allreduce_model(scene))):
             try:
@@ -473,6 +474,9 @@ def main():
             cfgd['speedup_vs_torch_gpu'] = tg['speedup']
         if 'in_band_fraction' in result:
             cfgd['in_band_fraction'] = result['in_band_fraction']
+        rn = result.get('replica_native_frame')
+        if isinstance(rn, dict) and 'rays_per_s' in rn:
+            cfgd['replica_native_frame'] = {k: rn[k] for k in ('ms_per_frame', 'rays_per_s', 'rays', 'samples_per_ray', 'far_clamp_segments')}
         print(json.dumps(result))
         sys.stdout.flush()
     if dist is not None:

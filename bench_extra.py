@@ -11,6 +11,9 @@ Extra legs of bench.py (rank 0, N = 1): BASELINE.json's other configurations and
                      camera tensor (ray gradients -> adfp_rays_from_uv_backward), Adam on the pose
   mesher_query       the Mesher's point query (reference src/utils/Mesher.py:437-447): 256^3 = 16.8 M float32 lattice points in
                      500 000-point chunks through eval_points_tsdf + eval_points, stages high and color
+  replica_native_frame  the frame the reference itself renders on Replica: 1200 x 680, fx = fy = 600 (configs/Replica/replica.yaml:46-53),
+                     N_samples 32 + N_surface 16 (configs/df_prior.yaml:94-95), ray_batch_size 100000 -> 816 000 rays in nine batches,
+                     39.2 M sample points, Renderer.render_img under no_grad (src/utils/Renderer.py:278-327)
   allreduce_model    SURVEY.md section 5/8e ring model of the training all-reduce at 2 / 4 / 8 GPUs (a PREDICTION to read the first
                      real multi-GPU record against; nothing here is measured)
 """
@@ -383,6 +386,32 @@ def fusion_leg(synthetic, scene, dev):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+def replica_native_leg(A, synthetic, scene, dec, dev, reps=5):
+    """Renderer.render_img at Replica's native camera (module docstring); same scene content (room0 box room, bench grids), same
+    decoders, layout caches cleared every frame like the headline step."""
+    import torch
+    H, W = 680, 1200
+    import copy
+    sc = copy.copy(scene)                                                # the bench scene's grids and volume behind another camera
+    sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy = H, W, 600.0, 600.0, 599.5, 339.5
+    rend = A.Renderer(_cfg(32, 16), None, sc)
+    tb = sc.tsdf_bnds.to(dev)
+    c2w = sc.default_c2w(yaw=0.7, pitch=-0.15)
+    gd = sc.depth_image(c2w)
+
+    def frame():
+        rend._engine._grid_cache.clear()
+        dec._packed.clear()
+        return rend.render_img(sc.c, dec, c2w, dev, sc.tsdf_volume, tb, 'color', gt_depth=gd)
+    t, out = _wall(frame, reps, dev)
+    assert bool(torch.isfinite(out[0]).all()) and bool(torch.isfinite(out[2]).all())
+    n = H * W
+    return {'ms_per_frame': t * 1e3, 'rays_per_s': n / t, 'rays': n, 'samples_per_ray': 48, 'points': n * 48,
+            'far_clamp_segments': (n + rend.ray_batch_size - 1) // rend.ray_batch_size,
+            'workload': '1200x680, fx = fy = 600, N_samples 32 + N_surface 16, ray_batch_size 100000, stage color, render_img as one call',
+            'reference': 'configs/Replica/replica.yaml:46-53, configs/df_prior.yaml:94-95, src/utils/Renderer.py:278-327'}
+
+
 def allreduce_model(scene, n_params=15899 + 33410):
     """ring all-reduce of B bytes over N GPUs moves 2 (N-1)/N B per GPU through one xGMI link direction
     (point-to-point links, the ring uses one link per neighbour): t = 2 (N-1)/N B / 153 GB/s + 2 (N-1) hops x ~5 us launch / link
