@@ -32,7 +32,7 @@ class AdfpGrid(C.Structure):
 
 class AdfpTsdf(C.Structure):
     _fields_ = [('data', C.c_void_p), ('Z', C.c_int), ('Y', C.c_int), ('X', C.c_int),
-                ('sZ', C.c_longlong), ('sY', C.c_longlong), ('sX', C.c_longlong)]
+                ('sZ', C.c_longlong), ('sY', C.c_longlong), ('sX', C.c_longlong), ('corner_blocks', C.c_void_p)]
 
 
 class AdfpScene(C.Structure):
@@ -128,6 +128,7 @@ SYMBOLS = [
     ('adfp_workspace_bytes', C.c_size_t, [C.c_longlong]),
     ('adfp_relayout_grid', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ('adfp_relayout_grid_back', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ('adfp_relayout_tsdf', C.c_int, [C.POINTER(AdfpTsdf), C.c_void_p, C.c_void_p]),
     ('adfp_pack_decoder', C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_pack_attention', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_decoder_packed_h_words', C.c_longlong, [C.c_int]),

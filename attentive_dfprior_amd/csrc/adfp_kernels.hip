@@ -639,7 +639,15 @@ __global__ __launch_bounds__(256, TSDF_MINW) void k_tsdf(TsdfArgs a) {
             } else load_point(a.P, q0 + ic, p[u]);
             normalize3(a.nt, p[u], pn[u]);
         }
-        if (paired) {
+        if (a.t.cb) {                                // the corner-block copy: one aligned 32-byte piece per point (adfp_device.h)
+            TriBlock tb[UB]; f32x4 vl[UB], vh[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) trilerp_block_prepare(a.t, pn[u], tb[u]);
+#pragma unroll
+            for (int u = 0; u < UB; ++u) { vl[u] = tb[u].a[0]; vh[u] = tb[u].a[1]; }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) tv[u] = trilerp_block_finish(tb[u], vl[u], vh[u]);
+        } else if (paired) {
             TriPair tp[UB]; f32x2_u v[UB][4];
 #pragma unroll
             for (int u = 0; u < UB; ++u) trilerp_pair_prepare(a.t, pn[u], tp[u]);
@@ -1096,7 +1104,7 @@ static GridDev make_grid(const adfp_grid& g) {
     return d;
 }
 static TsdfDev make_tsdf(const adfp_tsdf& t) {
-    TsdfDev d; d.data = t.data; d.Z = t.Z; d.Y = t.Y; d.X = t.X; d.sZ = t.sZ; d.sY = t.sY; d.sX = t.sX; return d;
+    TsdfDev d; d.data = t.data; d.Z = t.Z; d.Y = t.Y; d.X = t.X; d.sZ = t.sZ; d.sY = t.sY; d.sX = t.sX; d.cb = t.corner_blocks; return d;
 }
 static int make_pts(const adfp_points* p, PtsDev* d) {
     if (!p || p->n_points < 0) return ADFP_E_ARG;
@@ -1360,6 +1368,31 @@ static int sample_rays_impl(const float* rays_o, const float* rays_d, const floa
         a.dmax_ord = (const unsigned*)scratch;
     }
     hipLaunchKernelGGL(k_sample, dim3((n_rays + 4 * ADFP_SAMPLE_RPW - 1) / (4 * ADFP_SAMPLE_RPW)), dim3(256), 0, st, a);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+
+// corner-block copy of a TSDF volume (TriBlock, adfp_device.h): thread = voxel, z fastest like the reference's volume, so the
+// eight strided reads of a wave are (mostly) the same lines its neighbours read and the 32-byte pieces it writes are consecutive
+__global__ __launch_bounds__(256) void k_tsdf_corner_blocks(TsdfDev t, float* __restrict__ dst) {
+    const long long n = (long long)t.X * t.Y * t.Z;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int z0 = (int)(idx % t.Z), y0 = (int)((idx / t.Z) % t.Y), x0 = (int)(idx / ((long long)t.Z * t.Y));
+    const int x1 = x0 + 1 < t.X ? x0 + 1 : t.X - 1, y1 = y0 + 1 < t.Y ? y0 + 1 : t.Y - 1, z1 = z0 + 1 < t.Z ? z0 + 1 : t.Z - 1;
+    const float* d = t.data;
+    const long long ox0 = x0 * t.sX, ox1 = x1 * t.sX, oy0 = y0 * t.sY, oy1 = y1 * t.sY, oz0 = z0 * t.sZ, oz1 = z1 * t.sZ;
+    const f32x4 lo = {d[oz0 + oy0 + ox0], d[oz0 + oy0 + ox1], d[oz0 + oy1 + ox0], d[oz0 + oy1 + ox1]};
+    const f32x4 hi = {d[oz1 + oy0 + ox0], d[oz1 + oy0 + ox1], d[oz1 + oy1 + ox0], d[oz1 + oy1 + ox1]};
+    f32x4* o = (f32x4*)(dst + idx * 8);
+    o[0] = lo; o[1] = hi;
+}
+int adfp_relayout_tsdf(const adfp_tsdf* tsdf, float* dst, void* stream) {
+    if (!tsdf || !tsdf->data || !dst || tsdf->X <= 0 || tsdf->Y <= 0 || tsdf->Z <= 0) return ADFP_E_ARG;
+    const long long n = (long long)tsdf->X * tsdf->Y * tsdf->Z;
+    if ((n + 255) / 256 > 0x7fffffffll) return ADFP_E_UNSUPPORTED;
+    adfp_tsdf src = *tsdf; src.corner_blocks = nullptr;
+    hipLaunchKernelGGL(k_tsdf_corner_blocks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, make_tsdf(src), dst);
     ADFP_CHECK_LAUNCH();
     return 0;
 }

@@ -97,6 +97,7 @@ class Engine(object):
         self._bws = None         # backward scratch, same
         self._gcl = {}           # channels-last gradient scratch per grid (render_backward)
         self._grid_cache = {}    # key name -> (key, channels-last tensor)
+        self._tsdf_cb = None     # (key, corner-block copy, pinned source storage) of the last TSDF volume asked for (tsdf_blocks)
         self._bound_cache = {}   # id -> (key, host list)
 
     # ---- caches --------------------------------------------------------------------------
@@ -185,8 +186,38 @@ class Engine(object):
         self._grid_cache[name] = (key, dst, g.untyped_storage())
         return dst
 
+    def tsdf_blocks(self, tsdf_volume):
+        """The CORNER-BLOCK copy of a TSDF volume (adfp_relayout_tsdf: [X][Y][Z][8] float32, one aligned 32-byte piece per
+        trilinear lookup), built once per volume and cached on (data_ptr, _version, shape, strides) with the source's storage
+        pinned -- the TSDF is static for a whole run (get_tsdf.py writes it once, src/DF_Prior.py:86-91 loads it).  8 x the
+        volume's bytes (room0: 6.3 GB, the 1024^3 stress volume: 34 GB of the 288 GB); None when that does not fit in half of
+        the free memory."""
+        t = tsdf_volume
+        _lib.require_cuda(t, 'tsdf_volume')
+        if t.dtype != torch.float32 or t.dim() != 5 or t.shape[0] != 1 or t.shape[1] != 1:
+            return None
+        key = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()))
+        hit = self._tsdf_cb
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        Z, Y, X = t.shape[2:]
+        need = 32 * Z * Y * X
+        self._tsdf_cb = None                                  # a stale copy goes first
+        dev = t.device
+        free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        if need > free // 2:
+            return None
+        with _lib.device_guard(dev):
+            cb = torch.empty((X, Y, Z, 8), dtype=torch.float32, device=dev)
+            td = _lib.AdfpTsdf()
+            self.fill_tsdf(td, t, [])
+            check(lib().adfp_relayout_tsdf(C.byref(td), ptr(cb), _lib.current_stream(dev)), 'adfp_relayout_tsdf')
+        self._tsdf_cb = (key, cb, t.untyped_storage())
+        return cb
+
     # ---- descriptor ----------------------------------------------------------------------
-    def scene(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=False, ht_nets=(), keys=None, images=None, state=None):
+    def scene(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=False, ht_nets=(), keys=None, images=None, state=None,
+              tsdf_blocks=False):
         """Returns (AdfpScene, keepalive list).  Forward: every network of the stage takes its f16-split image (ADFP_MATH=f16x3 and
         not latched to exact, DF.uses_split) or its exact f32 image, plus -- when any split image is in use -- the flat parameters
         the device-side f32 repair path needs (adfp_scene.flat_*).  Backward: the exact f32 images, except for the decoders named
@@ -234,6 +265,11 @@ class Engine(object):
         if stage != 'low':
             _lib.fill_bound(sc.tsdf_bnds, self.host_bound(tsdf_bnds, 'tsdf_bnds'))
             self.fill_tsdf(sc.tsdf, tsdf_volume, keep)
+            if tsdf_blocks and not backward:
+                cb = self.tsdf_blocks(tsdf_volume)           # None: not float32 / no room -- the plain volume serves
+                if cb is not None:
+                    sc.tsdf.corner_blocks = cb.data_ptr()
+                    keep.append(cb)
         return sc, keep
 
     # ---- training state --------------------------------------------------------------------
@@ -574,7 +610,7 @@ class Engine(object):
     # ---- a4..a13 ---------------------------------------------------------------------------
     def render_forward(self, decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage,
                        n_samples, n_surface, lindisp=False, perturb=0.0, t_rand=None, depth_max=None,
-                       want_aux=False, train=False, need_flat=None, depth_max_segment=0, depth_max_first_ray=0):
+                       want_aux=False, train=False, need_flat=None, depth_max_segment=0, depth_max_first_ray=0, tsdf_blocks=False):
         _lib.require_cuda(rays_o, 'rays_o')
         dev = rays_o.device
         f32 = torch.float32
@@ -609,7 +645,7 @@ class Engine(object):
                                    for n in _STAGE_NETS[stage])
                 decoders.absorb_status()          # BEFORE the state is laid out (see eval_points_forward)
                 aux = self.train_state(P, stage, dev, decoders, need_flat, extra=extra)
-            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, keys=keys, state=aux)
+            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, keys=keys, state=aux, tsdf_blocks=tsdf_blocks)
             a = _lib.AdfpRenderArgs()
             a.stage = _lib.STAGE[stage]
             a.n_rays = N

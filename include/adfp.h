@@ -65,6 +65,12 @@ typedef struct adfp_tsdf {
     const float* data;      /* element (z,y,x) at data[z*sZ + y*sY + x*sX] */
     int Z, Y, X;
     long long sZ, sY, sX;   /* element strides (the reference's view has sZ=1) */
+    /* Optional: the CORNER-BLOCK copy of the same volume (adfp_relayout_tsdf), or NULL.  When given, the TSDF stage of the render
+     * path (a10 inside adfp_render_forward / adfp_eval_points / adfp_tsdf_stage) reads it instead of `data`: one aligned 32-byte
+     * piece per sample wherever the sample lies -- for batches whose neighbouring rays are NOT neighbouring pixels (every
+     * 8-corner lookup of the plain volume then costs four 64-byte sectors).  Same values bit for bit.  Every other consumer
+     * (adfp_sample_tsdf, the backward's TSDF gradient) reads `data`. */
+    const float* corner_blocks;
 } adfp_tsdf;
 
 /* Everything DF.forward reads besides the points: decoder.py:307-353. */
@@ -138,6 +144,11 @@ size_t adfp_workspace_bytes(long long n_points);
 /* [1,32,Z,Y,X] -> [Z,Y,X,32]  (and back, for gradients).  C must be 32. */
 int adfp_relayout_grid(const float* src_cm, float* dst_cl, int C, int Z, int Y, int X, void* stream);
 int adfp_relayout_grid_back(const float* src_cl, float* dst_cm, int C, int Z, int Y, int X, void* stream);
+/* TSDF volume (any strides; the reference's permuted view of get_tsdf.py:95-97 as it stands) -> its corner-block copy
+ * dst[X][Y][Z][8] (8 X Y Z floats, z fastest): block (x, y, z) = the eight values a trilinear lookup with lower corner (x, y, z)
+ * blends, v(min(x+dx, X-1), min(y+dy, Y-1), min(z+dz, Z-1)) at index dx + 2 dy + 4 dz.  Built once per volume (the TSDF is
+ * static for a run); adfp_tsdf.corner_blocks hands it to the render path.  tsdf->corner_blocks is ignored here. */
+int adfp_relayout_tsdf(const adfp_tsdf* tsdf /*host*/, float* dst, void* stream);
 /* flat state_dict-order parameters -> packed MFMA image (MLP: decoder.py:91-203) */
 int adfp_pack_decoder(int kind, const float* flat, float* packed, void* stream);
 /* same parameters -> "H" image (f16 hi/lo halves of every weight), adfp_decoder_packed_h_words(kind) 32-bit words.

@@ -53,6 +53,19 @@ def test_1024_cubed_tsdf_128_samples_vs_oracle():
         d0, u0, c0, w0 = rend.render_batch_ray(sc.c, dec, rd, ro, dev, sc.tsdf_volume, tsdf_bnds, 'color', gt_depth=gd)
     rend.sort_rays_min = 65536
     assert torch.equal(d, d0) and torch.equal(u, u0) and torch.equal(c, c0) and torch.equal(w, w0)
+    # ... and the sorted render read the CORNER-BLOCK copy of the volume (Renderer.tsdf_blocks = 'auto': one aligned 32-byte piece per
+    # lookup for incoherent batches, Engine.tsdf_blocks), the unsorted one above the volume as it stands: same values bit for bit.
+    # The copy alone (rays as given) and neither (the round-4 path) too.
+    eng = rend._engine
+    assert eng._tsdf_cb is not None and tuple(eng._tsdf_cb[1].shape) == tuple(sc.tsdf_volume.shape[2:][::-1]) + (8,)
+    with torch.no_grad():
+        d2, u2, c2, w2, _ = eng.render_forward(dec, sc.c, ro, rd, gd, sc.tsdf_volume, tsdf_bnds, sc.bound, 'color', 96, 32, tsdf_blocks=True)
+    assert torch.equal(d, d2) and torch.equal(u, u2) and torch.equal(c, c2) and torch.equal(w, w2)
+    rend.tsdf_blocks = False
+    with torch.no_grad():
+        d3, u3, c3, w3 = rend.render_batch_ray(sc.c, dec, rd, ro, dev, sc.tsdf_volume, tsdf_bnds, 'color', gt_depth=gd)
+    rend.tsdf_blocks = 'auto'
+    assert torch.equal(d, d3) and torch.equal(c, c3) and torch.equal(w, w3)
     c2w = sc.default_c2w(yaw=0.7, pitch=-0.2)
     rp, dp = get_rays(sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2w, dev)
     assert rend._coherent_order(rp.reshape(-1, 3)[:100000].contiguous(), dp.reshape(-1, 3)[:100000].contiguous(),
