@@ -15,6 +15,7 @@ STATUS_RANGE_BITS = {'low': 1, 'high': 2, 'color': 4, 'att': 8, 'bwd': 16}      
 BWD_SCATTER_IN_KERNEL = 1        # ADFP_BWD_SCATTER_IN_KERNEL
 BWD_GRIDS_PREZEROED = 2          # ADFP_BWD_GRIDS_PREZEROED
 BWD_STAGED_WGRAD = 4             # ADFP_BWD_STAGED_WGRAD
+BWD_FUSED_ONE_WAVE = 8           # ADFP_BWD_FUSED_ONE_WAVE
 STAGE = {'low': 0, 'high': 1, 'color': 2}
 DEC_KIND = {'low': 0, 'high': 1, 'color': 2}
 NET_ID = {'low': 0, 'high': 1, 'color': 2, 'att': 3}      # adfp_pack_split_image's `net`

@@ -182,12 +182,17 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
     if constexpr (TRAIN) {
         srow[0] = (rowbits & 1u) ? srow0 : nullptr;
         srow[1] = (rowbits & 2u) ? srow0 + 16 * ST::NXM : nullptr;
+#if defined(ADFP_EXP_TRAIN_NOX)            // timing experiment: no layer-input rows at all (masks only)
+        srow[0] = nullptr; srow[1] = nullptr;
+#endif
+#if !defined(ADFP_EXP_TRAIN_NOHEADC)      // timing experiment (tools/ab_train_fwd.sh): the training forward without the head and c pieces of the rows
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) if (srow[pb]) {
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
             *(f32x4*)(srow[pb] + ST::xm(ST::SX) + 4 * g) = g == 0 ? f32x4{pf[pb][0], pf[pb][1], pf[pb][2], 1.f} : z4;
             *(f32x4*)(srow[pb] + ST::xm(ST::SX) + 16 + 4 * g) = z4;
         }
+#endif
     }
     // every LDS access below is one of three lane-dependent bases plus an immediate: the weight rows (4 l), the unit-order rows
     // (biases, output layer: 4 g) and the Fourier rows (32 g)
@@ -211,11 +216,13 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
         float y[8] = {c[4], c[5], c[6], c[7], c[12], c[13], c[14], c[15]};
 #pragma unroll
         for (int s = 0; s < 8; ++s) swap_halves(x[s], y[s]);
+#if !defined(ADFP_EXP_TRAIN_NOHEADC)
         if constexpr (TRAIN) {
             static_assert(!TRAIN || CDIM == 32, "training rows: 32-channel decoders");
             if (srow[0]) { *(f32x4*)(srow[0] + ST::xm(ST::SC) + 4 * g) = f32x4{x[0], x[1], x[2], x[3]}; *(f32x4*)(srow[0] + ST::xm(ST::SC) + 16 + 4 * g) = f32x4{x[4], x[5], x[6], x[7]}; }
             if (srow[1]) { *(f32x4*)(srow[1] + ST::xm(ST::SC) + 4 * g) = f32x4{y[0], y[1], y[2], y[3]}; *(f32x4*)(srow[1] + ST::xm(ST::SC) + 16 + 4 * g) = f32x4{y[4], y[5], y[6], y[7]}; }
         }
+#endif
         split8(x, ch[kc][0], cl[kc][0], amax);      // block 0: channels unit16(8 g + j)
         split8(y, ch[kc][1], cl[kc][1], amax);      // block 1
     }
@@ -480,7 +487,11 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16_train(DecodeLCTrai
 // =============================================================================================
 template <int NT>
 __global__ __launch_bounds__(NT, NT / 256) void k_decode_high_g(DecodeArgs a) {
+#ifdef ADFP_EXP_HIGH_AS_LOW        // timing experiment (tools/inband_bisect.sh): the LOW network's body (32 grid channels, one gather) in THIS
+    using L = DecLayoutG<32, 1>;   // kernel's launch shape -- list-indexed tiles, one image in LDS, 512 threads; a.packed = the low G image
+#else
     using L = DecLayoutG<64, 1>;
+#endif
     __shared__ __attribute__((aligned(16))) unsigned ldsu[L::P_TOTAL];
     __shared__ int s_next;
     __shared__ unsigned long long s_ring[ADFP_POOL_RING];
@@ -524,7 +535,11 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_high_g(DecodeArgs a) {
         ph_[6] += 1;
 #endif
         ADFP_PHG(0);
+#ifdef ADFP_EXP_HIGH_AS_LOW
+        decode_net_g<32, 1>(ldsu, a.g1, a.g1, pn, pf, lane, amax, out, nullptr, nullptr, 0u ADFP_PHG_ARGS(0));
+#else
         decode_net_g<64, 1>(ldsu, a.g0, a.g1, pn, pf, lane, amax, out, nullptr, nullptr, 0u ADFP_PHG_ARGS(0));
+#endif
         if (valid && (g & 1) == 0) {
             const float o = g >> 1 ? out[1][0] : out[0][0];
             const float v = pnan ? __builtin_nanf("") : o;

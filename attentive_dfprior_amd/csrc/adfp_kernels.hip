@@ -984,6 +984,7 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
 #include "adfp_backward.h"
 #include "adfp_backward_h.h"
 #include "adfp_backward_fused.h"
+#include "adfp_backward_roles.h"
 #ifdef ADFP_STAMPS
 extern "C" int adfp_debug_phases_fused(unsigned long long* host_out, int reset) {
     int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_fused), 64);
@@ -1565,6 +1566,9 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
             hipLaunchKernelGGL((k_decode_h<64, 1, ROLE_HIGH, ADFP_HIGH_NT>), dim3(decode_grid(ntiles, ADFP_HIGH_NT / 64, 1)), dim3(ADFP_HIGH_NT), 0, st, a);
 #else
             a.packed = (const float*)((const unsigned*)sc->h_high + DecLayoutH<64, 1>::P_TOTAL);          // the G image
+#ifdef ADFP_EXP_HIGH_AS_LOW
+            a.packed = (const float*)((const unsigned*)sc->h_low + DecLayoutH<32, 1>::P_TOTAL);           // timing experiment: see k_decode_high_g
+#endif
             a.pool = ws.counter ? ws.counter + 11 : nullptr;
             hipLaunchKernelGGL((k_decode_high_g<ADFP_HIGH_NT>), dim3(decode_grid(ntiles, ADFP_HIGH_NT / 64, 1)), dim3(ADFP_HIGH_NT), 0, st, a);
 #endif
@@ -2274,8 +2278,24 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
             f.gc_out = binned ? bw.gc : nullptr; f.total = total; f.status = status; f.gmax = bw.gmax; f.skip = skip;
             f.partial = bw.partial; f.part_stride = bw.part_stride;
             // every workgroup OVERWRITES its slot of bw.partial (no 20 MB zero fill per network), and the reduction reads the slots in use
-            const int ntiles = (total + 31) / 32, nwg = (ntiles + 3) / 4, nslot = nwg < OUTER_NSLOT ? nwg : OUTER_NSLOT;
-            hipLaunchKernelGGL((k_decode_bwd_fused<NOUT, ROLE>), dim3(nslot), dim3(256), 0, st, f);
+            const int ntiles = (total + 31) / 32;
+            int nslot;
+            if (options & ADFP_BWD_FUSED_ONE_WAVE) {
+                const int nwg = (ntiles + 3) / 4;
+                nslot = nwg < OUTER_NSLOT ? nwg : OUTER_NSLOT;
+                hipLaunchKernelGGL((k_decode_bwd_fused<NOUT, ROLE>), dim3(nslot), dim3(256), 0, st, f);
+            } else {
+                // role-split kernel (adfp_backward_roles.h): one 512-thread workgroup per CU, dealt to the three roles in proportion to
+                // what a tile costs each; every role walks all tiles, so a small call still wants all three
+                int cus = num_cu(); if (cus > OUTER_NSLOT) cus = OUTER_NSLOT;
+                int g = 3 * ((ntiles + 7) / 8);
+                nslot = g < 3 ? 3 : (g > cus ? cus : g);
+                int nP = (nslot * ROLE_SHARE_P + 128) / 256, nH = (nslot * ROLE_SHARE_H + 128) / 256;
+                if (nP < 1) nP = 1;
+                if (nH < 1) nH = 1;
+                while (nP + nH > nslot - 1) { if (nP > nH) --nP; else --nH; }
+                hipLaunchKernelGGL((k_decode_bwd_roles<NOUT, ROLE>), dim3(nslot), dim3(512), 0, st, f, nP, nH);
+            }
             ADFP_CHECK_LAUNCH();
             hipLaunchKernelGGL(k_reduce_partials_scaled, dim3((DecLayout<CDIM, NOUT>::F_TOTAL + 31) / 32), dim3(256), 0, st, bw.partial, nslot, bw.part_stride,
                                DecLayout<CDIM, NOUT>::F_TOTAL, flat, bw.gmax);

@@ -123,7 +123,7 @@ class _SingleNet(object):
         params = tuple(self.parameters())
         key = (_version_key(params), fmt)
         hit = self.__dict__.get('_single')
-        if hit is not None and hit[0] == key:
+        if hit is not None and hit[0] == key and not self.__dict__.get('_foreign'):
             return hit[1]
         packed = pack_network(name, params, fmt)
         self.__dict__['_single'] = (key, packed)
@@ -134,6 +134,11 @@ class _SingleNet(object):
         d.pop('_single', None)
         d.pop('_single_exact', None)
         return d
+
+    def __setstate__(self, state):
+        # unpickled = received from another process (torch.multiprocessing spawn, src/DF_Prior.py:302-311): see DF.__setstate__
+        self.__dict__.update(state)
+        self.__dict__['_foreign'] = True
 
     @staticmethod
     def _refuse_autograd(*tensors_and_modules):
@@ -312,6 +317,8 @@ class DF(nn.Module):
         self._engine = None
         self._status = None     # pinned status word of THIS module (see _lib.new_status_word)
         self._exact_latch = set()   # networks ('low' / 'high' / 'color' / 'att' / 'bwd') switched to the exact f32 kernels
+        self._foreign = False       # True: the parameters live in ANOTHER process's memory (see __setstate__)
+        self._foreign_serial = 0
 
     def net_params(self, name):
         """The parameters of one sub-network ('low' / 'high' / 'color' / 'att') in state_dict order.  Cached:
@@ -379,8 +386,13 @@ class DF(nn.Module):
         return flat
 
     def net_key(self, name):
-        """(addresses, versions) of the network's parameters; hand it to packed_weights / flat_weights to compute it once per call."""
-        return _version_key(self.net_params(name))
+        """(addresses, versions) of the network's parameters; hand it to packed_weights / flat_weights to compute it once per call.
+        A module RECEIVED from another process (_foreign, __setstate__) never repeats a key: see there."""
+        key = _version_key(self.net_params(name))
+        if self._foreign:
+            self._foreign_serial += 1
+            return key[0], (self._foreign_serial,)
+        return key
 
     # ---- weight images for the kernels -------------------------------------------------
     def packed_weights(self, name, fmt='f32', key=None):
@@ -431,6 +443,9 @@ class DF(nn.Module):
         new._plists = {}
         new._engine = None
         new._status = None
+        for m in new.modules():
+            m.__dict__.pop('_foreign', None)
+        new._foreign, new._foreign_serial = False, 0     # the copy's tensors are this process's own
         for attr in _NET_ATTR.values():            # Parameter.__deepcopy__ clones each tensor on its own; the copy is private here
             home_parameters(getattr(new, attr))
         return new
@@ -443,6 +458,16 @@ class DF(nn.Module):
         d['_engine'] = None
         d['_status'] = None
         return d
+
+    def __setstate__(self, state):
+        """Unpickling = this module arrived from another process (torch.multiprocessing spawn pickles the arguments of
+        src/DF_Prior.py:302-311; its CUDA parameters are views of the SENDER's memory through CUDA IPC).  The sender -- the Mapper
+        -- trains them in place (src/Mapper.py:364-375), and a write from another process does not move THIS process's tensor
+        version counters, which is what every cached conversion of the parameters (packed weight images) is keyed on.  So a
+        received module re-packs its images on every call (four pack kernels, ~20 us): what it renders with is what the trainer
+        last wrote.  Its deep copies (src/Tracker.py:144 takes one per frame) are private again and cache normally."""
+        self.__dict__.update(state)
+        self._foreign, self._foreign_serial = True, 0
 
     def forward(self, p, c_grid, tsdf_volume, tsdf_bnds, stage='low', **kwargs):
         from .engine import Engine

@@ -87,6 +87,8 @@ class Engine(object):
         self.bwd_options = _lib.BWD_SCATTER_IN_KERNEL if os.environ.get('ADFP_SCATTER', '')[:1] == 'c' else 0
         if os.environ.get('ADFP_WGRAD', '')[:1] == 's':          # weight gradients through the staged two-kernel path (A/B runs)
             self.bwd_options |= _lib.BWD_STAGED_WGRAD
+        if os.environ.get('ADFP_WGRAD', '')[:1] == 'o':          # ... inside the chain kernel, the ONE-wave-per-SIMD kernel of round 3-4 (A/B runs)
+            self.bwd_options |= _lib.BWD_FUSED_ONE_WAVE
         # which part of the split weight images an INFERENCE call keeps current: 'g' (the 16x16x32 kernels of this library);
         # ADFP_IMAGES=hg in the host's environment keeps both (A/B runs against a library built with -DADFP_LC_32X32)
         self.inference_images = os.environ.get('ADFP_IMAGES', 'g')

@@ -49,6 +49,12 @@ class Renderer(object):
         # one aligned 32-byte piece per lookup instead of four 8-byte column pieces in four sectors; 8 x the volume's memory, built once),
         # False = never.  Coherent batches (frames in pixel order) always read the volume as it stands.
         self.tsdf_blocks = 'auto'
+        # Sorting an incoherent batch by (origin cell, surface cell) on top of that: round 4's answer to such batches (TSDF stage
+        # 0.66 -> 1.22 TB/s on the plain volume).  With the corner blocks the stage runs at 1.8 TB/s as given and 2.05 TB/s sorted, and
+        # keys + radix sort + four gathers + the outputs' way back cost more than the 0.04 ms that saves (whole 131 072-ray batch:
+        # 4.58 ms as given, 4.63 ms sorted; profiles/r05_config5.json) -- so it is taken only when the corner blocks are not (switched
+        # off, or no room for 8 x the volume).
+        self.sort_incoherent = 'auto'
         self._order_verdict = {}             # batch size -> pinned verdict words of adfp_ray_order_probe
         self._engine = Engine()
 
@@ -104,9 +110,13 @@ class Renderer(object):
             return render_with_grad(self._engine, decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds,
                                     self.bound, stage, self.N_samples, self.N_surface, self.lindisp, self.perturb,
                                     t_rand, depth_max, need_param_grad)
-        perm = None
+        perm, blocks = None, False
         if self.sort_rays_min and N >= self.sort_rays_min and stage != 'low' and gt_depth is not None and t_rand is None:
-            perm = self._coherent_order(rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds)
+            incoherent = self._batch_is_incoherent(rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds)
+            if incoherent:
+                blocks = bool(self.tsdf_blocks) and self._engine.tsdf_blocks(tsdf_volume) is not None
+                if self.sort_incoherent is True or (self.sort_incoherent == 'auto' and not blocks):
+                    perm = self._coherent_order(rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, probe=False)
         if perm is not None:
             # rays are independent units: the far clamp's batch maximum (Renderer.py:159, :195) is order-free, everything else is
             # per ray -- the sorted render returns the same values, restored to the caller's order
@@ -115,7 +125,7 @@ class Renderer(object):
             d, u, col, w, _ = self._engine.render_forward(
                 decoders, c, rays_o.detach().index_select(0, perm), rays_d.detach().index_select(0, perm),
                 gt_depth.detach().reshape(-1).index_select(0, perm), tsdf_volume, tsdf_bnds, self.bound, stage,
-                self.N_samples, self.N_surface, self.lindisp, self.perturb, None, depth_max, tsdf_blocks=bool(self.tsdf_blocks))
+                self.N_samples, self.N_surface, self.lindisp, self.perturb, None, depth_max, tsdf_blocks=blocks)
             depth, unc, color, weight = torch.empty_like(d), torch.empty_like(u), torch.empty_like(col), torch.empty_like(w)
             depth.index_copy_(0, perm, d)
             unc.index_copy_(0, perm, u)
@@ -124,27 +134,11 @@ class Renderer(object):
             return depth, unc, color, weight
         depth, unc, color, weight, _ = self._engine.render_forward(
             decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, self.bound, stage,
-            self.N_samples, self.N_surface, self.lindisp, self.perturb, t_rand, depth_max)
+            self.N_samples, self.N_surface, self.lindisp, self.perturb, t_rand, depth_max, tsdf_blocks=blocks)
         return depth, unc, color, weight
 
-    def _coherent_order(self, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, wait=False):
-        """None if the batch is to be rendered as it stands, otherwise the permutation (int64 [N]) that sorts its rays by (cell of
-        the origin, cell of the surface point) -- adfp_ray_sort_keys + the library's radix sort.
-
-        Why: the TSDF lookup fetches four 8-byte column pieces per sample.  In pixel order a wave's 64 lanes (the same sample of 64
-        neighbouring rays) find them in a few cache lines; with unrelated neighbours every piece is its own 64-byte sector and its
-        own page (1024^3 volume, 131 072 random rays x 128 samples: 175 B fetched per sample against 9 B in pixel order,
-        profiles/r04_pmc_hbm_config5_random.csv).  A 5 % random sample of an image stays sparser than the image after sorting, but
-        the rays a workgroup walks together are millimetres to centimetres apart again.
-
-        Whether a batch is coherent is measured by ONE tiny kernel (adfp_ray_order_probe: do consecutive rays land within a few
-        voxels of each other?) that writes its verdict to pinned host memory; nothing waits for it -- the verdict of a call steers
-        the NEXT call of the same batch size (callers send streams of like batches: frames in pixel order, or random draws).
-        `wait=True` (tests) waits for this batch's own verdict."""
-        import ctypes as C
-        dev = rays_o.device
-        N = rays_o.shape[0]
-        L = _lib.lib()
+    @staticmethod
+    def _f32_rays(rays_o, rays_d, gt_depth):
         ro = rays_o.detach()
         if ro.dtype != torch.float32 or not ro.is_contiguous():
             ro = ro.float().contiguous()
@@ -154,6 +148,26 @@ class Renderer(object):
         gd = gt_depth.detach().reshape(-1)
         if gd.dtype != torch.float32 or not gd.is_contiguous():
             gd = gd.float().contiguous()
+        return ro, rd, gd
+
+    def _batch_is_incoherent(self, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, wait=False):
+        """Are the neighbours of this batch's rays unrelated (a random subset of an image) rather than neighbouring pixels?
+
+        Why it matters: the TSDF lookup of the volume as it stands fetches four 8-byte column pieces per sample.  In pixel order a
+        wave's 64 lanes (the same sample of 64 neighbouring rays) find them in a few cache lines; with unrelated neighbours every piece
+        is its own 64-byte sector and its own page (1024^3 volume, 131 072 random rays x 128 samples: 175 B fetched per sample against
+        9 B in pixel order, profiles/r04_pmc_hbm_config5_random.csv).  Such a batch reads the corner-block copy of the volume instead
+        (one aligned 32-byte piece per lookup, Engine.tsdf_blocks) and / or is rendered in spatial order (_coherent_order).
+
+        Measured by ONE tiny kernel (adfp_ray_order_probe: do consecutive rays land within a few voxels of each other?) that writes
+        its verdict to pinned host memory; nothing waits for it -- the verdict of a call steers the NEXT call of the same batch size
+        (callers send streams of like batches: frames in pixel order, or random draws).  `wait=True` (tests, bench) waits for this
+        batch's own verdict."""
+        import ctypes as C
+        dev = rays_o.device
+        N = rays_o.shape[0]
+        L = _lib.lib()
+        ro, rd, gd = self._f32_rays(rays_o, rays_d, gt_depth)
         slot = self._order_verdict.get(N)
         if slot is None:
             ext = self._engine.host_bound(tsdf_bnds, 'tsdf_bnds')
@@ -164,15 +178,28 @@ class Renderer(object):
         word, far, pairs, far_distance = slot
         with _lib.device_guard(dev):
             st = _lib.current_stream(dev)
-            if not wait:
-                incoherent = pairs.value > 0 and 2 * far.value > pairs.value          # the PREVIOUS like batch's verdict
+            incoherent = pairs.value > 0 and 2 * far.value > pairs.value              # the PREVIOUS like batch's verdict
             _lib.check(L.adfp_ray_order_probe(_lib.ptr(ro), _lib.ptr(rd), _lib.ptr(gd), N, far_distance, C.c_void_p(word.data_ptr()), st),
                        'adfp_ray_order_probe')
             if wait:
                 torch.cuda.synchronize(dev)
                 incoherent = 2 * far.value > pairs.value
-            if not incoherent:
-                return None
+        return incoherent
+
+    def _coherent_order(self, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, wait=False, probe=True):
+        """None if the batch is coherent (probe=True: _batch_is_incoherent is asked first), otherwise the permutation (int64 [N]) that
+        sorts its rays by (cell of the origin, cell of the surface point) -- adfp_ray_sort_keys + the library's radix sort.  A 5 %
+        random sample of an image stays sparser than the image after sorting, but the rays a workgroup walks together are
+        millimetres to centimetres apart again."""
+        import ctypes as C
+        if probe and not self._batch_is_incoherent(rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, wait=wait):
+            return None
+        dev = rays_o.device
+        N = rays_o.shape[0]
+        L = _lib.lib()
+        ro, rd, gd = self._f32_rays(rays_o, rays_d, gt_depth)
+        with _lib.device_guard(dev):
+            st = _lib.current_stream(dev)
             key, val = torch.empty((N,), dtype=torch.int32, device=dev), torch.empty((N,), dtype=torch.int32, device=dev)
             kt, vt = torch.empty_like(key), torch.empty_like(val)
             b = _lib.Bound()

@@ -174,7 +174,7 @@ def pmc_traffic(kernel_prefix, samples_per_launch, fname='r03_pmc_hbm_traffic.cs
     is the PROFILED bytes/sample x this run's samples per launch.  Returns (bytes or None, provenance dict); the csv's
     header carries the source hash of the build it was taken from and `stale` says whether that is this build."""
     import csv
-    for name in (fname.replace('r03_', 'r04_'), fname, fname.replace('r03_', 'r02_'), fname.replace('r03_', 'r01_')):
+    for name in (fname.replace('r03_', 'r05_'), fname.replace('r03_', 'r04_'), fname, fname.replace('r03_', 'r02_'), fname.replace('r03_', 'r01_')):
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             break
@@ -861,13 +861,17 @@ def config5_leg(A, synthetic, _lib, L, dev, n_rays=131072, NS=96, NF=32):
         ap.mode, ap.n_points = _lib.PTS_RAYS, P
         ap.rays_o, ap.rays_d, ap.z_vals, ap.S = ro.data_ptr(), rd.data_ptr(), aux['z_vals'].data_ptr(), S
         t_all = ev_time(whole, 5)
-        t_tsdf = ev_time(lambda: _lib.check(L.adfp_tsdf_stage(C.byref(scn), C.byref(ap), _lib.ptr(flags), _lib.ptr(lst), _lib.ptr(attu),
-                                                              None, _lib.ptr(cnt), st), 'tsdf'), 10)
+
+        def tsdf_time(scene_desc, pts):
+            return ev_time(lambda: _lib.check(L.adfp_tsdf_stage(C.byref(scene_desc), C.byref(pts), _lib.ptr(flags), _lib.ptr(lst), _lib.ptr(attu),
+                                                                None, _lib.ptr(cnt), st), 'tsdf'), 10)
+        t_tsdf = tsdf_time(scn, ap)
         extra = None
         if order == 'random':
-            # what Renderer.render_batch_ray does with such a batch: the order probe's verdict makes it render in sorted order
-            # (Renderer._coherent_order) -- the whole call incl. keys, radix sort, gathers and the outputs' way back, and the TSDF
-            # stage alone on the sorted rays
+            # what Renderer.render_batch_ray does with such a batch: the order probe's verdict makes it read the CORNER-BLOCK copy of
+            # the volume (Engine.tsdf_blocks), in the caller's order; sorting on top (round 4's answer, Renderer.sort_incoherent) is
+            # timed beside it -- the whole call incl. keys, radix sort, gathers and the outputs' way back -- and the TSDF stage alone
+            # in the four combinations of (as given | sorted) x (volume as it stands | corner blocks)
             def auto():
                 with torch.no_grad():
                     return rend.render_batch_ray(sc.c, dec, rd, ro, dev, sc.tsdf_volume, tb, 'color', gt_depth=gd)
@@ -875,40 +879,64 @@ def config5_leg(A, synthetic, _lib, L, dev, n_rays=131072, NS=96, NF=32):
                 auto()
                 torch.cuda.synchronize(dev)
             t_auto = ev_time(auto, 5)
+            rend.sort_incoherent = True
+            for _ in range(2):
+                auto()
+            t_auto_sorted = ev_time(auto, 5)
+            rend.sort_incoherent = 'auto'
+
+            def whole_blocks():
+                with torch.no_grad():
+                    return eng.render_forward(dec, sc.c, ro, rd, gd, sc.tsdf_volume, tb, sc.bound, 'color', NS, NF, tsdf_blocks=True)
+            t_all_blocks = ev_time(whole_blocks, 5)
+            scn_b, keep_b = eng.scene(dec, sc.c, sc.tsdf_volume, tb, sc.bound, 'color', tsdf_blocks=True)
+            assert scn_b.tsdf.corner_blocks
             perm = rend._coherent_order(ro, rd, gd, sc.tsdf_volume, tb, wait=True)
+            assert perm is not None
             ro_s, rd_s, gd_s = ro.index_select(0, perm).contiguous(), rd.index_select(0, perm).contiguous(), gd.index_select(0, perm).contiguous()
             with torch.no_grad():
                 aux_s = eng.render_forward(dec, sc.c, ro_s, rd_s, gd_s, sc.tsdf_volume, tb, sc.bound, 'color', NS, NF, want_aux=True)[4]
             ap_s = _lib.AdfpPoints()
             ap_s.mode, ap_s.n_points = _lib.PTS_RAYS, P
             ap_s.rays_o, ap_s.rays_d, ap_s.z_vals, ap_s.S = ro_s.data_ptr(), rd_s.data_ptr(), aux_s['z_vals'].data_ptr(), S
-            t_tsdf_s = ev_time(lambda: _lib.check(L.adfp_tsdf_stage(C.byref(scn), C.byref(ap_s), _lib.ptr(flags), _lib.ptr(lst), _lib.ptr(attu),
-                                                                    None, _lib.ptr(cnt), st), 'tsdf'), 10)
-            extra = (t_auto, t_tsdf_s)
+            extra = {'t_auto': t_auto, 't_auto_sorted': t_auto_sorted, 't_all_blocks': t_all_blocks, 'given_blocks': tsdf_time(scn_b, ap), 'sorted_plain': tsdf_time(scn, ap_s),
+                     'sorted_blocks': tsdf_time(scn_b, ap_s)}
         return t_all, t_tsdf, float((w != 1).float().mean()), extra
     t_all, t_tsdf, band, _ = measure('pixel')
-    t_all_r, t_tsdf_r, band_r, (t_auto_r, t_tsdf_sorted) = measure('random')
+    t_all_r, t_tsdf_r, band_r, ex = measure('random')
     by = float(TSDF_BYTES_PER_SAMPLE) * P
     traffic, prov = pmc_traffic('k_tsdf', P, 'r03_pmc_hbm_config5.csv')
+    gb = lambda t: by / t / 1e9
     return {'workload': '16 m cube, 1024^3 TSDF (4.29 GB), 128 samples/ray (96 + 32), 131 072 rays = 8 poses x 16 384 consecutive pixels '
                         '(render_img order) = one GPU\'s share of BASELINE.json configs[4]', 'value': n_rays / t_all, 'unit': 'rays/s',
             'ms_per_batch': t_all * 1e3, 'in_band_fraction': band,
-            'roofline_tsdf': {'kernel': 'k_tsdf', 'bound': 'hbm', 'achieved': by / t_tsdf / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
-                              'frac': by / t_tsdf / 1e9 / PEAK_HBM_GBPS, 'traffic': traffic,
+            'roofline_tsdf': {'kernel': 'k_tsdf', 'bound': 'hbm', 'achieved': gb(t_tsdf), 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                              'frac': gb(t_tsdf) / PEAK_HBM_GBPS, 'traffic': traffic,
                               'real_hbm_gbps': (traffic / t_tsdf / 1e9) if traffic else None,
                               'traffic_source': prov, 'bytes_per_launch': by, 'avg_launch_ms': t_tsdf * 1e3},
-            'random_ray_order': {'value': n_rays / t_auto_r, 'unit': 'rays/s', 'ms_per_batch': t_auto_r * 1e3, 'in_band_fraction': band_r,
-                                 'tsdf_algorithmic_gbps': by / t_tsdf_sorted / 1e9, 'tsdf_avg_launch_ms': t_tsdf_sorted * 1e3,
-                                 'tsdf_frac_of_hbm_peak': by / t_tsdf_sorted / 1e9 / PEAK_HBM_GBPS,
-                                 'as_given': {'value': n_rays / t_all_r, 'ms_per_batch': t_all_r * 1e3, 'tsdf_algorithmic_gbps': by / t_tsdf_r / 1e9,
-                                              'tsdf_avg_launch_ms': t_tsdf_r * 1e3,
-                                              'tsdf_counter_bytes_per_sample': pmc_traffic('k_tsdf', 1, 'r04_pmc_hbm_config5_random.csv')[0]},
-                                 'note': 'the same volume and sample count with each pose\'s rays drawn at random from its image.  Rendered AS GIVEN '
-                                         '(`as_given`) consecutive rays share no cache lines: every 8-corner lookup costs four 64-byte sectors '
-                                         '(tsdf_counter_bytes_per_sample, rocprofv3 FETCH + WRITE, against 32 algorithmic bytes).  '
-                                         'Renderer.render_batch_ray notices the incoherent order of such a batch (adfp_ray_order_probe, no sync) '
-                                         'and renders it sorted by (origin cell, surface cell): `value` / `ms_per_batch` = the whole call incl. keys, '
-                                         'radix sort, gathers and the outputs\' way back; tsdf_* = the TSDF stage alone on the sorted rays'}}
+            'random_ray_order': {'value': n_rays / ex['t_auto'], 'unit': 'rays/s', 'ms_per_batch': ex['t_auto'] * 1e3, 'in_band_fraction': band_r,
+                                 'tsdf_algorithmic_gbps': gb(ex['given_blocks']), 'tsdf_avg_launch_ms': ex['given_blocks'] * 1e3,
+                                 'tsdf_frac_of_hbm_peak': gb(ex['given_blocks']) / PEAK_HBM_GBPS,
+                                 'as_given': {'value': n_rays / ex['t_all_blocks'], 'ms_per_batch': ex['t_all_blocks'] * 1e3,
+                                              'tsdf_algorithmic_gbps': gb(ex['given_blocks']), 'tsdf_avg_launch_ms': ex['given_blocks'] * 1e3,
+                                              'tsdf_frac_of_hbm_peak': gb(ex['given_blocks']) / PEAK_HBM_GBPS,
+                                              'tsdf_counter_bytes_per_sample': pmc_traffic('k_tsdf', 1, 'r05_pmc_hbm_config5_random.csv')[0]},
+                                 'sorted': {'value': n_rays / ex['t_auto_sorted'], 'ms_per_batch': ex['t_auto_sorted'] * 1e3,
+                                            'tsdf_algorithmic_gbps': gb(ex['sorted_blocks']), 'tsdf_avg_launch_ms': ex['sorted_blocks'] * 1e3,
+                                            'tsdf_frac_of_hbm_peak': gb(ex['sorted_blocks']) / PEAK_HBM_GBPS,
+                                            'what': 'Renderer.sort_incoherent = True: the same batch rendered sorted by (origin cell, surface cell) on top of the corner blocks; '
+                                                    'value / ms_per_batch include keys, radix sort, gathers and the outputs\' way back'},
+                                 'plain_volume': {'what': 'the same batches with the TSDF read as it stands (the round-4 path: four 8-byte column pieces per lookup)',
+                                                  'as_given': {'value': n_rays / t_all_r, 'ms_per_batch': t_all_r * 1e3, 'tsdf_algorithmic_gbps': gb(t_tsdf_r),
+                                                               'tsdf_avg_launch_ms': t_tsdf_r * 1e3,
+                                                               'tsdf_counter_bytes_per_sample': pmc_traffic('k_tsdf', 1, 'r04_pmc_hbm_config5_random.csv')[0]},
+                                                  'sorted': {'tsdf_algorithmic_gbps': gb(ex['sorted_plain']), 'tsdf_avg_launch_ms': ex['sorted_plain'] * 1e3}},
+                                 'tsdf_layout': 'corner blocks: [X][Y][Z][8] float32, one aligned 32-byte piece per trilinear lookup (adfp_relayout_tsdf, 34 GB for this volume, built once)',
+                                 'note': 'the same volume and sample count with each pose\'s rays drawn at random from its image: consecutive rays share no '
+                                         'cache lines, and in the volume as it stands every 8-corner lookup costs four 64-byte sectors (plain_volume.as_given).  '
+                                         'Renderer.render_batch_ray notices the incoherent order of such a batch (adfp_ray_order_probe, no sync) and reads the '
+                                         'corner-block copy of the volume, in the caller\'s order: `value` / `ms_per_batch` = that call, tsdf_* = its TSDF stage '
+                                         'alone (= as_given; as_given.value is the engine call without the probe); `sorted` = the same with round 4\'s ray sort on top'}}
 
 
 def torch_gpu_leg(rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF, n=100000):

@@ -363,6 +363,9 @@ typedef struct adfp_backward_args {
  * instead of inside the chain kernel (k_decode_bwd_fused); same values up to the summation order.  What the tests compare the
  * fused kernel against. */
 #define ADFP_BWD_STAGED_WGRAD 4
+/* weight gradients inside the chain kernel, but with round 3-4's one-wave-per-SIMD kernel (k_decode_bwd_fused: every wave keeps
+ * all sixteen gradient blocks) instead of the role-split kernel at two waves per SIMD (k_decode_bwd_roles).  A/B runs. */
+#define ADFP_BWD_FUSED_ONE_WAVE 8
 size_t adfp_backward_workspace_bytes(long long n_points);
 int adfp_render_backward(const adfp_scene* scene /*host*/, const adfp_backward_args* args /*host*/, void* stream);
 

@@ -44,32 +44,32 @@ def test_1024_cubed_tsdf_128_samples_vs_oracle():
             torch.cuda.synchronize()
     assert torch.isfinite(d).all() and torch.isfinite(c).all() and torch.isfinite(u).all()
     assert 0.02 < float((w != 1).float().mean()) < 0.9          # the band is hit, and not everywhere
-    # These rays are a random subset of every pose's pixels: the renderer took the SORTED path (Renderer._coherent_order: a batch of
-    # >= 65 536 rays whose neighbours are unrelated is rendered in spatial order and handed back in the caller's).  Rays are
-    # independent units, so the values must be the unsorted render's bit for bit; a batch in pixel order is left alone.
-    assert rend._coherent_order(ro, rd, gd, sc.tsdf_volume, tsdf_bnds, wait=True) is not None
-    rend.sort_rays_min = 0
+    # These rays are a random subset of every pose's pixels: the order probe says so (Renderer._batch_is_incoherent), and a batch of
+    # >= 65 536 such rays reads the CORNER-BLOCK copy of the volume (Renderer.tsdf_blocks = 'auto': one aligned 32-byte piece per
+    # lookup, Engine.tsdf_blocks) instead of the volume as it stands.  Same values bit for bit -- and the same again rendered in sorted
+    # order on top of that (round 4's path for such batches: rays are independent units) and with neither.
+    assert rend._batch_is_incoherent(ro, rd, gd, sc.tsdf_volume, tsdf_bnds, wait=True)
+    eng = rend._engine
+    assert eng._tsdf_cb is not None and tuple(eng._tsdf_cb[1].shape) == tuple(sc.tsdf_volume.shape[2:][::-1]) + (8,)
+    rend.sort_rays_min = 0                                       # nothing is looked at: the volume as it stands, the caller's order
     with torch.no_grad():
         d0, u0, c0, w0 = rend.render_batch_ray(sc.c, dec, rd, ro, dev, sc.tsdf_volume, tsdf_bnds, 'color', gt_depth=gd)
     rend.sort_rays_min = 65536
     assert torch.equal(d, d0) and torch.equal(u, u0) and torch.equal(c, c0) and torch.equal(w, w0)
-    # ... and the sorted render read the CORNER-BLOCK copy of the volume (Renderer.tsdf_blocks = 'auto': one aligned 32-byte piece per
-    # lookup for incoherent batches, Engine.tsdf_blocks), the unsorted one above the volume as it stands: same values bit for bit.
-    # The copy alone (rays as given) and neither (the round-4 path) too.
-    eng = rend._engine
-    assert eng._tsdf_cb is not None and tuple(eng._tsdf_cb[1].shape) == tuple(sc.tsdf_volume.shape[2:][::-1]) + (8,)
+    rend.sort_incoherent = True                                  # corner blocks AND sorted order
     with torch.no_grad():
-        d2, u2, c2, w2, _ = eng.render_forward(dec, sc.c, ro, rd, gd, sc.tsdf_volume, tsdf_bnds, sc.bound, 'color', 96, 32, tsdf_blocks=True)
+        d2, u2, c2, w2 = rend.render_batch_ray(sc.c, dec, rd, ro, dev, sc.tsdf_volume, tsdf_bnds, 'color', gt_depth=gd)
     assert torch.equal(d, d2) and torch.equal(u, u2) and torch.equal(c, c2) and torch.equal(w, w2)
-    rend.tsdf_blocks = False
+    rend.tsdf_blocks, rend.sort_incoherent = False, 'auto'       # no corner blocks: the sort takes over (round 4's path)
+    assert rend._coherent_order(ro, rd, gd, sc.tsdf_volume, tsdf_bnds, wait=True) is not None
     with torch.no_grad():
         d3, u3, c3, w3 = rend.render_batch_ray(sc.c, dec, rd, ro, dev, sc.tsdf_volume, tsdf_bnds, 'color', gt_depth=gd)
     rend.tsdf_blocks = 'auto'
-    assert torch.equal(d, d3) and torch.equal(c, c3) and torch.equal(w, w3)
+    assert torch.equal(d, d3) and torch.equal(u, u3) and torch.equal(c, c3) and torch.equal(w, w3)
     c2w = sc.default_c2w(yaw=0.7, pitch=-0.2)
     rp, dp = get_rays(sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2w, dev)
-    assert rend._coherent_order(rp.reshape(-1, 3)[:100000].contiguous(), dp.reshape(-1, 3)[:100000].contiguous(),
-                                sc.depth_image(c2w).reshape(-1)[:100000].contiguous(), sc.tsdf_volume, tsdf_bnds, wait=True) is None
+    assert not rend._batch_is_incoherent(rp.reshape(-1, 3)[:100000].contiguous(), dp.reshape(-1, 3)[:100000].contiguous(),      # pixel order: left alone
+                                         sc.depth_image(c2w).reshape(-1)[:100000].contiguous(), sc.tsdf_volume, tsdf_bnds, wait=True)
     idx = torch.arange(0, n_rays, n_rays // check, device=dev)[:check]
     idx[0] = int(torch.argmax(gd))                               # keeps the batch-global far clamp of the subset equal
     cpu = {k: v.cpu() for k, v in sc.c.items()}

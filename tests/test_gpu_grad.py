@@ -456,36 +456,41 @@ def test_sorted_scatter_equals_cached_scatter(mini):
 
 @pytest.mark.parametrize('stage', ['low', 'color'])
 def test_fused_weight_gradients_equal_the_staged_path(mini, stage):
-    """The 32-channel decoders' weight gradients from inside the chain kernel (k_decode_bwd_fused: blocks transposed by MFMA,
-    accumulators resident across tiles) against the staged two-kernel path (ADFP_BWD_STAGED_WGRAD: cotangent blocks written per
-    point, k_outer_h): the same forward state, the same 3-product split -- only the summation order over the points differs."""
+    """The 32-channel decoders' weight gradients from inside the chain kernel -- the role-split kernel at two waves per SIMD
+    (k_decode_bwd_roles, the default: three kinds of workgroup, each with a third of the gradient blocks) and round 3-4's one-wave
+    kernel (k_decode_bwd_fused, ADFP_BWD_FUSED_ONE_WAVE) -- against the staged two-kernel path (ADFP_BWD_STAGED_WGRAD: cotangent
+    blocks written per point, k_outer_h): the same forward state, the same 3-product split -- only the summation order over the
+    points differs."""
     from attentive_dfprior_amd import _lib
     rays = synthetic.make_ray_batch(synthetic.mini_scene(), 700, seed=5, poses=3)
     got = {}
-    for name, opt in (('fused', 0), ('staged', _lib.BWD_STAGED_WGRAD)):
+    for name, opt in (('fused', 0), ('one_wave', _lib.BWD_FUSED_ONE_WAVE), ('staged', _lib.BWD_STAGED_WGRAD)):
         loss, c, dec = run(mini, stage, stage != 'color', sd=O.random_state_dict(seed=23), n_samples=48, n_surface=16, rays=rays, bwd_options=opt)
         got[name] = {n: p.grad.detach().cpu().clone() for n, p in dec.named_parameters() if p.grad is not None}
         got[name].update({k: v.grad.cpu() for k, v in c.items() if v.grad is not None})
     assert set(got['fused']) == set(got['staged']) and any(k.startswith('low_decoder') for k in got['fused'])
     for k in got['fused']:
-        assert_close_scale(got['fused'][k], got['staged'][k], 3e-6, f'{k}: fused vs staged weight gradients')
+        assert_close_scale(got['fused'][k], got['staged'][k], 3e-6, f'{k}: role-split kernel vs staged weight gradients')
+        assert_close_scale(got['one_wave'][k], got['staged'][k], 3e-6, f'{k}: one-wave kernel vs staged weight gradients')
         if stage == 'color' and k.startswith('color_decoder'):
             assert got['fused'][k].abs().max() > 0, k
 
 
-@pytest.mark.parametrize('n_rays', [1, 5, 67])
+@pytest.mark.parametrize('n_rays', [1, 5, 67, 700])
 def test_fused_weight_gradients_on_ragged_point_counts(mini, n_rays):
     """Point counts that do not fill a 32-point tile, a wave or a workgroup (1 x 40 = 40 points: one partial second tile; 5 x 40 =
     200; 67 x 40 = 2 680 = 83.75 tiles): the fused kernel's idle waves, clamped DMA rows and zeroed tail lanes."""
     from attentive_dfprior_amd import _lib
     rays = synthetic.make_ray_batch(synthetic.mini_scene(), n_rays, seed=9, poses=1, zero_frac=0.0)
     got = {}
-    for name, opt in (('fused', 0), ('staged', _lib.BWD_STAGED_WGRAD)):
+    for name, opt in (('fused', 0), ('one_wave', _lib.BWD_FUSED_ONE_WAVE), ('staged', _lib.BWD_STAGED_WGRAD)):
         loss, c, dec = run(mini, 'color', False, sd=O.random_state_dict(seed=29), n_samples=24, n_surface=16, rays=rays, bwd_options=opt)
         got[name] = {n: p.grad.detach().cpu().clone() for n, p in dec.named_parameters() if p.grad is not None}
+        got[name].update({k: v.grad.cpu() for k, v in c.items() if v.grad is not None})
     for k in got['fused']:
         assert torch.isfinite(got['fused'][k]).all(), k
-        assert_close_scale(got['fused'][k], got['staged'][k], 3e-6, f'{k}: fused vs staged, {n_rays} rays')
+        assert_close_scale(got['fused'][k], got['staged'][k], 3e-6, f'{k}: role-split kernel vs staged, {n_rays} rays')
+        assert_close_scale(got['one_wave'][k], got['staged'][k], 3e-6, f'{k}: one-wave kernel vs staged, {n_rays} rays')
 
 
 def test_a_swapped_pair_of_weight_rows_fails_the_gradient_comparison(mini, monkeypatch):

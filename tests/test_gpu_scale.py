@@ -83,12 +83,19 @@ def test_trained_scale(monkeypatch, math):
     assert_close(w, ow, TOL, 'attention weight')
 
 
-def check(out, ref, what):
+def check(out, ref, what, extreme_logits=False):
+    """extreme_logits: the case puts a weight of 7e4 into the attention MLP.  Its two logits are then O(1e4) numbers whose float32
+    rounding (ulp 1e-3, in the oracle as much as in the kernel: both sum in float32, in different orders) IS the relative error
+    of the smaller softmax output, so that output is held to 1e-5 of the weight's range [0, 1] there instead of to a ratio."""
     d, u, c, w = out
     od, ou, oc, ow = ref
     assert_close(d, od, TOL, f'depth ({what})')
     assert_close(c, oc, TOL, f'colour ({what})')
-    assert_close(w, ow, TOL, f'attention weight ({what})')
+    if extreme_logits:
+        from conftest import assert_close_scale
+        assert_close_scale(w, ow, 1e-5, f'attention weight ({what})')
+    else:
+        assert_close(w, ow, TOL, f'attention weight ({what})')
 
 
 def test_f16_range_violation_on_features_is_repaired(monkeypatch):
@@ -125,7 +132,7 @@ def test_f16_range_violation_on_activations_and_weights_is_repaired(monkeypatch)
     big = {k: v.clone() for k, v in sd.items()}
     big['mlp.pts_linears.1.weight'][0, 0] = 7.0e4                    # a weight the split cannot hold (found at pack time)
     out, ref = render_both(sc, big, 'color', n=64, expect_latched={'att'})
-    check(out, ref, 'a weight beyond the f16 range')
+    check(out, ref, 'a weight beyond the f16 range', extreme_logits=True)
     big = {k: v.clone() for k, v in sd.items()}
     big['low_decoder.fc_c.2.weight'][5, 7] = -9.0e4                  # the low decoder: feeds the in-band list too (high + low)
     for stage in ('low', 'high', 'color'):

@@ -99,20 +99,21 @@ def test_scattered_parameters_stay_where_they_are_and_updates_are_seen():
     assert_close(out[2], ref[2], 1e-4, 'colour after the in-place update')
 
 
-def _tracker_process(dec, pipe, rays, steps):
+def _tracker_process(dec, pipe, rays_np, steps):
     """The other process of src/DF_Prior.py:302-311: renders with the SHARED module (and with a deep copy of it, Tracker.py:144)
-    each time the parent says so and sends the colour image back."""
+    each time the parent says so and sends the colour image back (as numpy: only the module travels as tensors, through CUDA IPC)."""
     try:
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        rays = tuple(torch.from_numpy(r) for r in rays_np)
         sc = synthetic.mini_scene()
         rend = A.Renderer(make_cfg(32, 16), None, sc)
         for _ in range(steps):
             pipe.recv()
-            shared = _render(rend, dec, sc, rays)[2].cpu()
-            copied = _render(rend, copy.deepcopy(dec), sc, rays)[2].cpu()
+            shared = _render(rend, dec, sc, rays)[2].cpu().numpy()
+            copied = _render(rend, copy.deepcopy(dec), sc, rays)[2].cpu().numpy()
             pipe.send((shared, copied))
     except Exception as e:                                               # the parent turns it into a failure (or a skip for IPC)
-        pipe.send(e)
+        pipe.send(RuntimeError(f'{type(e).__name__}: {e}'))
 
 
 def test_two_processes_share_the_parameters_through_ipc():
@@ -125,11 +126,18 @@ def test_two_processes_share_the_parameters_through_ipc():
     ctx = mp.get_context('spawn')
     here, there = ctx.Pipe()
     steps = 2
+    # The module also carries a CPU tensor (`bound`, as src/DF_Prior.py:191 assigns it).  CPU tensors of a spawn argument travel as
+    # file descriptors served by a socket in the parent's multiprocessing temp directory -- which a FORKED child of an earlier test
+    # removes on its exit (its inherited finalizers run).  The file-system strategy needs no server; set for this spawn only.
+    strategy = mp.get_sharing_strategy()
+    mp.set_sharing_strategy('file_system')
     try:
-        proc = ctx.Process(target=_tracker_process, args=(dec, there, rays, steps))
+        proc = ctx.Process(target=_tracker_process, args=(dec, there, tuple(r.numpy() for r in rays), steps))
         proc.start()
     except RuntimeError as e:                                            # no CUDA IPC for this user / driver
         pytest.skip(f'CUDA IPC not available here: {e}')
+    finally:
+        mp.set_sharing_strategy(strategy)
     try:
         sd_now = {k: v.clone() for k, v in sd.items()}
         for step in range(steps):
