@@ -173,6 +173,9 @@ SYMBOLS = [
                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     ('adfp_prefilter_mask', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_mapper_loss', C.c_int, [C.POINTER(AdfpLossArgs), C.c_void_p]),
+    ('adfp_mapper_loss_scratch_bytes', C.c_size_t, [C.c_int]),
+    ('adfp_mapper_loss_step', C.c_int, [C.POINTER(AdfpLossArgs), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float),
+                                        C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     ('adfp_adam_prep', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     ('adfp_masked_adam_dev', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int,
                                        C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),

@@ -574,7 +574,15 @@ struct OuterHArgs {
     int col_se, col_sgp;       // decoders: first column of the recomputed Fourier block / of the masked d/d pre block
     int* status;
     const int* skip;           // as DecodeBwdHArgs.skip
+    int overwrite;             // the call's ONLY chunk: a workgroup writes its sums into its slot instead of adding to it -- no zero fill of the
+                               // 256 slots (34 MB for the attention network) before the launch; k_reduce_partials_scaled then reads only the
+                               // slots of workgroups that had rows (slots_in_use)
 };
+// how many of the nslot partial-sum slots a k_outer_h launch over `rows` rows in blocks of `br` wrote
+__host__ __device__ inline int slots_in_use(int rows, int br, int nslot) {
+    const int nb = rows > 0 ? (rows + br - 1) / br : 0;
+    return nb < nslot ? nb : nslot;
+}
 __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
     const OuterArgs& a = b.o;
     __shared__ __attribute__((aligned(16))) float sf[OUTER_RT * OUTER_MAXCOLS];                 // the tile, f32, row-major
@@ -702,8 +710,13 @@ __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
             const int c = i - jb.j0;
             if (c >= 0 && c < jb.nc) {                     // read the 16 slots, then write them: a += per element serialises 16 round trips
                 float old[16];
+                if (b.overwrite) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { const int row = kmapH(r, h); old[r] = part[jb.dst + (row < jb.nr ? row : 0) * jb.rs + c * jb.cs]; }    // unconditional: 16 loads in flight
+                    for (int r = 0; r < 16; ++r) old[r] = 0.f;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const int row = kmapH(r, h); old[r] = part[jb.dst + (row < jb.nr ? row : 0) * jb.rs + c * jb.cs]; }    // unconditional: 16 loads in flight
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { const int row = kmapH(r, h); if (row < jb.nr) part[jb.dst + row * jb.rs + c * jb.cs] = old[r] + acc[j][r]; }
             }
@@ -714,8 +727,12 @@ __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
 // flat[e] += 2^-k sum over the workgroup slots of partial[slot][e]   (k_reduce_partials with the gradient scale undone).
 // A workgroup takes 32 elements; its 8 groups of 32 threads each sum every 8th slot and the groups are added in a fixed order
 // through LDS (reproducible).  One thread per element over all 256 slots left the chip at 0.26 waves per SIMD: 22 us per network.
+// count_ptr (may be NULL): the slots come from ONE k_outer_h launch in overwrite mode over min(*count_ptr, rows_max) rows in blocks of
+// br -- only the slots of workgroups that had rows hold sums.
 __global__ __launch_bounds__(256) void k_reduce_partials_scaled(const float* __restrict__ partial, int nslots, int stride, int n,
-                                                                float* __restrict__ flat, const float* __restrict__ gmax) {
+                                                                float* __restrict__ flat, const float* __restrict__ gmax,
+                                                                const int* __restrict__ count_ptr = nullptr, int rows_max = 0, int br = 1) {
+    if (count_ptr) { const int cnt = *count_ptr; nslots = slots_in_use(cnt < rows_max ? cnt : rows_max, br, nslots); }
     __shared__ float s_p[8][32];
     const int ex = threadIdx.x & 31, sg = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + ex;

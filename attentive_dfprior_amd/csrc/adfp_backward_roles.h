@@ -27,65 +27,101 @@
 // the flat gradient per workgroup (a role leaves the elements it does not own zero) reduced by k_reduce_partials_scaled.
 // Same values up to the summation order over tiles (tests/test_gpu_grad.py::test_fused_weight_gradients_equal_the_staged_path).
 #pragma once
+#include <type_traits>
 #include "adfp_backward_fused.h"
 
-// share of the workgroups per role, in 1/256 (what a tile costs a role: P ~ 8 100, H ~ 5 800, C ~ 6 200 SIMD cycles)
+// share of the workgroups per role, in 1/256: proportional to (time of the role alone) x (its workgroups) measured with the
+// timing-only builds -DADFP_EXP_ONLY_ROLE=0/1/2 (tools/ab_roles.sh, profiles/r05_ab_backward_roles.txt)
 #ifndef ROLE_SHARE_P
-#define ROLE_SHARE_P 104
+#define ROLE_SHARE_P 102
 #endif
 #ifndef ROLE_SHARE_H
-#define ROLE_SHARE_H 72
+#define ROLE_SHARE_H 89
+#endif
+
+#ifdef ADFP_STAMPS_ROLES           // debug build (tools/roles_span.py): per workgroup (role, wall-clock start, end of the tile loop, end), 100 MHz
+__device__ unsigned long long g_roles_span[4 * 256];
 #endif
 
 template <int NOUT, int ROLE>
 __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int nP, int nH) {
+#ifdef ADFP_STAMPS_ROLES
+    const unsigned long long t_start_ = wall_clock64();
+    unsigned long long t_loop_ = 0;
+#endif
     constexpr int CDIM = 32;
     using LT = DecLayoutHT<CDIM, NOUT>;
     using ST = DecStage<CDIM>;
     using F = DecLayout<CDIM, NOUT>;
     static_assert(ROLE == ROLE_LOW || ROLE == ROLE_COLOR, "32-channel decoders only");
-    // ONE shared array: the T image, then per wave 3 slots of 1 024 words (4 KB: one 32 x 32 block in the transposition format) and
-    // 64 spare words.  Slot 0 is always the wave's transposition slot S; slots 1, 2 are: role C the double buffer of the grid
-    // features' X block, role H the ring of the h_i X blocks, role P the parked d/d pre_3 block (S3) and the position table.
-    constexpr int SLOT = 1024, NWV = 8, XW = 3136;
-    static_assert(LT::P_TOTAL + NWV * XW <= 40960, "160 KB of LDS");
-    static_assert(F::F_TOTAL <= NWV * XW, "the reduction copy must fit the per-wave regions");
-    __shared__ __attribute__((aligned(16))) unsigned ldsu[LT::P_TOTAL + NWV * XW];
+    // ONE shared array of 160 KB: the role's PART of the T image, then one region per wave.  A role copies only the blocks its
+    // chains read, compacted, and its waves share what that frees:
+    //   P  no fc_c^T blocks (10 of 15 blocks):  S, S3, S0 (4 KB slots: transposition scratch, layer 3's and layer 0's d/d pre) + position table
+    //   H  the four main pts_linears^T blocks:   S + a ring of THREE X slots + the small-input buffer
+    //   C  fc_c^T and the main pts_linears^T:    S + the double buffer of the grid features' X block + the small-input buffer
+    constexpr int SLOT = 1024, NWV = 8, LDS_WORDS = 40960;
+    constexpr int WO_WORDS = 2 * NOUT * 16;
+    constexpr int IMG_P = LT::P_TOTAL - 5 * 1024, IMG_H = 4 * 1024 + WO_WORDS, IMG_C = 9 * 1024 + WO_WORDS;
+    constexpr int XW_P = ((LDS_WORDS - IMG_P) / NWV) & ~3, XW_H = ((LDS_WORDS - IMG_H) / NWV) & ~3, XW_C = ((LDS_WORDS - IMG_C) / NWV) & ~3;
+    constexpr int SMALL = 320;                                               // masks (32 x 6 words) + cotangent rows (32 x 4 floats) of one tile
+    static_assert(3 * SLOT + 128 <= XW_P && 4 * SLOT + SMALL <= XW_H && 3 * SLOT + SMALL <= XW_C, "per-wave regions");
+    static_assert(F::F_TOTAL <= NWV * XW_C && F::F_TOTAL <= NWV * XW_P && F::F_TOTAL <= NWV * XW_H, "the reduction copy must fit the per-wave regions");
+    __shared__ __attribute__((aligned(16))) unsigned ldsu[LDS_WORDS];
     const int bid = (int)blockIdx.x, nwg = (int)gridDim.x;
+#ifdef ADFP_EXP_COMPILE_ROLE       // ISA experiments: the kernel with one role's code only (tools/isa_mix.py per role)
+    const int role = ADFP_EXP_COMPILE_ROLE;
+#else
     const int role = bid < nP ? 0 : (bid < nP + nH ? 1 : 2);                 // block-uniform (scalar)
+#endif
 #ifdef ADFP_EXP_ONLY_ROLE          // timing experiment (tools/ab_roles.sh): only one role's workgroups do anything -- that role's own time at its share
     if (role != ADFP_EXP_ONLY_ROLE) return;
 #endif
-    // Role P never runs the fc_c^T chains: its copy of the image leaves the five T_WC blocks out (block (i, ib) of pts_linears^T
-    // moves down by i + 1 blocks, PW below), and the 20 KB go to its waves: a third slot each (S0, layer 0's d/d pre).
-    constexpr int P_CUT = 5 * 1024, XW_P = XW + P_CUT / NWV;
-    if (role == 0) {
-        for (int i = threadIdx.x; i < LT::P_TOTAL / 4; i += 512) {
-            const int w = 4 * i;                                              // word offset in the full image
-            int cut = 0; bool drop = false;
+    auto copy_words = [&](int dst, int src, int n) {                         // n words of the packed image -> LDS (multiples of 4)
+        for (int i = threadIdx.x; i < n / 4; i += 512) ((u32x4*)(ldsu + dst))[i] = ((const u32x4*)(a.packed_t + src))[i];
+    };
+    if (role == 0) {                                                         // block (i, ib) of pts_linears^T moves down by i + 1 blocks (PW below)
+        copy_words(0, 0, LT::T_WC(0));
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                if (w >= LT::T_WC(k) + 1024) cut += 1024;
-                else if (w >= LT::T_WC(k)) drop = true;
-            }
-            if (!drop) *(u32x4*)(ldsu + w - cut) = ((const u32x4*)a.packed_t)[i];
+        for (int i = 0; i < 5; ++i) copy_words(LT::T_WP(i, 0) - 1024 * (i + 1), LT::T_WP(i, 0), LT::nb(i) * 1024);
+        copy_words(LT::P_WO - 5 * 1024, LT::P_WO, WO_WORDS);
+    } else if (role == 1) {                                                  // HW(i) = (i - 1) * 1024: the main block of layer i = 1..4
+#pragma unroll
+        for (int i = 1; i < 5; ++i) copy_words((i - 1) * 1024, LT::T_WP(i, i == 3 ? 3 : 0), 1024);
+        copy_words(4 * 1024, LT::P_WO, WO_WORDS);
+    } else {                                                                 // CWC(i) = i ? (2 i - 1) * 1024 : 0, CWP(i) = 2 i * 1024
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            copy_words(i ? (2 * i - 1) * 1024 : 0, LT::T_WC(i), 1024);
+            if (i) copy_words(2 * i * 1024, LT::T_WP(i, i == 3 ? 3 : 0), 1024);
         }
-    } else {
-        for (int i = threadIdx.x; i < LT::P_TOTAL / 4; i += 512) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed_t)[i];
+        copy_words(9 * 1024, LT::P_WO, WO_WORDS);
     }
-    __syncthreads();
-    const float* lds = (const float*)ldsu;
-    const int img_words = role == 0 ? LT::P_TOTAL - P_CUT : LT::P_TOTAL;
-    const int xw = role == 0 ? XW_P : XW;
-    float* s_red = (float*)(ldsu + img_words);
-
     const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
     const int wvu = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int img_words = role == 0 ? IMG_P : (role == 1 ? IMG_H : IMG_C);
+    const int xw = role == 0 ? XW_P : (role == 1 ? XW_H : XW_C);
+    // Tiles of a workgroup are handed to its waves through an LDS ticket (the last word of wave 0's region, spare in every role): the
+    // SIMD arbiter favours the older of its two waves, and with a fixed split the four old waves of a workgroup were done a fifth
+    // of the launch before the four young ones, which then ran alone on their SIMDs (per-workgroup stamps, tools/roles_span.py).
+    int* s_ticket = (int*)(ldsu + img_words + xw - 1);
+    if (threadIdx.x == 0) *s_ticket = NWV;                                   // local tile numbers 0 .. 7 are the waves' first tiles
+    __syncthreads();
+    const float* lds = (const float*)ldsu;
+    float* s_red = (float*)(ldsu + img_words);
+
     const int lane_off = h * 128 + p * 4;
     const int rwg = role == 0 ? bid : (role == 1 ? bid - nP : bid - nP - nH);
     const int nrwg = role == 0 ? nP : (role == 1 ? nH : nwg - nP - nH);
-    const int wave = rwg * NWV + wvu, nwaves = nrwg * NWV;
     const int ntiles = (a.total + 31) >> 5;
+    // the workgroup's tiles: rwg, rwg + nrwg, ...; local number j <-> tile rwg + j nrwg.  A wave knows its NEXT tile (for the
+    // prefetches); the one after is drawn at the end of a tile.
+    const int ntl = rwg < ntiles ? (ntiles - rwg + nrwg - 1) / nrwg : 0;
+    auto claim = [&]() {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(s_ticket, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    auto tile_of = [&](int j) { return rwg + j * nrwg; };
     float amax = 0.f;
     const float gS = grad_scale(a.gmax);
 
@@ -110,16 +146,32 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
             *(f32x4*)(slot + q4 * 256 + (h * 32 + (p ^ (2 * q4 + h))) * 4) = f32x4{v[4 * q4] * s, v[4 * q4 + 1] * s, v[4 * q4 + 2] * s, v[4 * q4 + 3] * s};
     };
     // an X block (32 columns of the forward's layer-input rows from column `col`) of tile `tile_n` into slot `slot` by LDS-DMA, already
-    // in the slot format (the XOR is applied to the SOURCE row a lane fetches).  4 VMEM operations, counted by hand below.
+    // in the slot format (the XOR is applied to the SOURCE row a lane fetches).  4 VMEM operations, counted by hand below.  Address =
+    // a SCALAR base (the tile's first row + the column, 64-bit arithmetic on the scalar unit) + a 32-bit lane offset that does not
+    // depend on the tile (four loop-invariant registers): per-lane 64-bit pointers cost ~8 VALU instructions per operation and the
+    // registers that held their loop-invariant parts were spilled and reloaded every tile.  Rows beyond the end (last tile only) are
+    // fetched from the tile's first row (finite; their cotangents are zero).
+    int rowoff[4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) rowoff[q4] = ((p ^ (2 * q4 + h)) * ST::NXM + 8 * q4 + 4 * h) * 4;
+    auto lds_dma = [&](unsigned dst_bytes, int voff, const void* sbase, auto width) {     // width: 4 = dwordx4, 1 = dword
+        unsigned keep;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(dst_bytes);
+        if constexpr (decltype(width)::value == 4)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(dst), "s"(sbase) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(dst), "s"(sbase) : "memory");
+    };
     auto dma_x = [&](int slot, int col, int tile_n) {
+        const float* sbase = a.act + ((long long)tile_n * 32 * ST::NXM + col);
+        const int rows_left = a.total - tile_n * 32;                            // scalar; >= 1
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-            const int locn = tile_n * 32 + (p ^ (2 * q4 + h));
-            const float* src = a.act + (long long)(locn < a.total ? locn : 0) * ST::NXM + col + 8 * q4 + 4 * h;
-            unsigned keep;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(xs_addr + (unsigned)((slot * SLOT + q4 * 256) * 4));
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            int off = rowoff[q4];
+            if (rows_left < 32 && (p ^ (2 * q4 + h)) >= rows_left) off = (8 * q4 + 4 * h) * 4;
+            lds_dma(xs_addr + (unsigned)((slot * SLOT + q4 * 256) * 4), off, sbase, std::integral_constant<int, 4>{});
         }
     };
     auto operand = [&](const unsigned* slot, f16x8* th, f16x8* tl) {           // a block out of a slot as operand halves (lane = unit, k = points)
@@ -133,16 +185,38 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
         split16v<false>(v, th, tl, amax);
     };
 
+    // Roles H and C: the small per-point inputs of a tile (ReLU mask words, cotangent of the decoder output) come through LDS as
+    // well -- the tile's 32 mask rows (768 B) and 32 cotangent rows (512 B) are contiguous in memory: five 256-byte LDS-DMA
+    // operations copy them verbatim into the wave's small-input buffer, requested right after the previous tile's head has read
+    // the buffer out.  (As ordinary loads the compiler's own s_waitcnt for them drains every younger DMA request at each tile's
+    // head -- it does not know those exist -- which stalled a wave for a memory latency per tile.)
+    // (address arithmetic that is used once per tile starts from an OPAQUE copy of the lane index: hoisted out of the tile loop these
+    // values are loop-invariant registers the kernel does not have -- they were spilled before the loop and re-loaded every tile)
+    auto opaque_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+    auto dma_small = [&](unsigned* buf, int tile_n) {
+        const int lane = opaque_lane();
+        const unsigned base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned*)buf;
+        const unsigned* smask = a.masks + (long long)tile_n * 192;
+        const float* sgo = a.g_raw + (long long)tile_n * 128;
+        const int rows_left = a.total - tile_n * 32;                            // scalar; the last word a partial tile may read
+        const int lim_m = (rows_left < 32 ? rows_left * 6 - 1 : 191) * 4, lim_g = (rows_left < 32 ? rows_left * 4 - 1 : 127) * 4;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            int off = (64 * (k < 3 ? k : k - 3) + lane) * 4;
+            const int lim = k < 3 ? lim_m : lim_g;
+            off = off < lim ? off : lim;
+            lds_dma(base + (unsigned)(k * 256), off, k < 3 ? (const void*)smask : (const void*)sgo, std::integral_constant<int, 1>{});
+        }
+    };
     // the small per-point inputs of a tile, fetched one tile ahead into the same registers once the layers have consumed them
-    struct Small { double pt[3]; unsigned mw[3]; float go[4]; };
-    auto fetch_small = [&](int tile_n, Small& sm, bool with_point) {
-        const int locn = tile_n * 32 + p;
-        const int qn = locn < a.total ? locn : 0;
-        if (with_point) load_point(a.P, qn, sm.pt);
-        const unsigned* mrow = a.masks + ((long long)qn * 2 + h) * 3;
-        sm.mw[0] = mrow[0]; sm.mw[1] = mrow[1]; sm.mw[2] = mrow[2];
-        if (ROLE == ROLE_LOW) { sm.go[0] = a.g_raw[4ll * qn + 3]; sm.go[1] = 0.f; sm.go[2] = 0.f; }
-        else { sm.go[0] = a.g_raw[4ll * qn]; sm.go[1] = a.g_raw[4ll * qn + 1]; sm.go[2] = a.g_raw[4ll * qn + 2]; }
+    struct Small { unsigned mw[3]; float go[4]; };
+    auto read_small = [&](const unsigned* buf, Small& sm) {
+        const int lane = opaque_lane(), p = lane & 31, h = lane >> 5;
+        const unsigned* m = buf + (p * 2 + h) * 3;
+        sm.mw[0] = m[0]; sm.mw[1] = m[1]; sm.mw[2] = m[2];
+        const f32x4 g = *(const f32x4*)(buf + 192 + 4 * p);
+        if (ROLE == ROLE_LOW) { sm.go[0] = g.w; sm.go[1] = 0.f; sm.go[2] = 0.f; }
+        else { sm.go[0] = g.x; sm.go[1] = g.y; sm.go[2] = g.z; }
         sm.go[3] = 0.f;
     };
     // the head of a tile, common to the roles: d/d h_4 = Wo^T d out with the per-point power-of-two scale of the chain
@@ -195,32 +269,41 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
         // slots 1 / 2: the grid features of this / the next tile (double buffer).
         // =====================================================================================================================
         constexpr int COL_C = ST::xm(ST::SC);
+        auto CWC = [](int i) { return i ? (2 * i - 1) * 1024 : 0; };
+        auto CWP = [](int i) { return 2 * i * 1024; };
+        unsigned* small = xs + 3 * SLOT;
         f32x16 acc[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        if (wave < ntiles) { dma_x(1, COL_C, wave); fetch_small(wave, cur, false); }
+        int jc = wvu, jn = ntl;
+        if (jc < ntl) { jn = claim(); dma_x(1, COL_C, tile_of(jc)); dma_small(small, tile_of(jc)); }
         int it = 0;
-        for (int tile = wave; tile < ntiles; tile += nwaves, ++it) {
+        for (; jc < ntl; ++it) {
+            const int tile = tile_of(jc);
+            const bool more = jn < ntl;
+            const int tnext = tile_of(jn);
             const int loc = tile * 32 + p;
             const bool valid = loc < a.total;
             const int q = valid ? loc : 0;
-            const bool more = tile + nwaves < ntiles;
-            const int tnext = tile + nwaves;
             const int par = __builtin_amdgcn_readfirstlane(it & 1);
+            // this tile's c and small inputs were requested a tile ago; with d/d c rows wanted, the previous tile's four row stores
+            // are the only younger operations
+            if (a.gc_out && it > 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_small(small, cur);
+            f16x8 cTh[2], cTl[2];
+            operand_x(xs + (1 + par) * SLOT, cTh, cTl);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the small buffer has been read out
+            if (more) { dma_x(2 - par, COL_C, tnext); dma_small(small, tnext); }   // the other c buffer: read out a tile ago
             const unsigned mw0 = valid ? cur.mw[0] : 0u, mw1 = valid ? cur.mw[1] : 0u, mw2 = valid ? cur.mw[2] : 0u;
             const unsigned mk[5] = {mw0, mw0 >> 16, mw1, mw1 >> 16, mw2};
             float go[4]; f32x16 gh; float sc, isc;
-            head(cur, valid, go, gh, sc, isc);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) go[o] = valid ? cur.go[o] : 0.f;
+            head_at(9 * 1024, go, gh, sc, isc);
             const float ssc = isc * gS;
-            // this tile's c was requested a tile ago.  With d/d c rows wanted, the previous tile's four row stores are the youngest
-            // operations (or they passed the small loads: c is older than all of them either way); otherwise nothing countable is
-            if (a.gc_out && it > 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            f16x8 cTh[2], cTl[2];
-            operand_x(xs + (1 + par) * SLOT, cTh, cTl);
-            if (more) dma_x(2 - par, COL_C, tnext);                          // the other buffer: read out a tile ago
             f32x16 gc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) gc[r] = 0.f;
@@ -229,7 +312,7 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
                 f16x8 xh[2], xl[2], tTh[2], tTl[2];
                 write_blk(slotS, gh, ssc);
                 split16(gh, xh, xl, amax);
-                mfma_chain_h<2>(gc, ldsu + LT::T_WC(i), lane_off, xh, xl);
+                mfma_chain_h<2>(gc, ldsu + CWC(i), lane_off, xh, xl);
                 operand(slotS, tTh, tTl);
                 outer_job(acc[i], tTh, tTl, cTh, cTl);
                 rowsum_job(acc[5], tTh, tTl, p, FSLOT_BFC(i));
@@ -240,14 +323,17 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
                     f32x16 gn;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) gn[r] = 0.f;
-                    mfma_chain_h<2>(gn, ldsu + LT::T_WP(i, i == 3 ? 3 : 0), lane_off, xh, xl);
+                    mfma_chain_h<2>(gn, ldsu + CWP(i), lane_off, xh, xl);
                     gh = gn;
                 }
             }
-            if (more) fetch_small(tnext, cur, false);
             if (a.gc_out && valid) stage_block_scaled(a.gc_out + 32ll * q, 0, h, gc, isc);     // 4 stores (a tile has a valid point)
+            jc = jn; jn = more ? claim() : ntl;                               // drawn late: a wave never sits on more than one undone tile
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ADFP_STAMPS_ROLES
+        t_loop_ = wall_clock64();
+#endif
         __syncthreads();
         for (int i = threadIdx.x; i < F::F_TOTAL; i += 512) s_red[i] = 0.f;
         __syncthreads();
@@ -276,26 +362,58 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
         // layer 1 uses h_0 -> A <- next h_3: every block is requested two uses ahead, and exactly ONE request (4 operations) is
         // younger than the block a use waits for.
         // =====================================================================================================================
+        // The X ring: the five blocks of a tile are USED in the order h_4 (output_linear), h_3 (layer 4), h_2, h_1, h_0; use number
+        // n = 5 it + k of the wave sits in slot 1 + n mod 3 and is requested when use n - 3 has read that slot out -- three uses =
+        // about two layers of work ahead.  When a use waits, the requests of the next two uses (8 operations) are the only younger
+        // ones; the small inputs of the next tile are requested right after this tile's head and are older than all five of the
+        // tile's X requests (20 operations) when the next head waits for them.
+        unsigned* small = xs + 4 * SLOT;
         f32x16 acc[5];
 #pragma unroll
         for (int j = 0; j < 5; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        if (wave < ntiles) { dma_x(1, ST::xm(ST::SH(4)), wave); dma_x(2, ST::xm(ST::SH(3)), wave); fetch_small(wave, cur, false); }
+        auto col_of = [](int k) { return ST::xm(ST::SH(4 - k)); };            // use k reads h_{4-k}
+        int jc = wvu, jn = ntl;
+        if (jc < ntl) {
+            jn = claim();
+            const int t0 = tile_of(jc);
+            dma_small(small, t0); dma_x(1, col_of(0), t0); dma_x(2, col_of(1), t0); dma_x(3, col_of(2), t0);
+        }
         int it = 0;
-        for (int tile = wave; tile < ntiles; tile += nwaves, ++it) {
+        for (; jc < ntl; ++it) {
+            const int tile = tile_of(jc);
+            const bool more = jn < ntl;
+            const int tnext = tile_of(jn);
             const int loc = tile * 32 + p;
             const bool valid = loc < a.total;
-            const bool more = tile + nwaves < ntiles;
-            const int tnext = tile + nwaves;
-            const int par = __builtin_amdgcn_readfirstlane(it & 1);
-            const int sA = 1 + par, sB = 2 - par;
+            const int n0 = __builtin_amdgcn_readfirstlane((5 * it) % 3);       // ring position of the tile's first use
+            auto slot_of = [&](int k) { const int t = n0 + k; return 1 + (t >= 6 ? t - 6 : (t >= 3 ? t - 3 : t)); };
+            // use k: wait for its block, read it out, then request use k + 3 (of this or the next tile) into the same slot
+            auto take = [&](int k, f16x8* hTh, f16x8* hTl) {
+                const bool two = more || k < 3, one = more || k < 4;            // are the requests of the next two / one uses out?
+                if (two) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (one) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int sl = slot_of(k);
+                operand_x(xs + sl * SLOT, hTh, hTl);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the reads have returned before the DMA may overwrite the slot
+                if (k < 2) dma_x(sl, col_of(k + 3), tile);
+                else if (more) dma_x(sl, col_of(k - 2), tnext);
+            };
+            // the small inputs: requested a tile ago, 20 X-request operations younger (first tile: 12)
+            if (it > 0) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            read_small(small, cur);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (more) dma_small(small, tnext);
             const unsigned mw0 = valid ? cur.mw[0] : 0u, mw1 = valid ? cur.mw[1] : 0u, mw2 = valid ? cur.mw[2] : 0u;
             const unsigned mk[5] = {mw0, mw0 >> 16, mw1, mw1 >> 16, mw2};
             float go[4]; f32x16 gh; float sc, isc;
-            head(cur, valid, go, gh, sc, isc);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) go[o] = valid ? cur.go[o] : 0.f;
+            head_at(4 * 1024, go, gh, sc, isc);
             const float ssc = isc * gS;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // h_4, h_3 (requested two uses ago) and the small inputs
             // ---------------- output_linear: d out (x) h_4 and its bias ----------------
             {
                 float gob[16];
@@ -309,9 +427,7 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
                 write_blk(slotS, gob, gS);
                 f16x8 gTh[2], gTl[2], hTh[2], hTl[2];
                 operand(slotS, gTh, gTl);
-                operand_x(xs + sA * SLOT, hTh, hTl);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the reads have returned before the DMA may overwrite the slot
-                dma_x(sA, ST::xm(ST::SH(2)), tile);
+                take(0, hTh, hTl);
                 outer_job(acc[4], hTh, hTl, gTh, gTl);                        // [row = h_4 unit][column FSLOT_WO(o)]
                 rowsum_job(acc[4], gTh, gTl, p, FSLOT_BO);                    // [row FSLOT_WO(o)][column FSLOT_BO]
             }
@@ -326,30 +442,23 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
                     split16v(gp, xh, xl, amax);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) gn[r] = 0.f;
-                    mfma_chain_h<2>(gn, ldsu + LT::T_WP(i, i == 3 ? 3 : 0), lane_off, xh, xl);
+                    mfma_chain_h<2>(gn, ldsu + (i - 1) * 1024, lane_off, xh, xl);
                 }
                 operand(slotS, tTh, tTl);
                 rowsum_job(acc[4], tTh, tTl, p, FSLOT_BPL(i));
                 if (i > 0) {
-                    // layer 4: h_3 in B (waited for at the head of the tile); 3: h_2 in A; 2: h_1 in B; 1: h_0 in A
-                    const int sl = (i & 1) ? sA : sB;
-                    if (i < 4) {
-                        if (i > 1 || more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
                     f16x8 hTh[2], hTl[2];
-                    operand_x(xs + sl * SLOT, hTh, hTl);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (i == 4) dma_x(sl, ST::xm(ST::SH(1)), tile);
-                    else if (i == 3) dma_x(sl, ST::xm(ST::SH(0)), tile);
-                    else if (more) dma_x(sl, ST::xm(ST::SH(i == 2 ? 4 : 3)), tnext);
+                    take(5 - i, hTh, hTl);                                    // layer i multiplies with h_{i-1}: use 5 - i
                     outer_job(acc[i - 1], tTh, tTl, hTh, hTl);
                     gh = gn;
                 }
             }
-            if (more) fetch_small(tnext, cur, false);
+            jc = jn; jn = more ? claim() : ntl;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ADFP_STAMPS_ROLES
+        t_loop_ = wall_clock64();
+#endif
         __syncthreads();
         for (int i = threadIdx.x; i < F::F_TOTAL; i += 512) s_red[i] = 0.f;
         __syncthreads();
@@ -373,21 +482,30 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
         }
     } else {
         // =====================================================================================================================
-        // role P: pts_linears[0].weight and the Fourier columns of pts_linears[3].weight against sin(p @ B), embedder._B through
-        // cos(p @ B).  Blocks 0-2 = layer 0, 3-5 = layer 3, 6 = narrow columns FSLOT_EB.  No layer input is read: the chain runs
-        // on masks and cotangents alone.  slot 1 = S3 (layer 3's d/d pre, parked until the Fourier blocks), then the position table.
+        // role P: pts_linears[0].weight and the Fourier columns of pts_linears[3].weight against sin(p @ B) -- blocks 0-2 = layer 0,
+        // 3-5 = layer 3 -- and embedder._B through cos(p @ B).  No layer input is read: the chain runs on masks and cotangents alone.
+        // slots: S (transposition scratch), S3 and S0 (layer 3's / layer 0's d/d pre: written by the chain, read in the Fourier
+        // blocks), then the position table (32 x {x, y, z, scale}) and the small-input buffer (masks, cotangents, z, the tile's rays).
+        //
+        // d embedder._B[k][j] = sum_p x_k(p) cos(p @ B)_j ge_j(p) is formed on the VALU: in the transposed layout a lane IS feature j
+        // and holds ge_j of 16 points, so the sum over the tile's points is 16 fma per coordinate into 9 f32 accumulators per lane
+        // (3 feature blocks x 3 coordinates) that live across all tiles.  (The one-wave kernel sent it through the matrix pipe: a
+        // split of the 16 values, a masked positions operand per block and 6 MFMAs into a narrow accumulator block -- 32 + 72
+        // quarter-rate instructions and 16 registers more than 48 full-rate fma; this role is issue bound on exactly those.)
         // =====================================================================================================================
         unsigned* slotS3 = xs + SLOT;
         unsigned* slotS0 = xs + 2 * SLOT;
         float* ptab = (float*)(xs + 3 * SLOT);
-        static_assert(3 * SLOT + 128 <= XW_P, "role P: S, S3, S0 and the position table");
+        unsigned* small = xs + 3 * SLOT + 128;
+        static_assert(3 * SLOT + 128 + SMALL + 192 <= XW_P, "role P: three slots, the position table, the small-input buffer with the positions' sources");
         auto PW = [](int i, int ib) { return LT::T_WP(i, ib) - 1024 * (i + 1); };      // block (i, ib) in the compacted image
-        const int p_wo = LT::P_WO - P_CUT;
-        f32x16 acc[7];
+        const int p_wo = LT::P_WO - 5 * 1024;
+        f32x16 acc[6];
 #pragma unroll
-        for (int j = 0; j < 7; ++j)
+        for (int j = 0; j < 6; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        float eb[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};          // [feature block][coordinate]: this lane's feature, its half's points
         // a d/d pre block back out of its slot in the D layout, as the chain operand (stored x S / point scale, both powers of two)
         auto chain_operand = [&](const unsigned* slot, float back, f16x8* xh, f16x8* xl) {
             float t[16];
@@ -398,14 +516,89 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
             }
             split16v<false>(t, xh, xl, amax);
         };
-        if (wave < ntiles) fetch_small(wave, cur, true);
-        for (int tile = wave; tile < ntiles; tile += nwaves) {
+        auto park = [&](unsigned* slot, const f16x8* xh, const f16x8* xl) {
+            const int lane = opaque_lane();
+            *(u32x4*)(slot + (0 * 64 + lane) * 4) = __builtin_bit_cast(u32x4, xh[0]);
+            *(u32x4*)(slot + (1 * 64 + lane) * 4) = __builtin_bit_cast(u32x4, xh[1]);
+            *(u32x4*)(slot + (2 * 64 + lane) * 4) = __builtin_bit_cast(u32x4, xl[0]);
+            *(u32x4*)(slot + (3 * 64 + lane) * 4) = __builtin_bit_cast(u32x4, xl[1]);
+        };
+        auto unpark = [&](const unsigned* slot, f16x8* xh, f16x8* xl) {
+            xh[0] = __builtin_bit_cast(f16x8, *(const u32x4*)(slot + (0 * 64 + lane) * 4));
+            xh[1] = __builtin_bit_cast(f16x8, *(const u32x4*)(slot + (1 * 64 + lane) * 4));
+            xl[0] = __builtin_bit_cast(f16x8, *(const u32x4*)(slot + (2 * 64 + lane) * 4));
+            xl[1] = __builtin_bit_cast(f16x8, *(const u32x4*)(slot + (3 * 64 + lane) * 4));
+        };
+        // The tile's positions come through LDS as well (three more DMA operations, 192 words): in ray mode z_vals of its 32 points
+        // (64 words) and the up to five rays those points can belong to (S >= 8; lanes 0-29 fetch origin + direction of rays
+        // r0 .. r0 + 4); explicit points (adfp_eval_points_backward) are the tile's 32 rows verbatim, 192 (f64) or 96 (f32) words.
+        auto dma_pos = [&](unsigned* buf, int tile_n) {
+            const int lane = opaque_lane();
+            const unsigned base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned*)buf;
+            const int rows_left = a.total - tile_n * 32;
+            if (a.P.mode == ADFP_PTS_RAYS) {
+                // z: 32 doubles = 64 words verbatim; rays: lane = 6 ray + component of the up to five rays from the tile's first on
+                const unsigned* sz = (const unsigned*)a.P.z + (long long)tile_n * 64;
+                const int lim = (rows_left < 32 ? rows_left * 2 - 1 : 63) * 4;
+                int off = lane * 4;
+                off = off < lim ? off : lim;
+                lds_dma(base, off, sz, std::integral_constant<int, 1>{});
+                const int r0 = (int)((unsigned)(tile_n * 32) / (unsigned)a.P.S);
+                const int nrays = a.P.n / a.P.S;
+                const int rr = lane < 30 ? lane / 6 : 0, cc = lane < 30 ? lane % 6 : 0;
+                const int ray = (r0 + rr < nrays ? r0 + rr : nrays - 1) - r0;       // relative to the scalar base
+                const int roff = (3 * ray + (cc < 3 ? cc : cc - 3)) * 4;
+                const float* so = a.P.ro + 3ll * r0;
+                const float* sd = a.P.rd + 3ll * r0;
+                // origin and direction live in two arrays: two operations, each lane takes its word from the right one
+                lds_dma(base + 256u, cc < 3 ? roff : 0, so, std::integral_constant<int, 1>{});
+                lds_dma(base + 512u, cc < 3 ? 0 : roff, sd, std::integral_constant<int, 1>{});
+            } else {
+                const int wpp = a.P.mode == ADFP_PTS_F64 ? 6 : 3;                // words per point
+                const unsigned* sp = (const unsigned*)a.P.pts + (long long)tile_n * 32 * wpp;
+                const int lim = ((rows_left < 32 ? rows_left : 32) * wpp - 1) * 4;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    int off = (64 * k + lane) * 4;
+                    off = off < lim ? off : lim;
+                    lds_dma(base + (unsigned)(k * 256), off, sp, std::integral_constant<int, 1>{});
+                }
+            }
+        };
+        auto read_pos = [&](const unsigned* buf, int tile_n, double* pt) {
+            const int p = opaque_lane() & 31;
+            if (a.P.mode == ADFP_PTS_RAYS) {
+                const unsigned q0 = (unsigned)tile_n * 32u;
+                const int rr = (int)((q0 + (unsigned)p) / (unsigned)a.P.S) - (int)(q0 / (unsigned)a.P.S);      // 0 .. 4
+                const double z = *(const double*)(buf + 2 * p);
+                const float* ro_ = (const float*)(buf + 64 + 6 * rr);             // lane 6 rr + k of the origin operation
+                const float* rd_ = (const float*)(buf + 128 + 6 * rr + 3);        // lane 6 rr + 3 + k of the direction operation
+#pragma unroll
+                for (int k = 0; k < 3; ++k) pt[k] = __dadd_rn((double)ro_[k], __dmul_rn((double)rd_[k], z));   // load_point's arithmetic
+            } else if (a.P.mode == ADFP_PTS_F64) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) pt[k] = ((const double*)buf)[3 * p + k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) pt[k] = (double)((const float*)buf)[3 * p + k];
+            }
+        };
+        int jc = wvu, jn = ntl;
+        if (jc < ntl) { jn = claim(); dma_small(small, tile_of(jc)); dma_pos(small + SMALL, tile_of(jc)); }
+        while (jc < ntl) {
+            const int tile = tile_of(jc);
+            const bool more = jn < ntl;
+            const int tnext = tile_of(jn);
             const int loc = tile * 32 + p;
             const bool valid = loc < a.total;
-            const bool more = tile + nwaves < ntiles;
-            const int tnext = tile + nwaves;
-            float pf[3] = {(float)cur.pt[0], (float)cur.pt[1], (float)cur.pt[2]};
-            const bool pnan = (cur.pt[0] != cur.pt[0]) | (cur.pt[1] != cur.pt[1]) | (cur.pt[2] != cur.pt[2]);     // decoded at the origin by the forward
+            double pt[3];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // nothing else of this role is in the memory queue
+            read_small(small, cur);
+            read_pos(small + SMALL, tile, pt);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (more) { dma_small(small, tnext); dma_pos(small + SMALL, tnext); }
+            float pf[3] = {(float)pt[0], (float)pt[1], (float)pt[2]};
+            const bool pnan = (pt[0] != pt[0]) | (pt[1] != pt[1]) | (pt[2] != pt[2]);     // decoded at the origin by the forward
             if (pnan) { pf[0] = 0.f; pf[1] = 0.f; pf[2] = 0.f; }
             const unsigned mw0 = valid ? cur.mw[0] : 0u, mw1 = valid ? cur.mw[1] : 0u, mw2 = valid ? cur.mw[2] : 0u;
             const unsigned mk[5] = {mw0, mw0 >> 16, mw1, mw1 >> 16, mw2};
@@ -431,16 +624,26 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
                     gh = gn;
                 }
             }
-            if (more) fetch_small(tnext, cur, true);                          // in flight during the Fourier blocks
             // ---------------- the Fourier blocks, in the transposed layout: lane = feature 32 b + p, registers = the points kmapH(r, h) ----------------
-            // the two d/d pre blocks as the products' left operands stay in registers across the three blocks; as CHAIN operands
-            // (D layout) they are read back out of their slots per block -- 32 registers this role does not have
+            // the two d/d pre blocks as the products' left operands stay in registers across the three blocks ...
             f16x8 g0Th[2], g0Tl[2], g3Th[2], g3Tl[2];
             operand(slotS0, g0Th, g0Tl);
             operand(slotS3, g3Th, g3Tl);
-            const float back = sc * (1.0f / gS);
+            // ... and as chain operands (D layout): split ONCE, then parked as f16 pairs in the slot the block came from (16 words per lane,
+            // lane-major 16-byte pieces: conflict-free), read back per Fourier block with four ds_read_b128
+            {
+                const float back = sc * __uint_as_float((254u - (__float_as_uint(gS) >> 23)) << 23);      // sc / S: S is a power of two
+                f16x8 xh[2], xl[2];
+                chain_operand(slotS0, back, xh, xl);
+                f16x8 yh[2], yl[2];
+                chain_operand(slotS3, back, yh, yl);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // every read of the two slots (transposed and D layout) has returned
+                park(slotS0, xh, xl);
+                park(slotS3, yh, yl);
+            }
             int pl = p;                                                       // opaque per tile: what depends on it is recomputed, not hoisted and spilled
             asm volatile("" : "+v"(pl));
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
                 const f32x4 bm = *(const f32x4*)(lds + LT::P_BM + (32 * b + pl) * 4);
@@ -468,34 +671,30 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
                 for (int r = 0; r < 16; ++r) ge[r] = 0.f;
                 {
                     f16x8 xh[2], xl[2];
-                    chain_operand(slotS3, back, xh, xl);
+                    unpark(slotS3, xh, xl);
                     mfma_chain_h<2>(ge, ldsu + PW(3, b), lane_off, xh, xl);
-                    chain_operand(slotS0, back, xh, xl);
+                    unpark(slotS0, xh, xl);
                     mfma_chain_h<2>(ge, ldsu + PW(0, b), lane_off, xh, xl);
                 }
                 write_blk(slotS, ge, 1.f);
                 float ga[16];
                 read_T(slotS, ga);
+                float ex = 0.f, ey = 0.f, ez = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ga[r] *= cs[r];
-                f16x8 aTh[2], aTl[2], bTh[2], bTl[2];
-                split16v(ga, aTh, aTl, amax);
-                {
-                    // the positions as the B operand of the embedder._B products: lane FSLOT_EB(b, k) carries coordinate k of the 16 points
-                    const int ks3 = pl - FSLOT_EB(b, 0);
-                    const unsigned mx = ks3 == 0 ? ~0u : 0u, my = ks3 == 1 ? ~0u : 0u, mz = ks3 == 2 ? ~0u : 0u;
-                    float pk[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const f32x4 pv = *(const f32x4*)(ptab + 4 * kmapH(r, h));
-                        pk[r] = __uint_as_float((__float_as_uint(pv.x) & mx) | (__float_as_uint(pv.y) & my) | (__float_as_uint(pv.z) & mz));
-                    }
-                    split16v<false>(pk, bTh, bTl, amax);
+                for (int r = 0; r < 16; ++r) {
+                    const f32x4 pv = *(const f32x4*)(ptab + 4 * kmapH(r, h));
+                    const float g = ga[r] * cs[r];
+                    ex = fmaf(g, pv.x, ex); ey = fmaf(g, pv.y, ey); ez = fmaf(g, pv.z, ez);
                 }
-                outer_job(acc[6], aTh, aTl, bTh, bTl);                        // [row = feature 32 b + j][column FSLOT_EB(b, k)]
-            }
+                eb[b][0] += ex; eb[b][1] += ey; eb[b][2] += ez;
+                __builtin_amdgcn_sched_barrier(0);                            // one Fourier block at a time: hoisting the next block's sines above this
+            }                                                                 // block's tail keeps 32 more registers alive, and they do not exist
+            jc = jn; jn = more ? claim() : ntl;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ADFP_STAMPS_ROLES
+        t_loop_ = wall_clock64();
+#endif
         __syncthreads();
         for (int i = threadIdx.x; i < F::F_TOTAL; i += 512) s_red[i] = 0.f;
         __syncthreads();
@@ -511,12 +710,14 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
                 if (j == 3) add_rows(acc[3], F::F_PL(3), 125, ncol);
                 else if (j == 4) add_rows(acc[4], F::F_PL(3) + 32, 125, ncol);
                 else add_rows(acc[5], F::F_PL(3) + 64, 125, ncol);
-            } else if (j == 6) {
-                if (p >= 10 && p < 19) {
-                    const int bb = (p - 10) / 3, kk = (p - 10) % 3;
+            } else if (j == 6) {                                              // embedder._B [3][93]: the two lane halves hold different points
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { const int u = kmapH(r, h); if (32 * bb + u < 93) s_red[F::F_EB + kk * 93 + 32 * bb + u] += acc[6][r]; }
-                }
+                for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) {
+                        const float v = eb[b][kk] + __shfl_xor(eb[b][kk], 32);
+                        if (h == 0 && 32 * b + p < 93) s_red[F::F_EB + kk * 93 + 32 * b + p] += v;
+                    }
             }
             __syncthreads();
         }
@@ -524,4 +725,10 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
     if (!(a.skip && *a.skip)) report_range(a.status, amax, ADFP_STATUS_F16_RANGE_BWD);
     float* part = a.partial + (long long)blockIdx.x * a.part_stride;
     for (int i = threadIdx.x; i < F::F_TOTAL; i += 512) part[i] = s_red[i];   // the slot is this workgroup's alone and written whole
+#ifdef ADFP_STAMPS_ROLES
+    if (NOUT == 4 && threadIdx.x == 0 && blockIdx.x < 256) {
+        g_roles_span[4 * blockIdx.x] = (unsigned long long)role; g_roles_span[4 * blockIdx.x + 1] = t_start_;
+        g_roles_span[4 * blockIdx.x + 2] = t_loop_; g_roles_span[4 * blockIdx.x + 3] = wall_clock64();
+    }
+#endif
 }

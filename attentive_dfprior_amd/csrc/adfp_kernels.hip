@@ -985,6 +985,11 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
 #include "adfp_backward_h.h"
 #include "adfp_backward_fused.h"
 #include "adfp_backward_roles.h"
+#ifdef ADFP_STAMPS_ROLES
+extern "C" int adfp_debug_roles_span(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_roles_span), sizeof(unsigned long long) * 4 * 256);
+}
+#endif
 #ifdef ADFP_STAMPS
 extern "C" int adfp_debug_phases_fused(unsigned long long* host_out, int reset) {
     int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_fused), 64);
@@ -1881,7 +1886,19 @@ int adfp_prefilter_mask(const float* rays_o, const float* rays_d, const float* g
     ADFP_CHECK_LAUNCH();
     return 0;
 }
-int adfp_mapper_loss(const adfp_loss_args* l, void* stream) {
+static int mapper_loss_impl(const adfp_loss_args* l, const AdamPrepArgs* prep, double* scratch, void* stream);
+int adfp_mapper_loss(const adfp_loss_args* l, void* stream) { return mapper_loss_impl(l, nullptr, nullptr, stream); }
+int adfp_mapper_loss_step(const adfp_loss_args* l, void* scratch, size_t scratch_bytes, int* steps, float* derived, int n_groups, const float* lr,
+                          float beta1, float beta2, const int* skip_flag, void* stream) {
+    if (!l || !scratch || ((uintptr_t)scratch & 7) || n_groups < 0 || n_groups > ADFP_ADAM_MAX_GROUPS) return ADFP_E_ARG;
+    if (n_groups && (!steps || !derived || !lr)) return ADFP_E_ARG;
+    if (l->n_rays > 0 && scratch_bytes < adfp_mapper_loss_scratch_bytes(l->n_rays)) return ADFP_E_WORKSPACE;
+    AdamPrepArgs p; p.steps = steps; p.derived = derived; p.n = n_groups; p.beta1 = beta1; p.beta2 = beta2; p.skip = skip_flag;
+    for (int g = 0; g < ADFP_ADAM_MAX_GROUPS; ++g) p.lr[g] = g < n_groups ? lr[g] : -1.f;
+    return mapper_loss_impl(l, &p, (double*)scratch, stream);
+}
+size_t adfp_mapper_loss_scratch_bytes(int n_rays) { return n_rays < 0 ? 0 : (size_t)(1 + (n_rays + 255) / 256) * 8; }
+static int mapper_loss_impl(const adfp_loss_args* l, const AdamPrepArgs* prep, double* scratch, void* stream) {
     if (!l || !l->depth || !l->gt_depth || !l->g_depth || !l->loss || l->n_rays < 0 || l->S <= 0) return ADFP_E_ARG;
     if (l->stage < ADFP_STAGE_LOW || l->stage > ADFP_STAGE_COLOR) return ADFP_E_ARG;
     if (l->stage == ADFP_STAGE_COLOR && (!l->color || !l->gt_color || !l->g_color)) return ADFP_E_ARG;
@@ -1891,6 +1908,8 @@ int adfp_mapper_loss(const adfp_loss_args* l, void* stream) {
     a.n = l->n_rays; a.S = l->S; a.color_term = l->stage == ADFP_STAGE_COLOR; a.warmup = l->warmup; a.w_color = l->w_color_loss;
     a.depth = l->depth; a.color = l->color; a.weight = l->weight; a.gt_depth = l->gt_depth; a.gt_color = l->gt_color; a.keep = l->keep;
     a.loss = l->loss; a.g_depth = l->g_depth; a.g_color = l->g_color; a.g_weight = l->g_weight;
+    a.scratch = scratch; a.prep.n = 0;
+    if (prep) a.prep = *prep;
     hipLaunchKernelGGL(k_mapper_loss, dim3((l->n_rays + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);      // one thread per ray
     ADFP_CHECK_LAUNCH();
     return 0;
@@ -2040,7 +2059,11 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
 // ---------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------
-#define STG_ROWS_MAX 65536
+// Rows of the staging buffer (the widest row: the attention network's, 3.3 KB).  The list-indexed kernels (attention backward, its
+// weight gradients) are launched once per chunk of 2 x this many LIST entries -- the host cannot know how many entries the in-band
+// list has, so chunks beyond its end are launches that return at once (~5 us each inside a graph replay).  160 K rows make a
+// 5 000-ray x 64-sample iteration (320 000 points) ONE chunk: four launches fewer per iteration than with 64 K rows; 545 MB.
+#define STG_ROWS_MAX 163840
 
 #define OUTER_NSLOT 256         // workgroups per weight-gradient launch = private gradient copies (one per CU)
 struct BwdWorkspace { float* g_raw; float* att_g; float* g_pts; float* stage; int stage_rows; float* partial; int part_stride; float* gmax; float* gmax_parts;
@@ -2280,7 +2303,9 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
             // every workgroup OVERWRITES its slot of bw.partial (no 20 MB zero fill per network), and the reduction reads the slots in use
             const int ntiles = (total + 31) / 32;
             int nslot;
-            if (options & ADFP_BWD_FUSED_ONE_WAVE) {
+            // (role P stages a tile's positions through LDS and allows a 32-point tile to span five rays: fewer than 8 samples per
+            // ray keep the one-wave kernel)
+            if ((options & ADFP_BWD_FUSED_ONE_WAVE) || (o.P.mode == ADFP_PTS_RAYS && o.P.S < 8)) {
                 const int nwg = (ntiles + 3) / 4;
                 nslot = nwg < OUTER_NSLOT ? nwg : OUTER_NSLOT;
                 hipLaunchKernelGGL((k_decode_bwd_fused<NOUT, ROLE>), dim3(nslot), dim3(256), 0, st, f);
@@ -2313,7 +2338,7 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
     using ST = DecStage<CDIM>;
     OuterHArgs oa; decoder_jobs<CDIM, NOUT>(oa.o);
     oa.act = act; oa.nxm4 = ST::NXM / 4; oa.ngm4 = ST::NGM / 4; oa.g_dst4 = ST::SGH(0) / 4; oa.x_gap_at4 = 8; oa.x_gap4 = 24; oa.masks = masks; oa.bm = (const float*)t;   // P_BM = word 0 of the T image
-    oa.col_se = ST::SE; oa.col_sgp = ST::SGP(0); oa.status = status; oa.skip = skip;
+    oa.col_se = ST::SE; oa.col_sgp = ST::SGP(0); oa.status = status; oa.skip = skip; oa.overwrite = 0;
     a.stage = bw.stage;
     const int rows_cap = (int)((size_t)bw.stage_rows * AttStage::NCOLS / ST::NGM);
     int rc = outer_begin(bw, DecLayout<CDIM, NOUT>::F_TOTAL, st);
@@ -2434,7 +2459,11 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
             oh.masks = nullptr; oh.bm = nullptr; oh.col_se = 0; oh.col_sgp = 0; oh.status = sc->status; oh.skip = t.skip;
             OuterArgs& oa = oh.o;
             const int rows_cap = bw.stage_rows * 2;               // the G piece is half a row
-            if (go.flat_att) { rc = outer_begin(bw, AttLayout::F_TOTAL, st); if (rc) return rc; }
+            // ONE chunk (the usual case: STG_ROWS_MAX): the weight-gradient workgroups OVERWRITE their slots and the reduction reads only
+            // the slots in use -- no zero fill of the 256 x 134 KB partial sums (9.5 us + a launch per iteration)
+            const bool one_chunk = P <= rows_cap;
+            oh.overwrite = one_chunk ? 1 : 0;
+            if (go.flat_att && !one_chunk) { rc = outer_begin(bw, AttLayout::F_TOTAL, st); if (rc) return rc; }
             for (int lo = 0; lo < P; lo += rows_cap) {
                 const int hi = lo + rows_cap < P ? lo + rows_cap : P;
                 t.chunk_lo = lo; t.chunk_hi = hi;
@@ -2452,7 +2481,14 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
                     ADFP_CHECK_LAUNCH();
                 }
             }
-            if (go.flat_att) { rc = outer_end_scaled(bw, AttLayout::F_TOTAL, go.flat_att, st); if (rc) return rc; }
+            if (go.flat_att) {
+                if (one_chunk) {
+                    const int nblk = (P + 63) / 64;
+                    hipLaunchKernelGGL(k_reduce_partials_scaled, dim3((AttLayout::F_TOTAL + 31) / 32), dim3(256), 0, st, bw.partial, nblk < OUTER_NSLOT ? nblk : OUTER_NSLOT,
+                                       bw.part_stride, AttLayout::F_TOTAL, go.flat_att, bw.gmax, state.counter, P, 64);
+                    ADFP_CHECK_LAUNCH();
+                } else { rc = outer_end_scaled(bw, AttLayout::F_TOTAL, go.flat_att, st); if (rc) return rc; }
+            }
         } else {
         if (!sc->w_att) return ADFP_E_ARG;
         AttBwdArgs t;

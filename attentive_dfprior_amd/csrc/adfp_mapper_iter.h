@@ -46,13 +46,31 @@ __global__ __launch_bounds__(1024) void k_prefilter_mask(const float* __restrict
     }
 }
 
+#define ADFP_ADAM_MAX_GROUPS 8
+struct AdamPrepArgs { int* steps; float* derived; int n; float beta1, beta2; float lr[ADFP_ADAM_MAX_GROUPS]; const int* skip; };
 struct LossArgs {
     int n, S, color_term, warmup;
     float w_color;
     const double* depth; const float* color; const float* weight;
     const float* gt_depth; const float* gt_color; const unsigned char* keep;
     double* loss; double* g_depth; float* g_color; float* g_weight;
+    // adfp_mapper_loss_step: the loss is WRITTEN (per-workgroup partial sums in scratch + 8, added up in order by the workgroup that
+    // draws the last ticket from the int at scratch, which it leaves zero again), and workgroup 0 does k_adam_prep's work on the side
+    double* scratch;
+    AdamPrepArgs prep;             // prep.n == 0: none
 };
+ADFP_DEV void adam_prep_group(const AdamPrepArgs& a, int g) {
+    if (a.skip && *a.skip) {          // the iteration's gradients are not valid (f16-range repair): nobody steps, see masked_adam_block
+        a.derived[2 * g] = 0.f; a.derived[2 * g + 1] = 0.f;
+        return;
+    }
+    if (a.lr[g] < 0.f) return;
+    const int t = a.steps[g] + 1;
+    a.steps[g] = t;
+    const double bc1 = 1.0 - pow((double)a.beta1, (double)t), bc2 = 1.0 - pow((double)a.beta2, (double)t);
+    a.derived[2 * g] = (float)((double)a.lr[g] / bc1);
+    a.derived[2 * g + 1] = (float)sqrt(bc2);
+}
 ADFP_DEV float sign_f(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }     // torch.sign: 0 at 0, NaN -> 0 here
 // One thread per ray for the depth and colour terms, then all threads stride over the N x S attention weights of the warm-up
 // term; the loss is summed in registers and leaves a wave through ONE f64 atomic (one atomic per ray serialised 5 000 adders on
@@ -97,7 +115,36 @@ __global__ __launch_bounds__(256) void k_mapper_loss(LossArgs a) {
             a.g_weight[i] = g;
         }
     }
-    if (a.loss) {
+    if (a.scratch) {
+        // one launch instead of three (a zero fill of the loss word, this kernel, k_adam_prep): ~5 us each inside a graph replay
+        if (blockIdx.x == 0 && (int)threadIdx.x < a.prep.n) adam_prep_group(a.prep, (int)threadIdx.x);
+        __shared__ double s_part[4];
+        __shared__ int s_last;
+        part = wave_sum(part);
+        if (lane == 0) s_part[threadIdx.x >> 6] = part;
+        __syncthreads();
+        // Cross-workgroup hand-off without fences (MI355X_MICROARCH.md, "hand-offs measured with sc1 loads", first row: a
+        // __threadfence() is ~3.5 us, most of this kernel): ONE lane per workgroup stores its partial sum write-through (agent-scope
+        // atomic store = sc1), waits for it, then adds to the ticket (agent-scope atomic); the workgroup whose add came last -- told by
+        // the returned value -- reads the partial sums with agent-scope loads (sc1: past its L1), its other lanes after the barrier.
+        if (threadIdx.x == 0) {
+            const double mine = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+            __hip_atomic_store((unsigned long long*)a.scratch + 1 + blockIdx.x, (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_last = __hip_atomic_fetch_add((int*)a.scratch, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+        }
+        __syncthreads();
+        if (s_last && threadIdx.x < 64) {          // the last workgroup: added up in workgroup order (reproducible)
+            double t = 0.0;
+            for (int b = lane; b < (int)gridDim.x; b += 64)
+                t += __longlong_as_double((long long)__hip_atomic_load((unsigned long long*)a.scratch + 1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            t = wave_sum(t);
+            if (lane == 0) {
+                if (a.loss) *a.loss = t;
+                __hip_atomic_store((int*)a.scratch, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the ticket is zero again for the next call
+            }
+        }
+    } else if (a.loss) {
         part = wave_sum(part);
         if (lane == 0 && part != 0.0) atomicAdd(a.loss, part);
     }
@@ -106,19 +153,8 @@ __global__ __launch_bounds__(256) void k_mapper_loss(LossArgs a) {
 // Per parameter group g < n with lr[g] >= 0:  t = ++steps[g],  derived[g] = { lr[g] / (1 - beta1^t), sqrt(1 - beta2^t) } -- the
 // python-float (double) arithmetic of torch.optim.Adam, rounded to f32 once.  A negative lr marks a group that does not step
 // in this iteration (torch skips parameters without a gradient).  One launch for all groups.
-#define ADFP_ADAM_MAX_GROUPS 8
-struct AdamPrepArgs { int* steps; float* derived; int n; float beta1, beta2; float lr[ADFP_ADAM_MAX_GROUPS]; const int* skip; };
 __global__ void k_adam_prep(AdamPrepArgs a) {
     const int g = threadIdx.x;
     if (blockIdx.x != 0 || g >= a.n) return;
-    if (a.skip && *a.skip) {          // the iteration's gradients are not valid (f16-range repair): nobody steps, see masked_adam_block
-        a.derived[2 * g] = 0.f; a.derived[2 * g + 1] = 0.f;
-        return;
-    }
-    if (a.lr[g] < 0.f) return;
-    const int t = a.steps[g] + 1;
-    a.steps[g] = t;
-    const double bc1 = 1.0 - pow((double)a.beta1, (double)t), bc2 = 1.0 - pow((double)a.beta2, (double)t);
-    a.derived[2 * g] = (float)((double)a.lr[g] / bc1);
-    a.derived[2 * g + 1] = (float)sqrt(bc2);
+    adam_prep_group(a, g);
 }

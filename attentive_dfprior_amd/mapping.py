@@ -183,6 +183,7 @@ class MapperIteration(object):
         self.derived = torch.empty((len(self.groups), 2), dtype=torch.float32, device=dev)
         self._pool = None
         self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._loss_scratch = {}                                          # ray count -> scratch of adfp_mapper_loss_step (its ticket word starts at zero)
         self.bound_dev = torch.as_tensor(renderer.bound).to(dev, torch.float64).contiguous()
         # Ray-sharded iteration (new; the reference has no distributed code): every rank passes ITS rays to step(); the loss
         # gradients are combined by ONE RCCL all-reduce (SUM) of a contiguous bucket -- the backward writes the grid and
@@ -291,10 +292,28 @@ class MapperIteration(object):
         g_depth = torch.empty((N,), dtype=torch.float64, device=dev)
         g_color = torch.empty((N, 3), dtype=torch.float32, device=dev)
         g_weight = torch.empty((N, S), dtype=torch.float32, device=dev) if warmup else None
-        self.loss.zero_()
         la.loss, la.g_depth, la.g_color = self.loss.data_ptr(), g_depth.data_ptr(), g_color.data_ptr()
         la.g_weight = g_weight.data_ptr() if warmup else None
-        check(L.adfp_mapper_loss(C.byref(la), st), 'adfp_mapper_loss')
+        # ONE launch for the loss, its cotangents, the loss word (written, not accumulated: no zero fill) and -- when an optimiser step
+        # follows -- the step counters / bias corrections of torch.optim.Adam for this stage's groups (adfp_mapper_loss_step)
+        used_groups = self._stage_groups(stage, need_grid, need_flat) if adam else []
+        lrs = (C.c_float * len(self.groups))(*([-1.0] * len(self.groups)))
+        for gname, lrv in used_groups:
+            lrs[self.groups.index(gname)] = float(lrv)
+        scratch = self._loss_scratch.get(N)
+        if scratch is None:
+            scratch = self._loss_scratch[N] = torch.zeros(int(L.adfp_mapper_loss_scratch_bytes(N)) // 8 + 1, dtype=torch.float64, device=dev)
+        # the forward call's f16-range flag (adfp_train_state.counter[8]): a repaired forward means this iteration's gradients are
+        # zero by construction -- then nobody steps (parameters, moments and step counters stay as they are)
+        skip = C.c_void_p(aux['counter_ptr'] + 32)
+        b1, b2 = self.betas
+        if N > 0:
+            check(L.adfp_mapper_loss_step(C.byref(la), ptr(scratch), scratch.numel() * 8, ptr(self.step_count), ptr(self.derived),
+                                          len(self.groups) if adam else 0, lrs, b1, b2, skip, st), 'adfp_mapper_loss_step')
+        else:                                   # an empty ray shard: nothing to launch for the loss
+            self.loss.zero_()
+            if adam:
+                check(L.adfp_adam_prep(ptr(self.step_count), ptr(self.derived), len(self.groups), lrs, b1, b2, skip, st), 'adfp_adam_prep')
         out_grids, out_flats, end = {}, {}, 0
         for kind, name, key, off, n in self._bucket_layout:
             view = self.bucket[off:off + n]
@@ -321,7 +340,6 @@ class MapperIteration(object):
                 g.zero_()
             return ret, flats
         lr = self.stage_lr[stage]
-        b1, b2 = self.betas
         # Adam (src/Mapper.py:374-378, :472): a group whose parameters received no gradient in this stage is skipped by torch
         # (grad is None) and is skipped here; a group with lr 0 still advances its moments
         groups, cl_groups = [], []
@@ -333,13 +351,6 @@ class MapperIteration(object):
             if n in flats:
                 f = self.flat[n]
                 groups.append((n, f, flats[n], self.fstate[n], None, f.numel(), 1, lr['decoders' if n in ('high', 'color') else 'mlp']))
-        lrs = (C.c_float * len(self.groups))(*([-1.0] * len(self.groups)))
-        for (gname, *_rest, lrv) in groups + cl_groups:
-            lrs[self.groups.index(gname)] = float(lrv)
-        # the forward call's f16-range flag (adfp_train_state.counter[8]): a repaired forward means this iteration's gradients are
-        # zero by construction -- then nobody steps (parameters, moments and step counters stay as they are)
-        skip = C.c_void_p(aux['counter_ptr'] + 32)
-        check(L.adfp_adam_prep(ptr(self.step_count), ptr(self.derived), len(self.groups), lrs, b1, b2, skip, st), 'adfp_adam_prep')
         arr = (_lib.AdfpAdamGroup * len(groups))()                   # one launch for all groups
         for k, (gname, p, g, (m, v), mask, nvox, ch, lrv) in enumerate(groups):
             a = arr[k]
@@ -360,6 +371,14 @@ class MapperIteration(object):
         if cl_groups:
             check(L.adfp_adam_grids_cl(len(cl_groups), C.byref(carr), b1, b2, self.eps, st), 'adfp_adam_grids_cl')
         return grids, flats
+
+    def _stage_groups(self, stage, need_grid, need_flat):
+        """(group name, lr) of every parameter group that receives a gradient in this stage (= steps, like torch.optim.Adam, which
+        skips parameters whose .grad is None; a group with lr 0 still advances its moments)."""
+        lr = self.stage_lr[stage]
+        out = [(key, lr[name]) for name, key in (('low', 'grid_low'), ('high', 'grid_high'), ('color', 'grid_color')) if need_grid[name]]
+        out += [(n, lr['decoders' if n in ('high', 'color') else 'mlp']) for n in self.nets if need_flat[n]]
+        return out
 
     def _sync_shadows(self):
         """Before a forward: every grid's channels-last shadow is what the engine's layout cache holds for it.  A grid somebody

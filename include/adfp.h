@@ -451,6 +451,16 @@ typedef struct adfp_loss_args {
     float* g_weight;             /* [N,S] out (warm-up; may be NULL otherwise) */
 } adfp_loss_args;
 int adfp_mapper_loss(const adfp_loss_args* args /*host*/, void* stream);
+/* The same kernel doing three launches' work (inside a graph replay a launch costs ~5 us whatever it does):
+ *  - the loss is WRITTEN, not accumulated (no zero fill first): per-workgroup partial sums go to scratch + 8 and the workgroup
+ *    that draws the last ticket adds them up in order (reproducible, unlike the atomics of adfp_mapper_loss).  scratch: device
+ *    memory, 8-byte aligned, adfp_mapper_loss_scratch_bytes(n_rays) bytes, whose first int is ZERO before the first call (the
+ *    kernel leaves it zero);
+ *  - adfp_adam_prep's work (below: same arguments, n_groups may be 0) is done by the first workgroup on the side.
+ * With n_rays == 0 nothing is launched: zero the loss and call adfp_adam_prep yourself. */
+size_t adfp_mapper_loss_scratch_bytes(int n_rays);
+int adfp_mapper_loss_step(const adfp_loss_args* args /*host*/, void* scratch, size_t scratch_bytes, int* steps, float* derived, int n_groups,
+                          const float* lr /*host*/, float beta1, float beta2, const int* skip_flag, void* stream);
 /* torch.optim.Adam's step counters and bias corrections on the device, for n_groups <= 8 parameter groups in ONE launch:
  * for every group g with lr[g] >= 0:  steps[g] += 1,  derived[2g] = lr[g] / (1 - beta1^steps[g]),  derived[2g+1] =
  * sqrt(1 - beta2^steps[g])  (double arithmetic, one rounding, like the python floats of torch.optim); a negative lr[g]

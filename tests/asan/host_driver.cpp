@@ -234,6 +234,19 @@ int main() {
     EXPECT_NEG(adfp_mapper_loss(nullptr, st));
     { adfp_loss_args l2 = la; l2.loss = nullptr; EXPECT_NEG(adfp_mapper_loss(&l2, st)); l2 = la; l2.warmup = 1; EXPECT_NEG(adfp_mapper_loss(&l2, st)); }    // warm-up needs g_weight
     EXPECT_REACHES_LAUNCH(adfp_mapper_loss(&la, st));
+    {   // the three-in-one form: scratch must be there, aligned and large enough; at most 8 Adam groups, with their arrays
+        float lrs[8] = {0.1f, -1.f, 0.005f, 0.005f, 0.005f, 0.f, 0.f, 0.f};
+        const size_t sb = adfp_mapper_loss_scratch_bytes(la.n_rays);
+        if (sb != (size_t)(1 + (500 + 255) / 256) * 8 || adfp_mapper_loss_scratch_bytes(-3) != 0) { printf("FAIL adfp_mapper_loss_scratch_bytes\n"); ++g_fail; }
+        EXPECT_NEG(adfp_mapper_loss_step(&la, nullptr, sb, dev<int>(9), dev<float>(10), 5, lrs, 0.9f, 0.999f, nullptr, st));
+        EXPECT_NEG(adfp_mapper_loss_step(&la, (char*)dev<double>(11) + 4, sb, dev<int>(9), dev<float>(10), 5, lrs, 0.9f, 0.999f, nullptr, st));
+        EXPECT_CODE(adfp_mapper_loss_step(&la, dev<double>(11), sb - 8, dev<int>(9), dev<float>(10), 5, lrs, 0.9f, 0.999f, nullptr, st), ADFP_E_WORKSPACE);
+        EXPECT_NEG(adfp_mapper_loss_step(&la, dev<double>(11), sb, dev<int>(9), dev<float>(10), 9, lrs, 0.9f, 0.999f, nullptr, st));
+        EXPECT_NEG(adfp_mapper_loss_step(&la, dev<double>(11), sb, nullptr, dev<float>(10), 5, lrs, 0.9f, 0.999f, nullptr, st));
+        EXPECT_NEG(adfp_mapper_loss_step(nullptr, dev<double>(11), sb, dev<int>(9), dev<float>(10), 5, lrs, 0.9f, 0.999f, nullptr, st));
+        EXPECT_REACHES_LAUNCH(adfp_mapper_loss_step(&la, dev<double>(11), sb, dev<int>(9), dev<float>(10), 5, lrs, 0.9f, 0.999f, dev<int>(12), st));
+        EXPECT_REACHES_LAUNCH(adfp_mapper_loss_step(&la, dev<double>(11), sb, nullptr, nullptr, 0, nullptr, 0.9f, 0.999f, nullptr, st));
+    }
     adfp_track_loss_args tl; memset(&tl, 0, sizeof(tl));
     tl.n_rays = 200; tl.handle_dynamic = 1; tl.w_color_loss = 0.5f; tl.depth = dev<double>(1); tl.uncertainty = dev<double>(2); tl.color = dev<float>(3); tl.gt_depth = dev<float>(4);
     tl.gt_color = dev<float>(5); tl.loss = dev<double>(6); tl.g_depth = dev<double>(7); tl.g_color = dev<float>(8);
