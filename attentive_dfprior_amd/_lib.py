@@ -19,7 +19,7 @@ BWD_FUSED_ONE_WAVE = 8           # ADFP_BWD_FUSED_ONE_WAVE
 STAGE = {'low': 0, 'high': 1, 'color': 2}
 DEC_KIND = {'low': 0, 'high': 1, 'color': 2}
 NET_ID = {'low': 0, 'high': 1, 'color': 2, 'att': 3}      # adfp_pack_split_image's `net`
-IMAGE_H, IMAGE_G = 1, 2
+IMAGE_H, IMAGE_G, IMAGE_HT = 1, 2, 4        # ADFP_IMAGE_*
 PTS_RAYS, PTS_F64, PTS_F32 = 0, 1, 2
 
 ERRORS = {-1: 'ADFP_E_ARG (null pointer / bad size)',
@@ -34,6 +34,10 @@ class AdfpGrid(C.Structure):
 class AdfpTsdf(C.Structure):
     _fields_ = [('data', C.c_void_p), ('Z', C.c_int), ('Y', C.c_int), ('X', C.c_int),
                 ('sZ', C.c_longlong), ('sY', C.c_longlong), ('sX', C.c_longlong), ('corner_blocks', C.c_void_p)]
+
+
+class AdfpPackJob(C.Structure):
+    _fields_ = [('net', C.c_int), ('format', C.c_int), ('flat', C.c_void_p), ('packed', C.c_void_p)]
 
 
 class AdfpScene(C.Structure):
@@ -135,6 +139,7 @@ SYMBOLS = [
     ('adfp_decoder_packed_h_words', C.c_longlong, [C.c_int]),
     ('adfp_pack_decoder_h', C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_pack_split_image', C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_pack_images', C.c_int, [C.c_int, C.POINTER(AdfpPackJob), C.c_void_p, C.c_void_p]),
     ('adfp_decoder_packed_ht_words', C.c_longlong, [C.c_int]),
     ('adfp_pack_decoder_ht', C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_train_act_floats', C.c_longlong, [C.c_int]),

@@ -81,8 +81,8 @@ __device__ HSrc dec_ht_src(int t) {
 }
 
 template <int CDIM, int NOUT>
-__global__ void k_pack_decoder_ht(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status, int bit) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+ADFP_DEV void pack_decoder_ht_block(int blk, const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status, int bit) {
+    const int t = blk * 256 + (int)threadIdx.x;
     if (t >= DecLayoutHT<CDIM, NOUT>::P_TOTAL) return;
     const HSrc s = dec_ht_src<CDIM, NOUT>(t);
     if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(flat[s.s0]); return; }
@@ -96,6 +96,8 @@ __global__ void k_pack_decoder_ht(const float* __restrict__ flat, unsigned* __re
     else { x = (_Float16)(a - ah); y = (_Float16)(b - bh); }
     packed[t] = (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
+template <int CDIM, int NOUT>
+__global__ void k_pack_decoder_ht(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status, int bit) { pack_decoder_ht_block<CDIM, NOUT>((int)blockIdx.x, flat, packed, status, bit); }
 
 struct DecodeBwdHArgs {
     PtsDev P; NormDev nb;
@@ -789,8 +791,8 @@ __device__ HSrc att_ht_src(int t) {
     const int u = t - L::P_WO, h = u >> 6, o = (u >> 5) & 1, j = u & 31;
     return HSrc{0, F::F_WO + o * 64 + unit_of(j, h), -1};
 }
-__global__ void k_pack_attention_ht(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+ADFP_DEV void pack_attention_ht_block(int blk, const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status) {
+    const int t = blk * 256 + (int)threadIdx.x;
     if (t >= AttLayoutHT::P_TOTAL) return;
     const HSrc s = att_ht_src(t);
     if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(flat[s.s0]); return; }
@@ -804,6 +806,7 @@ __global__ void k_pack_attention_ht(const float* __restrict__ flat, unsigned* __
     else { x = (_Float16)(a - ah); y = (_Float16)(b - bh); }
     packed[t] = (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
+__global__ void k_pack_attention_ht(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status) { pack_attention_ht_block((int)blockIdx.x, flat, packed, status); }
 
 struct AttBwdHArgs {
     const unsigned* packed_t; const int* list; const int* count_ptr;

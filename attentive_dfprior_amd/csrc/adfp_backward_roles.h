@@ -33,10 +33,10 @@
 // share of the workgroups per role, in 1/256: proportional to (time of the role alone) x (its workgroups) measured with the
 // timing-only builds -DADFP_EXP_ONLY_ROLE=0/1/2 (tools/ab_roles.sh, profiles/r05_ab_backward_roles.txt)
 #ifndef ROLE_SHARE_P
-#define ROLE_SHARE_P 102
+#define ROLE_SHARE_P 98
 #endif
 #ifndef ROLE_SHARE_H
-#define ROLE_SHARE_H 89
+#define ROLE_SHARE_H 98
 #endif
 
 #ifdef ADFP_STAMPS_ROLES           // debug build (tools/roles_span.py): per workgroup (role, wall-clock start, end of the tile loop, end), 100 MHz
@@ -113,8 +113,9 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
     const int rwg = role == 0 ? bid : (role == 1 ? bid - nP : bid - nP - nH);
     const int nrwg = role == 0 ? nP : (role == 1 ? nH : nwg - nP - nH);
     const int ntiles = (a.total + 31) >> 5;
-    // the workgroup's tiles: rwg, rwg + nrwg, ...; local number j <-> tile rwg + j nrwg.  A wave knows its NEXT tile (for the
-    // prefetches); the one after is drawn at the end of a tile.
+    // the workgroup's tiles: rwg, rwg + nrwg, ...; local number j <-> tile rwg + j nrwg.  A wave draws its NEXT tile at the top of a
+    // tile (the answer takes an LDS round trip and is needed after the head, for the prefetches): it never sits on more than one
+    // undone tile.  (Drawn at the END of a tile instead, the loop-carried draw made the register allocator spill 350 registers.)
     const int ntl = rwg < ntiles ? (ntiles - rwg + nrwg - 1) / nrwg : 0;
     auto claim = [&]() {
         int v = 0;
@@ -255,13 +256,21 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
         }
     };
     // D layout of a product: lane (n = p, h) register r = [row kmapH(r, h)][column p]; adds one block into the workgroup's copy
+    // (the sixteen elements are READ first, then written: `+=` per element is sixteen dependent LDS round trips, and the eight rounds
+    // of the reduction below were ~10 us of every workgroup's ~14 us epilogue)
     auto add_rows = [&](const f32x16& acc, int base, int row_stride, int ncols) {
         if (p < ncols) {
+            float old[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s_red[base + kmapH(r, h) * row_stride + p] += acc[r];
+            for (int r = 0; r < 16; ++r) old[r] = s_red[base + kmapH(r, h) * row_stride + p];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_red[base + kmapH(r, h) * row_stride + p] = old[r] + acc[r];
         }
     };
 
+#ifdef ADFP_EXP_ROLES_PRIO          // timing experiment: the YOUNG wave of every SIMD (waves 4-7 start later) at a raised issue priority
+    if (wvu >= 4) __builtin_amdgcn_s_setprio(2);
+#endif
     Small cur;
     if (role == 2) {
         // =====================================================================================================================
@@ -277,11 +286,12 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
         for (int j = 0; j < 6; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        int jc = wvu, jn = ntl;
-        if (jc < ntl) { jn = claim(); dma_x(1, COL_C, tile_of(jc)); dma_small(small, tile_of(jc)); }
+        int jc = wvu;
+        if (jc < ntl) { dma_x(1, COL_C, tile_of(jc)); dma_small(small, tile_of(jc)); }
         int it = 0;
         for (; jc < ntl; ++it) {
             const int tile = tile_of(jc);
+            const int jn = claim();                                          // the wave's NEXT tile: drawn first thing, needed after the head
             const bool more = jn < ntl;
             const int tnext = tile_of(jn);
             const int loc = tile * 32 + p;
@@ -328,7 +338,7 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
                 }
             }
             if (a.gc_out && valid) stage_block_scaled(a.gc_out + 32ll * q, 0, h, gc, isc);     // 4 stores (a tile has a valid point)
-            jc = jn; jn = more ? claim() : ntl;                               // drawn late: a wave never sits on more than one undone tile
+            jc = jn;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef ADFP_STAMPS_ROLES
@@ -347,8 +357,11 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
             else if (j == 4) add_rows(acc[4], F::F_FC(4), CDIM, 32);
             else if (j == 5) {
                 if (p >= 5 && p < 10) {
+                    float old[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s_red[F::F_FC(p - 5) + 32 * CDIM + kmapH(r, h)] += acc[5][r];
+                    for (int r = 0; r < 16; ++r) old[r] = s_red[F::F_FC(p - 5) + 32 * CDIM + kmapH(r, h)];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s_red[F::F_FC(p - 5) + 32 * CDIM + kmapH(r, h)] = old[r] + acc[5][r];
                 }
             }
             __syncthreads();
@@ -374,15 +387,15 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         auto col_of = [](int k) { return ST::xm(ST::SH(4 - k)); };            // use k reads h_{4-k}
-        int jc = wvu, jn = ntl;
+        int jc = wvu;
         if (jc < ntl) {
-            jn = claim();
             const int t0 = tile_of(jc);
             dma_small(small, t0); dma_x(1, col_of(0), t0); dma_x(2, col_of(1), t0); dma_x(3, col_of(2), t0);
         }
         int it = 0;
         for (; jc < ntl; ++it) {
             const int tile = tile_of(jc);
+            const int jn = claim();
             const bool more = jn < ntl;
             const int tnext = tile_of(jn);
             const int loc = tile * 32 + p;
@@ -453,7 +466,7 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
                     gh = gn;
                 }
             }
-            jc = jn; jn = more ? claim() : ntl;
+            jc = jn;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef ADFP_STAMPS_ROLES
@@ -469,13 +482,17 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
             else if (j == 2) add_rows(acc[2], F::F_PL(3) + 93, 125, 32);
             else if (j == 3) add_rows(acc[3], F::F_PL(4), 32, 32);
             else if (j == 4) {
+                // column p of the narrow block is a slot: one destination row per lane (or none), element kmapH(r, h) of it
+                const int dst = p < 5 ? F::F_PL(p) + 32 * F::in_dim(p) : ((p >= 19 && p < 19 + NOUT) ? F::F_OW + (p - 19) * 32 : -1);
+                if (dst >= 0) {
+                    float old[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int u = kmapH(r, h);
-                    const float v = acc[4][r];
-                    if (p < 5) s_red[F::F_PL(p) + 32 * F::in_dim(p) + u] += v;
-                    else if (p >= 19 && p < 19 + NOUT) s_red[F::F_OW + (p - 19) * 32 + u] += v;
-                    else if (p == FSLOT_BO && u >= 19 && u < 19 + NOUT) s_red[F::F_OB + (u - 19)] += v;
+                    for (int r = 0; r < 16; ++r) old[r] = s_red[dst + kmapH(r, h)];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s_red[dst + kmapH(r, h)] = old[r] + acc[4][r];
+                } else if (p == FSLOT_BO) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const int u = kmapH(r, h); if (u >= 19 && u < 19 + NOUT) s_red[F::F_OB + (u - 19)] += acc[4][r]; }
                 }
             }
             __syncthreads();
@@ -583,10 +600,11 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
                 for (int k = 0; k < 3; ++k) pt[k] = (double)((const float*)buf)[3 * p + k];
             }
         };
-        int jc = wvu, jn = ntl;
-        if (jc < ntl) { jn = claim(); dma_small(small, tile_of(jc)); dma_pos(small + SMALL, tile_of(jc)); }
+        int jc = wvu;
+        if (jc < ntl) { dma_small(small, tile_of(jc)); dma_pos(small + SMALL, tile_of(jc)); }
         while (jc < ntl) {
             const int tile = tile_of(jc);
+            const int jn = claim();
             const bool more = jn < ntl;
             const int tnext = tile_of(jn);
             const int loc = tile * 32 + p;
@@ -689,7 +707,7 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
                 eb[b][0] += ex; eb[b][1] += ey; eb[b][2] += ez;
                 __builtin_amdgcn_sched_barrier(0);                            // one Fourier block at a time: hoisting the next block's sines above this
             }                                                                 // block's tail keeps 32 more registers alive, and they do not exist
-            jc = jn; jn = more ? claim() : ntl;
+            jc = jn;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef ADFP_STAMPS_ROLES

@@ -94,16 +94,16 @@ __device__ HSrc dec_g_src(int t) {
 }
 
 template <int CDIM, int NOUT>
-__global__ void k_pack_decoder_g(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status, int bit) {
+ADFP_DEV void pack_decoder_g_block(int blk, const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status, int bit) {
     using L = DecLayoutG<CDIM, NOUT>;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blk * 256 + (int)threadIdx.x;
     HSrc s{0, -1, -1};
     float a = 0.f, b = 0.f;
     if (t < L::P_FLAG) {
         s = dec_g_src<CDIM, NOUT>(t);
         a = s.s0 < 0 ? 0.f : flat[s.s0]; b = s.s1 < 0 ? 0.f : flat[s.s1];
     }
-    pack_block_flag(!(fmaxf(fabsf(a), fabsf(b)) < 65504.0f), packed + L::P_FLAG + blockIdx.x, status, bit);
+    pack_block_flag(!(fmaxf(fabsf(a), fabsf(b)) < 65504.0f), packed + L::P_FLAG + blk, status, bit);
     if (t >= L::P_FLAG) return;
     if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(a); return; }
     a = f16_clamp(a); b = f16_clamp(b);
@@ -113,6 +113,8 @@ __global__ void k_pack_decoder_g(const float* __restrict__ flat, unsigned* __res
     else { x = (_Float16)(a - ah); y = (_Float16)(b - bh); }
     packed[t] = (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
+template <int CDIM, int NOUT>
+__global__ void k_pack_decoder_g(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status, int bit) { pack_decoder_g_block<CDIM, NOUT>((int)blockIdx.x, flat, packed, status, bit); }
 
 typedef float f32x4g __attribute__((ext_vector_type(4)));
 
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16(DecodeLCArgs a) {
     unsigned long long ph_[24] = {}, last_ = clock64();
     const unsigned long long wstart_ = wall_clock64();
 #endif
-    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile_pool<NT / 64>(j, &s_next, s_ring, plan, ntiles, a.pool)) >= 0;) {
+    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile_pool<NT / 64>(j, &s_next, s_ring, plan, ntiles, a.pool, a.status)) >= 0;) {
         // front point: point n of block 0 on lanes 0-31 (both K-groups g = 0, 1 of the pair), of block 1 on lanes 32-63
         const int idx = tile * 32 + 16 * (g >> 1) + n;
         const bool valid = idx < count;
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_high_g(DecodeArgs a) {
 #ifdef ADFP_STAMPS_G
     unsigned long long ph_[8] = {}, last_ = clock64();
 #endif
-    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile_pool<NT / 64>(j, &s_next, s_ring, plan, ntiles, a.pool)) >= 0;) {
+    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile_pool<NT / 64>(j, &s_next, s_ring, plan, ntiles, a.pool, a.status)) >= 0;) {
         const int idx = tile * 32 + 16 * (g >> 1) + n;
         const bool valid = idx < count;
 #ifdef ADFP_HIGH_IDENTITY      // timing experiment: the same number of tiles over CONTIGUOUS points (no list indirection; results are not the network's)
@@ -600,16 +602,16 @@ __device__ HSrc att_g_src(int t) {
     return HSrc{0, o < 2 ? F::F_BO + o : -1, -1};
 }
 
-__global__ void k_pack_attention_g(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status) {
+ADFP_DEV void pack_attention_g_block(int blk, const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status) {
     using L = AttLayoutG;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blk * 256 + (int)threadIdx.x;
     HSrc s{0, -1, -1};
     float a = 0.f, b = 0.f;
     if (t < L::P_FLAG) {
         s = att_g_src(t);
         a = s.s0 < 0 ? 0.f : flat[s.s0]; b = s.s1 < 0 ? 0.f : flat[s.s1];
     }
-    pack_block_flag(!(fmaxf(fabsf(a), fabsf(b)) < 65504.0f), packed + L::P_FLAG + blockIdx.x, status, ADFP_STATUS_F16_RANGE_ATT);
+    pack_block_flag(!(fmaxf(fabsf(a), fabsf(b)) < 65504.0f), packed + L::P_FLAG + blk, status, ADFP_STATUS_F16_RANGE_ATT);
     if (t >= L::P_FLAG) return;
     if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(a); return; }
     a = f16_clamp(a); b = f16_clamp(b);
@@ -619,6 +621,7 @@ __global__ void k_pack_attention_g(const float* __restrict__ flat, unsigned* __r
     else { x = (_Float16)(a - ah); y = (_Float16)(b - bh); }
     packed[t] = (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
+__global__ void k_pack_attention_g(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status) { pack_attention_g_block((int)blockIdx.x, flat, packed, status); }
 
 // AttArgs is k_attention_h's; a.packed points at the G image
 template <int NT>
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(NT) void k_attention_g(AttArgs a) {
     const int ntiles = (count + 31) >> 5;
     const TilePlan plan = tile_plan(ntiles, (int)gridDim.x, NT / 64, a.pool != nullptr);
     float amax = image_out_of_range<A::P_FLAG, A::NFLAG>(ldsu) ? INFINITY : 0.f;
-    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile_pool<NT / 64>(j, &s_next, s_ring, plan, ntiles, a.pool)) >= 0;) {
+    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile_pool<NT / 64>(j, &s_next, s_ring, plan, ntiles, a.pool, a.status)) >= 0;) {
         int idx[2]; bool valid[2]; float occ[2], u[2];
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {

@@ -120,16 +120,16 @@ ADFP_DEV void pack_block_flag(bool bad, unsigned* __restrict__ flag_word, int* _
     }
 }
 template <int CDIM, int NOUT>
-__global__ void k_pack_decoder_h(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status, int bit) {
+ADFP_DEV void pack_decoder_h_block(int blk, const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status, int bit) {
     using L = DecLayoutH<CDIM, NOUT>;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blk * 256 + (int)threadIdx.x;
     HSrc s{0, -1, -1};
     float a = 0.f, b = 0.f;
     if (t < L::P_FLAG) {
         s = dec_h_src<CDIM, NOUT>(t);
         a = s.s0 < 0 ? 0.f : flat[s.s0]; b = s.s1 < 0 ? 0.f : flat[s.s1];
     }
-    pack_block_flag(!(fmaxf(fabsf(a), fabsf(b)) < 65504.0f), packed + L::P_FLAG + blockIdx.x, status, bit);      // every f32 word and every weight passes through here once
+    pack_block_flag(!(fmaxf(fabsf(a), fabsf(b)) < 65504.0f), packed + L::P_FLAG + blk, status, bit);      // every f32 word and every weight passes through here once
     if (t >= L::P_FLAG) return;
     if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(a); return; }
     a = f16_clamp(a); b = f16_clamp(b);          // out of range (flagged above / by pack_range_flag): stay finite, 0 x inf must not appear downstream
@@ -139,6 +139,8 @@ __global__ void k_pack_decoder_h(const float* __restrict__ flat, unsigned* __res
     else { x = (_Float16)(a - ah); y = (_Float16)(b - bh); }
     packed[t] = (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
+template <int CDIM, int NOUT>
+__global__ void k_pack_decoder_h(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status, int bit) { pack_decoder_h_block<CDIM, NOUT>((int)blockIdx.x, flat, packed, status, bit); }
 
 // 8 f32 -> 8 hi halves + 8 lo halves.  `amax` tracks max |x| of everything that was split (one v_max3_f32 per
 // pair): an operand at or beyond the f16 range (65504) cannot be split -- cvt_pkrtz saturates it -- so the kernels
@@ -576,16 +578,16 @@ __device__ HSrc att_h_src(int t) {
     const int o = t - L::P_BO;
     return HSrc{0, o < 2 ? F::F_BO + o : -1, -1};
 }
-__global__ void k_pack_attention_h(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status) {
+ADFP_DEV void pack_attention_h_block(int blk, const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status) {
     using L = AttLayoutH;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blk * 256 + (int)threadIdx.x;
     HSrc s{0, -1, -1};
     float a = 0.f, b = 0.f;
     if (t < L::P_FLAG) {
         s = att_h_src(t);
         a = s.s0 < 0 ? 0.f : flat[s.s0]; b = s.s1 < 0 ? 0.f : flat[s.s1];
     }
-    pack_block_flag(!(fmaxf(fabsf(a), fabsf(b)) < 65504.0f), packed + L::P_FLAG + blockIdx.x, status, ADFP_STATUS_F16_RANGE_ATT);
+    pack_block_flag(!(fmaxf(fabsf(a), fabsf(b)) < 65504.0f), packed + L::P_FLAG + blk, status, ADFP_STATUS_F16_RANGE_ATT);
     if (t >= L::P_FLAG) return;
     if (s.kind == 0) { packed[t] = s.s0 < 0 ? 0u : __float_as_uint(a); return; }
     a = f16_clamp(a); b = f16_clamp(b);          // out of range (flagged above / by pack_range_flag): stay finite, 0 x inf must not appear downstream
@@ -595,6 +597,7 @@ __global__ void k_pack_attention_h(const float* __restrict__ flat, unsigned* __r
     else { x = (_Float16)(a - ah); y = (_Float16)(b - bh); }
     packed[t] = (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
+__global__ void k_pack_attention_h(const float* __restrict__ flat, unsigned* __restrict__ packed, int* __restrict__ status) { pack_attention_h_block((int)blockIdx.x, flat, packed, status); }
 
 // relu(v) with its activity bit shifted into `m` (see relu_bias_mask)
 ADFP_DEV float relu_mask(float v, unsigned& m) {

@@ -564,14 +564,26 @@ __host__ __device__ inline TilePlan tile_plan(int ntiles, int nwg, int nww, bool
     if (!pooled || rows < 6) { p.j_static = 0x7fffffff; p.pool_base = 0; }
     return p;
 }
+// The wait for a ring entry is BOUNDED: the entry is published by a sibling wave a tile ahead of its use, so a poll normally matches at
+// once; should it never match (a counter block that was not zero at launch, an entry overwritten early), the wave raises
+// ADFP_STATUS_POOL_TIMEOUT in `status` after ~2^22 polls and leaves its tile loop -- an error the host sees, not a hung GPU.
 template <int NWW>
-ADFP_DEV int claim_tile_pool(int& j, int* s_next, unsigned long long* s_ring, const TilePlan plan, int ntiles, int* pool) {
+ADFP_DEV int claim_tile_pool(int& j, int* s_next, unsigned long long* s_ring, const TilePlan plan, int ntiles, int* pool, int* status = nullptr) {
     int tile;
     if (j < plan.j_static) tile = blockIdx.x * NWW + (j % NWW) + (j / NWW) * (gridDim.x * NWW);
     else {
         const int d = j - plan.j_static, c = d / NWW, slot = d - c * NWW;
         unsigned long long e;
-        do { e = __hip_atomic_load(s_ring + (c & (ADFP_POOL_RING - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while ((int)(e >> 32) != c + 1);
+        int polls = 0;
+        for (;;) {
+            e = __hip_atomic_load(s_ring + (c & (ADFP_POOL_RING - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((int)(e >> 32) == c + 1) break;
+            if (++polls > (1 << 22)) {
+                if (status && (threadIdx.x & 63) == 0) __hip_atomic_fetch_or(status, 32 /* ADFP_STATUS_POOL_TIMEOUT */, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return -1;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
         tile = plan.pool_base + (int)(unsigned)e + slot;
     }
     if (tile >= ntiles) return -1;

@@ -1144,6 +1144,42 @@ static Workspace carve(void* base, long long P) {
     return w;
 }
 
+// Several images in ONE launch: a training iteration re-packs four per step (the trained networks' forward and transposed images) and
+// a pack kernel is ~5 us inside a graph replay whatever it packs.  A workgroup belongs to one job (its first block is in `first`).
+struct PackJobs { int n; int first[ADFP_PACK_MAX_JOBS + 1]; int net[ADFP_PACK_MAX_JOBS]; int fmt[ADFP_PACK_MAX_JOBS];
+                  const float* flat[ADFP_PACK_MAX_JOBS]; unsigned* out[ADFP_PACK_MAX_JOBS]; int* status; };
+static int pack_job_blocks(int net, int fmt) {
+    const bool h = fmt == ADFP_IMAGE_H, g = fmt == ADFP_IMAGE_G, t = fmt == ADFP_IMAGE_HT;
+    switch (net) {
+        case ADFP_DEC_LOW: return h ? DecLayoutH<32, 1>::NFLAG : (g ? DecLayoutG<32, 1>::NFLAG : (t ? (DecLayoutHT<32, 1>::P_TOTAL + 255) / 256 : -1));
+        case ADFP_DEC_HIGH: return h ? DecLayoutH<64, 1>::NFLAG : (g ? DecLayoutG<64, 1>::NFLAG : (t ? (DecLayoutHT<64, 1>::P_TOTAL + 255) / 256 : -1));
+        case ADFP_DEC_COLOR: return h ? DecLayoutH<32, 4>::NFLAG : (g ? DecLayoutG<32, 4>::NFLAG : (t ? (DecLayoutHT<32, 4>::P_TOTAL + 255) / 256 : -1));
+        case ADFP_NET_ATT: return h ? AttLayoutH::NFLAG : (g ? AttLayoutG::NFLAG : (t ? (AttLayoutHT::P_TOTAL + 255) / 256 : -1));
+    }
+    return -1;
+}
+template <int CDIM, int NOUT>
+ADFP_DEV void pack_decoder_any(int fmt, int blk, const float* flat, unsigned* out, int* status, int bit) {
+    if (fmt == ADFP_IMAGE_H) pack_decoder_h_block<CDIM, NOUT>(blk, flat, out, status, bit);
+    else if (fmt == ADFP_IMAGE_G) pack_decoder_g_block<CDIM, NOUT>(blk, flat, out + DecLayoutH<CDIM, NOUT>::P_TOTAL, status, bit);      // the G part lies behind the H part
+    else pack_decoder_ht_block<CDIM, NOUT>(blk, flat, out, status, bit);
+}
+__global__ __launch_bounds__(256) void k_pack_multi(PackJobs j) {
+    int k = 0;
+    while (k + 1 < j.n && (int)blockIdx.x >= j.first[k + 1]) ++k;          // block-uniform
+    const int blk = (int)blockIdx.x - j.first[k], fmt = j.fmt[k];
+    const float* flat = j.flat[k];
+    unsigned* out = j.out[k];
+    switch (j.net[k]) {
+        case ADFP_DEC_LOW: pack_decoder_any<32, 1>(fmt, blk, flat, out, j.status, ADFP_STATUS_F16_RANGE_LOW); break;
+        case ADFP_DEC_HIGH: pack_decoder_any<64, 1>(fmt, blk, flat, out, j.status, ADFP_STATUS_F16_RANGE_HIGH); break;
+        case ADFP_DEC_COLOR: pack_decoder_any<32, 4>(fmt, blk, flat, out, j.status, ADFP_STATUS_F16_RANGE_COLOR); break;
+        default:
+            if (fmt == ADFP_IMAGE_H) pack_attention_h_block(blk, flat, out, j.status);
+            else if (fmt == ADFP_IMAGE_G) pack_attention_g_block(blk, flat, out + AttLayoutH::P_TOTAL, j.status);
+            else pack_attention_ht_block(blk, flat, out, j.status);
+    }
+}
 extern "C" {
 
 int adfp_version(void) { return ADFP_VERSION; }
@@ -1241,6 +1277,20 @@ int adfp_pack_split_image(int net, int which, const float* flat, void* packed, i
             break;
         default: return ADFP_E_ARG;
     }
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+int adfp_pack_images(int n_jobs, const adfp_pack_job* jobs, int* status, void* stream) {
+    if (n_jobs < 0 || n_jobs > ADFP_PACK_MAX_JOBS || (n_jobs && !jobs)) return ADFP_E_ARG;
+    if (n_jobs == 0) return 0;
+    PackJobs j; j.n = n_jobs; j.status = status; j.first[0] = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        const int nb = pack_job_blocks(jobs[k].net, jobs[k].format);
+        if (nb <= 0 || !jobs[k].flat || !jobs[k].packed) return ADFP_E_ARG;
+        j.net[k] = jobs[k].net; j.fmt[k] = jobs[k].format; j.flat[k] = jobs[k].flat; j.out[k] = (unsigned*)jobs[k].packed;
+        j.first[k + 1] = j.first[k] + nb;
+    }
+    hipLaunchKernelGGL(k_pack_multi, dim3(j.first[n_jobs]), dim3(256), 0, (hipStream_t)stream, j);
     ADFP_CHECK_LAUNCH();
     return 0;
 }

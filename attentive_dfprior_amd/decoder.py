@@ -61,13 +61,29 @@ def _pack_size(name, fmt):
     return hit
 
 
-def pack_network(name, params, fmt='f32', status=None, flat=None, out=None):
+def flush_pack_jobs(jobs, status, device):
+    """ONE launch for the deferred split-image / transposed-image packs of a call (pack_network(..., defer=jobs)): a pack kernel
+    costs ~5 us inside a graph replay whatever it packs, and a training iteration re-packs four images per step."""
+    if not jobs:
+        return
+    arr = (_lib.AdfpPackJob * len(jobs))()
+    for k, (net, fmt, flat, packed) in enumerate(jobs):
+        arr[k].net, arr[k].format, arr[k].flat, arr[k].packed = net, fmt, flat.data_ptr(), packed.data_ptr()
+    sptr = _lib.status_ptr() if status is None else _lib.C.c_void_p(status.data_ptr())
+    with _lib.device_guard(device):
+        _lib.check(lib().adfp_pack_images(len(jobs), arr, sptr, _lib.current_stream(device)), 'adfp_pack_images')
+    del jobs[:]
+
+
+def pack_network(name, params, fmt='f32', status=None, flat=None, out=None, defer=None):
     """Packed image of one sub-network ('low' / 'high' / 'color' / 'att') from its parameters in state_dict order.
     fmt: 'f32' (adfp_pack_decoder / adfp_pack_attention), 'ht' (adfp_pack_*_ht); 'h' / 'g' / 'hg': the split image with its H
     (32x32x16 order: training forward, single-network entries) / G (16x16x32 order: inference kernels) / both parts written.
     status: the pinned status word a weight outside the f16 range is reported to (default: the process-wide one).
     out: an image of the same network and format to overwrite (a training iteration re-packs the trained networks every step:
-    same-stream ordering makes the in-place rebuild safe, and the image keeps its address)."""
+    same-stream ordering makes the in-place rebuild safe, and the image keeps its address).
+    defer: a list -- the split-image parts and the transposed image are not packed here but appended as jobs
+    (net, ADFP_IMAGE_*, flat, packed) for flush_pack_jobs; the caller flushes before it launches anything that reads an image."""
     if flat is None:
         flat = _flat_params(params)
     sptr = _lib.status_ptr() if status is None else _lib.C.c_void_p(status.data_ptr())
@@ -81,6 +97,11 @@ def pack_network(name, params, fmt='f32', status=None, flat=None, out=None):
     with _lib.device_guard(dev):
         stream = _lib.current_stream(dev)
         packed = out if out is not None else torch.empty(n, dtype=dtype, device=dev)
+        if defer is not None and fmt in ('h', 'g', 'hg', 'ht') and len(defer) + 2 <= 8:
+            for part, bit in (('h', _lib.IMAGE_H), ('g', _lib.IMAGE_G), ('ht', _lib.IMAGE_HT)):
+                if part == fmt or (fmt == 'hg' and part != 'ht'):
+                    defer.append((_lib.NET_ID[name], bit, flat, packed))
+            return packed
         if fmt in ('h', 'g', 'hg'):
             which = {'h': _lib.IMAGE_H, 'g': _lib.IMAGE_G, 'hg': _lib.IMAGE_H | _lib.IMAGE_G}[fmt]
             _lib.check(L.adfp_pack_split_image(_lib.NET_ID[name], which, _lib.ptr(flat), _lib.ptr(packed), sptr, stream), 'adfp_pack_split_image')
@@ -317,6 +338,7 @@ class DF(nn.Module):
         self._engine = None
         self._status = None     # pinned status word of THIS module (see _lib.new_status_word)
         self._exact_latch = set()   # networks ('low' / 'high' / 'color' / 'att' / 'bwd') switched to the exact f32 kernels
+        self._pack_jobs = None      # a list while Engine.scene() collects this call's pack jobs (flush_pack_jobs), else None
         self._foreign = False       # True: the parameters live in ANOTHER process's memory (see __setstate__)
         self._foreign_serial = 0
 
@@ -414,7 +436,7 @@ class DF(nn.Module):
                 return hit[1]
             flat = self.flat_weights(name, key)
             packed = pack_network(name, module, 'hg' if len(need) == 2 else need[0], status=self.status_word(), flat=flat,
-                                  out=None if hit is None else hit[1])
+                                  out=None if hit is None else hit[1], defer=self._pack_jobs)
             keys = dict(hit[2]) if hit is not None and hit[1] is packed else {}
             for p in need:
                 keys[p] = key
@@ -425,7 +447,8 @@ class DF(nn.Module):
         if hit is not None and hit[0] == key:
             return hit[1]
         flat = self.flat_weights(name, key)
-        packed = pack_network(name, module, fmt, status=self.status_word(), flat=flat, out=None if hit is None else hit[1])
+        packed = pack_network(name, module, fmt, status=self.status_word(), flat=flat, out=None if hit is None else hit[1],
+                              defer=self._pack_jobs if fmt == 'ht' else None)
         self._packed[slot] = (key, packed)
         return packed
 
@@ -436,13 +459,14 @@ class DF(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k in ('_packed', '_engine', '_plists', '_status'):
+            if k in ('_packed', '_engine', '_plists', '_status', '_pack_jobs'):
                 continue
             setattr(new, k, copy.deepcopy(v, memo))
         new._packed = {}
         new._plists = {}
         new._engine = None
         new._status = None
+        new._pack_jobs = None
         for m in new.modules():
             m.__dict__.pop('_foreign', None)
         new._foreign, new._foreign_serial = False, 0     # the copy's tensors are this process's own
@@ -457,6 +481,7 @@ class DF(nn.Module):
         d['_plists'] = {}
         d['_engine'] = None
         d['_status'] = None
+        d['_pack_jobs'] = None
         return d
 
     def __setstate__(self, state):

@@ -156,6 +156,17 @@ def allreduce_grads(tensors, group=None, skip_single=True):
     if not tensors:
         return 0
     span = _common_bucket([t.grad for t in tensors])
+    if dist.get_world_size(group) > 1:
+        # WHICH path a rank takes depends on local state (did autograd keep the handed views or clone them? did a rank accumulate two
+        # backward calls?), and ranks on different paths would issue collectives of different sizes.  So the choice is made
+        # collectively: one tiny all-reduce (MIN of [n, -n], n = the span's element count or 0) tells every rank whether ALL ranks
+        # hold the same contiguous bucket; otherwise all of them pack.
+        n = span.numel() if span is not None else 0
+        probe = torch.tensor([n, -n], dtype=torch.int64, device=tensors[0].device)
+        dist.all_reduce(probe, op=dist.ReduceOp.MIN, group=group)
+        lo, hi = int(probe[0]), -int(probe[1])
+        if not (lo == hi == n and n > 0):
+            span = None
     if span is not None:
         # The backward of Renderer.render_batch_ray hands autograd views of ONE buffer (engine.render_backward), and autograd
         # keeps them as the .grad tensors: the bucket is contiguous as it stands -- all-reduce it in place, no packing copies

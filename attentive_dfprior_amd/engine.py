@@ -247,20 +247,30 @@ class Engine(object):
         split = math_mode() == 'f16x3'
         latch = decoders._exact_latch
         any_split = False
-        for n in nets:
-            k = keys.get(n)
-            if k is None:
-                k = keys[n] = decoders.net_key(n)
-            if backward:
-                if n in ht_nets:
-                    setattr(sc, 'ht_' + n, decoders.packed_weights(n, 'ht', k).data_ptr())
+        from .decoder import flush_pack_jobs
+        jobs = decoders._pack_jobs = []          # the split / transposed images this call has to (re)build: packed in ONE launch below
+        try:
+            for n in nets:
+                k = keys.get(n)
+                if k is None:
+                    k = keys[n] = decoders.net_key(n)
+                if backward:
+                    if n in ht_nets:
+                        setattr(sc, 'ht_' + n, decoders.packed_weights(n, 'ht', k).data_ptr())
+                    else:
+                        setattr(sc, 'w_' + n, decoders.packed_weights(n, 'f32', k).data_ptr())
+                elif split and n not in latch:
+                    setattr(sc, 'h_' + n, decoders.packed_weights(n, images or self.image_parts(stage, n, latch, state), k).data_ptr())
+                    any_split = True
+                    # a TRAINING forward whose state has mask room for the network: its backward will read the transposed image --
+                    # packed now, in the same launch (the backward finds it current: the parameters do not change in between)
+                    if state is not None and ('masks_' + n) in state and not state.get('bwd_exact'):
+                        decoders.packed_weights(n, 'ht', k)
                 else:
                     setattr(sc, 'w_' + n, decoders.packed_weights(n, 'f32', k).data_ptr())
-            elif split and n not in latch:
-                setattr(sc, 'h_' + n, decoders.packed_weights(n, images or self.image_parts(stage, n, latch, state), k).data_ptr())
-                any_split = True
-            else:
-                setattr(sc, 'w_' + n, decoders.packed_weights(n, 'f32', k).data_ptr())
+            flush_pack_jobs(jobs, decoders.status_word(), next(iter(c.values())).device)
+        finally:
+            decoders._pack_jobs = None
         if any_split:
             for n in nets:
                 setattr(sc, 'flat_' + n, decoders.flat_weights(n, keys[n]).data_ptr())

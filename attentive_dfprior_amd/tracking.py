@@ -185,12 +185,15 @@ class TrackerIteration(object):
             if sh is None or sh.shape != (Z, Y, X, 32) or sh.device != g.device:
                 sh = self._shadow[k] = torch.empty((Z, Y, X, 32), dtype=torch.float32, device=g.device)
                 self._shadow_src[k] = None
-            if self._shadow_src[k] != src:
+            held = self._shadow_src[k]
+            if held is None or held[0] != src:
                 gc = g.detach()
                 if gc.dtype != torch.float32 or not gc.is_contiguous():
                     gc = gc.float().contiguous()
                 check(lib().adfp_relayout_grid(ptr(gc), ptr(sh), 32, Z, Y, X, _lib.current_stream(g.device)), 'adfp_relayout_grid')
-                self._shadow_src[k] = src
+                # the entry keeps the source's STORAGE alive: (data_ptr, _version) names the contents only as long as the allocator
+                # cannot hand the same address, at version 0, to the next grid (a grid replaced twice between two steps)
+                self._shadow_src[k] = (src, g.untyped_storage())
             eng.adopt_grid_cl(k, g, sh)
 
     def _draw(self, n):
@@ -262,3 +265,7 @@ class TrackerIteration(object):
             self.dec = decoders
         if c is not None:
             self.c = c
+            # re-lay the handed-over grids out at the next step WHATEVER their address and version say: a writer that goes through raw
+            # pointers (another process's kernels on IPC memory) does not bump this process's version counters.  External writers
+            # that keep writing a grid the iteration holds must call this again (or bump the version).
+            self._shadow_src = {k: None for k in self._shadow_src}

@@ -119,6 +119,10 @@ typedef struct adfp_scene {
 #define ADFP_STATUS_F16_RANGE_ATT   8
 #define ADFP_STATUS_F16_RANGE_BWD   16
 #define ADFP_STATUS_F16_RANGE       31   /* any of them */
+/* NOT a range bit, an ERROR: a wave of a persistent decoder kernel waited for a chunk of the chip-wide tile pool that was never
+ * published (the counter block was not zero at launch, or a ring entry was overwritten early) and gave up after ~2^22 polls -- the
+ * launch ended instead of hanging, tiles of that call were NOT computed.  The Python binding raises RuntimeError on it. */
+#define ADFP_STATUS_POOL_TIMEOUT    32
 
 typedef struct adfp_points {
     int mode;                 /* ADFP_PTS_* */
@@ -178,6 +182,14 @@ int adfp_pack_attention_h(const float* flat, void* packed, int* status, void* st
 #define ADFP_IMAGE_H 1
 #define ADFP_IMAGE_G 2
 int adfp_pack_split_image(int net, int which, const float* flat, void* packed, int* status, void* stream);
+/* Several packed images in ONE launch (a Mapper iteration re-packs four per step: the trained networks' forward parts and their
+ * transposed images): job = one image of one network.  format is exactly one of ADFP_IMAGE_H / ADFP_IMAGE_G (that part of the
+ * split image buffer `packed`, as adfp_pack_split_image writes it) or ADFP_IMAGE_HT (`packed` = the transposed image of
+ * adfp_pack_decoder_ht / adfp_pack_attention_ht).  Same kernels' arithmetic, same status reporting; at most ADFP_PACK_MAX_JOBS jobs. */
+#define ADFP_IMAGE_HT 4
+#define ADFP_PACK_MAX_JOBS 8
+typedef struct adfp_pack_job { int net; int format; const float* flat; void* packed; } adfp_pack_job;
+int adfp_pack_images(int n_jobs, const adfp_pack_job* jobs /*host*/, int* status, void* stream);
 /* mlp_tsdf parameters (decoder.py:206-258) */
 int adfp_pack_attention(const float* flat, float* packed, void* stream);
 
