@@ -33,10 +33,10 @@
 // share of the workgroups per role, in 1/256: proportional to (time of the role alone) x (its workgroups) measured with the
 // timing-only builds -DADFP_EXP_ONLY_ROLE=0/1/2 (tools/ab_roles.sh, profiles/r05_ab_backward_roles.txt)
 #ifndef ROLE_SHARE_P
-#define ROLE_SHARE_P 98
+#define ROLE_SHARE_P 104
 #endif
 #ifndef ROLE_SHARE_H
-#define ROLE_SHARE_H 98
+#define ROLE_SHARE_H 82
 #endif
 
 #ifdef ADFP_STAMPS_ROLES           // debug build (tools/roles_span.py): per workgroup (role, wall-clock start, end of the tile loop, end), 100 MHz
@@ -370,16 +370,13 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
         // =====================================================================================================================
         // role H: pts_linears[i].weight against h_{i-1} (i = 1..4; layer 3: the h_2 columns), the five pts_linears biases,
         // output_linear.  Blocks 0-3 = layers 1-4, 4 = narrow columns (FSLOT_BPL, FSLOT_WO, FSLOT_BO).
-        // slots 1 / 2: a ring of two X blocks.  A tile starts with h_4 in A and h_3 in B (A = slot 1 on even tiles), and refills:
-        // h_4 used -> A <- h_2;  layer 4 uses h_3 -> B <- h_1;  layer 3 uses h_2 -> A <- h_0;  layer 2 uses h_1 -> B <- next h_4;
-        // layer 1 uses h_0 -> A <- next h_3: every block is requested two uses ahead, and exactly ONE request (4 operations) is
-        // younger than the block a use waits for.
         // =====================================================================================================================
         // The X ring: the five blocks of a tile are USED in the order h_4 (output_linear), h_3 (layer 4), h_2, h_1, h_0; use number
         // n = 5 it + k of the wave sits in slot 1 + n mod 3 and is requested when use n - 3 has read that slot out -- three uses =
-        // about two layers of work ahead.  When a use waits, the requests of the next two uses (8 operations) are the only younger
-        // ones; the small inputs of the next tile are requested right after this tile's head and are older than all five of the
-        // tile's X requests (20 operations) when the next head waits for them.
+        // about two layers of work ahead.  When a use waits, the requests of the next two uses (8 operations) are younger -- and, for
+        // uses 0-2, the five operations of the next tile's small inputs, requested right after this tile's head (counting only 8
+        // there made the wave wait for most of the NEXT block as well: a lead of two uses instead of three).  The small inputs are
+        // older than all five of the tile's X requests (20 operations) when the next head waits for them.
         unsigned* small = xs + 4 * SLOT;
         f32x16 acc[5];
 #pragma unroll
@@ -405,9 +402,13 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
             // use k: wait for its block, read it out, then request use k + 3 (of this or the next tile) into the same slot
             auto take = [&](int k, f16x8* hTh, f16x8* hTl) {
                 const bool two = more || k < 3, one = more || k < 4;            // are the requests of the next two / one uses out?
-                if (two) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                // uses 0-2: the next tile's small inputs (5 operations, requested after this tile's head) are younger as well
+#ifndef ADFP_EXP_H_NOWAIT          // timing experiment: the blocks are not waited for (what the memory waits of this role cost)
+                if (k < 3 && more) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+                else if (two) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else if (one) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                 const int sl = slot_of(k);
                 operand_x(xs + sl * SLOT, hTh, hTl);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the reads have returned before the DMA may overwrite the slot
@@ -625,7 +626,8 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
             for (int o = 0; o < 4; ++o) go[o] = valid ? cur.go[o] : 0.f;
             head_at(p_wo, go, gh, sc, isc);
             const float ssc = isc * gS;
-            if (h == 0) *(f32x4*)(ptab + 4 * p) = f32x4{pf[0], pf[1], pf[2], ssc};
+            if (h == 0) *(f32x4*)(ptab + 4 * p) = f32x4{pf[0], pf[1], pf[2], 0.f};
+            const float pxy = h ? pf[1] : pf[0], pz0 = h ? 0.f : pf[2];      // the A operands of the p @ B products below
 #pragma unroll
             for (int i = 4; i >= 0; --i) {
                 float gp[16];
@@ -669,15 +671,23 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
                 float cs[16];
                 f16x8 eTh[2], eTl[2];
                 {
+                    // p @ B of the tile's 32 points x this block's 32 features on the f32 matrix pipe: D[point][feature] with A = the
+                    // positions (lane = point, k = lane half) and B = embedder._B (lane = feature, k = lane half) lands in the
+                    // transposed layout directly (lane = feature, registers = points kmapH(r, h)).  K = 3: (x, y) then (z, 0); each
+                    // k step is an f32 fma, so the sum is the forward's fmaf(z, bz, fmaf(y, by, x * bx)).  (On the VALU the same
+                    // numbers cost 48 instructions and 16 broadcast ds_read_b128 of the position table per block.)
+                    f32x16 argv;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) argv[r] = 0.f;
+                    argv = __builtin_amdgcn_mfma_f32_32x32x2f32(pxy, h ? bm.y : bm.x, argv, 0, 0, 0);
+                    argv = __builtin_amdgcn_mfma_f32_32x32x2f32(pz0, h ? 0.f : bm.z, argv, 0, 0, 0);
                     float e[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const f32x4 pv = *(const f32x4*)(ptab + 4 * kmapH(r, h));
-                        const float arg = fmaf(pv.z, bm.z, fmaf(pv.y, bm.y, pv.x * bm.x));
                         float sn, c1;
-                        adfp_sincosf(arg, sn, c1);
+                        adfp_sincosf(argv[r], sn, c1);
                         e[r] = real ? sn : 0.f;
-                        cs[r] = c1 * pv.w;                                    // cos(p @ B) times the point's scale
+                        cs[r] = c1;
                     }
                     split16v<false>(e, eTh, eTl, amax);
                 }
@@ -694,7 +704,7 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
                     unpark(slotS0, xh, xl);
                     mfma_chain_h<2>(ge, ldsu + PW(0, b), lane_off, xh, xl);
                 }
-                write_blk(slotS, ge, 1.f);
+                write_blk(slotS, ge, ssc);                                    // the point's scale goes in here: in this layout a lane IS the point
                 float ga[16];
                 read_T(slotS, ga);
                 float ex = 0.f, ey = 0.f, ez = 0.f;

@@ -18,6 +18,8 @@
 #include "adfp_device.h"
 #include <math.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #define ADFP_CHECK_LAUNCH()                         \
     do {                                            \
@@ -2269,6 +2271,12 @@ static int run_decode_bwd_p(DecodeBwdArgs a, int total, const int* count_ptr, fl
 // left.  Weight gradients: the G part of the staging rows is chunked like the exact path's rows (so that a chunk is still in
 // the Infinity Cache when k_outer_h reads it back); the X part lies in `act` for all rows.
 #define ADFP_BWDH_NT 384
+static int role_share_env(int which, int dflt) {
+    const char* e = getenv("ADFP_ROLE_SHARES");
+    int v[2];
+    if (!e || sscanf(e, "%d,%d", &v[0], &v[1]) != 2 || v[0] < 1 || v[1] < 1 || v[0] + v[1] > 254) return dflt;
+    return v[which];
+}
 // sort of the call's points for k_scatter_sorted (set up once per backward call by backward_points)
 // Sorts n (key, value) pairs by the low key_bits bits of the key, stable.  The two buffer pairs are used in turn; *key_fin / *val_fin
 // = the pair the last pass wrote (a / b).  table: 256 * ceil(n / ADFP_RS_TILE) + 256 ints.
@@ -2365,7 +2373,9 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
                 int cus = num_cu(); if (cus > OUTER_NSLOT) cus = OUTER_NSLOT;
                 int g = 3 * ((ntiles + 7) / 8);
                 nslot = g < 3 ? 3 : (g > cus ? cus : g);
-                int nP = (nslot * ROLE_SHARE_P + 128) / 256, nH = (nslot * ROLE_SHARE_H + 128) / 256;
+                // tuning knob: ADFP_ROLE_SHARES="<P>,<H>" (of 256) overrides the built-in split (read once per process)
+                static const int share_p = role_share_env(0, ROLE_SHARE_P), share_h = role_share_env(1, ROLE_SHARE_H);
+                int nP = (nslot * share_p + 128) / 256, nH = (nslot * share_h + 128) / 256;
                 if (nP < 1) nP = 1;
                 if (nH < 1) nH = 1;
                 while (nP + nH > nslot - 1) { if (nP > nH) --nP; else --nH; }

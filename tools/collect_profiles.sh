@@ -1,42 +1,130 @@
-# Round-4 measurement collection (one gpurun call; everything lands in gpurun_out/, the summaries are copied to profiles/ by hand).
+# Round-5 measurement collection (one gpurun call; everything lands in gpurun_out/, the summaries are copied to profiles/ by hand
+# apart from the three PMC files bench.py reads, which are copied here so that the bench lines carry this build's traffic).
+#
+#   bash tools/collect_profiles.sh [section ...]        sections: tests pmc bench train diag config5 loops ab    (default: all)
+#
+# Every command's stderr is kept (gpurun_out/r05_logs/<step>.err) and a step that exits non-zero is reported, its target file is
+# removed (no empty or half-written summary is left to be copied), and the script itself exits 1 at the end.
 # rocprofv3: program directly after `--`; PMC passes separate from --stats passes, FETCH_SIZE and WRITE_SIZE in separate passes.
+set -o pipefail
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out
-R=r04
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_${R}_fetch -- python3 tools/ab_stage.py > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_${R}_write -- python3 tools/ab_stage.py > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_${R}_c5_fetch -- python3 tools/stress_config5.py pixel > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_${R}_c5_write -- python3 tools/stress_config5.py pixel > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $O/pmc_${R}_sq2 -- python3 tools/ab_stage.py > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_${R}_sq1 -- python3 tools/ab_stage.py > /dev/null 2>&1
-python tools/pmc_traffic.py $O/pmc_${R}_fetch $O/pmc_${R}_write 6400000 $O/${R}_pmc_hbm_traffic.csv "tools/ab_stage.py: one 100000-ray batch" > /dev/null
-python tools/pmc_traffic.py $O/pmc_${R}_c5_fetch $O/pmc_${R}_c5_write 16777216 $O/${R}_pmc_hbm_config5.csv "tools/stress_config5.py pixel: 131072 rays x 128 samples, 1024^3 TSDF" > /dev/null
-python tools/pmc_summary.py $O/pmc_${R}_sq1 $O/pmc_${R}_sq2 --match k_ > $O/${R}_pmc_sq_forward.txt
-cp $O/${R}_pmc_hbm_traffic.csv $O/${R}_pmc_hbm_config5.csv $O/${R}_pmc_sq_forward.txt profiles/     # bench.py reads roofline.traffic / limiter.pmc from here: stamp = this build
-python bench.py > $O/${R}_bench_f16x3.json 2> $O/${R}_bench_f16x3.err
-ADFP_MATH=f32 python bench.py --cpu-rays 0 --no-extra > $O/${R}_bench_f32.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${R}_bench -- python3 bench.py --cpu-rays 0 > /dev/null 2>&1
-python profiles/summarize.py $O/prof_${R}_bench $O/${R}_kernel_stats_bench.csv > /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${R}_headline -- python3 bench.py --cpu-rays 0 --no-extra --no-stage-timing > /dev/null 2>&1
-python profiles/summarize.py $O/prof_${R}_headline $O/${R}_kernel_stats_headline.csv > /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${R}_train -- python3 tools/profile_iteration.py --rays 5000 --samples 48 --masked > /dev/null 2>&1
-python profiles/summarize.py $O/prof_${R}_train $O/${R}_kernel_stats_train.csv > /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${R}_unch -- python3 tools/host_breakdown.py --rays 5000 --no-tracker --iters 100 > /dev/null 2>&1
-python profiles/summarize.py $O/prof_${R}_unch $O/${R}_kernel_stats_unchanged_5000x64.csv > /dev/null
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_${R}_train_fetch -- python3 tools/profile_iteration.py --rays 5000 --samples 48 --masked --iters 10 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_${R}_train_write -- python3 tools/profile_iteration.py --rays 5000 --samples 48 --masked --iters 10 > /dev/null 2>&1
-python tools/pmc_traffic.py $O/pmc_${R}_train_fetch $O/pmc_${R}_train_write 320000 $O/${R}_pmc_hbm_train.csv "tools/profile_iteration.py --rays 5000 --samples 48 --masked: 320000 samples per iteration" > /dev/null
-python tools/diag_bwd.py > $O/${R}_diag_backward_modes.txt 2>/dev/null
-python bench_train.py > $O/${R}_bench_train.json 2>/dev/null
-ADFP_MATH=f32 python bench_train.py --rays 5000 2>/dev/null | sed 's/^{/{"math": "f32 (exact forward + backward)", /' >> $O/${R}_bench_train.json
-ADFP_HOST_TIMING=1 python tools/host_breakdown.py --rays 1000 5000 > $O/${R}_host_breakdown_box2.txt 2>&1   # (r04_host_breakdown.txt = the lease DESIGN section 4.6 quotes)
-python tools/mapping_loop.py --frames 200 --every-frame 5 2>/dev/null | tail -1 > $O/${R}_mapping_loop.json
-python tools/mapping_loop.py --frames 200 --every-frame 5 --fused 2>/dev/null | tail -1 >> $O/${R}_mapping_loop.json
-python tools/stress_config5.py pixel 2>/dev/null | tail -1 > $O/${R}_config5.json
-python tools/stress_config5.py random 2>/dev/null | tail -1 >> $O/${R}_config5.json
-bash tools/ab_lc.sh > $O/${R}_ab_lc16.txt 2>/dev/null
-(cd tools/micro && ./mfma_shape_ab > ../../$O/${R}_micro_mfma_shape_ab.txt 2>/dev/null)
-hostname > $O/${R}_box.txt; rocm-smi --showproductname 2>/dev/null | head -8 >> $O/${R}_box.txt
+R=r05
+L=$O/${R}_logs
+mkdir -p $L
+FAILED=""
+SECTIONS="${*:-tests pmc bench train diag config5 loops ab}"
+want() { case " $SECTIONS " in *" $1 "*) return 0;; esac; return 1; }
+
+# run <step> <command ...>: stdout -> logs/<step>.out
+run() {
+  local step=$1; shift
+  "$@" > $L/$step.out 2> $L/$step.err
+  local rc=$?
+  if [ $rc -ne 0 ]; then FAILED="$FAILED $step"; echo "FAILED rc=$rc: $step: $*"; tail -n 8 $L/$step.err; fi
+  return $rc
+}
+# into <file> <step> <command ...>: stdout -> <file>; the file is removed when the command fails
+into() {
+  local file=$1 step=$2; shift 2
+  "$@" > $file 2> $L/$step.err
+  local rc=$?
+  if [ $rc -ne 0 ]; then FAILED="$FAILED $step"; echo "FAILED rc=$rc: $step: $*"; tail -n 8 $L/$step.err; rm -f $file; fi
+  return $rc
+}
+prof_stats() {   # <dir> <step> <program ...>: rocprofv3 --kernel-trace --stats
+  local d=$1 step=$2; shift 2
+  rm -rf $d; run $step rocprofv3 --kernel-trace --stats --output-format csv -d $d -- "$@"
+}
+prof_pmc() {     # <dir> <step> "<counters>" <program ...>
+  local d=$1 step=$2 ctr=$3; shift 3
+  rm -rf $d; run $step rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $d -- "$@"
+}
+
+if want pmc; then
+  prof_pmc $O/pmc_fetch pmc_fetch FETCH_SIZE python3 tools/ab_stage.py
+  prof_pmc $O/pmc_write pmc_write WRITE_SIZE python3 tools/ab_stage.py
+  run pmc_traffic python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write 6400000 $O/${R}_pmc_hbm_traffic.csv "tools/ab_stage.py: one 100000-ray batch"
+  prof_pmc $O/pmc_c5_fetch pmc_c5_fetch FETCH_SIZE python3 tools/stress_config5.py pixel
+  prof_pmc $O/pmc_c5_write pmc_c5_write WRITE_SIZE python3 tools/stress_config5.py pixel
+  run pmc_c5_traffic python tools/pmc_traffic.py $O/pmc_c5_fetch $O/pmc_c5_write 16777216 $O/${R}_pmc_hbm_config5.csv "tools/stress_config5.py pixel: 131072 rays x 128 samples, 1024^3 TSDF"
+  prof_pmc $O/pmc_c5r_fetch pmc_c5r_fetch FETCH_SIZE python3 tools/stress_config5.py random
+  prof_pmc $O/pmc_c5r_write pmc_c5r_write WRITE_SIZE python3 tools/stress_config5.py random
+  run pmc_c5r_traffic python tools/pmc_traffic.py $O/pmc_c5r_fetch $O/pmc_c5r_write 16777216 $O/${R}_pmc_hbm_config5_random.csv "tools/stress_config5.py random: 131072 rays x 128 samples, 1024^3 TSDF, each pose's rays drawn at random from its image; the renderer's own choice (corner blocks, no sort)"
+  prof_pmc $O/pmc_sq1 pmc_sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" python3 tools/ab_stage.py
+  prof_pmc $O/pmc_sq2 pmc_sq2 "SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" python3 tools/ab_stage.py
+  into $O/${R}_pmc_sq_forward.txt pmc_sq_summary python tools/pmc_summary.py $O/pmc_sq1 $O/pmc_sq2 --match k_
+  prof_pmc $O/pmc_train_fetch pmc_train_fetch FETCH_SIZE python3 tools/profile_iteration.py --rays 5000 --samples 48 --masked --iters 10
+  prof_pmc $O/pmc_train_write pmc_train_write WRITE_SIZE python3 tools/profile_iteration.py --rays 5000 --samples 48 --masked --iters 10
+  run pmc_train_traffic python tools/pmc_traffic.py $O/pmc_train_fetch $O/pmc_train_write 320000 $O/${R}_pmc_hbm_train.csv "tools/profile_iteration.py --rays 5000 --samples 48 --masked: 320000 samples per iteration"
+  # bench.py reads roofline.traffic / limiter.pmc from profiles/: the stamp inside each file says which build it belongs to
+  for f in ${R}_pmc_hbm_traffic.csv ${R}_pmc_hbm_config5.csv ${R}_pmc_hbm_config5_random.csv ${R}_pmc_sq_forward.txt; do [ -s $O/$f ] && cp $O/$f profiles/; done
+fi
+
+if want bench; then
+  into $O/${R}_bench_f16x3.json bench_f16x3 python bench.py
+  ADFP_MATH=f32 into $O/${R}_bench_f32.json bench_f32 python bench.py --cpu-rays 0 --no-extra
+  prof_stats $O/prof_bench prof_bench python3 bench.py --cpu-rays 0
+  run sum_bench python profiles/summarize.py $O/prof_bench $O/${R}_kernel_stats_bench.csv
+  prof_stats $O/prof_headline prof_headline python3 bench.py --cpu-rays 0 --no-extra --no-stage-timing
+  run sum_headline python profiles/summarize.py $O/prof_headline $O/${R}_kernel_stats_headline.csv
+fi
+
+if want train; then
+  prof_stats $O/prof_train prof_train python3 tools/profile_iteration.py --rays 5000 --samples 48 --masked
+  run sum_train python profiles/summarize.py $O/prof_train $O/${R}_kernel_stats_train.csv
+  into $O/${R}_bench_train.json bench_train python bench_train.py
+  ADFP_MATH=f32 into $O/${R}_bench_train_f32.json bench_train_f32 python bench_train.py --rays 5000
+  {
+    for rep in 1 2; do
+      python tools/profile_iteration.py --rays 5000 --samples 48 --masked --iters 200 --graph | tail -1 | sed "s/^/fused iteration, graph replay, 5000 x 64: /"
+      python tools/profile_iteration.py --rays 1000 --samples 32 --masked --iters 200 --graph | tail -1 | sed "s/^/fused iteration, graph replay, 1000 x 48: /"
+    done
+  } > $O/${R}_fused_iteration.txt 2> $L/fused_iteration.err || FAILED="$FAILED fused_iteration"
+fi
+
+if want tests; then
+  # the whole GPU suite, with every comparison logged: the pass / fail line, r05_parity_stats.txt, r05_grad_stats.txt
+  rm -f $O/${R}_parity_raw.txt $O/${R}_grad_raw.txt
+  ADFP_PARITY_STATS=$PWD/$O/${R}_parity_raw.txt ADFP_GRAD_STATS=$PWD/$O/${R}_grad_raw.txt into $O/${R}_pytest_gpu.txt pytest_gpu timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider
+  tail -n 3 $O/${R}_pytest_gpu.txt
+  into $O/${R}_parity_stats.txt parity_stats python tools/stats_summary.py parity $O/${R}_parity_raw.txt
+  into $O/${R}_grad_stats.txt grad_stats python tools/stats_summary.py grad $O/${R}_grad_raw.txt
+  rm -f $O/${R}_parity_raw.txt $O/${R}_grad_raw.txt
+fi
+
+if want diag; then
+  into $O/${R}_diag_backward_modes.txt diag_bwd python tools/diag_bwd.py
+fi
+
+if want config5; then
+  into $O/${R}_config5.json c5_pixel python tools/stress_config5.py pixel
+  for order in random random-sorted; do
+    python tools/stress_config5.py $order 2> $L/c5_$order.err | tail -1 >> $O/${R}_config5.json || FAILED="$FAILED c5_$order"
+  done
+fi
+
+if want loops; then
+  into $O/${R}_mapping_loop.json loop_plain python tools/mapping_loop.py --frames 200 --every-frame 5
+  python tools/mapping_loop.py --frames 200 --every-frame 5 --fused 2> $L/loop_fused.err | tail -1 >> $O/${R}_mapping_loop.json || FAILED="$FAILED loop_fused"
+  ADFP_HOST_TIMING=1 into $O/${R}_host_breakdown.txt host_breakdown python tools/host_breakdown.py --rays 1000 5000
+fi
+
+if want ab; then
+  into $O/${R}_ab_backward_roles.txt ab_roles bash tools/ab_roles.sh
+  ADFP_LIB_PATH=$PWD/tools/ab_libs/libadfp_roles_span.so python tools/roles_span.py 2> $L/roles_span.err | tail -4 >> $O/${R}_ab_backward_roles.txt || FAILED="$FAILED roles_span"
+  {
+    for lib in "" train_NOX train_NOHEADC; do
+      for rep in 1 2; do
+        if [ -n "$lib" ]; then ADFP_LIB_PATH=$PWD/tools/ab_libs/libadfp_$lib.so python tools/ab_train_fwd.py 5000 48 300; else python tools/ab_train_fwd.py 5000 48 300; fi
+      done
+    done
+  } > $O/${R}_ab_train_forward.txt 2> $L/ab_train_forward.err || FAILED="$FAILED ab_train_forward"
+fi
+
+{ hostname; rocm-smi --showproductname 2> $L/box.err | head -8; } > $O/${R}_box.txt
 # the raw rocprofv3 output directories are large (gpurun merges at most 64 MiB back): keep the summaries only
-rm -rf $O/pmc_${R}_* $O/prof_${R}_*
-wc -c $O/${R}_bench_f16x3.json; tail -c 300 $O/${R}_bench_f16x3.err; head -14 $O/${R}_kernel_stats_headline.csv
+rm -rf $O/pmc_* $O/prof_*
+ls -la $O | grep ${R}_ | awk '{print $5, $9}'
+if [ -n "$FAILED" ]; then echo "collect_profiles: FAILED steps:$FAILED"; exit 1; fi
+echo "collect_profiles: all steps ended with exit code 0"
