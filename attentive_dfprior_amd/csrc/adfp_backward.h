@@ -124,31 +124,37 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
             }
         }
     }
-    if (gmax) {                  // per-ray maximum; k_max_reduce folds them (5 000 atomics on one address cost 60 us)
+    if (gmax) {                  // per-ray maximum, folded by max_fold_block (k_bin_keys' side job) or k_max_reduce
         // The cotangent of the attention-weight output enters the attention backward beside d/d raw (gl = a (ga - dot), |gl| <=
         // |g_w| / 4): it belongs to the same scale, or a loss that lives mostly on w would push S up until the staged rows leave
         // the f16 range.
         if (g_weight) for (int s = lane; s < S; s += 64) mx = fmaxf(mx, fabsf(g_weight[(long long)ray * S + s]));
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        // (5 000 atomics on one address cost 60 us; so do 5 000 agent-scope LOOKS at one address before a rare atomic: every access
+        // to one L2 line takes its turn, ~10 ns each)
         if (lane == 0) gmax[ray] = mx;
     }
 }
 
-// out[0] = max(parts[0 .. n)): one workgroup
-__global__ __launch_bounds__(1024) void k_max_reduce(const float* __restrict__ parts, int n, float* __restrict__ out) {
-    __shared__ float s_m[16];
+// out[0] = max(parts[0 .. n)) by ONE workgroup of NT threads (all of them call)
+template <int NT>
+ADFP_DEV void max_fold_block(const float* __restrict__ parts, int n, float* __restrict__ out) {
+    __shared__ float s_m[NT / 64];
     float mx = 0.f;
-    for (int i = threadIdx.x; i < n; i += 1024) mx = fmaxf(mx, parts[i]);
+    for (int i = threadIdx.x; i < n; i += NT) mx = fmaxf(mx, parts[i]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
     __syncthreads();
     if (threadIdx.x == 0) {
         float m = s_m[0];
-        for (int w = 1; w < 16; ++w) m = fmaxf(m, s_m[w]);
+        for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, s_m[w]);
         *out = m;
     }
+}
+__global__ __launch_bounds__(1024) void k_max_reduce(const float* __restrict__ parts, int n, float* __restrict__ out) {
+    max_fold_block<1024>(parts, n, out);
 }
 
 // ------------------------------------------------------------------------------------------

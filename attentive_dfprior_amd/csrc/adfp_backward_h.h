@@ -379,16 +379,24 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
 //                               the atomics, and nothing goes through LDS atomics (ds_add_f32 measured at ~170 cycles per
 //                               64-lane instruction here, which made an LDS-accumulator variant slower than the cache).
 // ---------------------------------------------------------------------------------------------
-#define ADFP_BIN_MAXBITS 8            // cells per axis <= 256: 24-bit keys
-__host__ __device__ inline unsigned morton_spread(unsigned v) {       // 8 bits -> every third bit
-    v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u;
-    return v;
+#define ADFP_BIN_MAXBITS 8            // cells per axis <= 256
+// bits of the sort key: the coarse cell's LINEAR index (x fastest) + 6 bits of fine-cell offset.  (A Morton code spends 3 x the bits
+// of the LONGEST axis -- 18 for a 37 x 28 x 21 grid whose cells number 21 756 < 2^15 -- and those three bits are a radix pass: 24-bit
+// keys sort in three passes, 21-bit keys in two.  The order of the coarse cells among each other does not matter to the runs.)
+__host__ __device__ inline int bin_key_bits(int CX, int CY, int CZ) {
+    const long long cells = (long long)CX * CY * CZ;
+    int b = 0;
+    while ((1ll << b) < cells) ++b;
+    return b + 6;
 }
 struct BinArgs {
     PtsDev P; NormDev nb;
     int CX, CY, CZ;            // dims of the coarsest grid that is scattered
     int RX, RY, RZ;            // dims of the finest one (may be the same grid)
     int* key; int* val;        // out: sort key and point id of every point (the radix sort's input)
+    // side job of the LAST workgroup (one more than the points need): fold the call's per-ray maxima into the gradient scale's word --
+    // this is the first launch after k_composite_bwd, and a launch of its own for one workgroup's work costs ~5 us inside a graph replay
+    const float* max_parts; int max_n; float* max_out;
 };
 ADFP_DEV int cell_axis(float pn, int size) {                 // i0 of tri_axis
     float c = ((pn + 1.f) / 2.f) * (float)(size - 1);
@@ -397,13 +405,14 @@ ADFP_DEV int cell_axis(float pn, int size) {                 // i0 of tri_axis
     return i0 < 0 ? 0 : i0;
 }
 __global__ __launch_bounds__(256) void k_bin_keys(BinArgs a) {
+    if (a.max_parts && blockIdx.x == gridDim.x - 1) { max_fold_block<256>(a.max_parts, a.max_n, a.max_out); return; }
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= a.P.n) return;
     double pt[3]; float pn[3];
     load_point(a.P, q, pt);
     normalize3(a.nb, pt, pn);
     // The lattices of a 0.32 m and a 0.16 m grid are incommensurate (align_corners: cell = extent / (dim - 1)), so no order makes
-    // the runs of both exact.  Key = Morton code of the COARSE cell, then the fine cell's offset inside it (2 bits per axis): the
+    // the runs of both exact.  Key = index of the COARSE cell, then the fine cell's offset inside it (2 bits per axis): the
     // coarse grid's runs are exact, and a fine cell is cut only where it straddles a coarse face.  (Sorted by the fine cell alone,
     // the points inside a fine cell alternate between coarse cells: a flush per point, 374 us for the coarse grid.)
     const int dims_c[3] = {a.CX, a.CY, a.CZ}, dims_f[3] = {a.RX, a.RY, a.RZ};
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(256) void k_bin_keys(BinArgs a) {
         d = d < 0 ? 0 : (d > 3 ? 3 : d);
         off |= (unsigned)d << (2 * k);
     }
-    a.key[q] = (int)(((morton_spread(cc[0]) | (morton_spread(cc[1]) << 1) | (morton_spread(cc[2]) << 2)) << 6) | off);
+    a.key[q] = (int)(((((cc[2] * (unsigned)a.CY) + cc[1]) * (unsigned)a.CX + cc[0]) << 6) | off);
     a.val[q] = q;
 }
 
@@ -446,15 +455,21 @@ struct ScatterSortedArgs {
 // now four waves = eight consecutive ranges: a range adds its INTERIOR runs to memory as before, but parks its first and its
 // last run (the two that may continue next door) in LDS; after a barrier half a wave walks the sixteen records in order and
 // adds up neighbours of one cell before they go to memory -- one set of atomics per cell and workgroup instead of one per range.
-__global__ __launch_bounds__(64 * ADFP_SCATTER_NW) void k_scatter_sorted(ScatterSortedArgs a) {
+// One launch for all grids of a backward call (the points and their order are the same; a job = one grid with its d/d c rows):
+// three launches of 625 workgroups each ended in their own tail, and a launch costs ~5 us inside a graph replay.
+#define ADFP_SCATTER_MAX_JOBS 3
+struct ScatterMultiArgs { ScatterSortedArgs j[ADFP_SCATTER_MAX_JOBS]; int n_jobs, blocks_per_job; };
+__global__ __launch_bounds__(64 * ADFP_SCATTER_NW) void k_scatter_sorted(ScatterMultiArgs m) {
     constexpr int PPW = ADFP_SCATTER_PPW, PPH = PPW / 2, NW = ADFP_SCATTER_NW;
+    const int job = (int)blockIdx.x / m.blocks_per_job, blk = (int)blockIdx.x - job * m.blocks_per_job;
+    const ScatterSortedArgs& a = m.j[job];
     __shared__ int s_q[NW][PPW];
     __shared__ int s_cell[NW][PPW];                   // x0 | y0 << 10 | z0 << 20
     __shared__ __attribute__((aligned(16))) float s_w[NW][PPW][8];     // the 8 corner weights (wx wy) wz, corner k = dx + 2 dy + 4 dz
     __shared__ float s_rec[NW * 4][8][32];            // edge records: [range * 2 + (first | last)][corner][channel]
     __shared__ int s_rcell[NW * 4];
     const int lane = threadIdx.x & 63, ch = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-    const int w0 = (blockIdx.x * NW + wv) * PPW;
+    const int w0 = (blk * NW + wv) * PPW;
     // ---- phase A
 #pragma unroll
     for (int b = 0; b < PPW / 64; ++b) {

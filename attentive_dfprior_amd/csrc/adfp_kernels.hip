@@ -1529,7 +1529,7 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
     // in a training call, where `counter` is the caller's -- the backward entries and the Adam step gate on.
     const bool any_h = sc->h_low || (fuse && (sc->h_high || sc->h_att)) || (stage == ADFP_STAGE_COLOR && sc->h_color);
     int* call_flag = (any_h && ws.counter) ? ws.counter + 8 : nullptr;
-    if ((fuse || any_h || state) && ws.counter && !(ws_counter_is_zero && !state)) {      // (a training call's counter is the caller's buffer)
+    if ((fuse || any_h || state) && ws.counter && !ws_counter_is_zero) {      // (a training call's counter is the caller's buffer: ws.counter above)
         e = zero_async(ws.counter, 64, st);
         if (e != hipSuccess) return (int)e;
     }
@@ -2094,7 +2094,13 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
     float* raw = r->raw ? r->raw : ws.raw;
     // ONE zero fill for the call's small device words: the in-band counter and range flag (bytes 0-63) and the depth-max
     // reduction's scratch (bytes 64-255: up to 48 per-segment maxima) share the first 256 bytes of the workspace
-    { hipError_t e = zero_async(ws.counter, 256, st); if (e != hipSuccess) return (int)e; }
+    {   // ... and, in a training call, the caller's counter block that eval_points_impl uses instead: one launch for both
+        ZeroBatch zb;
+        hipError_t e = zb.add(ws.counter, 256, st);
+        if (e == hipSuccess && r->state && r->state->counter && r->state->counter != ws.counter) e = zb.add(r->state->counter, 64, st);
+        if (e == hipSuccess) e = zb.flush(st);
+        if (e != hipSuccess) return (int)e;
+    }
     rc = sample_rays_impl(r->rays_o, r->rays_d, r->gt_depth, r->n_rays, scene->bound, r->n_samples, r->n_surface, r->lindisp,
                           r->perturb, r->t_rand, r->depth_max, z, (char*)ws.counter + 64, stream, true, r->depth_max_segment, r->depth_max_first_ray);
     if (rc) return rc;
@@ -2119,10 +2125,12 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
 
 #define OUTER_NSLOT 256         // workgroups per weight-gradient launch = private gradient copies (one per CU)
 struct BwdWorkspace { float* g_raw; float* att_g; float* g_pts; float* stage; int stage_rows; float* partial; int part_stride; float* gmax; float* gmax_parts;
-                      float* gc; int* bin_key; int* bin_val; int* bin_key_sorted; int* bin_perm; int* sort_table;
+                      int gmax_pending;              // > 0: gmax_parts[0 .. gmax_pending) still wait to be folded into gmax (backward_points)
+                      float* gc; size_t gc_stride; int* bin_key; int* bin_val; int* bin_key_sorted; int* bin_perm; int* sort_table;
                       size_t bytes; };
 static BwdWorkspace carve_bwd(void* base, long long P) {
     BwdWorkspace w; size_t o = 0;
+    w.gmax_pending = 0;
     w.g_raw = at<float>(base, o); o += align256((size_t)P * 16);
     w.att_g = at<float>(base, o); o += align256((size_t)P * 4);
     w.g_pts = at<float>(base, o); o += align256((size_t)P * 12);
@@ -2138,12 +2146,13 @@ static BwdWorkspace carve_bwd(void* base, long long P) {
     w.gmax = at<float>(base, o); o += 256;            // largest |cotangent of raw| of the call (grad_scale)
     w.gmax_parts = at<float>(base, o); o += align256((size_t)P * 4);     // ... per ray / per workgroup, before k_max_reduce
     // spatially ordered grid-gradient scatter of the f16-split backward (k_scatter_sorted): d/d c rows, sort keys, sorted order
-    w.gc = at<float>(base, o); o += align256((size_t)P * 128);
+    w.gc_stride = align256((size_t)P * 128) / 4;                          // one [P][32] block of rows per grid (ADFP_SCATTER_MAX_JOBS of them)
+    w.gc = at<float>(base, o); o += ADFP_SCATTER_MAX_JOBS * w.gc_stride * 4;
     w.bin_key = at<int>(base, o); o += align256((size_t)P * 4);
     w.bin_val = at<int>(base, o); o += align256((size_t)P * 4);
     w.bin_key_sorted = at<int>(base, o); o += align256((size_t)P * 4);
     w.bin_perm = at<int>(base, o); o += align256((size_t)P * 4);
-    w.sort_table = at<int>(base, o); o += align256((((size_t)P + ADFP_RS_TILE - 1) / ADFP_RS_TILE) * 256 * 4 + 1024);     // [256 digits][tiles] + [256] totals
+    w.sort_table = at<int>(base, o); o += align256(((((size_t)P + ADFP_RS_TILE - 1) / ADFP_RS_TILE) + 1) * ADFP_RS_DIGITS * 4);     // [digits][tiles] + [digits] totals
     w.bytes = o;
     return w;
 }
@@ -2279,20 +2288,21 @@ static int role_share_env(int which, int dflt) {
 }
 // sort of the call's points for k_scatter_sorted (set up once per backward call by backward_points)
 // Sorts n (key, value) pairs by the low key_bits bits of the key, stable.  The two buffer pairs are used in turn; *key_fin / *val_fin
-// = the pair the last pass wrote (a / b).  table: 256 * ceil(n / ADFP_RS_TILE) + 256 ints.
+// = the pair the last pass wrote (a / b).  table: ADFP_RS_DIGITS * (ceil(n / ADFP_RS_TILE) + 1) ints.
 static int radix_sort_pairs(int* key_a, int* val_a, int* key_b, int* val_b, int n, int key_bits, int* table, const int** key_fin,
                             const int** val_fin, hipStream_t st) {
     RadixArgs rs; rs.table = table; rs.n = n; rs.ntiles = (n + ADFP_RS_TILE - 1) / ADFP_RS_TILE;
-    rs.totals = table + (size_t)256 * rs.ntiles;
-    const int passes = (key_bits + 7) / 8;
+    constexpr int db = ADFP_RS_DIGIT_BITS, nd = ADFP_RS_DIGITS;
+    rs.totals = table + (size_t)nd * rs.ntiles;
+    const int passes = (key_bits + db - 1) / db;
     int* kin = key_a; int* vin = val_a; int* kout = key_b; int* vout = val_b;
     for (int ps = 0; ps < passes; ++ps) {
-        rs.key_in = kin; rs.val_in = vin; rs.key_out = kout; rs.val_out = vout; rs.shift = 8 * ps;
-        hipLaunchKernelGGL(k_rs_hist, dim3(rs.ntiles), dim3(256), 0, st, rs);
+        rs.key_in = kin; rs.val_in = vin; rs.key_out = kout; rs.val_out = vout; rs.shift = db * ps;
+        hipLaunchKernelGGL(k_rs_hist<db>, dim3(rs.ntiles), dim3(256), 0, st, rs);
         ADFP_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_rs_scan, dim3(256), dim3(256), 0, st, rs.table, rs.ntiles, rs.totals);
+        hipLaunchKernelGGL(k_rs_scan, dim3(nd / 4), dim3(256), 0, st, rs.table, rs.ntiles, rs.totals);
         ADFP_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_rs_scatter, dim3(rs.ntiles), dim3(256), 0, st, rs);
+        hipLaunchKernelGGL(k_rs_scatter<db>, dim3(rs.ntiles), dim3(256), 0, st, rs);
         ADFP_CHECK_LAUNCH();
         int* tk = kin; kin = kout; kout = tk; int* tv = vin; vin = vout; vout = tv;
     }
@@ -2300,7 +2310,7 @@ static int radix_sort_pairs(int* key_a, int* val_a, int* key_b, int* val_b, int 
     if (val_fin) *val_fin = vin;
     return 0;
 }
-extern "C" size_t adfp_sort_workspace_bytes(long long n) { return n < 0 ? 0 : ((size_t)((n + ADFP_RS_TILE - 1) / ADFP_RS_TILE) * 256 + 256) * 4; }
+extern "C" size_t adfp_sort_workspace_bytes(long long n) { return n < 0 ? 0 : ((size_t)((n + ADFP_RS_TILE - 1) / ADFP_RS_TILE) + 1) * ADFP_RS_DIGITS * 4; }
 extern "C" int adfp_sort_pairs(int* key, int* val, int* key_tmp, int* val_tmp, long long n, int key_bits, void* workspace, size_t workspace_bytes,
                                void* stream) {
     if (!key || !val || !key_tmp || !val_tmp || !workspace || n < 0 || key_bits < 1 || key_bits > 31) return ADFP_E_ARG;
@@ -2318,19 +2328,29 @@ extern "C" int adfp_sort_pairs(int* key, int* val, int* key_tmp, int* val_tmp, l
     return 0;
 }
 
-struct BinPlan { bool ok; BinArgs args; const int* perm; };
-static int scatter_bins(const BinPlan& bp, const DecodeBwdArgs& o, const BwdWorkspace& bw, const unsigned char* flags, hipStream_t st) {
-    ScatterSortedArgs s;
-    s.P = o.P; s.nb = o.nb; s.g = o.g0; s.gc = bw.gc; s.g_grid = o.g_grid; s.perm = bp.perm; s.n = o.P.n; s.flags = flags; s.flag_mask = ADFP_F_BAND;
+// the grids whose d/d c rows wait for the call's ONE k_scatter_sorted launch (flush_scatter): job k has rows in bw.gc + k * gc_stride
+struct BinPlan { bool ok; BinArgs args; const int* perm; ScatterMultiArgs pend; };
+static int scatter_bins(BinPlan& bp, const DecodeBwdArgs& o, float* gc, const unsigned char* flags) {
     if (o.g0.X > 1023 || o.g0.Y > 1023 || o.g0.Z > 1023) return ADFP_E_UNSUPPORTED;          // packed cell coordinates
-    hipLaunchKernelGGL(k_scatter_sorted, dim3((o.P.n + ADFP_SCATTER_PPW * ADFP_SCATTER_NW - 1) / (ADFP_SCATTER_PPW * ADFP_SCATTER_NW)), dim3(64 * ADFP_SCATTER_NW), 0, st, s);
+    if (bp.pend.n_jobs >= ADFP_SCATTER_MAX_JOBS) return ADFP_E_UNSUPPORTED;
+    ScatterSortedArgs& s = bp.pend.j[bp.pend.n_jobs++];
+    s.P = o.P; s.nb = o.nb; s.g = o.g0; s.gc = gc; s.g_grid = o.g_grid; s.perm = bp.perm; s.n = o.P.n; s.flags = flags; s.flag_mask = ADFP_F_BAND;
+    return 0;
+}
+static int flush_scatter(BinPlan& bp, hipStream_t st) {
+    if (!bp.ok || bp.pend.n_jobs == 0) return 0;
+    const int n = bp.pend.j[0].n;
+    bp.pend.blocks_per_job = (n + ADFP_SCATTER_PPW * ADFP_SCATTER_NW - 1) / (ADFP_SCATTER_PPW * ADFP_SCATTER_NW);
+    for (int k = bp.pend.n_jobs; k < ADFP_SCATTER_MAX_JOBS; ++k) bp.pend.j[k] = bp.pend.j[0];
+    hipLaunchKernelGGL(k_scatter_sorted, dim3(bp.pend.blocks_per_job * bp.pend.n_jobs), dim3(64 * ADFP_SCATTER_NW), 0, st, bp.pend);
     ADFP_CHECK_LAUNCH();
+    bp.pend.n_jobs = 0;
     return 0;
 }
 
 template <int CDIM, int NOUT, int ROLE>
 static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigned* masks, const float* act, int* status, const int* skip, int total,
-                            const int* count_ptr, float* flat, BwdWorkspace& bw, const BinPlan& bp, const unsigned char* flags, int options, hipStream_t st) {
+                            const int* count_ptr, float* flat, BwdWorkspace& bw, BinPlan& bp, const unsigned char* flags, int options, hipStream_t st) {
     if (total == 0) return 0;
     // d/d c rows + k_scatter_sorted instead of the in-kernel scatter: for a grid on one of the two lattices the points were
     // sorted by (k_bin_keys); a third lattice keeps the in-kernel scatter
@@ -2340,7 +2360,8 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
     DecodeBwdHArgs a;
     a.P = o.P; a.nb = o.nb; a.g0 = o.g0; a.packed_t = (const unsigned*)t; a.list = o.list; a.count_ptr = o.count_ptr;
     a.g_raw = o.g_raw; a.att_g = o.att_g; a.masks = masks; a.g_grid = o.g_grid; a.stage = nullptr; a.status = status; a.gmax = bw.gmax; a.skip = skip;
-    a.gc_out = binned ? bw.gc : nullptr;
+    float* const gc_rows = binned ? bw.gc + (size_t)bp.pend.n_jobs * bw.gc_stride : nullptr;       // this grid's d/d c rows
+    a.gc_out = gc_rows;
     a.g_pts = o.g_pts;
     constexpr int NW = ADFP_BWDH_NT / 64;
     if (o.g_pts) {                                      // position gradient only (backward_points' use_h): frozen network and grid
@@ -2356,7 +2377,7 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
         if (flat && !count_ptr && (binned || !o.g_grid) && !(options & ADFP_BWD_STAGED_WGRAD)) {
             DecodeBwdFArgs f;
             f.P = o.P; f.nb = o.nb; f.packed_t = (const unsigned*)t; f.g_raw = o.g_raw; f.masks = masks; f.act = act;
-            f.gc_out = binned ? bw.gc : nullptr; f.total = total; f.status = status; f.gmax = bw.gmax; f.skip = skip;
+            f.gc_out = gc_rows; f.total = total; f.status = status; f.gmax = bw.gmax; f.skip = skip;
             f.partial = bw.partial; f.part_stride = bw.part_stride;
             // every workgroup OVERWRITES its slot of bw.partial (no 20 MB zero fill per network), and the reduction reads the slots in use
             const int ntiles = (total + 31) / 32;
@@ -2385,7 +2406,7 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
             hipLaunchKernelGGL(k_reduce_partials_scaled, dim3((DecLayout<CDIM, NOUT>::F_TOTAL + 31) / 32), dim3(256), 0, st, bw.partial, nslot, bw.part_stride,
                                DecLayout<CDIM, NOUT>::F_TOTAL, flat, bw.gmax);
             ADFP_CHECK_LAUNCH();
-            return binned ? scatter_bins(bp, o, bw, flags, st) : 0;
+            return binned ? scatter_bins(bp, o, gc_rows, flags) : 0;
         }
     }
     if (!flat) {
@@ -2393,7 +2414,7 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
         if (o.g_grid && !binned) hipLaunchKernelGGL((k_decode_bwd_h<CDIM, NOUT, ROLE, false, true, ADFP_BWDH_NT>), dim3(decode_grid((total + 31) / 32, NW, 1)), dim3(ADFP_BWDH_NT), 0, st, a);
         else hipLaunchKernelGGL((k_decode_bwd_h<CDIM, NOUT, ROLE, false, false, 512>), dim3(decode_grid((total + 31) / 32, 8, 1)), dim3(512), 0, st, a);
         ADFP_CHECK_LAUNCH();
-        return binned ? scatter_bins(bp, o, bw, flags, st) : 0;
+        return binned ? scatter_bins(bp, o, gc_rows, flags) : 0;
     }
     using ST = DecStage<CDIM>;
     OuterHArgs oa; decoder_jobs<CDIM, NOUT>(oa.o);
@@ -2423,7 +2444,7 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
     }
     rc = outer_end_scaled(bw, DecLayout<CDIM, NOUT>::F_TOTAL, flat, st);
     if (rc) return rc;
-    return binned ? scatter_bins(bp, o, bw, flags, st) : 0;
+    return binned ? scatter_bins(bp, o, gc_rows, flags) : 0;
 }
 
 template <int CDIM, int NOUT, int ROLE>
@@ -2469,7 +2490,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
     };
     // The grid gradients of the decoders that take the f16-split backward are scattered in spatial order (k_scatter_sorted): one
     // radix sort of the points by (coarsest such grid's cell, finest grid's cell inside it), shared by all of them.
-    BinPlan bp; bp.ok = false;
+    BinPlan bp; bp.ok = false; bp.pend.n_jobs = 0;
     {
         const bool h_low = go.grid_low && use_h(sc->ht_low, state.masks_low, state.act_low, go.flat_low, go.grid_low);
         const bool h_high = fuse && go.grid_high && use_h(sc->ht_high, state.masks_high, state.act_high, go.flat_high, go.grid_high);
@@ -2492,11 +2513,13 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
                 BinArgs& b = bp.args;
                 b.P = Pd; b.nb = a.nb; b.CX = coarse->X; b.CY = coarse->Y; b.CZ = coarse->Z; b.RX = fine->X; b.RY = fine->Y; b.RZ = fine->Z;
                 b.key = bw.bin_key; b.val = bw.bin_val;
-                hipLaunchKernelGGL(k_bin_keys, dim3((P + 255) / 256), dim3(256), 0, st, b);
+                b.max_parts = bw.gmax_pending > 0 ? bw.gmax_parts : nullptr; b.max_n = bw.gmax_pending; b.max_out = bw.gmax;
+                hipLaunchKernelGGL(k_bin_keys, dim3((P + 255) / 256 + (b.max_parts ? 1 : 0)), dim3(256), 0, st, b);
+                bw.gmax_pending = 0;
                 ADFP_CHECK_LAUNCH();
-                // stable LSD radix sort, 8 bits per pass (adfp_sort.h), ping-pong between the two buffer pairs
+                // stable LSD radix sort (adfp_sort.h), ping-pong between the two buffer pairs
                 const int* vfin = nullptr;
-                rc = radix_sort_pairs(bw.bin_key, bw.bin_val, bw.bin_key_sorted, bw.bin_perm, P, 3 * bits + 6, bw.sort_table, nullptr, &vfin, st);
+                rc = radix_sort_pairs(bw.bin_key, bw.bin_val, bw.bin_key_sorted, bw.bin_perm, P, bin_key_bits(coarse->X, coarse->Y, coarse->Z), bw.sort_table, nullptr, &vfin, st);
                 if (rc) return rc;
                 const int* vin = vfin;
                 bp.perm = vin;                      // the pair the last pass wrote
@@ -2505,6 +2528,11 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         }
     }
 
+    if (bw.gmax_pending > 0) {                       // no sorted scatter in this call: the fold is a launch of its own
+        hipLaunchKernelGGL(k_max_reduce, dim3(1), dim3(1024), 0, st, bw.gmax_parts, bw.gmax_pending, bw.gmax);
+        ADFP_CHECK_LAUNCH();
+        bw.gmax_pending = 0;
+    }
     if (fuse) {
         const bool att_full_h = use_h(sc->ht_att, state.masks_att, state.act_att, go.flat_att);
         if (att_full_h) {
@@ -2602,7 +2630,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         else rc = sc->w_color ? run_decode_bwd<32, 4, ROLE_COLOR>(cl, P, nullptr, go.flat_color, bw, st) : ADFP_E_ARG;
         if (rc) return rc;
     }
-    return 0;
+    return flush_scatter(bp, st);
 }
 
 static int check_backward_scene(const adfp_scene* sc, int stage) {
@@ -2636,8 +2664,7 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
     hipLaunchKernelGGL(k_composite_bwd, dim3((r->n_rays + 3) / 4), dim3(256), 0, st, r->raw, r->z_vals, r->n_rays, r->S,
                        r->g_depth, r->g_uncertainty, r->g_color, bw.g_raw, r->ray_keep, bw.gmax_parts, r->g_weight, r->state.counter ? r->state.counter + 8 : nullptr);
     ADFP_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_max_reduce, dim3(1), dim3(1024), 0, st, bw.gmax_parts, r->n_rays, bw.gmax);
-    ADFP_CHECK_LAUNCH();
+    bw.gmax_pending = r->n_rays;                     // folded into bw.gmax by backward_points' first launch
 
     PtsDev Pd;
     Pd.mode = ADFP_PTS_RAYS; Pd.S = r->S; Pd.n = P; Pd.pts = nullptr; Pd.ro = r->rays_o; Pd.rd = r->rays_d; Pd.z = r->z_vals;

@@ -429,8 +429,12 @@ class MapperIteration(object):
             if st is None:
                 st = self._static[N] = (torch.empty((N, 3), device=dev), torch.empty((N, 3), device=dev), torch.empty((N,), device=dev),
                                         torch.empty((N, 3), device=dev))
-            for dst, src in zip(st, (rays_o, rays_d, gt_depth, gt_color)):
-                dst.copy_(src)
+            srcs = (rays_o, rays_d, gt_depth, gt_color)
+            if all(s_.dtype == torch.float32 and s_.device == d_.device and s_.shape == d_.shape for d_, s_ in zip(st, srcs)):
+                torch._foreach_copy_(list(st), list(srcs))      # ONE multi-tensor launch (four copies were ~15 us of GPU time per replay)
+            else:
+                for dst, src in zip(st, srcs):
+                    dst.copy_(src)
             g = self._graphs.get(key)
             if g is None:
                 # warm the host-side caches (bounds, workspace) without touching any optimiser state, then capture with the

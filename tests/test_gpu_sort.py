@@ -1,5 +1,5 @@
 """GPU: adfp_sort_pairs (the hand-written stable LSD radix sort that orders the sample points by grid cell for the backward's
-scatter, csrc/adfp_sort.h) against torch.sort(stable=True): sizes around the 2 048-key tile, one to four passes, all-equal
+scatter, csrc/adfp_sort.h) against torch.sort(stable=True): sizes around the 1 024-key tile and its multiples, one to four passes, all-equal
 keys, a handful of hot keys (what a camera frustum produces)."""
 import pytest
 import torch
@@ -22,8 +22,8 @@ def sort_pairs(key, val, bits):
     return k, v
 
 
-@pytest.mark.parametrize('n', [1, 63, 64, 2047, 2048, 2049, 5000, 320000, 1000003])
-@pytest.mark.parametrize('bits', [7, 8, 15, 24, 30])
+@pytest.mark.parametrize('n', [1, 63, 64, 1023, 1024, 1025, 2047, 2048, 2049, 5000, 320000, 1000003])
+@pytest.mark.parametrize('bits', [7, 8, 15, 17, 21, 24, 30])
 def test_sort_pairs_is_a_stable_sort(n, bits):
     g = torch.Generator(device='cpu').manual_seed(n * 31 + bits)
     key = torch.randint(0, 2 ** bits, (n,), generator=g, dtype=torch.int64).to(torch.int32).to(DEV)
