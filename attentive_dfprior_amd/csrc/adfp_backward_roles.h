@@ -23,8 +23,9 @@
 // to what a tile costs each (ROLE_SHARE_*).
 //
 // Everything else is the one-wave kernel's: the slot format of the transposition through LDS, the per-point power-of-two scale
-// of the chain, the global scale S of the summed products, the narrow-product block with its column slots, the private copy of
-// the flat gradient per workgroup (a role leaves the elements it does not own zero) reduced by k_reduce_partials_scaled.
+// of the chain, the global scale S of the summed products, the narrow-product block with its column slots, the slot of partial
+// sums per workgroup -- of which a workgroup here writes only its role's elements; k_reduce_partials_roles adds up each element over
+// its owners' slots.
 // Same values up to the summation order over tiles (tests/test_gpu_grad.py::test_fused_weight_gradients_equal_the_staged_path).
 #pragma once
 #include <type_traits>
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
     constexpr int XW_P = ((LDS_WORDS - IMG_P) / NWV) & ~3, XW_H = ((LDS_WORDS - IMG_H) / NWV) & ~3, XW_C = ((LDS_WORDS - IMG_C) / NWV) & ~3;
     constexpr int SMALL = 320;                                               // masks (32 x 6 words) + cotangent rows (32 x 4 floats) of one tile
     static_assert(3 * SLOT + 128 <= XW_P && 4 * SLOT + SMALL <= XW_H && 3 * SLOT + SMALL <= XW_C, "per-wave regions");
-    static_assert(F::F_TOTAL <= NWV * XW_C && F::F_TOTAL <= NWV * XW_P && F::F_TOTAL <= NWV * XW_H, "the reduction copy must fit the per-wave regions");
+    static_assert(NWV * 3 * 16 * 64 <= LDS_WORDS, "the reduction's three blocks per wave");
     __shared__ __attribute__((aligned(16))) unsigned ldsu[LDS_WORDS];
     const int bid = (int)blockIdx.x, nwg = (int)gridDim.x;
 #ifdef ADFP_EXP_COMPILE_ROLE       // ISA experiments: the kernel with one role's code only (tools/isa_mix.py per role)
@@ -107,7 +108,6 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
     if (threadIdx.x == 0) *s_ticket = NWV;                                   // local tile numbers 0 .. 7 are the waves' first tiles
     __syncthreads();
     const float* lds = (const float*)ldsu;
-    float* s_red = (float*)(ldsu + img_words);
 
     const int lane_off = h * 128 + p * 4;
     const int rwg = role == 0 ? bid : (role == 1 ? bid - nP : bid - nP - nH);
@@ -255,16 +255,28 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
             gp[r] = __uint_as_float(__float_as_uint(gh[r]) & (unsigned)keep);
         }
     };
-    // D layout of a product: lane (n = p, h) register r = [row kmapH(r, h)][column p]; adds one block into the workgroup's copy
-    // (the sixteen elements are READ first, then written: `+=` per element is sixteen dependent LDS round trips, and the eight rounds
-    // of the reduction below were ~10 us of every workgroup's ~14 us epilogue)
-    auto add_rows = [&](const f32x16& acc, int base, int row_stride, int ncols) {
-        if (p < ncols) {
-            float old[16];
+    // ---- the end of the launch: the eight waves' accumulators are added up and leave as this workgroup's slot of partial sums.
+    // D layout of a product: lane (n = p, h) register r = [row kmapH(r, h)][column p].  Three blocks at a time go through LDS
+    // (the whole array: nothing of the tile loop is live any more) as [wave][block][register][lane] -- 48 conflict-free ds_write_b32
+    // per lane -- and after a barrier wave w adds up six of the 48 (block, register) rows over the eight waves, in wave order, and
+    // stores them straight to memory: the two 128-byte runs of a row.  A workgroup writes ONLY the elements its role owns
+    // (role_of_element below: k_reduce_partials_roles reads each element from its owners' slots only) -- a third of the bytes of a
+    // whole-slot copy, written and read back.  (Eight rounds of read-modify-write on a whole-slot LDS copy + the copy-out were
+    // ~12 us of every workgroup's launch.)
+    float* const red = (float*)ldsu;
+    float* const part = a.partial + (long long)blockIdx.x * a.part_stride;
+    auto put = [&](int b, const f32x16& acc) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) old[r] = s_red[base + kmapH(r, h) * row_stride + p];
+        for (int r = 0; r < 16; ++r) red[((wvu * 3 + b) * 16 + r) * 64 + lane] = acc[r];
+    };
+    auto rows = [&](auto&& dest) {
+#pragma unroll 1
+        for (int k = 0; k < 6; ++k) {
+            const int row = wvu * 6 + k, b = row >> 4, r = row & 15;      // wave-uniform
+            float v = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s_red[base + kmapH(r, h) * row_stride + p] = old[r] + acc[r];
+            for (int w = 0; w < NWV; ++w) v += red[((w * 3 + b) * 16 + r) * 64 + lane];
+            dest(b, r, v);
         }
     };
 
@@ -345,27 +357,16 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
         t_loop_ = wall_clock64();
 #endif
         __syncthreads();
-        for (int i = threadIdx.x; i < F::F_TOTAL; i += 512) s_red[i] = 0.f;
+        put(0, acc[0]); put(1, acc[1]); put(2, acc[2]);
         __syncthreads();
-        // round k: wave w adds its block (w + k) mod 8 -- different waves, different blocks: no two waves touch the same elements
-        for (int k = 0; k < NWV; ++k) {
-            const int j = (wvu + k) & 7;
-            if (j == 0) add_rows(acc[0], F::F_FC(0), CDIM, 32);
-            else if (j == 1) add_rows(acc[1], F::F_FC(1), CDIM, 32);
-            else if (j == 2) add_rows(acc[2], F::F_FC(2), CDIM, 32);
-            else if (j == 3) add_rows(acc[3], F::F_FC(3), CDIM, 32);
-            else if (j == 4) add_rows(acc[4], F::F_FC(4), CDIM, 32);
-            else if (j == 5) {
-                if (p >= 5 && p < 10) {
-                    float old[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) old[r] = s_red[F::F_FC(p - 5) + 32 * CDIM + kmapH(r, h)];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s_red[F::F_FC(p - 5) + 32 * CDIM + kmapH(r, h)] = old[r] + acc[5][r];
-                }
-            }
-            __syncthreads();
-        }
+        rows([&](int b, int r, float v) { part[F::F_FC(b) + kmapH(r, h) * CDIM + p] = v; });
+        __syncthreads();
+        put(0, acc[3]); put(1, acc[4]); put(2, acc[5]);
+        __syncthreads();
+        rows([&](int b, int r, float v) {
+            if (b < 2) part[F::F_FC(3 + b) + kmapH(r, h) * CDIM + p] = v;
+            else if (p >= 5 && p < 10) part[F::F_FC(p - 5) + 32 * CDIM + kmapH(r, h)] = v;       // the bias columns
+        });
     } else if (role == 1) {
         // =====================================================================================================================
         // role H: pts_linears[i].weight against h_{i-1} (i = 1..4; layer 3: the h_2 columns), the five pts_linears biases,
@@ -474,30 +475,25 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
         t_loop_ = wall_clock64();
 #endif
         __syncthreads();
-        for (int i = threadIdx.x; i < F::F_TOTAL; i += 512) s_red[i] = 0.f;
+        put(0, acc[0]); put(1, acc[1]); put(2, acc[2]);
         __syncthreads();
-        for (int k = 0; k < NWV; ++k) {
-            const int j = (wvu + k) & 7;
-            if (j == 0) add_rows(acc[0], F::F_PL(1), 32, 32);
-            else if (j == 1) add_rows(acc[1], F::F_PL(2), 32, 32);
-            else if (j == 2) add_rows(acc[2], F::F_PL(3) + 93, 125, 32);
-            else if (j == 3) add_rows(acc[3], F::F_PL(4), 32, 32);
-            else if (j == 4) {
+        rows([&](int b, int r, float v) {
+            const int base = b == 0 ? F::F_PL(1) : (b == 1 ? F::F_PL(2) : F::F_PL(3) + 93), stride = b == 2 ? 125 : 32;
+            part[base + kmapH(r, h) * stride + p] = v;
+        });
+        __syncthreads();
+        put(0, acc[3]); put(1, acc[4]);
+        __syncthreads();
+        rows([&](int b, int r, float v) {
+            if (b == 0) part[F::F_PL(4) + kmapH(r, h) * 32 + p] = v;
+            else if (b == 1) {
                 // column p of the narrow block is a slot: one destination row per lane (or none), element kmapH(r, h) of it
                 const int dst = p < 5 ? F::F_PL(p) + 32 * F::in_dim(p) : ((p >= 19 && p < 19 + NOUT) ? F::F_OW + (p - 19) * 32 : -1);
-                if (dst >= 0) {
-                    float old[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) old[r] = s_red[dst + kmapH(r, h)];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s_red[dst + kmapH(r, h)] = old[r] + acc[4][r];
-                } else if (p == FSLOT_BO) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { const int u = kmapH(r, h); if (u >= 19 && u < 19 + NOUT) s_red[F::F_OB + (u - 19)] += acc[4][r]; }
-                }
-            }
-            __syncthreads();
-        }
+                const int u = kmapH(r, h);
+                if (dst >= 0) part[dst + u] = v;
+                else if (p == FSLOT_BO && u >= 19 && u < 19 + NOUT) part[F::F_OB + (u - 19)] = v;
+            }                                                                 // (the third block of this round holds nothing)
+        });
     } else {
         // =====================================================================================================================
         // role P: pts_linears[0].weight and the Fourier columns of pts_linears[3].weight against sin(p @ B) -- blocks 0-2 = layer 0,
@@ -724,39 +720,78 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
         t_loop_ = wall_clock64();
 #endif
         __syncthreads();
-        for (int i = threadIdx.x; i < F::F_TOTAL; i += 512) s_red[i] = 0.f;
+        put(0, acc[0]); put(1, acc[1]); put(2, acc[2]);
         __syncthreads();
-        for (int k = 0; k < NWV; ++k) {
-            const int j = (wvu + k) & 7;
-            if (j < 3) {
-                const int ncol = j < 2 ? 32 : 29;                             // 93 features
-                if (j == 0) add_rows(acc[0], F::F_PL(0), 93, ncol);
-                else if (j == 1) add_rows(acc[1], F::F_PL(0) + 32, 93, ncol);
-                else add_rows(acc[2], F::F_PL(0) + 64, 93, ncol);
-            } else if (j < 6) {
-                const int ncol = j < 5 ? 32 : 29;
-                if (j == 3) add_rows(acc[3], F::F_PL(3), 125, ncol);
-                else if (j == 4) add_rows(acc[4], F::F_PL(3) + 32, 125, ncol);
-                else add_rows(acc[5], F::F_PL(3) + 64, 125, ncol);
-            } else if (j == 6) {                                              // embedder._B [3][93]: the two lane halves hold different points
+        rows([&](int b, int r, float v) { if (p < (b < 2 ? 32 : 29)) part[F::F_PL(0) + 32 * b + kmapH(r, h) * 93 + p] = v; });      // 93 features
+        __syncthreads();
+        put(0, acc[3]); put(1, acc[4]); put(2, acc[5]);
+        __syncthreads();
+        rows([&](int b, int r, float v) { if (p < (b < 2 ? 32 : 29)) part[F::F_PL(3) + 32 * b + kmapH(r, h) * 125 + p] = v; });
+        __syncthreads();
+        {   // embedder._B [3][93]: nine sums per lane (register 3 b + k = feature block b, coordinate k) as one more block
+            f32x16 e;
 #pragma unroll
-                for (int b = 0; b < 3; ++b)
-#pragma unroll
-                    for (int kk = 0; kk < 3; ++kk) {
-                        const float v = eb[b][kk] + __shfl_xor(eb[b][kk], 32);
-                        if (h == 0 && 32 * b + p < 93) s_red[F::F_EB + kk * 93 + 32 * b + p] += v;
-                    }
-            }
-            __syncthreads();
+            for (int r = 0; r < 16; ++r) e[r] = r < 9 ? eb[r / 3][r % 3] : 0.f;
+            put(0, e);
         }
+        __syncthreads();
+        rows([&](int b, int r, float v) {
+            if (b != 0 || r >= 9) return;                                     // wave-uniform
+            v += __shfl_xor(v, 32);                                           // the two lane halves hold different points
+            const int fb = r / 3, kk = r - 3 * fb;
+            if (h == 0 && 32 * fb + p < 93) part[F::F_EB + kk * 93 + 32 * fb + p] = v;
+        });
     }
     if (!(a.skip && *a.skip)) report_range(a.status, amax, ADFP_STATUS_F16_RANGE_BWD);
-    float* part = a.partial + (long long)blockIdx.x * a.part_stride;
-    for (int i = threadIdx.x; i < F::F_TOTAL; i += 512) part[i] = s_red[i];   // the slot is this workgroup's alone and written whole
 #ifdef ADFP_STAMPS_ROLES
     if (NOUT == 4 && threadIdx.x == 0 && blockIdx.x < 256) {
         g_roles_span[4 * blockIdx.x] = (unsigned long long)role; g_roles_span[4 * blockIdx.x + 1] = t_start_;
         g_roles_span[4 * blockIdx.x + 2] = t_loop_; g_roles_span[4 * blockIdx.x + 3] = wall_clock64();
     }
 #endif
+}
+
+// Which role's workgroups hold element e of the flat gradient (0 = P, 1 = H, 2 = C): the write-out at the end of k_decode_bwd_roles.
+template <int CDIM, int NOUT>
+ADFP_DEV int role_of_element(int e) {
+    using F = DecLayout<CDIM, NOUT>;
+    if (e < F::F_EB) return 2;                                   // fc_c weights and biases
+    if (e < F::F_PL(0)) return 0;                                // embedder._B
+    if (e >= F::F_OW) return 1;                                  // output_linear
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < 5; ++k) i = e >= F::F_PL(k) ? k : i;
+    const int off = e - F::F_PL(i), ind = F::in_dim(i);
+    if (off >= 32 * ind) return 1;                               // a pts_linears bias
+    if (i == 0) return 0;
+    if (i == 3) return off % ind < 93 ? 0 : 1;                   // layer 3: the Fourier columns, then the h_2 columns
+    return 1;
+}
+// flat[e] += 2^-k sum over the slots of e's role of partial[slot][e]: k_reduce_partials_scaled for the slots k_decode_bwd_roles
+// wrote (slots [0, nP) = role P, [nP, nP + nH) = H, the rest = C; elements a role does not own are NOT written there).
+template <int CDIM, int NOUT>
+__global__ __launch_bounds__(256) void k_reduce_partials_roles(const float* __restrict__ partial, int nP, int nH, int nslots, int stride,
+                                                               float* __restrict__ flat, const float* __restrict__ gmax) {
+    constexpr int n = DecLayout<CDIM, NOUT>::F_TOTAL;
+    __shared__ float s_p[8][32];
+    const int ex = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + ex;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < n) {
+        const int role = role_of_element<CDIM, NOUT>(e);
+        const int lo = role == 0 ? 0 : (role == 1 ? nP : nP + nH), hi = role == 0 ? nP : (role == 1 ? nP + nH : nslots);
+        int k = lo + sg;
+        for (; k + 8 < hi; k += 16) { s0 += partial[(long long)k * stride + e]; s1 += partial[(long long)(k + 8) * stride + e]; }
+        if (k < hi) s0 += partial[(long long)k * stride + e];
+    }
+    s_p[sg][ex] = s0 + s1;
+    __syncthreads();
+    if (sg == 0 && e < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += s_p[g][ex];
+        const float S = grad_scale(gmax);
+        const float inv = __uint_as_float((254u - (__float_as_uint(S) >> 23)) << 23);      // exact reciprocal of a power of two
+        flat[e] += t * inv;
+    }
 }

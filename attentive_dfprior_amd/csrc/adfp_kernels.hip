@@ -2280,12 +2280,16 @@ static int run_decode_bwd_p(DecodeBwdArgs a, int total, const int* count_ptr, fl
 // left.  Weight gradients: the G part of the staging rows is chunked like the exact path's rows (so that a chunk is still in
 // the Infinity Cache when k_outer_h reads it back); the X part lies in `act` for all rows.
 #define ADFP_BWDH_NT 384
+#ifdef ADFP_TUNE_ROLE_SHARES       // tuning builds only (the product library reads no environment): ADFP_ROLE_SHARES="<P>,<H>" of 256
 static int role_share_env(int which, int dflt) {
     const char* e = getenv("ADFP_ROLE_SHARES");
     int v[2];
     if (!e || sscanf(e, "%d,%d", &v[0], &v[1]) != 2 || v[0] < 1 || v[1] < 1 || v[0] + v[1] > 254) return dflt;
     return v[which];
 }
+#else
+static constexpr int role_share_env(int, int dflt) { return dflt; }
+#endif
 // sort of the call's points for k_scatter_sorted (set up once per backward call by backward_points)
 // Sorts n (key, value) pairs by the low key_bits bits of the key, stable.  The two buffer pairs are used in turn; *key_fin / *val_fin
 // = the pair the last pass wrote (a / b).  table: ADFP_RS_DIGITS * (ceil(n / ADFP_RS_TILE) + 1) ints.
@@ -2388,23 +2392,27 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
                 const int nwg = (ntiles + 3) / 4;
                 nslot = nwg < OUTER_NSLOT ? nwg : OUTER_NSLOT;
                 hipLaunchKernelGGL((k_decode_bwd_fused<NOUT, ROLE>), dim3(nslot), dim3(256), 0, st, f);
+                ADFP_CHECK_LAUNCH();
+                hipLaunchKernelGGL(k_reduce_partials_scaled, dim3((DecLayout<CDIM, NOUT>::F_TOTAL + 31) / 32), dim3(256), 0, st, bw.partial, nslot, bw.part_stride,
+                                   DecLayout<CDIM, NOUT>::F_TOTAL, flat, bw.gmax);
             } else {
                 // role-split kernel (adfp_backward_roles.h): one 512-thread workgroup per CU, dealt to the three roles in proportion to
                 // what a tile costs each; every role walks all tiles, so a small call still wants all three
                 int cus = num_cu(); if (cus > OUTER_NSLOT) cus = OUTER_NSLOT;
                 int g = 3 * ((ntiles + 7) / 8);
                 nslot = g < 3 ? 3 : (g > cus ? cus : g);
-                // tuning knob: ADFP_ROLE_SHARES="<P>,<H>" (of 256) overrides the built-in split (read once per process)
+                // (a -DADFP_TUNE_ROLE_SHARES build takes the split from the environment: how the shares were tuned, tools/build_ab_libs.sh)
                 static const int share_p = role_share_env(0, ROLE_SHARE_P), share_h = role_share_env(1, ROLE_SHARE_H);
                 int nP = (nslot * share_p + 128) / 256, nH = (nslot * share_h + 128) / 256;
                 if (nP < 1) nP = 1;
                 if (nH < 1) nH = 1;
                 while (nP + nH > nslot - 1) { if (nP > nH) --nP; else --nH; }
                 hipLaunchKernelGGL((k_decode_bwd_roles<NOUT, ROLE>), dim3(nslot), dim3(512), 0, st, f, nP, nH);
+                ADFP_CHECK_LAUNCH();
+                // a slot holds only the elements of its workgroup's role: each element is added up over its owners
+                hipLaunchKernelGGL((k_reduce_partials_roles<CDIM, NOUT>), dim3((DecLayout<CDIM, NOUT>::F_TOTAL + 31) / 32), dim3(256), 0, st, bw.partial, nP, nH, nslot,
+                                   bw.part_stride, flat, bw.gmax);
             }
-            ADFP_CHECK_LAUNCH();
-            hipLaunchKernelGGL(k_reduce_partials_scaled, dim3((DecLayout<CDIM, NOUT>::F_TOTAL + 31) / 32), dim3(256), 0, st, bw.partial, nslot, bw.part_stride,
-                               DecLayout<CDIM, NOUT>::F_TOTAL, flat, bw.gmax);
             ADFP_CHECK_LAUNCH();
             return binned ? scatter_bins(bp, o, gc_rows, flags) : 0;
         }

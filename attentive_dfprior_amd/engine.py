@@ -217,6 +217,14 @@ class Engine(object):
         self._tsdf_cb = (key, cb, t.untyped_storage())
         return cb
 
+    def refresh_tsdf_blocks(self, tsdf_volume, cb):
+        """Re-lay `tsdf_volume` into an existing corner-block copy `cb` IN PLACE (a holder whose captured graphs carry cb's address:
+        MapperIteration after somebody wrote the volume)."""
+        with _lib.device_guard(tsdf_volume.device):
+            td = _lib.AdfpTsdf()
+            self.fill_tsdf(td, tsdf_volume, [])
+            check(lib().adfp_relayout_tsdf(C.byref(td), ptr(cb), _lib.current_stream(tsdf_volume.device)), 'adfp_relayout_tsdf')
+
     # ---- descriptor ----------------------------------------------------------------------
     def scene(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=False, ht_nets=(), keys=None, images=None, state=None,
               tsdf_blocks=False):
@@ -277,8 +285,9 @@ class Engine(object):
         if stage != 'low':
             _lib.fill_bound(sc.tsdf_bnds, self.host_bound(tsdf_bnds, 'tsdf_bnds'))
             self.fill_tsdf(sc.tsdf, tsdf_volume, keep)
-            if tsdf_blocks and not backward:
-                cb = self.tsdf_blocks(tsdf_volume)           # None: not float32 / no room -- the plain volume serves
+            if tsdf_blocks is not None and tsdf_blocks is not False and not backward:
+                # True: this engine's cached copy (None: not float32 / no room -- the plain volume serves); a tensor: the caller's own copy
+                cb = tsdf_blocks if isinstance(tsdf_blocks, torch.Tensor) else self.tsdf_blocks(tsdf_volume)
                 if cb is not None:
                     sc.tsdf.corner_blocks = cb.data_ptr()
                     keep.append(cb)

@@ -185,6 +185,12 @@ class MapperIteration(object):
         self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
         self._loss_scratch = {}                                          # ray count -> scratch of adfp_mapper_loss_step (its ticket word starts at zero)
         self.bound_dev = torch.as_tensor(renderer.bound).to(dev, torch.float64).contiguous()
+        # The Mapper's rays are random pixels of several keyframes (src/Mapper.py:421-436): no two neighbours share a cache line of the
+        # TSDF volume.  The iteration reads the corner-block copy (one aligned 32-byte piece per lookup, Engine.tsdf_blocks) when the
+        # renderer allows it and it fits; the copy is held HERE (captured graphs carry its address) and re-laid in place when
+        # somebody writes the volume (_sync_tsdf_blocks).
+        self._cb = renderer._engine.tsdf_blocks(tsdf_volume) if (getattr(renderer, 'tsdf_blocks', False) and tsdf_volume is not None) else None
+        self._cb_version = tsdf_volume._version if self._cb is not None else None
         # Ray-sharded iteration (new; the reference has no distributed code): every rank passes ITS rays to step(); the loss
         # gradients are combined by ONE RCCL all-reduce (SUM) of a contiguous bucket -- the backward writes the grid and
         # parameter gradients straight into slices of it, in the order low grid | attention net | high grid | colour net |
@@ -266,6 +272,11 @@ class MapperIteration(object):
         return buf.numel() * 4
 
     # ---- the kernel sequence ------------------------------------------------------------------------------------------
+    def _sync_tsdf_blocks(self):
+        if self._cb is not None and self.tsdf._version != self._cb_version:
+            self.rend._engine.refresh_tsdf_blocks(self.tsdf, self._cb)
+            self._cb_version = self.tsdf._version
+
     def _sequence(self, ro, rd, gd, gc, stage, warmup, adam=True):
         L = lib()
         dev, eng, dec, rend = self.dev, self.rend._engine, self.dec, self.rend
@@ -283,7 +294,7 @@ class MapperIteration(object):
         need_flat = {n: (n in used and n in self.nets) for n in ('low', 'high', 'color', 'att')}
         depth, unc, color, weight, aux = eng.render_forward(dec, self.c, ro, rd, gd, self.tsdf, self.tsdf_bnds, rend.bound, stage,
                                                             rend.N_samples, rend.N_surface, rend.lindisp, rend.perturb, None, dmax,
-                                                            train=True, need_flat=need_flat)
+                                                            train=True, need_flat=need_flat, tsdf_blocks=self._cb)
         S = aux['S']
         la = _lib.AdfpLossArgs()
         la.n_rays, la.S, la.stage, la.warmup, la.w_color_loss = N, S, _lib.STAGE[stage], 1 if warmup else 0, self.w_color
@@ -411,6 +422,7 @@ class MapperIteration(object):
         dev = self.dev
         with torch.cuda.device(dev):
             N = rays_o.shape[0]
+            self._sync_tsdf_blocks()
             if not self.use_graph or self.distributed:      # collectives stay out of the graph
                 self._sequence(rays_o.float().contiguous(), rays_d.float().contiguous(), gt_depth.float().contiguous(),
                                gt_color.float().contiguous(), stage, warmup)

@@ -168,13 +168,15 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel_prefix, samples_per_launch, fname='r03_pmc_hbm_traffic.csv'):
+def pmc_traffic(kernel_prefix, samples_per_launch, fname='r05_pmc_hbm_traffic.csv', exact=False):
     """HBM bytes per launch of one kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE,
     separate runs; the csv holds bytes per sample): the counters cannot be read from inside this process, so the figure
     is the PROFILED bytes/sample x this run's samples per launch.  Returns (bytes or None, provenance dict); the csv's
     header carries the source hash of the build it was taken from and `stale` says whether that is this build."""
     import csv
-    for name in (fname.replace('r03_', 'r05_'), fname.replace('r03_', 'r04_'), fname, fname.replace('r03_', 'r02_'), fname.replace('r03_', 'r01_')):
+    stem = fname.split('_', 1)[1]                       # the newest round's file of that name, unless `exact`
+    names = (fname,) if exact else tuple(f'r{r:02d}_{stem}' for r in range(5, 0, -1))
+    for name in names:
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
             break
@@ -202,10 +204,13 @@ GRID_STD_SCALE, GRID_HIGH_EXTRA = 20.0, 100.0
 LC16_MFMA_PER_TILE, LC16_VALU_PER_TILE, LC16_LDS_PER_TILE = 360, 2415, 250      # static counts; ~35 of the VALU are the other branch of the tile hand-out
 
 
-def pmc_sq(kernel_prefix, fname='r04_pmc_sq_forward.txt'):
+def pmc_sq(kernel_prefix, fname='r05_pmc_sq_forward.txt'):
     """MFMA-busy fraction and delivered clock of one kernel from the committed SQ counter summary (tools/pmc_summary.py output)."""
     path = os.path.join(ROOT, 'profiles', fname)
     out = {'file': None}
+    if not os.path.exists(path):
+        fname = fname.replace('r05_', 'r04_')
+        path = os.path.join(ROOT, 'profiles', fname)
     if not os.path.exists(path):
         return out
     out['file'] = 'profiles/' + fname
@@ -905,7 +910,7 @@ def config5_leg(A, synthetic, _lib, L, dev, n_rays=131072, NS=96, NF=32):
     t_all, t_tsdf, band, _ = measure('pixel')
     t_all_r, t_tsdf_r, band_r, ex = measure('random')
     by = float(TSDF_BYTES_PER_SAMPLE) * P
-    traffic, prov = pmc_traffic('k_tsdf', P, 'r03_pmc_hbm_config5.csv')
+    traffic, prov = pmc_traffic('k_tsdf', P, 'r05_pmc_hbm_config5.csv')
     gb = lambda t: by / t / 1e9
     return {'workload': '16 m cube, 1024^3 TSDF (4.29 GB), 128 samples/ray (96 + 32), 131 072 rays = 8 poses x 16 384 consecutive pixels '
                         '(render_img order) = one GPU\'s share of BASELINE.json configs[4]', 'value': n_rays / t_all, 'unit': 'rays/s',
@@ -920,7 +925,7 @@ def config5_leg(A, synthetic, _lib, L, dev, n_rays=131072, NS=96, NF=32):
                                  'as_given': {'value': n_rays / ex['t_all_blocks'], 'ms_per_batch': ex['t_all_blocks'] * 1e3,
                                               'tsdf_algorithmic_gbps': gb(ex['given_blocks']), 'tsdf_avg_launch_ms': ex['given_blocks'] * 1e3,
                                               'tsdf_frac_of_hbm_peak': gb(ex['given_blocks']) / PEAK_HBM_GBPS,
-                                              'tsdf_counter_bytes_per_sample': pmc_traffic('k_tsdf', 1, 'r05_pmc_hbm_config5_random.csv')[0]},
+                                              'tsdf_counter_bytes_per_sample': pmc_traffic('k_tsdf', 1, 'r05_pmc_hbm_config5_random.csv', exact=True)[0]},
                                  'sorted': {'value': n_rays / ex['t_auto_sorted'], 'ms_per_batch': ex['t_auto_sorted'] * 1e3,
                                             'tsdf_algorithmic_gbps': gb(ex['sorted_blocks']), 'tsdf_avg_launch_ms': ex['sorted_blocks'] * 1e3,
                                             'tsdf_frac_of_hbm_peak': gb(ex['sorted_blocks']) / PEAK_HBM_GBPS,
@@ -929,7 +934,8 @@ def config5_leg(A, synthetic, _lib, L, dev, n_rays=131072, NS=96, NF=32):
                                  'plain_volume': {'what': 'the same batches with the TSDF read as it stands (the round-4 path: four 8-byte column pieces per lookup)',
                                                   'as_given': {'value': n_rays / t_all_r, 'ms_per_batch': t_all_r * 1e3, 'tsdf_algorithmic_gbps': gb(t_tsdf_r),
                                                                'tsdf_avg_launch_ms': t_tsdf_r * 1e3,
-                                                               'tsdf_counter_bytes_per_sample': pmc_traffic('k_tsdf', 1, 'r04_pmc_hbm_config5_random.csv')[0]},
+                                                               'tsdf_counter_bytes_per_sample': pmc_traffic('k_tsdf', 1, 'r04_pmc_hbm_config5_random.csv', exact=True)[0],
+                                                               'tsdf_counter_file': 'profiles/r04_pmc_hbm_config5_random.csv (round 4, the plain volume rendered as given)'},
                                                   'sorted': {'tsdf_algorithmic_gbps': gb(ex['sorted_plain']), 'tsdf_avg_launch_ms': ex['sorted_plain'] * 1e3}},
                                  'tsdf_layout': 'corner blocks: [X][Y][Z][8] float32, one aligned 32-byte piece per trilinear lookup (adfp_relayout_tsdf, 34 GB for this volume, built once)',
                                  'note': 'the same volume and sample count with each pose\'s rays drawn at random from its image: consecutive rays share no '

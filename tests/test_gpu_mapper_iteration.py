@@ -116,6 +116,37 @@ def test_graph_replays_with_new_rays():
         assert_adam_trajectory(p, q, 0.005, 3, n)
 
 
+def test_iteration_reads_the_corner_block_tsdf_and_follows_a_rewritten_volume():
+    """The iteration reads the corner-block copy of the TSDF volume (Engine.tsdf_blocks) -- the same values as the volume itself, so
+    the losses are the plain-volume iteration's bit for bit -- and when somebody writes the volume in place (TSDF fusion between
+    keyframes) the copy is re-laid at its address, which the captured graph keeps using."""
+    sc, dec, rend, rays, masks = setup()
+    dec_b, dec_c = copy.deepcopy(dec), copy.deepcopy(dec)
+    tsdf, tb = sc.tsdf_volume.to(DEV).clone(), sc.tsdf_bnds.to(DEV)
+    tsdf_b = tsdf.clone()
+    ga, gb, gc_ = ({k: v.clone().to(DEV) for k, v in sc.c.items()} for _ in range(3))
+    rend_plain = A.Renderer(make_cfg(32, 16), None, sc)
+    rend_plain.tsdf_blocks = False
+    it_a = mapping.MapperIteration(A.Renderer(make_cfg(32, 16), None, sc), dec, ga, masks, tsdf, tb, STAGE_LR, use_graph=True)
+    it_b = mapping.MapperIteration(rend_plain, dec_b, gb, masks, tsdf_b, tb, STAGE_LR, use_graph=False)
+    assert it_a._cb is not None and it_b._cb is None
+    address = it_a._cb.data_ptr()
+    for k in range(2):
+        la, lb = float(it_a.step(*rays, 'color')), float(it_b.step(*rays, 'color'))
+        assert la == lb if k == 0 else abs(la - lb) <= 1e-6 * abs(lb), (k, la, lb)      # (from the second step on the atomics' order tells)
+    # the volume changes under both (in place): every value moved, the band with it
+    for t in (tsdf, tsdf_b):
+        t.mul_(0.5).add_(0.01)
+    for k in range(2):
+        la, lb = float(it_a.step(*rays, 'color')), float(it_b.step(*rays, 'color'))
+        assert abs(la - lb) <= 1e-6 * abs(lb), ('after the rewrite', k, la, lb)
+    assert it_a._cb.data_ptr() == address
+    # and differs from an iteration that still saw the old volume
+    it_c = mapping.MapperIteration(rend_plain, dec_c, gc_, masks, sc.tsdf_volume.to(DEV), tb, STAGE_LR, use_graph=False)
+    lc = [float(it_c.step(*rays, 'color')) for _ in range(4)]
+    assert abs(lc[3] - la) > 1e-3 * abs(la)
+
+
 def test_eager_calls_between_graph_replays_see_valid_caches():
     """Three stages captured into one shared graph pool, replayed out of capture order, and an eager render with the SAME
     decoders / grids in between (what Visualizer.vis, the Tracker and the Mesher do while the Mapper iterates): the eager

@@ -11,6 +11,7 @@ one role1 -DADFP_EXP_ONLY_ROLE=1 &
 one role2 -DADFP_EXP_ONLY_ROLE=2 &
 one roles_span -DADFP_STAMPS_ROLES &
 wait
+one tune_shares -DADFP_TUNE_ROLE_SHARES &
 one train_NOX -DADFP_EXP_TRAIN_NOX &
 one train_NOHEADC -DADFP_EXP_TRAIN_NOHEADC &
 wait
