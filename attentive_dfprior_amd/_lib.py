@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ADFP_LIB_PATH', os.path.join(_HERE, 'libadfp.so'))   # override: kernel A/B builds
 
-ABI_VERSION = 126                 # ADFP_VERSION of include/adfp.h this binding was written against
+ABI_VERSION = 127                 # ADFP_VERSION of include/adfp.h this binding was written against
 STATUS_F16_RANGE = 31              # ADFP_STATUS_F16_RANGE: any of the bits below
 STATUS_RANGE_BITS = {'low': 1, 'high': 2, 'color': 4, 'att': 8, 'bwd': 16}      # ADFP_STATUS_F16_RANGE_<net>
 BWD_SCATTER_IN_KERNEL = 1        # ADFP_BWD_SCATTER_IN_KERNEL
@@ -38,6 +38,13 @@ class AdfpTsdf(C.Structure):
 
 class AdfpPackJob(C.Structure):
     _fields_ = [('net', C.c_int), ('format', C.c_int), ('flat', C.c_void_p), ('packed', C.c_void_p)]
+
+
+class AdfpKeyframe(C.Structure):
+    _fields_ = [('idx', C.c_void_p), ('c2w', C.c_void_p), ('c2w_host', C.c_float * 12), ('depth_img', C.c_void_p), ('color_img', C.c_void_p)]
+
+
+KEYFRAMES_MAX = 16
 
 
 class AdfpScene(C.Structure):
@@ -190,6 +197,8 @@ SYMBOLS = [
     ('adfp_camera_from_tensor_backward', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_select_pixels', C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_sample_keyframes', C.c_int, [C.c_int, C.POINTER(AdfpKeyframe), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_tracker_loss', C.c_int, [C.POINTER(AdfpTrackLossArgs), C.c_void_p]),
     ('adfp_track_keep_best', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_sort_workspace_bytes', C.c_size_t, [C.c_longlong]),

@@ -134,6 +134,61 @@ def get_samples(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, c2w, depth, color, devi
     return rays_o, rays_d, sample_depth, sample_color
 
 
+def get_samples_multi(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, frames, device, out=None):
+    """The Mapper's ray batch of one iteration (reference src/Mapper.py:421-436): ``get_samples`` for every ``(c2w, depth, color)`` of
+    ``frames`` and the four ``torch.cat`` after it, as the per-frame ``torch.randint`` draws (in order: the index stream of the
+    sequential calls) and ONE kernel (``adfp_sample_keyframes``).  Returns ``(rays_o, rays_d, gt_depth, gt_color)`` with ``n`` rows per
+    frame, equal bit for bit to the concatenated ``get_samples`` results; ``out`` = four tensors to fill instead (the static input
+    buffers of ``mapping.MapperIteration.input_buffers``).  No gradient towards the poses: a pose that requires grad, a frame on the
+    host or more than 16 frames take the per-frame path."""
+    dev = torch.device(device)
+    fast = dev.type == 'cuda' and 0 < len(frames) <= _lib.KEYFRAMES_MAX
+    for c2w, depth, color in frames:
+        fast = fast and (isinstance(depth, torch.Tensor) and depth.is_cuda and color.is_cuda and depth.dtype == torch.float32
+                         and color.dtype == torch.float32 and depth.dim() == 2 and tuple(color.shape) == (depth.shape[0], depth.shape[1], 3)
+                         and tuple(depth.shape) == tuple(frames[0][1].shape) and depth.device == frames[0][1].device
+                         and not (isinstance(c2w, torch.Tensor) and c2w.requires_grad and torch.is_grad_enabled()))
+    if not fast:
+        parts = [get_samples(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, c2w, depth, color, device) for c2w, depth, color in frames]
+        res = tuple(torch.cat([p[k].float() for p in parts]) for k in range(4))
+        if out is not None:
+            for dst, src in zip(out, res):
+                dst.copy_(src)
+            return tuple(out)
+        return res
+    d0 = frames[0][1]
+    Hd, Wd = d0.shape
+    total = n * len(frames)
+    with _lib.device_guard(d0.device):
+        if out is None:
+            out = (torch.empty((total, 3), dtype=torch.float32, device=d0.device), torch.empty((total, 3), dtype=torch.float32, device=d0.device),
+                   torch.empty((total,), dtype=torch.float32, device=d0.device), torch.empty((total, 3), dtype=torch.float32, device=d0.device))
+        for t, shape in zip(out, ((total, 3), (total, 3), (total,), (total, 3))):
+            _lib.require_cuda(t, 'out')
+            if tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError(f'get_samples_multi: out tensors must be contiguous float32 of shapes [{total},3], [{total},3], [{total}], [{total},3]')
+        jobs = (_lib.AdfpKeyframe * len(frames))()
+        keep = []
+        for k, (c2w, depth, color) in enumerate(frames):
+            pick = torch.randint((H1 - H0) * (W1 - W0), (n,), device=d0.device)            # src/common.py:101 (its clamp changes nothing)
+            d, c = depth.contiguous(), color.contiguous()
+            keep += [pick, d, c]
+            jobs[k].idx, jobs[k].depth_img, jobs[k].color_img = pick.data_ptr(), d.data_ptr(), c.data_ptr()
+            if isinstance(c2w, torch.Tensor) and c2w.is_cuda:
+                m = c2w.detach().float().contiguous()                     # [4,4] or [3,4]: rows 0-2 are read with a stride of 4
+                if tuple(m.shape) not in ((4, 4), (3, 4)):
+                    raise ValueError(f'c2w: expected [4,4] or [3,4], got {tuple(m.shape)}')
+                keep.append(m)
+                jobs[k].c2w = m.data_ptr()
+            else:
+                m = np.asarray(c2w.detach().cpu().numpy() if isinstance(c2w, torch.Tensor) else c2w, dtype=np.float32)
+                jobs[k].c2w = None
+                jobs[k].c2w_host[:] = [float(v) for v in m[:3, :4].reshape(-1)]
+        check(lib().adfp_sample_keyframes(len(frames), jobs, n, H0, H1, W0, W1, Hd, Wd, float(fx), float(fy), float(cx), float(cy),
+                                          ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), _lib.current_stream(d0.device)), 'adfp_sample_keyframes')
+    return tuple(out)
+
+
 def filter_rays_in_bound(batch_rays_o, batch_rays_d, batch_gt_depth, batch_gt_color, bound):
     """The Mapper's pre-filter "should pre-filter those out of bounding box depth value"
     (reference src/Mapper.py:438-449): keeps the rays whose sensor depth lies inside the bounding box,

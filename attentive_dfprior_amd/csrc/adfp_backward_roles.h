@@ -34,10 +34,10 @@
 // share of the workgroups per role, in 1/256: proportional to (time of the role alone) x (its workgroups) measured with the
 // timing-only builds -DADFP_EXP_ONLY_ROLE=0/1/2 (tools/ab_roles.sh, profiles/r05_ab_backward_roles.txt)
 #ifndef ROLE_SHARE_P
-#define ROLE_SHARE_P 104
+#define ROLE_SHARE_P 106
 #endif
 #ifndef ROLE_SHARE_H
-#define ROLE_SHARE_H 82
+#define ROLE_SHARE_H 78
 #endif
 
 #ifdef ADFP_STAMPS_ROLES           // debug build (tools/roles_span.py): per workgroup (role, wall-clock start, end of the tile loop, end), 100 MHz

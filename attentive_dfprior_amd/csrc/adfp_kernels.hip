@@ -1989,6 +1989,25 @@ int adfp_select_pixels(const long long* idx, int n, int H0, int H1, int W0, int 
     ADFP_CHECK_LAUNCH();
     return 0;
 }
+int adfp_sample_keyframes(int n_frames, const adfp_keyframe* frames, int n, int H0, int H1, int W0, int W1, int H, int W, float fx, float fy, float cx,
+                          float cy, float* rays_o, float* rays_d, float* gt_depth, float* gt_color, void* stream) {
+    if (n_frames < 0 || n_frames > ADFP_KEYFRAMES_MAX || n < 0 || H0 < 0 || W0 < 0 || H1 > H || W1 > W || H1 <= H0 || W1 <= W0) return ADFP_E_ARG;
+    if (n_frames == 0 || n == 0) return 0;
+    if (!frames || !rays_o || !rays_d || !gt_depth || !gt_color) return ADFP_E_ARG;
+    if ((long long)n_frames * n > 0x7fffffffll) return ADFP_E_UNSUPPORTED;
+    KeyframeJobs a;
+    for (int f = 0; f < ADFP_KEYFRAMES_MAX; ++f) {
+        const adfp_keyframe& k = frames[f < n_frames ? f : 0];
+        if (f < n_frames && (!k.idx || !k.depth_img || !k.color_img)) return ADFP_E_ARG;
+        a.idx[f] = k.idx; a.c2w[f] = k.c2w; a.depth[f] = k.depth_img; a.color[f] = k.color_img;
+        for (int m = 0; m < 12; ++m) a.pose[f][m] = k.c2w_host[m];
+    }
+    a.n_frames = n_frames; a.n = n; a.H0 = H0; a.W0 = W0; a.Ww = W1 - W0; a.W = W; a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy;
+    a.ro = rays_o; a.rd = rays_d; a.gd = gt_depth; a.gc = gt_color;
+    hipLaunchKernelGGL(k_sample_keyframes, dim3((n_frames * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
 int adfp_track_keep_best(const double* loss, const float* cam, double* best_loss, float* best_cam, void* stream) {
     if (!loss || !cam || !best_loss || !best_cam) return ADFP_E_ARG;
     hipLaunchKernelGGL(k_keep_best, dim3(1), dim3(64), 0, (hipStream_t)stream, loss, cam, best_loss, best_cam);

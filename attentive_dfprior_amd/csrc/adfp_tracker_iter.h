@@ -62,6 +62,35 @@ __global__ __launch_bounds__(256) void k_select_pixels(const long long* __restri
     gc[3 * t] = color[3 * p]; gc[3 * t + 1] = color[3 * p + 1]; gc[3 * t + 2] = color[3 * p + 2];
 }
 
+// k_select_pixels + k_rays_from_uv for every keyframe of the Mapper's window in one launch (adfp_sample_keyframes): thread t = ray
+// t % n of frame t / n.  The ray arithmetic is k_rays_from_uv's, operation by operation.
+struct KeyframeJobs {
+    const long long* idx[ADFP_KEYFRAMES_MAX]; const float* c2w[ADFP_KEYFRAMES_MAX]; const float* depth[ADFP_KEYFRAMES_MAX];
+    const float* color[ADFP_KEYFRAMES_MAX]; float pose[ADFP_KEYFRAMES_MAX][12];
+    int n_frames, n, H0, W0, Ww, W; float fx, fy, cx, cy;
+    float* ro; float* rd; float* gd; float* gc;
+};
+__global__ __launch_bounds__(256) void k_sample_keyframes(KeyframeJobs a) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.n_frames * a.n) return;
+    const int f = t / a.n;
+    const long long k = a.idx[f][t - f * a.n];
+    const int row = a.H0 + (int)(k / a.Ww), col = a.W0 + (int)(k % a.Ww);
+    const long long p = (long long)row * a.W + col;
+    a.gd[t] = a.depth[f][p];
+    a.gc[3 * t] = a.color[f][3 * p]; a.gc[3 * t + 1] = a.color[f][3 * p + 1]; a.gc[3 * t + 2] = a.color[f][3 * p + 2];
+    const float pi = (float)col, pj = (float)row;
+    const float dx = (pi - a.cx) / a.fx, dy = -(pj - a.cy) / a.fy, dz = -1.f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        float c0, c1, c2, c3;
+        if (a.c2w[f]) { c0 = a.c2w[f][4 * m]; c1 = a.c2w[f][4 * m + 1]; c2 = a.c2w[f][4 * m + 2]; c3 = a.c2w[f][4 * m + 3]; }
+        else { c0 = a.pose[f][4 * m]; c1 = a.pose[f][4 * m + 1]; c2 = a.pose[f][4 * m + 2]; c3 = a.pose[f][4 * m + 3]; }
+        a.rd[3 * t + m] = __fadd_rn(__fadd_rn(__fmul_rn(dx, c0), __fmul_rn(dy, c1)), __fmul_rn(dz, c2));
+        a.ro[3 * t + m] = c3;
+    }
+}
+
 // loss = sum_mask |gt_d - d| / sqrt(unc + 1e-10)  +  w_color sum_mask |gt_c - c|,   mask = kept & (gt_d > 0) [& tmp < 10 median(tmp)]
 // (handle_dynamic; torch.median = the lower middle element of the kept rays' tmp).  ONE workgroup: tracking batches are a few
 // hundred to a few thousand rays.  uncertainty is detached in the reference (:115), so it gets no cotangent.

@@ -417,6 +417,17 @@ class MapperIteration(object):
             self.rend._engine.adopt_grid_cl(k, g, self.shadow[k])
 
     @torch.no_grad()
+    def input_buffers(self, N):
+        """The four static tensors (rays_o [N,3], rays_d [N,3], gt_depth [N], gt_color [N,3]) the captured graphs of an N-ray iteration
+        read.  A caller that produces its batch straight into them (``common.get_samples_multi(..., out=it.input_buffers(N))``) and
+        passes them to ``step`` saves the copy."""
+        st = self._static.get(N)
+        if st is None:
+            dev = self.dev
+            st = self._static[N] = (torch.empty((N, 3), device=dev), torch.empty((N, 3), device=dev), torch.empty((N,), device=dev),
+                                    torch.empty((N, 3), device=dev))
+        return st
+
     def step(self, rays_o, rays_d, gt_depth, gt_color, stage, warmup=False):
         """One iteration; returns the loss as a device float64 tensor (reading it synchronises -- do so sparingly)."""
         dev = self.dev
@@ -437,12 +448,11 @@ class MapperIteration(object):
             def graph_key():
                 return (N, stage, bool(warmup), frozenset(self.dec._exact_latch))
             key = graph_key()
-            st = self._static.get(N)
-            if st is None:
-                st = self._static[N] = (torch.empty((N, 3), device=dev), torch.empty((N, 3), device=dev), torch.empty((N,), device=dev),
-                                        torch.empty((N, 3), device=dev))
+            st = self.input_buffers(N)
             srcs = (rays_o, rays_d, gt_depth, gt_color)
-            if all(s_.dtype == torch.float32 and s_.device == d_.device and s_.shape == d_.shape for d_, s_ in zip(st, srcs)):
+            if all(s_ is d_ for d_, s_ in zip(st, srcs)):
+                pass                                            # the caller filled the static buffers itself (common.get_samples_multi(out=...))
+            elif all(s_.dtype == torch.float32 and s_.device == d_.device and s_.shape == d_.shape for d_, s_ in zip(st, srcs)):
                 torch._foreach_copy_(list(st), list(srcs))      # ONE multi-tensor launch (four copies were ~15 us of GPU time per replay)
             else:
                 for dst, src in zip(st, srcs):

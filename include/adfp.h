@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 126
+#define ADFP_VERSION 127
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -524,6 +524,22 @@ int adfp_camera_from_tensor_backward(const float* cam, const float* g_c2w /*[16]
 int adfp_select_pixels(const long long* idx /*[n] int64 device*/, int n, int H0, int H1, int W0, int W1, int H, int W,
                        const float* depth_img, const float* color_img, float* pix_i, float* pix_j, float* gt_depth, float* gt_color,
                        void* stream);
+/* The Mapper's ray batch of one iteration (src/Mapper.py:421-436: get_samples per keyframe of the optimisation window, then four
+ * torch.cat) in ONE launch: frame f contributes n rays -- pixel idx[t] of the window like adfp_select_pixels, its ray like
+ * adfp_rays_from_uv (bit for bit), sensor depth and colour -- at rows [f n, f n + n) of the outputs.  The draws stay the caller's (one
+ * torch.randint per frame: the reference's index stream).  c2w: device [4,4] row-major fp32, or NULL and the pose in c2w_host (rows
+ * 0-2 of the matrix, row-major).  No gradient towards the poses (bundle adjustment takes the per-frame entries). */
+#define ADFP_KEYFRAMES_MAX 16
+typedef struct adfp_keyframe {
+    const long long* idx;      /* [n] int64, device */
+    const float* c2w;          /* device, or NULL */
+    float c2w_host[12];
+    const float* depth_img;    /* [H,W] fp32 */
+    const float* color_img;    /* [H,W,3] fp32 */
+} adfp_keyframe;
+int adfp_sample_keyframes(int n_frames, const adfp_keyframe* frames /*host*/, int n, int H0, int H1, int W0, int W1, int H, int W,
+                          float fx, float fy, float cx, float cy, float* rays_o /*[n_frames n,3]*/, float* rays_d, float* gt_depth /*[n_frames n]*/,
+                          float* gt_color /*[n_frames n,3]*/, void* stream);
 /* The tracking loss (src/Tracker.py:115-129) and its cotangents:
  *   tmp = |gt_depth - depth| / sqrt(uncertainty + 1e-10)        (float64, uncertainty detached)
  *   mask = keep & (gt_depth > 0) [& tmp < 10 median(tmp over the kept rays) when handle_dynamic]

@@ -258,6 +258,21 @@ int main() {
     EXPECT_NEG(adfp_select_pixels(dev<long long>(1), 100, 5, 4, 0, 64, 48, 64, dev<float>(2), dev<float>(3), dev<float>(4), dev<float>(5), dev<float>(6), dev<float>(7), st));      // H1 <= H0
     EXPECT_NEG(adfp_select_pixels(dev<long long>(1), 100, 0, 49, 0, 64, 48, 64, dev<float>(2), dev<float>(3), dev<float>(4), dev<float>(5), dev<float>(6), dev<float>(7), st));     // window beyond the image
     EXPECT_REACHES_LAUNCH(adfp_select_pixels(dev<long long>(1), 100, 4, 44, 4, 60, 48, 64, dev<float>(2), dev<float>(3), dev<float>(4), dev<float>(5), dev<float>(6), dev<float>(7), st));
+    {
+        adfp_keyframe kf[2];
+        memset(kf, 0, sizeof(kf));
+        for (int f = 0; f < 2; ++f) { kf[f].idx = dev<long long>(1 + f); kf[f].depth_img = dev<float>(3); kf[f].color_img = dev<float>(4); }
+        kf[1].c2w = dev<float>(5);
+        EXPECT_NEG(adfp_sample_keyframes(2, kf, 100, 5, 4, 0, 64, 48, 64, 50.f, 50.f, 32.f, 24.f, dev<float>(6), dev<float>(7), dev<float>(8), dev<float>(9), st));       // H1 <= H0
+        EXPECT_NEG(adfp_sample_keyframes(ADFP_KEYFRAMES_MAX + 1, kf, 100, 0, 48, 0, 64, 48, 64, 50.f, 50.f, 32.f, 24.f, dev<float>(6), dev<float>(7), dev<float>(8), dev<float>(9), st));
+        EXPECT_NEG(adfp_sample_keyframes(2, nullptr, 100, 0, 48, 0, 64, 48, 64, 50.f, 50.f, 32.f, 24.f, dev<float>(6), dev<float>(7), dev<float>(8), dev<float>(9), st));
+        EXPECT_NEG(adfp_sample_keyframes(2, kf, 100, 0, 48, 0, 64, 48, 64, 50.f, 50.f, 32.f, 24.f, nullptr, dev<float>(7), dev<float>(8), dev<float>(9), st));
+        kf[1].idx = nullptr;
+        EXPECT_NEG(adfp_sample_keyframes(2, kf, 100, 0, 48, 0, 64, 48, 64, 50.f, 50.f, 32.f, 24.f, dev<float>(6), dev<float>(7), dev<float>(8), dev<float>(9), st));
+        kf[1].idx = dev<long long>(2);
+        EXPECT_CODE(adfp_sample_keyframes(0, kf, 100, 0, 48, 0, 64, 48, 64, 50.f, 50.f, 32.f, 24.f, dev<float>(6), dev<float>(7), dev<float>(8), dev<float>(9), st), 0);
+        EXPECT_REACHES_LAUNCH(adfp_sample_keyframes(2, kf, 100, 4, 44, 4, 60, 48, 64, 50.f, 50.f, 32.f, 24.f, dev<float>(6), dev<float>(7), dev<float>(8), dev<float>(9), st));
+    }
     EXPECT_NEG(adfp_track_keep_best(nullptr, dev<float>(1), dev<double>(2), dev<float>(3), st));
     EXPECT_REACHES_LAUNCH(adfp_track_keep_best(dev<double>(4), dev<float>(1), dev<double>(2), dev<float>(3), st));
     EXPECT_NEG(adfp_sort_pairs(dev<int>(1), dev<int>(2), dev<int>(3), dev<int>(4), 1000, 0, dev<void>(5), 1 << 20, st));

@@ -134,6 +134,48 @@ def test_get_samples_fast_path_equals_the_reference_composition():
     assert gd3.dtype == torch.float64 and ro3.shape == (500, 3)
 
 
+def test_get_samples_multi_equals_the_sequential_calls():
+    """common.get_samples_multi (the per-frame draws + ONE adfp_sample_keyframes launch) against get_samples per keyframe and the four
+    torch.cat of src/Mapper.py:421-436, on the same generator state: bit for bit; poses on the device ([4,4] and [3,4]), on the host
+    (tensor, numpy), filling caller-owned buffers, and the per-frame fallback (a float64 depth image)."""
+    import numpy as np
+    sc = synthetic.mini_scene(device=DEV)
+    H, W = sc.H, sc.W
+    g = torch.Generator().manual_seed(11)
+    frames = []
+    for k in range(5):
+        c2w = sc.default_c2w(yaw=0.3 * k, pitch=0.05 * k, offset=(0.1 * k, 0.0, 0.05 * k))
+        c2w = (c2w.to(DEV), c2w.to(DEV)[:3].contiguous(), c2w.cpu(), c2w.cpu().numpy(), c2w.to(DEV))[k]
+        frames.append((c2w, torch.rand(H, W, generator=g).to(DEV), torch.rand(H, W, 3, generator=g).to(DEV)))
+    args = (H, W, sc.fx, sc.fy, sc.cx, sc.cy)
+    for (H0, H1, W0, W1) in ((0, H, 0, W), (EDGE, H - EDGE, EDGE, W - EDGE)):
+        torch.manual_seed(7)
+        parts = [common.get_samples(H0, H1, W0, W1, 333, *args, c2w if not isinstance(c2w, np.ndarray) else c2w, d, c, DEV) for c2w, d, c in frames]
+        want = [torch.cat([p[k].float() for p in parts]) for k in range(4)]
+        torch.manual_seed(7)
+        got = common.get_samples_multi(H0, H1, W0, W1, 333, *args, frames, DEV)
+        for a, b, name in zip(got, want, ('rays_o', 'rays_d', 'gt_depth', 'gt_color')):
+            assert a.shape == b.shape and torch.equal(a, b), name
+        out = tuple(torch.full_like(t, float('nan')) for t in want)
+        torch.manual_seed(7)
+        res = common.get_samples_multi(H0, H1, W0, W1, 333, *args, frames, DEV, out=out)
+        assert all(r is o for r, o in zip(res, out)) and all(torch.equal(a, b) for a, b in zip(out, want))
+    # the next draw continues the stream where the sequential calls would
+    torch.manual_seed(7)
+    for c2w, d, c in frames:
+        common.get_samples(0, H, 0, W, 333, *args, c2w, d, c, DEV)
+    nxt = torch.randint(1000, (4,), device=DEV)
+    torch.manual_seed(7)
+    common.get_samples_multi(0, H, 0, W, 333, *args, frames, DEV)
+    assert torch.equal(torch.randint(1000, (4,), device=DEV), nxt)
+    # per-frame fallback
+    torch.manual_seed(7)
+    slow = common.get_samples_multi(0, H, 0, W, 50, *args, [(frames[0][0], frames[0][1].double(), frames[0][2])], DEV)
+    assert slow[0].shape == (50, 3) and slow[2].dtype == torch.float32
+    with pytest.raises(ValueError):
+        common.get_samples_multi(0, H, 0, W, 50, *args, frames, DEV, out=tuple(t[:10] for t in want))
+
+
 def run_loss(depth, unc, color, gd, gc, keep, handle_dynamic, w_color):
     n = depth.shape[0]
     la = _lib.AdfpTrackLossArgs()

@@ -171,14 +171,14 @@ def _map_frame_fused(self, f, n_iters, lr_factor, c2w, depth, frames):
     first = last = None
     for i in range(n_iters):
         stage = stage_of(i, n_iters)
-        ros, rds, gds, gcs = [], [], [], []
-        for kc2w, kdepth in frames:
-            ro, rd, gd, gc = common.get_samples(0, H, 0, W, self.rays // len(frames), H, W, fx, fy, cx, cy, kc2w, kdepth, self.target_color, dev)
-            ros.append(ro.float()); rds.append(rd.float()); gds.append(gd.float()); gcs.append(gc.float())
-        loss = it.step(torch.cat(ros), torch.cat(rds), torch.cat(gds), torch.cat(gcs), stage, warmup=(low_end < i <= low_end + 5 and f <= 1))
+        # the window's rays (src/Mapper.py:421-436: get_samples per keyframe + four torch.cat) straight into the iteration's input buffers
+        n_each = self.rays // len(frames)
+        batch = common.get_samples_multi(0, H, 0, W, n_each, H, W, fx, fy, cx, cy, [(kc2w, kdepth, self.target_color) for kc2w, kdepth in frames],
+                                         dev, out=it.input_buffers(n_each * len(frames)))
+        loss = it.step(*batch, stage, warmup=(low_end < i <= low_end + 5 and f <= 1))
         self.n_iter += 1
         if i == 0 or i == n_iters - 1:
-            n_rays = sum(r.shape[0] for r in ros)
+            n_rays = n_each * len(frames)
             v = float(loss) / n_rays                       # total loss per ray (the loop's only read-backs: first and last iteration)
             first = v if i == 0 else first
             last = v
