@@ -71,6 +71,7 @@ def parse():
     ap.add_argument('--scene', default='room0')
     ap.add_argument('--cpu-rays', type=int, default=20000, help='ray sample of the CPU baseline leg (0 = skip)')
     ap.add_argument('--no-stage-timing', action='store_true')
+    ap.add_argument('--no-shard-model', action='store_true', help='skip config.shard_model (its shard-sized launches would mix into a kernel-trace profile of the timed loop)')
     ap.add_argument('--no-extra', action='store_true', help='headline + roofline only (skip sustained / config5 / torch-gpu / dist legs)')
     return ap.parse_args()
 
@@ -358,7 +359,7 @@ def main():
         result['weak'] = {'value': n_gpus * n_rays * max(2, min(args.steps, 5)) / el_w, 'unit': 'rays/s', 'n_gpus': n_gpus, 'scaling': 'weak',
                           'ms_per_step': el_w / max(2, min(args.steps, 5)) * 1e3,
                           'workload': 'one whole 640x480 frame per rank per step (one pose per rank), no data-path collective'}
-    elif rank == 0:
+    elif rank == 0 and not args.no_shard_model:
         try:
             result['config']['shard_model'] = shard_model(rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, n_rays)
         except Exception as e:

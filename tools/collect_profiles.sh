@@ -66,7 +66,7 @@ if want bench; then
   ADFP_MATH=f32 into $O/${R}_bench_f32.json bench_f32 python bench.py --cpu-rays 0 --no-extra
   prof_stats $O/prof_bench prof_bench python3 bench.py --cpu-rays 0
   run sum_bench python profiles/summarize.py $O/prof_bench $O/${R}_kernel_stats_bench.csv
-  prof_stats $O/prof_headline prof_headline python3 bench.py --cpu-rays 0 --no-extra --no-stage-timing
+  prof_stats $O/prof_headline prof_headline python3 bench.py --cpu-rays 0 --no-extra --no-stage-timing --no-shard-model
   run sum_headline python profiles/summarize.py $O/prof_headline $O/${R}_kernel_stats_headline.csv
 fi
 
