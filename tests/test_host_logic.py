@@ -130,3 +130,40 @@ def test_get_tensor_from_camera_normalises_like_mathutils():
         noisy[:3, :3] += 1e-4 * torch.randn(3, 3, generator=g)                     # accumulated float error: not exactly a rotation
         q = common.get_tensor_from_camera(noisy)
         assert abs(float(q[:4].norm()) - 1.0) < 1e-6 and (q - ref).abs().max() < 1e-3
+
+
+def test_get_tensor_from_camera_against_scipy_rotation():
+    """mathutils (what src/common.py:192-195 converts the matrix with) is absent from the image, so the conversion has no vector of
+    the reference's own.  An INDEPENDENT implementation of the same map pins it instead: scipy.spatial.transform.Rotation
+    (matrix -> unit quaternion), over random rotations, rotations by almost 180 degrees about every axis (the trace <= 0
+    branches) and the identity -- the same rotation, with the sign the r >= 0 convention picks."""
+    import numpy as np
+    import torch
+    from scipy.spatial.transform import Rotation
+    from attentive_dfprior_amd import common
+    rng = np.random.default_rng(5)
+    mats = [Rotation.random(random_state=int(k)).as_matrix() for k in range(200)]
+    for axis in np.eye(3):
+        for ang in (np.pi - 1e-3, np.pi - 1e-6, np.pi, 2.5, -3.0):
+            mats.append(Rotation.from_rotvec(axis * ang).as_matrix())
+    for k in range(40):                                                   # near-180-degree turns about random axes
+        v = rng.normal(size=3)
+        mats.append(Rotation.from_rotvec(v / np.linalg.norm(v) * (np.pi - 10.0 ** -rng.uniform(1, 7))).as_matrix())
+    mats.append(np.eye(3))
+    for R in mats:
+        RT = np.eye(4)
+        RT[:3, :3] = R
+        RT[:3, 3] = rng.normal(size=3)
+        got = common.get_tensor_from_camera(torch.from_numpy(RT)).double().numpy()
+        x, y, z, w = Rotation.from_matrix(R).as_quat()
+        ref = np.array([w, x, y, z])
+        ref = -ref if ref[0] < 0 else ref
+        q = got[:4]
+        assert abs(np.linalg.norm(q) - 1.0) < 1e-6
+        assert min(np.abs(q - ref).max(), np.abs(q + ref).max()) < 2e-6, (q, ref)      # (r = 0 exactly: either sign is the r >= 0 branch)
+        assert q[0] >= 0
+        assert np.abs(got[4:] - RT[:3, 3]).max() < 1e-6
+        # and it is the quaternion get_camera_from_tensor (src/common.py:165-178, pinned by mini_pose.npz) turns back into R
+        back = common.get_camera_from_tensor(torch.from_numpy(got).float()).double().numpy()
+        assert np.abs(back[:3, :3] - R).max() < 5e-6
+
