@@ -1,7 +1,7 @@
 // adfp_backward.h -- backward kernels of the render path (Mapper loss -> grids + decoder
 // parameters, reference src/Mapper.py:457-473 through autograd).  Included by adfp_kernels.hip.
 //
-//   k_composite_bwd    d(depth, uncertainty, colour)/d(raw)               common.py:234-251
+//   composite_bwd_block  d(depth, uncertainty, colour)/d(raw), part of k_backward_head    common.py:234-251
 //   k_attention_bwd    mlp_tsdf backward on the in-band list              decoder.py:240-258
 //   k_decode_bwd<...>  decoder backward: recompute forward (ReLU masks), transposed MFMA chains
 //                      out of the SAME padded LDS image, feature-gradient scatter into the
@@ -44,13 +44,19 @@ ADFP_DEV void stage_block_mul(float* __restrict__ row, int col, int h, const VT&
 //   G_s = gD' z_s + gV (z_s - depth)^2 + gC . c_s,  gD' = gD - 2 gV (swz - depth sw)
 // ------------------------------------------------------------------------------------------
 #define CB_MAXC 4
-__global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__ raw, const double* __restrict__ z, int n_rays, int S,
-                                                       const double* __restrict__ g_depth, const double* __restrict__ g_var,
-                                                       const float* __restrict__ g_color, float* __restrict__ g_raw,
-                                                       const unsigned char* __restrict__ keep, float* __restrict__ gmax,
-                                                       const float* __restrict__ g_weight, const int* __restrict__ skip) {
+struct CompositeBwdArgs {
+    const float* raw; const double* z; int n_rays, S;
+    const double* g_depth; const double* g_var; const float* g_color; float* g_raw;
+    const unsigned char* keep; float* gmax; const float* g_weight; const int* skip;
+};
+// workgroup `blk` of the launch (256 threads: four rays); a device function so that k_backward_head can run it beside other jobs
+ADFP_DEV void composite_bwd_block(const CompositeBwdArgs& a, int blk) {
+    const float* __restrict__ raw = a.raw; const double* __restrict__ z = a.z; const int n_rays = a.n_rays, S = a.S;
+    const double* __restrict__ g_depth = a.g_depth; const double* __restrict__ g_var = a.g_var; const float* __restrict__ g_color = a.g_color;
+    float* __restrict__ g_raw = a.g_raw; const unsigned char* __restrict__ keep = a.keep; float* __restrict__ gmax = a.gmax;
+    const float* __restrict__ g_weight = a.g_weight; const int* __restrict__ skip = a.skip;
     const int lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ray = blk * 4 + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
     // skip: the forward call was repaired by the f32 fallback (adfp_fallback.h) -- its training state is not valid, the whole
     // call returns zero gradients
@@ -137,22 +143,6 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
     }
 }
 
-// out[0] = max(parts[0 .. n)) by ONE workgroup of NT threads (all of them call)
-template <int NT>
-ADFP_DEV void max_fold_block(const float* __restrict__ parts, int n, float* __restrict__ out) {
-    __shared__ float s_m[NT / 64];
-    float mx = 0.f;
-    for (int i = threadIdx.x; i < n; i += NT) mx = fmaxf(mx, parts[i]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float m = s_m[0];
-        for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, s_m[w]);
-        *out = m;
-    }
-}
 __global__ __launch_bounds__(1024) void k_max_reduce(const float* __restrict__ parts, int n, float* __restrict__ out) {
     max_fold_block<1024>(parts, n, out);
 }

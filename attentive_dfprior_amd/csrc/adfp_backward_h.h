@@ -404,9 +404,8 @@ ADFP_DEV int cell_axis(float pn, int size) {                 // i0 of tri_axis
     const int i0 = (int)floorf(c);
     return i0 < 0 ? 0 : i0;
 }
-__global__ __launch_bounds__(256) void k_bin_keys(BinArgs a) {
-    if (a.max_parts && blockIdx.x == gridDim.x - 1) { max_fold_block<256>(a.max_parts, a.max_n, a.max_out); return; }
-    const int q = blockIdx.x * 256 + threadIdx.x;
+ADFP_DEV void bin_keys_block(const BinArgs& a, int blk) {
+    const int q = blk * 256 + threadIdx.x;
     if (q >= a.P.n) return;
     double pt[3]; float pn[3];
     load_point(a.P, q, pt);
@@ -428,6 +427,10 @@ __global__ __launch_bounds__(256) void k_bin_keys(BinArgs a) {
     }
     a.key[q] = (int)(((((cc[2] * (unsigned)a.CY) + cc[1]) * (unsigned)a.CX + cc[0]) << 6) | off);
     a.val[q] = q;
+}
+__global__ __launch_bounds__(256) void k_bin_keys(BinArgs a) {
+    if (a.max_parts && blockIdx.x == gridDim.x - 1) { max_fold_block<256>(a.max_parts, a.max_n, a.max_out); return; }
+    bin_keys_block(a, (int)blockIdx.x);
 }
 
 struct ScatterSortedArgs {

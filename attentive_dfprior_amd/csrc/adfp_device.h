@@ -638,3 +638,20 @@ ADFP_DEV int claim_tile(int& j, int* s_next, int ntiles) {
 #endif
     return tile;
 }
+
+// out[0] = max(parts[0 .. n)) by ONE workgroup of NT threads (all of them call)
+template <int NT>
+ADFP_DEV void max_fold_block(const float* __restrict__ parts, int n, float* __restrict__ out) {
+    __shared__ float s_m[NT / 64];
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < n; i += NT) mx = fmaxf(mx, parts[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = s_m[0];
+        for (int w = 1; w < NT / 64; ++w) m = fmaxf(m, s_m[w]);
+        *out = m;
+    }
+}

@@ -43,12 +43,12 @@ __global__ __launch_bounds__(256) void k_zero(unsigned* __restrict__ p, long lon
 // several buffers in ONE launch
 #define ZERO_MULTI 8
 struct ZeroJobs { unsigned* p[ZERO_MULTI]; long long words[ZERO_MULTI]; unsigned first_block[ZERO_MULTI + 1]; int n; };
-__global__ __launch_bounds__(256) void k_zero_multi(ZeroJobs z) {
+__device__ inline void zero_multi_block(const ZeroJobs& z, unsigned blk) {
     int j = 0;
-    while (j + 1 < z.n && blockIdx.x >= z.first_block[j + 1]) ++j;
+    while (j + 1 < z.n && blk >= z.first_block[j + 1]) ++j;
     unsigned* p = z.p[j];
     const long long n_words = z.words[j], n4 = n_words >> 2;
-    const long long b = blockIdx.x - z.first_block[j], stride = (long long)(z.first_block[j + 1] - z.first_block[j]) * 256;
+    const long long b = blk - z.first_block[j], stride = (long long)(z.first_block[j + 1] - z.first_block[j]) * 256;
     if ((((unsigned long long)p) & 15ull) == 0) {
         for (long long i = b * 256 + threadIdx.x; i < n4; i += stride) ((uint4*)p)[i] = uint4{0u, 0u, 0u, 0u};
         for (long long i = (n4 << 2) + b * 256 + threadIdx.x; i < n_words; i += stride) p[i] = 0u;
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void k_zero_multi(ZeroJobs z) {
         for (long long i = b * 256 + threadIdx.x; i < n_words; i += stride) p[i] = 0u;
     }
 }
+__global__ __launch_bounds__(256) void k_zero_multi(ZeroJobs z) { zero_multi_block(z, blockIdx.x); }
 struct ZeroBatch {
     ZeroJobs z; unsigned blocks;
     ZeroBatch() : blocks(0) { z.n = 0; z.first_block[0] = 0; }
@@ -2145,11 +2146,14 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
 #define OUTER_NSLOT 256         // workgroups per weight-gradient launch = private gradient copies (one per CU)
 struct BwdWorkspace { float* g_raw; float* att_g; float* g_pts; float* stage; int stage_rows; float* partial; int part_stride; float* gmax; float* gmax_parts;
                       int gmax_pending;              // > 0: gmax_parts[0 .. gmax_pending) still wait to be folded into gmax (backward_points)
+                      // adfp_render_backward's first two launches (zero fill of the gradient outputs, k_composite_bwd), held back so that
+                      // backward_points can send them off in ONE launch with k_bin_keys (k_backward_head)
+                      bool head_pending; ZeroJobs head_zero; unsigned head_zero_blocks; CompositeBwdArgs head_comp;
                       float* gc; size_t gc_stride; int* bin_key; int* bin_val; int* bin_key_sorted; int* bin_perm; int* sort_table;
                       size_t bytes; };
 static BwdWorkspace carve_bwd(void* base, long long P) {
     BwdWorkspace w; size_t o = 0;
-    w.gmax_pending = 0;
+    w.gmax_pending = 0; w.head_pending = false;
     w.g_raw = at<float>(base, o); o += align256((size_t)P * 16);
     w.att_g = at<float>(base, o); o += align256((size_t)P * 4);
     w.g_pts = at<float>(base, o); o += align256((size_t)P * 12);
@@ -2313,16 +2317,19 @@ static constexpr int role_share_env(int, int dflt) { return dflt; }
 // Sorts n (key, value) pairs by the low key_bits bits of the key, stable.  The two buffer pairs are used in turn; *key_fin / *val_fin
 // = the pair the last pass wrote (a / b).  table: ADFP_RS_DIGITS * (ceil(n / ADFP_RS_TILE) + 1) ints.
 static int radix_sort_pairs(int* key_a, int* val_a, int* key_b, int* val_b, int n, int key_bits, int* table, const int** key_fin,
-                            const int** val_fin, hipStream_t st) {
+                            const int** val_fin, hipStream_t st, const float* max_parts = nullptr, int max_n = 0, float* max_out = nullptr) {
     RadixArgs rs; rs.table = table; rs.n = n; rs.ntiles = (n + ADFP_RS_TILE - 1) / ADFP_RS_TILE;
+    rs.max_parts = nullptr; rs.max_n = 0; rs.max_out = nullptr;
     constexpr int db = ADFP_RS_DIGIT_BITS, nd = ADFP_RS_DIGITS;
     rs.totals = table + (size_t)nd * rs.ntiles;
     const int passes = (key_bits + db - 1) / db;
     int* kin = key_a; int* vin = val_a; int* kout = key_b; int* vout = val_b;
     for (int ps = 0; ps < passes; ++ps) {
         rs.key_in = kin; rs.val_in = vin; rs.key_out = kout; rs.val_out = vout; rs.shift = db * ps;
-        hipLaunchKernelGGL(k_rs_hist<db>, dim3(rs.ntiles), dim3(256), 0, st, rs);
+        if (ps == 0 && max_parts) { rs.max_parts = max_parts; rs.max_n = max_n; rs.max_out = max_out; }      // one more workgroup: the fold
+        hipLaunchKernelGGL(k_rs_hist<db>, dim3(rs.ntiles + (rs.max_parts ? 1 : 0)), dim3(256), 0, st, rs);
         ADFP_CHECK_LAUNCH();
+        rs.max_parts = nullptr;
         hipLaunchKernelGGL(k_rs_scan, dim3(nd / 4), dim3(256), 0, st, rs.table, rs.ntiles, rs.totals);
         ADFP_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_rs_scatter<db>, dim3(rs.ntiles), dim3(256), 0, st, rs);
@@ -2348,6 +2355,30 @@ extern "C" int adfp_sort_pairs(int* key, int* val, int* key_tmp, int* val_tmp, l
         if (e == hipSuccess) e = hipMemcpyAsync(val, vf, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
     }
+    return 0;
+}
+
+// The head of a backward call in ONE launch: the zero fill of the gradient outputs, the compositing backward and the sort keys are
+// independent of each other (three launches of 5-7 us each inside a graph replay).  Workgroups [0, nb_comp) = k_composite_bwd's,
+// then nb_bin of k_bin_keys', then the zero fill's; nb_bin may be 0 (no sorted scatter in the call).
+struct BwdHeadArgs { CompositeBwdArgs c; BinArgs b; ZeroJobs z; int nb_comp, nb_bin; };
+__global__ __launch_bounds__(256) void k_backward_head(BwdHeadArgs h) {
+    int blk = (int)blockIdx.x;
+    if (blk < h.nb_comp) { composite_bwd_block(h.c, blk); return; }
+    blk -= h.nb_comp;
+    if (blk < h.nb_bin) { bin_keys_block(h.b, blk); return; }
+    zero_multi_block(h.z, (unsigned)(blk - h.nb_bin));
+}
+static int launch_backward_head(BwdWorkspace& bw, const BinArgs* bins, int P, hipStream_t st) {
+    BwdHeadArgs h;
+    h.c = bw.head_comp; h.z = bw.head_zero;
+    h.nb_comp = (bw.head_comp.n_rays + 3) / 4;
+    h.nb_bin = bins ? (P + 255) / 256 : 0;
+    if (bins) h.b = *bins; else memset(&h.b, 0, sizeof(h.b));
+    h.b.max_parts = nullptr;
+    hipLaunchKernelGGL(k_backward_head, dim3(h.nb_comp + h.nb_bin + bw.head_zero_blocks), dim3(256), 0, st, h);
+    ADFP_CHECK_LAUNCH();
+    bw.head_pending = false;
     return 0;
 }
 
@@ -2483,7 +2514,13 @@ static int run_decode_bwd(DecodeBwdArgs a, int total, const int* count_ptr, floa
 // gradient outputs shared by the two backward entries
 struct GradOut { float* grid_low; float* grid_high; float* grid_color; float* flat_low; float* flat_high; float* flat_color; float* flat_att; };
 
+static int zero_grad_jobs(const adfp_scene* sc, const GradOut& g, int options, ZeroBatch& zb, hipStream_t st);
 static int zero_grad_outputs(const adfp_scene* sc, const GradOut& g, int options, hipStream_t st) {
+    ZeroBatch zb;
+    int rc = zero_grad_jobs(sc, g, options, zb, st); if (rc) return rc;
+    return (int)zb.flush(st);
+}
+static int zero_grad_jobs(const adfp_scene* sc, const GradOut& g, int options, ZeroBatch& zb, hipStream_t st) {
     const bool zg = !(options & ADFP_BWD_GRIDS_PREZEROED);
     struct { float* p; size_t n; } zs[7] = {
         {zg ? g.grid_low : nullptr, (size_t)sc->low.Z * sc->low.Y * sc->low.X * 32},
@@ -2491,10 +2528,9 @@ static int zero_grad_outputs(const adfp_scene* sc, const GradOut& g, int options
         {zg ? g.grid_color : nullptr, (size_t)sc->color.Z * sc->color.Y * sc->color.X * 32},
         {g.flat_low, (size_t)DecLayout<32, 1>::F_TOTAL}, {g.flat_high, (size_t)DecLayout<64, 1>::F_TOTAL},
         {g.flat_color, (size_t)DecLayout<32, 4>::F_TOTAL}, {g.flat_att, (size_t)AttLayout::F_TOTAL}};
-    ZeroBatch zb;
     for (int k = 0; k < 7; ++k)
         if (zs[k].p) { hipError_t e = zb.add(zs[k].p, zs[k].n * 4, st); if (e != hipSuccess) return (int)e; }
-    return (int)zb.flush(st);
+    return 0;
 }
 
 // DF.forward backward over P points: bw.g_raw holds the cotangent of raw [P,4] (the attention pass reads .w and rewrites it
@@ -2540,13 +2576,21 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
                 BinArgs& b = bp.args;
                 b.P = Pd; b.nb = a.nb; b.CX = coarse->X; b.CY = coarse->Y; b.CZ = coarse->Z; b.RX = fine->X; b.RY = fine->Y; b.RZ = fine->Z;
                 b.key = bw.bin_key; b.val = bw.bin_val;
-                b.max_parts = bw.gmax_pending > 0 ? bw.gmax_parts : nullptr; b.max_n = bw.gmax_pending; b.max_out = bw.gmax;
-                hipLaunchKernelGGL(k_bin_keys, dim3((P + 255) / 256 + (b.max_parts ? 1 : 0)), dim3(256), 0, st, b);
+                const float* fold_parts = nullptr;            // the per-ray maxima still to be folded: by the sort's first launch when the
+                int fold_n = 0;                               // head carries k_composite_bwd (they are not written yet), else by k_bin_keys
+                if (bw.head_pending) {
+                    rc = launch_backward_head(bw, &b, P, st); if (rc) return rc;
+                    if (bw.gmax_pending > 0) { fold_parts = bw.gmax_parts; fold_n = bw.gmax_pending; }
+                } else {
+                    b.max_parts = bw.gmax_pending > 0 ? bw.gmax_parts : nullptr; b.max_n = bw.gmax_pending; b.max_out = bw.gmax;
+                    hipLaunchKernelGGL(k_bin_keys, dim3((P + 255) / 256 + (b.max_parts ? 1 : 0)), dim3(256), 0, st, b);
+                    ADFP_CHECK_LAUNCH();
+                }
                 bw.gmax_pending = 0;
-                ADFP_CHECK_LAUNCH();
                 // stable LSD radix sort (adfp_sort.h), ping-pong between the two buffer pairs
                 const int* vfin = nullptr;
-                rc = radix_sort_pairs(bw.bin_key, bw.bin_val, bw.bin_key_sorted, bw.bin_perm, P, bin_key_bits(coarse->X, coarse->Y, coarse->Z), bw.sort_table, nullptr, &vfin, st);
+                rc = radix_sort_pairs(bw.bin_key, bw.bin_val, bw.bin_key_sorted, bw.bin_perm, P, bin_key_bits(coarse->X, coarse->Y, coarse->Z), bw.sort_table, nullptr, &vfin, st,
+                                      fold_parts, fold_n, bw.gmax);
                 if (rc) return rc;
                 const int* vin = vfin;
                 bp.perm = vin;                      // the pair the last pass wrote
@@ -2555,6 +2599,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         }
     }
 
+    if (bw.head_pending) { rc = launch_backward_head(bw, nullptr, P, st); if (rc) return rc; }      // no sorted scatter: zero fill + compositing backward
     if (bw.gmax_pending > 0) {                       // no sorted scatter in this call: the fold is a launch of its own
         hipLaunchKernelGGL(k_max_reduce, dim3(1), dim3(1024), 0, st, bw.gmax_parts, bw.gmax_pending, bw.gmax);
         ADFP_CHECK_LAUNCH();
@@ -2684,14 +2729,20 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
     if (fuse && (!r->state.flags || !r->state.list || !r->state.counter || !r->state.att_occ || !r->state.att_u)) return ADFP_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     const GradOut go = {r->g_grid_low, r->g_grid_high, r->g_grid_color, r->g_flat_low, r->g_flat_high, r->g_flat_color, r->g_flat_att};
-    rc = zero_grad_outputs(sc, go, r->options, st); if (rc) return rc;       // every non-NULL output is zeroed, then accumulated into
-    if (r->n_rays == 0) return 0;
+    if (r->n_rays == 0) return zero_grad_outputs(sc, go, r->options, st);    // every non-NULL output is zeroed, then accumulated into
     const int P = (int)Pn;
-
-    hipLaunchKernelGGL(k_composite_bwd, dim3((r->n_rays + 3) / 4), dim3(256), 0, st, r->raw, r->z_vals, r->n_rays, r->S,
-                       r->g_depth, r->g_uncertainty, r->g_color, bw.g_raw, r->ray_keep, bw.gmax_parts, r->g_weight, r->state.counter ? r->state.counter + 8 : nullptr);
-    ADFP_CHECK_LAUNCH();
-    bw.gmax_pending = r->n_rays;                     // folded into bw.gmax by backward_points' first launch
+    // the zero fill and the compositing backward leave with backward_points' first launch (k_backward_head)
+    {
+        ZeroBatch zb;
+        rc = zero_grad_jobs(sc, go, r->options, zb, st); if (rc) return rc;
+        bw.head_zero = zb.z; bw.head_zero_blocks = zb.blocks;
+        bw.head_zero.n = zb.z.n;
+        CompositeBwdArgs& c = bw.head_comp;
+        c.raw = r->raw; c.z = r->z_vals; c.n_rays = r->n_rays; c.S = r->S; c.g_depth = r->g_depth; c.g_var = r->g_uncertainty; c.g_color = r->g_color;
+        c.g_raw = bw.g_raw; c.keep = r->ray_keep; c.gmax = bw.gmax_parts; c.g_weight = r->g_weight; c.skip = r->state.counter ? r->state.counter + 8 : nullptr;
+        bw.head_pending = true;
+    }
+    bw.gmax_pending = r->n_rays;                     // folded into bw.gmax by the sort's first launch (or k_max_reduce)
 
     PtsDev Pd;
     Pd.mode = ADFP_PTS_RAYS; Pd.S = r->S; Pd.n = P; Pd.pts = nullptr; Pd.ro = r->rays_o; Pd.rd = r->rays_d; Pd.z = r->z_vals;

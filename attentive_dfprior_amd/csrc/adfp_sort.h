@@ -23,6 +23,9 @@ struct RadixArgs {
     int* table;                // [digits][ntiles] tile counts, row-scanned by k_rs_scan
     int* totals;               // [digits] keys per digit
     int n, ntiles, shift;
+    // side job of one more workgroup of k_rs_hist (the first pass of the backward's sort only): out[0] = max(parts[0 .. max_n)), the
+    // fold of the per-ray cotangent maxima (adfp_backward.h: max_fold_block); NULL = none
+    const float* max_parts; int max_n; float* max_out;
 };
 
 // lanes of the wave whose `active` digit equals mine
@@ -40,6 +43,7 @@ ADFP_DEV unsigned long long match_digit(int d, bool active) {
 template <int BITS>
 __global__ __launch_bounds__(256) void k_rs_hist(RadixArgs a) {
     constexpr int NB = 1 << BITS;
+    if (a.max_parts && (int)blockIdx.x == a.ntiles) { max_fold_block<256>(a.max_parts, a.max_n, a.max_out); return; }
     __shared__ int s_cnt[4][NB];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 4 * NB; i += 256) (&s_cnt[0][0])[i] = 0;

@@ -38,11 +38,12 @@ def main(template, d):
     iters = int(next(r for k, r in tr.items() if 'k_mapper_loss' in k)['calls'])
     per = lambda *names: sum(float(r['total_ms']) * 1e3 / iters for k, r in tr.items() if any(n in k for n in names))
     zero = per('k_zero_multi')
-    v['train_head'] = '%.0f' % (per('k_prefilter_mask', 'k_pack_multi', 'k_sample', 'k_tsdf(') + zero / 2)
+    head = per('k_backward_head')
+    v['train_head'] = '%.0f' % (per('k_prefilter_mask', 'k_pack_multi', 'k_sample', 'k_tsdf(') + (zero if head else zero / 2))
     v['k_decode_lc16_train'] = '%.0f' % per('k_decode_lc16_train')
     v['train_inband_fwd'] = '%.0f' % per('k_decode_h<64', 'k_attention_h<1')
     v['train_mid'] = '%.0f' % per('k_fallback_points', 'k_composite(', 'k_mapper_loss')
-    v['train_bwd_head'] = '%.0f' % (per('k_composite_bwd', 'k_bin_keys') + zero / 2)
+    v['train_bwd_head'] = '%.0f' % (head if head else per('k_composite_bwd', 'k_bin_keys') + zero / 2)
     v['train_sort'] = '%.0f' % per('k_rs_')
     v['train_att_bwd'] = '%.0f' % per('k_attention_bwd_h', 'k_outer_h', 'k_reduce_partials_scaled')
     v['train_hl_bwd'] = '%.0f' % per('k_decode_bwd_h<')
