@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ADFP_LIB_PATH', os.path.join(_HERE, 'libadfp.so'))   # override: kernel A/B builds
 
-ABI_VERSION = 127                 # ADFP_VERSION of include/adfp.h this binding was written against
+ABI_VERSION = 129                 # ADFP_VERSION of include/adfp.h this binding was written against
 STATUS_F16_RANGE = 31              # ADFP_STATUS_F16_RANGE: any of the bits below
 STATUS_RANGE_BITS = {'low': 1, 'high': 2, 'color': 4, 'att': 8, 'bwd': 16}      # ADFP_STATUS_F16_RANGE_<net>
 BWD_SCATTER_IN_KERNEL = 1        # ADFP_BWD_SCATTER_IN_KERNEL
@@ -94,7 +94,8 @@ class AdfpRenderArgs(C.Structure):
                 ('depth', C.c_void_p), ('uncertainty', C.c_void_p), ('color', C.c_void_p),
                 ('weight', C.c_void_p), ('z_vals', C.c_void_p), ('raw', C.c_void_p),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('state', C.POINTER(AdfpTrainState)),
-                ('depth_max_segment', C.c_int), ('depth_max_first_ray', C.c_int)]
+                ('depth_max_segment', C.c_int), ('depth_max_first_ray', C.c_int),
+                ('pack_jobs', C.c_void_p), ('n_pack_jobs', C.c_int)]
 
 
 class AdfpBackwardArgs(C.Structure):
@@ -193,6 +194,7 @@ SYMBOLS = [
                                        C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     ('adfp_masked_adam_multi', C.c_int, [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     ('adfp_adam_grids_cl', C.c_int, [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    ('adfp_adam_step', C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     ('adfp_camera_from_tensor', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_camera_from_tensor_backward', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_select_pixels', C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -1167,10 +1167,10 @@ ADFP_DEV void pack_decoder_any(int fmt, int blk, const float* flat, unsigned* ou
     else if (fmt == ADFP_IMAGE_G) pack_decoder_g_block<CDIM, NOUT>(blk, flat, out + DecLayoutH<CDIM, NOUT>::P_TOTAL, status, bit);      // the G part lies behind the H part
     else pack_decoder_ht_block<CDIM, NOUT>(blk, flat, out, status, bit);
 }
-__global__ __launch_bounds__(256) void k_pack_multi(PackJobs j) {
+__device__ inline void pack_multi_block(const PackJobs& j, int block) {
     int k = 0;
-    while (k + 1 < j.n && (int)blockIdx.x >= j.first[k + 1]) ++k;          // block-uniform
-    const int blk = (int)blockIdx.x - j.first[k], fmt = j.fmt[k];
+    while (k + 1 < j.n && block >= j.first[k + 1]) ++k;                     // block-uniform
+    const int blk = block - j.first[k], fmt = j.fmt[k];
     const float* flat = j.flat[k];
     unsigned* out = j.out[k];
     switch (j.net[k]) {
@@ -1182,6 +1182,25 @@ __global__ __launch_bounds__(256) void k_pack_multi(PackJobs j) {
             else if (fmt == ADFP_IMAGE_G) pack_attention_g_block(blk, flat, out + AttLayoutH::P_TOTAL, j.status);
             else pack_attention_ht_block(blk, flat, out, j.status);
     }
+}
+__global__ __launch_bounds__(256) void k_pack_multi(PackJobs j) { pack_multi_block(j, (int)blockIdx.x); }
+// the first launch of a render call: the weight images it was handed to pack (adfp_render_args.pack_jobs) and the zero fill of its
+// device words
+struct ForwardHeadArgs { PackJobs p; ZeroJobs z; int nb_pack; };
+__global__ __launch_bounds__(256) void k_forward_head(ForwardHeadArgs h) {
+    if ((int)blockIdx.x < h.nb_pack) pack_multi_block(h.p, (int)blockIdx.x);
+    else zero_multi_block(h.z, blockIdx.x - (unsigned)h.nb_pack);
+}
+static int pack_jobs_table(int n_jobs, const adfp_pack_job* jobs, int* status, PackJobs& j) {
+    if (n_jobs < 0 || n_jobs > ADFP_PACK_MAX_JOBS || (n_jobs && !jobs)) return ADFP_E_ARG;
+    j.n = n_jobs; j.status = status; j.first[0] = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        const int nb = pack_job_blocks(jobs[k].net, jobs[k].format);
+        if (nb <= 0 || !jobs[k].flat || !jobs[k].packed) return ADFP_E_ARG;
+        j.net[k] = jobs[k].net; j.fmt[k] = jobs[k].format; j.flat[k] = jobs[k].flat; j.out[k] = (unsigned*)jobs[k].packed;
+        j.first[k + 1] = j.first[k] + nb;
+    }
+    return 0;
 }
 extern "C" {
 
@@ -1284,15 +1303,9 @@ int adfp_pack_split_image(int net, int which, const float* flat, void* packed, i
     return 0;
 }
 int adfp_pack_images(int n_jobs, const adfp_pack_job* jobs, int* status, void* stream) {
-    if (n_jobs < 0 || n_jobs > ADFP_PACK_MAX_JOBS || (n_jobs && !jobs)) return ADFP_E_ARG;
+    PackJobs j;
+    int rc = pack_jobs_table(n_jobs, jobs, status, j); if (rc) return rc;
     if (n_jobs == 0) return 0;
-    PackJobs j; j.n = n_jobs; j.status = status; j.first[0] = 0;
-    for (int k = 0; k < n_jobs; ++k) {
-        const int nb = pack_job_blocks(jobs[k].net, jobs[k].format);
-        if (nb <= 0 || !jobs[k].flat || !jobs[k].packed) return ADFP_E_ARG;
-        j.net[k] = jobs[k].net; j.fmt[k] = jobs[k].format; j.flat[k] = jobs[k].flat; j.out[k] = (unsigned*)jobs[k].packed;
-        j.first[k + 1] = j.first[k] + nb;
-    }
     hipLaunchKernelGGL(k_pack_multi, dim3(j.first[n_jobs]), dim3(256), 0, (hipStream_t)stream, j);
     ADFP_CHECK_LAUNCH();
     return 0;
@@ -1895,9 +1908,9 @@ int adfp_masked_adam_dev(float* param, const float* grad, float* exp_avg, float*
     ADFP_CHECK_LAUNCH();
     return 0;
 }
-int adfp_masked_adam_multi(int n_groups, const adfp_adam_group* groups, float beta1, float beta2, float eps, void* stream) {
+static int adam_multi_table(int n_groups, const adfp_adam_group* groups, float beta1, float beta2, float eps, AdamMultiArgs& m) {
     if (n_groups < 0 || n_groups > ADFP_ADAM_MULTI || (n_groups && !groups)) return ADFP_E_ARG;
-    AdamMultiArgs m; m.n = 0; m.first_block[0] = 0;
+    m.n = 0; m.first_block[0] = 0;
     for (int k = 0; k < n_groups; ++k) {
         const adfp_adam_group& g = groups[k];
         if (!g.param || !g.grad || !g.exp_avg || !g.exp_avg_sq || !g.derived || g.nvox < 0 || g.channels <= 0) return ADFP_E_ARG;
@@ -1909,14 +1922,11 @@ int adfp_masked_adam_multi(int n_groups, const adfp_adam_group* groups, float be
         m.first_block[m.n + 1] = m.first_block[m.n] + (unsigned)((threads + 255) / 256);
         ++m.n;
     }
-    if (m.n == 0) return 0;
-    hipLaunchKernelGGL(k_masked_adam_multi, dim3(m.first_block[m.n]), dim3(256), 0, (hipStream_t)stream, m);
-    ADFP_CHECK_LAUNCH();
     return 0;
 }
-int adfp_adam_grids_cl(int n_groups, const adfp_adam_cl_group* groups, float beta1, float beta2, float eps, void* stream) {
+static int adam_cl_table(int n_groups, const adfp_adam_cl_group* groups, float beta1, float beta2, float eps, AdamClMultiArgs& m) {
     if (n_groups < 0 || n_groups > ADFP_ADAM_CL_MULTI || (n_groups && !groups)) return ADFP_E_ARG;
-    AdamClMultiArgs m; m.n = 0; m.first_block[0] = 0;
+    m.n = 0; m.first_block[0] = 0;
     for (int k = 0; k < n_groups; ++k) {
         const adfp_adam_cl_group& g = groups[k];
         if (!g.param_cl || !g.param_cm || !g.grad_cl || !g.exp_avg_cl || !g.exp_avg_sq_cl || !g.derived || g.nvox < 0) return ADFP_E_ARG;
@@ -1927,8 +1937,33 @@ int adfp_adam_grids_cl(int n_groups, const adfp_adam_cl_group* groups, float bet
         m.first_block[m.n + 1] = m.first_block[m.n] + (unsigned)((g.nvox + 63) / 64);
         ++m.n;
     }
+    return 0;
+}
+int adfp_masked_adam_multi(int n_groups, const adfp_adam_group* groups, float beta1, float beta2, float eps, void* stream) {
+    AdamMultiArgs m;
+    int rc = adam_multi_table(n_groups, groups, beta1, beta2, eps, m); if (rc) return rc;
+    if (m.n == 0) return 0;
+    hipLaunchKernelGGL(k_masked_adam_multi, dim3(m.first_block[m.n]), dim3(256), 0, (hipStream_t)stream, m);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+int adfp_adam_grids_cl(int n_groups, const adfp_adam_cl_group* groups, float beta1, float beta2, float eps, void* stream) {
+    AdamClMultiArgs m;
+    int rc = adam_cl_table(n_groups, groups, beta1, beta2, eps, m); if (rc) return rc;
     if (m.n == 0) return 0;
     hipLaunchKernelGGL(k_adam_cl_multi, dim3(m.first_block[m.n]), dim3(256), 0, (hipStream_t)stream, m);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+int adfp_adam_step(int n_cl_groups, const adfp_adam_cl_group* cl_groups, int n_groups, const adfp_adam_group* groups, float beta1, float beta2,
+                   float eps, void* stream) {
+    AdamStepArgs s;
+    int rc = adam_cl_table(n_cl_groups, cl_groups, beta1, beta2, eps, s.cl); if (rc) return rc;
+    rc = adam_multi_table(n_groups, groups, beta1, beta2, eps, s.fl); if (rc) return rc;
+    s.cl_blocks = s.cl.n ? s.cl.first_block[s.cl.n] : 0u;
+    const unsigned fl_blocks = s.fl.n ? s.fl.first_block[s.fl.n] : 0u;
+    if (s.cl_blocks + fl_blocks == 0) return 0;
+    hipLaunchKernelGGL(k_adam_step, dim3(s.cl_blocks + fl_blocks), dim3(256), 0, (hipStream_t)stream, s);
     ADFP_CHECK_LAUNCH();
     return 0;
 }
@@ -2097,6 +2132,7 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
     if (!r->rays_o || !r->rays_d || !r->depth || !r->uncertainty || !r->color || !r->weight || !r->workspace) return ADFP_E_ARG;
     if (r->n_rays < 0 || r->n_samples <= 0 || r->n_surface < 0 || r->depth_max_segment < 0) return ADFP_E_ARG;
     if (r->depth_max_first_ray < 0 || (r->depth_max_first_ray > 0 && (!r->depth_max || r->depth_max_segment <= 0 || !r->gt_depth))) return ADFP_E_ARG;
+    if (r->n_pack_jobs < 0 || r->n_pack_jobs > ADFP_PACK_MAX_JOBS || (r->n_pack_jobs && !r->pack_jobs)) return ADFP_E_ARG;
     if (r->state && r->stage != ADFP_STAGE_LOW &&
         (!r->state->flags || !r->state->list || !r->state->counter || !r->state->att_occ || !r->state->att_u)) return ADFP_E_ARG;
     const int S = r->n_samples + (r->gt_depth ? r->n_surface : 0);
@@ -2108,18 +2144,28 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
         return ADFP_E_UNSUPPORTED;
     Workspace ws = carve(r->workspace, Pn);
     if (r->workspace_bytes < ws.bytes) return ADFP_E_WORKSPACE;
-    if (r->n_rays == 0) return 0;
+    if (r->n_rays == 0) return r->n_pack_jobs ? adfp_pack_images(r->n_pack_jobs, r->pack_jobs, scene->status, stream) : 0;   // the images are still owed
     hipStream_t st = (hipStream_t)stream;
     double* z = r->z_vals ? r->z_vals : ws.z;
     float* raw = r->raw ? r->raw : ws.raw;
     // ONE zero fill for the call's small device words: the in-band counter and range flag (bytes 0-63) and the depth-max
     // reduction's scratch (bytes 64-255: up to 48 per-segment maxima) share the first 256 bytes of the workspace
-    {   // ... and, in a training call, the caller's counter block that eval_points_impl uses instead: one launch for both
+    {   // ... and, in a training call, the caller's counter block that eval_points_impl uses instead: one launch for both -- and for
+        // the weight images the caller handed over to pack (k_forward_head)
         ZeroBatch zb;
         hipError_t e = zb.add(ws.counter, 256, st);
         if (e == hipSuccess && r->state && r->state->counter && r->state->counter != ws.counter) e = zb.add(r->state->counter, 64, st);
-        if (e == hipSuccess) e = zb.flush(st);
         if (e != hipSuccess) return (int)e;
+        if (r->n_pack_jobs > 0) {
+            ForwardHeadArgs h;
+            rc = pack_jobs_table(r->n_pack_jobs, r->pack_jobs, scene->status, h.p); if (rc) return rc;
+            h.z = zb.z; h.nb_pack = h.p.first[h.p.n];
+            hipLaunchKernelGGL(k_forward_head, dim3((unsigned)h.nb_pack + zb.blocks), dim3(256), 0, st, h);
+            ADFP_CHECK_LAUNCH();
+        } else {
+            e = zb.flush(st);
+            if (e != hipSuccess) return (int)e;
+        }
     }
     rc = sample_rays_impl(r->rays_o, r->rays_d, r->gt_depth, r->n_rays, scene->bound, r->n_samples, r->n_surface, r->lindisp,
                           r->perturb, r->t_rand, r->depth_max, z, (char*)ws.counter + 64, stream, true, r->depth_max_segment, r->depth_max_first_ray);

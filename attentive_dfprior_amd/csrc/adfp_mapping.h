@@ -141,11 +141,12 @@ __global__ __launch_bounds__(256) void k_masked_adam(AdamArgs a) { masked_adam_b
 // several parameter groups in ONE launch (a Mapper iteration steps five: three grids and two networks)
 #define ADFP_ADAM_MULTI 8
 struct AdamMultiArgs { AdamArgs g[ADFP_ADAM_MULTI]; unsigned first_block[ADFP_ADAM_MULTI + 1]; int n; };
-__global__ __launch_bounds__(256) void k_masked_adam_multi(AdamMultiArgs m) {
+ADFP_DEV void masked_adam_multi_block(const AdamMultiArgs& m, unsigned blk) {
     int j = 0;
-    while (j + 1 < m.n && blockIdx.x >= m.first_block[j + 1]) ++j;
-    masked_adam_block(m.g[j], (long long)blockIdx.x - m.first_block[j]);
+    while (j + 1 < m.n && blk >= m.first_block[j + 1]) ++j;
+    masked_adam_block(m.g[j], (long long)blk - m.first_block[j]);
 }
+__global__ __launch_bounds__(256) void k_masked_adam_multi(AdamMultiArgs m) { masked_adam_multi_block(m, blockIdx.x); }
 ADFP_DEV void masked_adam_block(const AdamArgs& a, long long block) {
     const long long quads = (a.nvox + 3) >> 2;
     const long long t = block * 256 + threadIdx.x;
@@ -175,13 +176,13 @@ struct AdamClArgs {
 };
 #define ADFP_ADAM_CL_MULTI 8
 struct AdamClMultiArgs { AdamClArgs g[ADFP_ADAM_CL_MULTI]; unsigned first_block[ADFP_ADAM_CL_MULTI + 1]; int n; };
-__global__ __launch_bounds__(256) void k_adam_cl_multi(AdamClMultiArgs m) {
+ADFP_DEV void adam_cl_multi_block(const AdamClMultiArgs& m, unsigned blk) {
     __shared__ float tile[32][65];
     __shared__ unsigned char s_mask[64];
     int j = 0;
-    while (j + 1 < m.n && blockIdx.x >= m.first_block[j + 1]) ++j;
+    while (j + 1 < m.n && blk >= m.first_block[j + 1]) ++j;
     const AdamClArgs& a = m.g[j];
-    const long long v0 = ((long long)blockIdx.x - m.first_block[j]) * 64;
+    const long long v0 = ((long long)blk - m.first_block[j]) * 64;
     const int nv = a.nvox - v0 < 64 ? (int)(a.nvox - v0) : 64;
     if (threadIdx.x < 64) s_mask[threadIdx.x] = ((int)threadIdx.x < nv && (!a.mask || a.mask[v0 + threadIdx.x])) ? 1 : 0;
     __syncthreads();
@@ -215,4 +216,12 @@ __global__ __launch_bounds__(256) void k_adam_cl_multi(AdamClMultiArgs m) {
     if (tx < nv && s_mask[tx])
 #pragma unroll
         for (int c = ty; c < 32; c += 4) a.p_cm[(long long)c * a.nvox + v0 + tx] = tile[c][tx];
+}
+__global__ __launch_bounds__(256) void k_adam_cl_multi(AdamClMultiArgs m) { adam_cl_multi_block(m, blockIdx.x); }
+// every parameter group of a Mapper iteration in ONE launch (adfp_adam_step): the channels-last grids' workgroups first, then the flat
+// network buffers' (two launches of 5 + 18 us were 5 us more than one)
+struct AdamStepArgs { AdamClMultiArgs cl; AdamMultiArgs fl; unsigned cl_blocks; };
+__global__ __launch_bounds__(256) void k_adam_step(AdamStepArgs s) {
+    if (blockIdx.x < s.cl_blocks) adam_cl_multi_block(s.cl, blockIdx.x);
+    else masked_adam_multi_block(s.fl, blockIdx.x - s.cl_blocks);
 }

@@ -61,14 +61,20 @@ def _pack_size(name, fmt):
     return hit
 
 
+def pack_jobs_array(jobs):
+    """The ctypes form of a list of deferred pack jobs: (array, keep-alive list)."""
+    arr = (_lib.AdfpPackJob * max(1, len(jobs)))()
+    for k, (net, fmt, flat, packed) in enumerate(jobs):
+        arr[k].net, arr[k].format, arr[k].flat, arr[k].packed = net, fmt, flat.data_ptr(), packed.data_ptr()
+    return arr, [t for j in jobs for t in j[2:]]
+
+
 def flush_pack_jobs(jobs, status, device):
     """ONE launch for the deferred split-image / transposed-image packs of a call (pack_network(..., defer=jobs)): a pack kernel
     costs ~5 us inside a graph replay whatever it packs, and a training iteration re-packs four images per step."""
     if not jobs:
         return
-    arr = (_lib.AdfpPackJob * len(jobs))()
-    for k, (net, fmt, flat, packed) in enumerate(jobs):
-        arr[k].net, arr[k].format, arr[k].flat, arr[k].packed = net, fmt, flat.data_ptr(), packed.data_ptr()
+    arr, _ = pack_jobs_array(jobs)
     sptr = _lib.status_ptr() if status is None else _lib.C.c_void_p(status.data_ptr())
     with _lib.device_guard(device):
         _lib.check(lib().adfp_pack_images(len(jobs), arr, sptr, _lib.current_stream(device)), 'adfp_pack_images')

@@ -227,7 +227,7 @@ class Engine(object):
 
     # ---- descriptor ----------------------------------------------------------------------
     def scene(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=False, ht_nets=(), keys=None, images=None, state=None,
-              tsdf_blocks=False):
+              tsdf_blocks=False, hand_over_packs=False):
         """Returns (AdfpScene, keepalive list).  Forward: every network of the stage takes its f16-split image (ADFP_MATH=f16x3 and
         not latched to exact, DF.uses_split) or its exact f32 image, plus -- when any split image is in use -- the flat parameters
         the device-side f32 repair path needs (adfp_scene.flat_*).  Backward: the exact f32 images, except for the decoders named
@@ -276,7 +276,16 @@ class Engine(object):
                         decoders.packed_weights(n, 'ht', k)
                 else:
                     setattr(sc, 'w_' + n, decoders.packed_weights(n, 'f32', k).data_ptr())
-            flush_pack_jobs(jobs, decoders.status_word(), next(iter(c.values())).device)
+            # hand_over_packs: the caller's render call packs them in its first launch (adfp_render_args.pack_jobs); at most
+            # ADFP_PACK_MAX_JOBS fit one table
+            self._owed_packs = None
+            if hand_over_packs and 0 < len(jobs) <= 8:
+                from .decoder import pack_jobs_array
+                arr, alive = pack_jobs_array(jobs)
+                self._owed_packs = (arr, len(jobs), alive)
+                del jobs[:]
+            else:
+                flush_pack_jobs(jobs, decoders.status_word(), next(iter(c.values())).device)
         finally:
             decoders._pack_jobs = None
         if any_split:
@@ -666,45 +675,55 @@ class Engine(object):
                                    for n in _STAGE_NETS[stage])
                 decoders.absorb_status()          # BEFORE the state is laid out (see eval_points_forward)
                 aux = self.train_state(P, stage, dev, decoders, need_flat, extra=extra)
-            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, keys=keys, state=aux, tsdf_blocks=tsdf_blocks)
-            a = _lib.AdfpRenderArgs()
-            a.stage = _lib.STAGE[stage]
-            a.n_rays = N
-            a.n_samples = n_samples
-            a.n_surface = n_surface
-            a.lindisp = 1 if lindisp else 0
-            a.perturb = float(perturb)
-            a.rays_o = ro.data_ptr()
-            a.rays_d = rd.data_ptr()
-            a.gt_depth = gd.data_ptr() if gd is not None else None
-            if perturb > 0:
-                t_rand = t_rand.to(dev, f32).contiguous()
-                a.t_rand = t_rand.data_ptr()
-            a.depth_max_segment = int(depth_max_segment)
-            a.depth_max_first_ray = int(depth_max_first_ray)
-            if depth_max is not None:
-                depth_max = depth_max.to(dev, f32).reshape(-1).contiguous()
-                a.depth_max = depth_max.data_ptr()
-            a.depth = depth.data_ptr()
-            a.uncertainty = unc.data_ptr()
-            a.color = color.data_ptr()
-            a.weight = weight.data_ptr()
-            if train:
-                a.z_vals, a.raw = aux['ptrs']['z_vals'], aux['ptrs']['raw']
-                aux.update(rays_o=ro, rays_d=rd, S=S, N=N, keys=keys)
-                a.state = C.pointer(aux['_state'])
-                if want_aux:
-                    aux['z_vals'] = self.state_tensor(aux, 'z_vals', torch.float64, (N, S))
-                    aux['raw'] = self.state_tensor(aux, 'raw', f32, (N, S, 4))
-            elif want_aux:
-                aux = {'z_vals': torch.empty((N, S), dtype=torch.float64, device=dev),
-                       'raw': torch.empty((N, S, 4), dtype=f32, device=dev)}
-                a.z_vals = aux['z_vals'].data_ptr()
-                a.raw = aux['raw'].data_ptr()
-            ws = self.workspace(N * S, dev)
-            a.workspace = ws.data_ptr()
-            a.workspace_bytes = ws.numel()
-            check(lib().adfp_render_forward(C.byref(sc), C.byref(a), _lib.current_stream(dev)), 'adfp_render_forward')
+            sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, keys=keys, state=aux, tsdf_blocks=tsdf_blocks,
+                                  hand_over_packs=True)
+            owed, self._owed_packs = self._owed_packs, None
+            launched = False
+            try:
+                a = _lib.AdfpRenderArgs()
+                if owed is not None:                     # this call's first launch packs them beside its zero fill
+                    a.pack_jobs, a.n_pack_jobs = C.cast(owed[0], C.c_void_p), owed[1]
+                a.stage = _lib.STAGE[stage]
+                a.n_rays = N
+                a.n_samples = n_samples
+                a.n_surface = n_surface
+                a.lindisp = 1 if lindisp else 0
+                a.perturb = float(perturb)
+                a.rays_o = ro.data_ptr()
+                a.rays_d = rd.data_ptr()
+                a.gt_depth = gd.data_ptr() if gd is not None else None
+                if perturb > 0:
+                    t_rand = t_rand.to(dev, f32).contiguous()
+                    a.t_rand = t_rand.data_ptr()
+                a.depth_max_segment = int(depth_max_segment)
+                a.depth_max_first_ray = int(depth_max_first_ray)
+                if depth_max is not None:
+                    depth_max = depth_max.to(dev, f32).reshape(-1).contiguous()
+                    a.depth_max = depth_max.data_ptr()
+                a.depth = depth.data_ptr()
+                a.uncertainty = unc.data_ptr()
+                a.color = color.data_ptr()
+                a.weight = weight.data_ptr()
+                if train:
+                    a.z_vals, a.raw = aux['ptrs']['z_vals'], aux['ptrs']['raw']
+                    aux.update(rays_o=ro, rays_d=rd, S=S, N=N, keys=keys)
+                    a.state = C.pointer(aux['_state'])
+                    if want_aux:
+                        aux['z_vals'] = self.state_tensor(aux, 'z_vals', torch.float64, (N, S))
+                        aux['raw'] = self.state_tensor(aux, 'raw', f32, (N, S, 4))
+                elif want_aux:
+                    aux = {'z_vals': torch.empty((N, S), dtype=torch.float64, device=dev),
+                           'raw': torch.empty((N, S, 4), dtype=f32, device=dev)}
+                    a.z_vals = aux['z_vals'].data_ptr()
+                    a.raw = aux['raw'].data_ptr()
+                ws = self.workspace(N * S, dev)
+                a.workspace = ws.data_ptr()
+                a.workspace_bytes = ws.numel()
+                check(lib().adfp_render_forward(C.byref(sc), C.byref(a), _lib.current_stream(dev)), 'adfp_render_forward')
+                launched = True
+            finally:
+                if owed is not None and not launched:      # the images the cache already calls current were never packed
+                    decoders._packed = {}
         return depth, unc, color, weight, aux
 
     # ---- a15 -------------------------------------------------------------------------------

@@ -362,15 +362,13 @@ class MapperIteration(object):
             if n in flats:
                 f = self.flat[n]
                 groups.append((n, f, flats[n], self.fstate[n], None, f.numel(), 1, lr['decoders' if n in ('high', 'color') else 'mlp']))
-        arr = (_lib.AdfpAdamGroup * len(groups))()                   # one launch for all groups
+        arr = (_lib.AdfpAdamGroup * max(1, len(groups)))()
         for k, (gname, p, g, (m, v), mask, nvox, ch, lrv) in enumerate(groups):
             a = arr[k]
             a.param, a.grad, a.exp_avg, a.exp_avg_sq = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
             a.mask = mask.data_ptr() if mask is not None else None
             a.nvox, a.channels = int(nvox), int(ch)
             a.derived = self.derived[self.groups.index(gname)].data_ptr()
-        if groups:
-            check(L.adfp_masked_adam_multi(len(groups), C.byref(arr), b1, b2, self.eps, st), 'adfp_masked_adam_multi')
         carr = (_lib.AdfpAdamClGroup * max(1, len(cl_groups)))()
         for k, (gname, g, grad, (m, v), mask, nvox, lrv) in enumerate(cl_groups):
             a = carr[k]
@@ -379,8 +377,8 @@ class MapperIteration(object):
             a.mask = mask.data_ptr() if mask is not None else None
             a.nvox = int(nvox)
             a.derived = self.derived[self.groups.index(gname)].data_ptr()
-        if cl_groups:
-            check(L.adfp_adam_grids_cl(len(cl_groups), C.byref(carr), b1, b2, self.eps, st), 'adfp_adam_grids_cl')
+        if cl_groups or groups:                                      # grids and networks: one launch
+            check(L.adfp_adam_step(len(cl_groups), C.byref(carr), len(groups), C.byref(arr), b1, b2, self.eps, st), 'adfp_adam_step')
         return grids, flats
 
     def _stage_groups(self, stage, need_grid, need_flat):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 127
+#define ADFP_VERSION 129
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -321,6 +321,12 @@ typedef struct adfp_render_args {
      * to segment (first + i) / depth_max_segment, and depth_max holds the maxima of the WHOLE frame's segments.  0 otherwise
      * (non-zero without depth_max is ADFP_E_ARG: the call cannot know the maxima of rays it does not hold). */
     int depth_max_first_ray;
+    /* Optional: weight images this call's kernels read and that are not packed yet (adfp_pack_images' jobs, host array, at most
+     * ADFP_PACK_MAX_JOBS) -- packed by the call's FIRST launch, beside the zero fill of its device words (two launches of ~5 us
+     * inside a graph replay otherwise; a Mapper iteration re-packs the trained networks' images every step).  A weight outside
+     * the f16 range is reported to scene->status as by adfp_pack_images.  NULL / 0: none. */
+    const adfp_pack_job* pack_jobs;
+    int n_pack_jobs;
 } adfp_render_args;
 
 int adfp_render_forward(const adfp_scene* scene /*host*/, const adfp_render_args* args /*host*/, void* stream);
@@ -511,6 +517,9 @@ typedef struct adfp_adam_cl_group {
     const float* derived;        /* {step size, sqrt(bias correction 2)} from adfp_adam_prep */
 } adfp_adam_cl_group;
 int adfp_adam_grids_cl(int n_groups, const adfp_adam_cl_group* groups /*host*/, float beta1, float beta2, float eps, void* stream);
+/* adfp_adam_grids_cl and adfp_masked_adam_multi in ONE launch: every parameter group a Mapper iteration steps (either list may be empty) */
+int adfp_adam_step(int n_cl_groups, const adfp_adam_cl_group* cl_groups /*host*/, int n_groups, const adfp_adam_group* groups /*host*/,
+                   float beta1, float beta2, float eps, void* stream);
 
 /* ---- One Tracker iteration as a fixed, sync-free kernel sequence (src/Tracker.py:75-134) ---------------------------------- */
 /* Camera tensor (quaternion r, i, j, k + translation, 7 floats ON THE DEVICE) -> camera-to-world [4,4] row-major, and the

@@ -161,6 +161,15 @@ int main() {
       r2 = ra; r2.stage = 3; EXPECT_NEG(adfp_render_forward(&sc, &r2, st));
       r2 = ra; r2.n_rays = 0; EXPECT_CODE(adfp_render_forward(&sc, &r2, st), 0);
       r2 = ra; r2.state = &ts; EXPECT_REACHES_LAUNCH(adfp_render_forward(&sc, &r2, st));
+      {   // weight images handed over to the call's first launch
+          adfp_pack_job pj[2] = {{ADFP_DEC_COLOR, ADFP_IMAGE_H, dev<float>(31), dev<float>(32)}, {ADFP_NET_ATT, ADFP_IMAGE_HT, dev<float>(33), dev<float>(34)}};
+          r2 = ra; r2.pack_jobs = pj; r2.n_pack_jobs = -1; EXPECT_NEG(adfp_render_forward(&sc, &r2, st));
+          r2 = ra; r2.pack_jobs = pj; r2.n_pack_jobs = ADFP_PACK_MAX_JOBS + 1; EXPECT_NEG(adfp_render_forward(&sc, &r2, st));
+          r2 = ra; r2.pack_jobs = nullptr; r2.n_pack_jobs = 2; EXPECT_NEG(adfp_render_forward(&sc, &r2, st));
+          r2 = ra; r2.pack_jobs = pj; r2.n_pack_jobs = 2; pj[1].format = 99; EXPECT_NEG(adfp_render_forward(&sc, &r2, st)); pj[1].format = ADFP_IMAGE_HT;
+          r2 = ra; r2.pack_jobs = pj; r2.n_pack_jobs = 2; EXPECT_REACHES_LAUNCH(adfp_render_forward(&sc, &r2, st));
+          r2 = ra; r2.pack_jobs = pj; r2.n_pack_jobs = 2; r2.n_rays = 0; EXPECT_REACHES_LAUNCH(adfp_render_forward(&sc, &r2, st));     // no rays: the images are still packed
+      }
       adfp_train_state t0; memset(&t0, 0, sizeof(t0)); r2.state = &t0; EXPECT_NEG(adfp_render_forward(&sc, &r2, st));
       r2 = ra; r2.n_rays = 60000000; r2.workspace_bytes = (size_t)1 << 44; EXPECT_CODE(adfp_render_forward(&sc, &r2, st), ADFP_E_UNSUPPORTED); }     // 2.9e9 points
     EXPECT_REACHES_LAUNCH(adfp_render_forward(&sc, &ra, st));
@@ -228,6 +237,14 @@ int main() {
     EXPECT_CODE(adfp_adam_grids_cl(0, cg, 0.9f, 0.999f, 1e-8f, st), 0);
     EXPECT_NEG(adfp_adam_grids_cl(99, cg, 0.9f, 0.999f, 1e-8f, st));
     EXPECT_REACHES_LAUNCH(adfp_adam_grids_cl(3, cg, 0.9f, 0.999f, 1e-8f, st));
+    EXPECT_CODE(adfp_adam_step(0, cg, 0, groups, 0.9f, 0.999f, 1e-8f, st), 0);              // nothing to step
+    EXPECT_NEG(adfp_adam_step(99, cg, 3, groups, 0.9f, 0.999f, 1e-8f, st));
+    EXPECT_NEG(adfp_adam_step(3, cg, 99, groups, 0.9f, 0.999f, 1e-8f, st));
+    EXPECT_NEG(adfp_adam_step(3, nullptr, 3, groups, 0.9f, 0.999f, 1e-8f, st));
+    EXPECT_NEG(adfp_adam_step(3, cg, 3, nullptr, 0.9f, 0.999f, 1e-8f, st));
+    EXPECT_REACHES_LAUNCH(adfp_adam_step(3, cg, 0, nullptr, 0.9f, 0.999f, 1e-8f, st));
+    EXPECT_REACHES_LAUNCH(adfp_adam_step(0, nullptr, 3, groups, 0.9f, 0.999f, 1e-8f, st));
+    EXPECT_REACHES_LAUNCH(adfp_adam_step(3, cg, 3, groups, 0.9f, 0.999f, 1e-8f, st));
     adfp_loss_args la; memset(&la, 0, sizeof(la));
     la.n_rays = 500; la.S = 48; la.stage = ADFP_STAGE_COLOR; la.w_color_loss = 0.2f; la.depth = dev<double>(1); la.color = dev<float>(2); la.weight = dev<float>(3);
     la.gt_depth = dev<float>(4); la.gt_color = dev<float>(5); la.loss = dev<double>(6); la.g_depth = dev<double>(7); la.g_color = dev<float>(8);
