@@ -441,13 +441,16 @@ struct ScatterSortedArgs {
     const int* perm; int n;    // the points in sorted order
     const unsigned char* flags; unsigned flag_mask;      // HIGH: only points with (flags[q] & flag_mask) carry a row
 };
-// Half h of wave w owns the 64 consecutive sorted points [128 w + 64 h, + 64) (phase A: one lane per point computes cell and
-// weights of the wave's 128 points; phase B: lane = channel).  A run that a range boundary cuts is added in pieces.  (Longer ranges
-// per wave only lengthen the critical path: 128 points 1.90 ms per iteration, 1 024 points 2.15 ms; shorter ones cut more runs: 64
-// points per wave (-DADFP_SCATTER_PPW=64) 71 us per grid against 46.  Collecting the pieces in records and merging them in a
-// SECOND kernel cost more than the atomics it saved; merging them inside the workgroup, below, did not.)
+// Half h of wave w owns the PPW / 2 consecutive sorted points [PPW w + PPW / 2 h, + PPW / 2) (phase A: one lane per point computes
+// cell and weights of the wave's PPW points; phase B: lane = channel).  A run that a range boundary cuts is added in pieces.  (Longer
+// ranges per wave only lengthen the critical path: 128 points 1.90 ms per iteration, 1 024 points 2.15 ms; shorter ones cut more
+// runs: in round 3, one launch per grid and no merging, 64 points per wave cost 71 us per grid against 46.  Collecting the pieces in
+// records and merging them in a SECOND kernel cost more than the atomics it saved; merging them inside the workgroup, below, did not.)
 #ifndef ADFP_SCATTER_PPW
-#define ADFP_SCATTER_PPW 128          // sorted points per wave (two halves)
+#define ADFP_SCATTER_PPW 64           // sorted points per wave (two halves of 32).  Round 5, with all grids in ONE launch and the runs
+                                      // merged inside the workgroup: 64 points per wave 57 us against 64 us for 128 (NW = 2 / 3 / 6 / 8 at
+                                      // 64 points: 63 / 58 / 60 / 59 us; 256 points: 103 us) -- the shorter serial walk wins once the
+                                      // launch no longer ends in three tails
 #endif
 #ifndef ADFP_SCATTER_NW
 #define ADFP_SCATTER_NW 4             // waves per workgroup: the runs that the eight half-wave ranges of a workgroup cut are merged in LDS

@@ -39,7 +39,7 @@ def main(template, d):
     per = lambda *names: sum(float(r['total_ms']) * 1e3 / iters for k, r in tr.items() if any(n in k for n in names))
     zero = per('k_zero_multi')
     head = per('k_backward_head')
-    v['train_head'] = '%.0f' % (per('k_prefilter_mask', 'k_pack_multi', 'k_sample', 'k_tsdf(') + (zero if head else zero / 2))
+    v['train_head'] = '%.0f' % (per('k_prefilter_mask', 'k_pack_multi', 'k_forward_head', 'k_sample', 'k_tsdf(') + (zero if head else zero / 2))
     v['k_decode_lc16_train'] = '%.0f' % per('k_decode_lc16_train')
     v['train_inband_fwd'] = '%.0f' % per('k_decode_h<64', 'k_attention_h<1')
     v['train_mid'] = '%.0f' % per('k_fallback_points', 'k_composite(', 'k_mapper_loss')
@@ -50,7 +50,7 @@ def main(template, d):
     v['k_decode_bwd_roles'] = '%.0f' % per('k_decode_bwd_roles')
     v['k_reduce_roles'] = '%.0f' % per('k_reduce_partials_roles')
     v['k_scatter_sorted'] = '%.0f' % per('k_scatter_sorted')
-    v['train_adam'] = '%.0f' % per('k_masked_adam_multi', 'k_adam_cl_multi')
+    v['train_adam'] = '%.0f' % per('k_masked_adam_multi', 'k_adam_cl_multi', 'k_adam_step')
     v['n_launches'] = '%.0f' % sum(int(r['calls']) / iters for k, r in tr.items() if (k.startswith('k_') or k.startswith('void k_')) and int(r['calls']) >= iters)
     # ---- bench line
     b = json.loads(open(P('r05_bench_f16x3.json')).read().strip().split('\n')[-1])
