@@ -57,6 +57,7 @@ def main(template, d):
     v['headline_value'] = '%.1f' % (b['value'] / 1e6); v['headline_ms'] = '%.2f' % b['ms_per_step']
     v['value_f32'] = '%.1f' % (b['config']['value_exact_f32_mode'] / 1e6)
     ro = b['roofline']
+    v['avg_launch_ms'] = '%.2f' % ro['avg_launch_ms']
     v['roofline_achieved'] = '%.0f' % ro['achieved']; v['roofline_frac'] = '%.3f' % ro['frac']; v['roofline_exec_frac'] = '%.3f' % ro['frac_executed']
     pmc = ro['limiter'].get('pmc', {})
     v['mfma_busy'] = '%.3f' % pmc['mfma_busy_frac'] if 'mfma_busy_frac' in pmc else '@@mfma_busy@@'
