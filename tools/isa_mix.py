@@ -1,6 +1,7 @@
 """Instruction mix of one kernel of libadfp (compile with `hipcc -S --cuda-device-only`, then count per class).
 
   python tools/isa_mix.py /tmp/isa/adfp.s k_decode_h 'ILi32ELi4ELi2E'
+  python tools/isa_mix.py --loop /tmp/isa/role0.s k_decode_bwd_roles ILi4ELi2E      # the tile loop only
 """
 import collections
 import re
@@ -21,11 +22,34 @@ def kernels(path):
     return out
 
 
+def mfma_loop(body):
+    """The smallest loop (label ... backward branch to it) that holds every MFMA of the kernel: the tile loop of the decoder kernels."""
+    labels = {}
+    for i, l in enumerate(body):
+        m = re.match(r'^(\.LBB\d+_\d+):', l)
+        if m:
+            labels[m.group(1)] = i
+    mf = [i for i, l in enumerate(body) if l.strip().startswith('v_mfma')]
+    best = None
+    for i, l in enumerate(body):
+        m = re.search(r's_(?:cbranch_\w+|branch) (\.LBB\d+_\d+)', l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i and mf and labels[m.group(1)] <= mf[0] and i >= mf[-1]:
+            if best is None or i - labels[m.group(1)] < best[1] - best[0]:
+                best = (labels[m.group(1)], i)
+    return body[best[0]:best[1] + 1] if best else body
+
+
 def main():
-    path, *pats = sys.argv[1:]
+    args = sys.argv[1:]
+    loop_only = '--loop' in args
+    args = [a for a in args if a != '--loop']
+    path, *pats = args
     for name, body in kernels(path).items():
         if not all(p in name for p in pats):
             continue
+        if loop_only:
+            body = mfma_loop(body)
+            name += '  [tile loop only]'
         c = collections.Counter()
         for l in body:
             t = l.strip().split()
