@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ADFP_LIB_PATH', os.path.join(_HERE, 'libadfp.so'))   # override: kernel A/B builds
 
-ABI_VERSION = 129                 # ADFP_VERSION of include/adfp.h this binding was written against
+ABI_VERSION = 130                 # ADFP_VERSION of include/adfp.h this binding was written against
 STATUS_F16_RANGE = 31              # ADFP_STATUS_F16_RANGE: any of the bits below
 STATUS_RANGE_BITS = {'low': 1, 'high': 2, 'color': 4, 'att': 8, 'bwd': 16}      # ADFP_STATUS_F16_RANGE_<net>
 BWD_SCATTER_IN_KERNEL = 1        # ADFP_BWD_SCATTER_IN_KERNEL
@@ -38,6 +38,25 @@ class AdfpTsdf(C.Structure):
 
 class AdfpPackJob(C.Structure):
     _fields_ = [('net', C.c_int), ('format', C.c_int), ('flat', C.c_void_p), ('packed', C.c_void_p)]
+
+
+class AdfpTrackerHeadArgs(C.Structure):
+    _fields_ = [('cam', C.c_void_p), ('c2w', C.c_void_p), ('idx', C.c_void_p), ('n', C.c_int),
+                ('H0', C.c_int), ('H1', C.c_int), ('W0', C.c_int), ('W1', C.c_int), ('H', C.c_int), ('W', C.c_int),
+                ('depth_img', C.c_void_p), ('color_img', C.c_void_p),
+                ('fx', C.c_float), ('fy', C.c_float), ('cx', C.c_float), ('cy', C.c_float), ('bound', C.c_void_p),
+                ('pix_i', C.c_void_p), ('pix_j', C.c_void_p), ('gt_depth', C.c_void_p), ('gt_color', C.c_void_p),
+                ('rays_o', C.c_void_p), ('rays_d', C.c_void_p), ('keep', C.c_void_p), ('depth_max', C.c_void_p)]
+
+
+class AdfpTrackerTailArgs(C.Structure):
+    _fields_ = [('pix_i', C.c_void_p), ('pix_j', C.c_void_p), ('n', C.c_int),
+                ('fx', C.c_float), ('fy', C.c_float), ('cx', C.c_float), ('cy', C.c_float),
+                ('g_rays_o', C.c_void_p), ('g_rays_d', C.c_void_p), ('cam', C.c_void_p), ('g_c2w', C.c_void_p), ('g_cam', C.c_void_p),
+                ('step', C.c_int), ('exp_avg', C.c_void_p), ('exp_avg_sq', C.c_void_p),
+                ('steps', C.c_void_p), ('derived', C.c_void_p), ('n_groups', C.c_int), ('lr', C.c_float * 2),
+                ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float), ('skip_flag', C.c_void_p),
+                ('loss', C.c_void_p), ('best_loss', C.c_void_p), ('best_cam', C.c_void_p)]
 
 
 class AdfpKeyframe(C.Structure):
@@ -201,6 +220,8 @@ SYMBOLS = [
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_sample_keyframes', C.c_int, [C.c_int, C.POINTER(AdfpKeyframe), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('adfp_tracker_head', C.c_int, [C.POINTER(AdfpTrackerHeadArgs), C.c_void_p]),
+    ('adfp_tracker_tail', C.c_int, [C.POINTER(AdfpTrackerTailArgs), C.c_void_p]),
     ('adfp_tracker_loss', C.c_int, [C.POINTER(AdfpTrackLossArgs), C.c_void_p]),
     ('adfp_track_keep_best', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_sort_workspace_bytes', C.c_size_t, [C.c_longlong]),

@@ -416,6 +416,9 @@ struct DecodeLCTrainArgs {
     DecodeLCArgs f;
     unsigned* masks_low; unsigned* masks_color;
     float* act_low; float* act_color;              // or NULL
+    // SMALL batches (fewer tiles than half the launch's waves: a Tracker iteration, a 1 000-ray Mapper batch): a wave takes ONE network
+    // of a tile instead of both in turn -- the launch is then the latency of one network's five dependent layers, not of two
+    int split_networks;
 };
 template <int NT>
 __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16_train(DecodeLCTrainArgs t) {
@@ -436,7 +439,11 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16_train(DecodeLCTrai
     const int ntiles = (count + 31) >> 5;
     float amax_low = image_out_of_range<LL::P_FLAG, LL::NFLAG>(lds_low) ? INFINITY : 0.f;
     float amax_col = image_out_of_range<LC::P_FLAG, LC::NFLAG>(lds_col) ? INFINITY : 0.f;
-    for (int j = threadIdx.x >> 6, tile; (tile = claim_tile<NT / 64>(j, &s_next, ntiles)) >= 0;) {
+    const bool split = t.split_networks != 0;      // uniform over the launch
+    const int njobs = split ? 2 * ntiles : ntiles;
+    for (int j = threadIdx.x >> 6, job; (job = claim_tile<NT / 64>(j, &s_next, njobs)) >= 0;) {
+        const int tile = split ? job >> 1 : job;
+        const bool do_low = !split || (job & 1) == 0, do_col = !split || (job & 1) == 1;      // wave-uniform
         const int idx = tile * 32 + 16 * (g >> 1) + n;
         const bool valid = idx < count;
         const int q = valid ? idx : 0;
@@ -464,19 +471,34 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16_train(DecodeLCTrai
         unsigned mw[3];
         int off_low = 0, off_col = LL::P_TOTAL;
         asm volatile("" : "+v"(off_low), "+v"(off_col));
-        decode_net_g<32, 1, 1>(lds_all + off_low, a.g_low, a.g_low, pn, pf, lane, amax_low, occ, mw, t.act_low + (long long)i0 * ST::NXM, t.act_low ? rowbits : 0u ADFP_PHG_ARGS(8));
-        if (valid) { unsigned* mrow = t.masks_low + ((long long)q * 2 + (g & 1)) * 3; mrow[0] = mw[0]; mrow[1] = mw[1]; mrow[2] = mw[2]; }
+        occ[0][0] = 0.f; occ[1][0] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { rgb[0][k] = 0.f; rgb[1][k] = 0.f; }
+        if (do_low) {
+            decode_net_g<32, 1, 1>(lds_all + off_low, a.g_low, a.g_low, pn, pf, lane, amax_low, occ, mw, t.act_low + (long long)i0 * ST::NXM, t.act_low ? rowbits : 0u ADFP_PHG_ARGS(8));
+            if (valid) { unsigned* mrow = t.masks_low + ((long long)q * 2 + (g & 1)) * 3; mrow[0] = mw[0]; mrow[1] = mw[1]; mrow[2] = mw[2]; }
+        }
         asm volatile("" : "+v"(pn[0]), "+v"(pn[1]), "+v"(pn[2]), "+v"(occ[0][0]), "+v"(occ[1][0]));
         __builtin_amdgcn_sched_barrier(0);
-        decode_net_g<32, 4, 1>(lds_all + off_col, a.g_color, a.g_color, pn, pf, lane, amax_col, rgb, mw, t.act_color + (long long)i0 * ST::NXM, t.act_color ? rowbits : 0u ADFP_PHG_ARGS(16));
-        if (valid) { unsigned* mrow = t.masks_color + ((long long)q * 2 + (g & 1)) * 3; mrow[0] = mw[0]; mrow[1] = mw[1]; mrow[2] = mw[2]; }
+        if (do_col) {
+            decode_net_g<32, 4, 1>(lds_all + off_col, a.g_color, a.g_color, pn, pf, lane, amax_col, rgb, mw, t.act_color + (long long)i0 * ST::NXM, t.act_color ? rowbits : 0u ADFP_PHG_ARGS(16));
+            if (valid) { unsigned* mrow = t.masks_color + ((long long)q * 2 + (g & 1)) * 3; mrow[0] = mw[0]; mrow[1] = mw[1]; mrow[2] = mw[2]; }
+        }
         if (valid && (g & 1) == 0) {
             const int pb = g >> 1;
             const float nanv = __builtin_nanf("");
             const float o = pnan ? nanv : (keep_occ ? (pb ? occ[1][0] : occ[0][0]) : 100.f);
             const f32x4 c4 = pb ? f32x4{rgb[1][0], rgb[1][1], rgb[1][2], o} : f32x4{rgb[0][0], rgb[0][1], rgb[0][2], o};
-            *(f32x4*)(a.raw + 4ll * q) = pnan ? f32x4{nanv, nanv, nanv, o} : c4;
-            if (a.write_w) a.w[q] = 1.f;
+            const f32x4 row = pnan ? f32x4{nanv, nanv, nanv, o} : c4;
+            if (!split) {
+                *(f32x4*)(a.raw + 4ll * q) = row;
+                if (a.write_w) a.w[q] = 1.f;
+            } else if (do_low) {                     // the row's two parts leave from the two waves that made them
+                a.raw[4ll * q + 3] = row.w;
+                if (a.write_w) a.w[q] = 1.f;
+            } else {
+                a.raw[4ll * q] = row.x; a.raw[4ll * q + 1] = row.y; a.raw[4ll * q + 2] = row.z;
+            }
         }
     }
     report_range(a.status, amax_low, ADFP_STATUS_F16_RANGE_LOW, a.call_flag);

@@ -562,6 +562,7 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
 struct TsdfArgs {
     PtsDev P; NormDev nt; TsdfDev t; double b[6];
     unsigned char* flags; int* list; float* att_u; float* w; int* counter; float* tsdf_out;
+    int rays_per_block;        // ray mode: RB, a power of two with RB * S <= TSDF_CHUNK (tsdf_rays_per_block)
 };
 #ifndef TSDF_CHUNK
 #define TSDF_CHUNK 2048
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(256, TSDF_MINW) void k_tsdf(TsdfArgs a) {
     const int SF = rays ? 4 * (((S + 3) >> 2) | 1) : 0;          // flag row stride in LDS (ray mode)
     int RB = 1, q0, npts, rb = 1;
     if (rays) {
-        while (RB * 2 * S <= TSDF_CHUNK && RB < 64) RB *= 2;
+        RB = a.rays_per_block;
         const int r0 = blockIdx.x * RB;
         const int nr = a.P.n / S;
         rb = (r0 + RB <= nr) ? RB : nr - r0;
@@ -1476,11 +1477,17 @@ static int launch_tsdf(const adfp_scene* sc, const PtsDev& P, unsigned char* fla
     a.flags = flags; a.list = list; a.att_u = att_u; a.w = w; a.counter = counter; a.tsdf_out = tsdf_out;
     if (P.n == 0) return 0;
     int blocks = (P.n + TSDF_CHUNK - 1) / TSDF_CHUNK;
+    a.rays_per_block = 1;
     if (P.mode == ADFP_PTS_RAYS) {
         if (P.S > TSDF_CHUNK) return ADFP_E_UNSUPPORTED;
         int RB = 1;
         while (RB * 2 * P.S <= TSDF_CHUNK && RB < 64) RB *= 2;
         const int nr = P.n / P.S;
+        // A block walks its points 256 at a time, so a small batch in few large blocks is a chain of dependent gathers on a handful
+        // of CUs (200 rays x 64 samples in 7 blocks: 19 us; a Mapper batch of 1 000 rays: 11 us).  Fewer rays per block until there
+        // are ~100 blocks -- not more: every block with in-band points ends in one atomic on the list counter, ~17 ns each in turn.
+        while (RB > 1 && nr / RB < 96) RB >>= 1;
+        a.rays_per_block = RB;
         blocks = (nr + RB - 1) / RB;
     }
     hipLaunchKernelGGL(k_tsdf, dim3(blocks), dim3(256), 0, st, a);
@@ -1587,7 +1594,9 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         f.packed_low = (const unsigned*)sc->h_low + DecLayoutH<32, 1>::P_TOTAL; f.packed_color = (const unsigned*)sc->h_color + DecLayoutH<32, 4>::P_TOTAL;   // the G images
         f.flags = a.flags; f.raw = raw; f.w = w; f.write_w = 1; f.apply_bound = apply_bound; f.status = sc->status; f.call_flag = call_flag; f.pool = nullptr;
         t.masks_low = state->masks_low; t.masks_color = state->masks_color; t.act_low = state->act_low; t.act_color = state->act_color;
-        hipLaunchKernelGGL((k_decode_lc16_train<ADFP_LCT_NT>), dim3(decode_grid(ntiles, ADFP_LCT_NT / 64, 1)), dim3(ADFP_LCT_NT), 0, st, t);
+        // few tiles (every (tile, network) pair can have a wave of its own): one network per wave
+        t.split_networks = 2 * ntiles <= num_cu() * (ADFP_LCT_NT / 64) ? 1 : 0;
+        hipLaunchKernelGGL((k_decode_lc16_train<ADFP_LCT_NT>), dim3(decode_grid(t.split_networks ? 2 * ntiles : ntiles, ADFP_LCT_NT / 64, 1)), dim3(ADFP_LCT_NT), 0, st, t);
         ADFP_CHECK_LAUNCH();
     }
 #endif
@@ -2003,6 +2012,139 @@ static int mapper_loss_impl(const adfp_loss_args* l, const AdamPrepArgs* prep, d
     return 0;
 }
 
+}  // extern "C"
+// ---- the Tracker iteration's head and tail, one workgroup each (adfp_tracker_head / adfp_tracker_tail) ----------------------------
+__global__ __launch_bounds__(1024) void k_tracker_head(adfp_tracker_head_args a) {
+    __shared__ float s_m[16];
+    float c2w[16];
+    camera_from_tensor_dev(a.cam, c2w);                     // every thread: 30 operations, the same values
+    if (threadIdx.x < 16) a.c2w[threadIdx.x] = c2w[threadIdx.x];
+    double b[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) b[k] = a.bound[k];
+    const int Ww = a.W1 - a.W0;
+    float mx = -INFINITY;
+    for (int t = threadIdx.x; t < a.n; t += 1024) {
+        // k_select_pixels
+        const long long k = a.idx[t];
+        const int row = a.H0 + (int)(k / Ww), col = a.W0 + (int)(k % Ww);
+        const float pi = (float)col, pj = (float)row;
+        a.pix_i[t] = pi; a.pix_j[t] = pj;
+        const long long p = (long long)row * a.W + col;
+        const float dep = a.depth_img[p];
+        a.gt_depth[t] = dep;
+        a.gt_color[3 * t] = a.color_img[3 * p]; a.gt_color[3 * t + 1] = a.color_img[3 * p + 1]; a.gt_color[3 * t + 2] = a.color_img[3 * p + 2];
+        // k_rays_from_uv
+        const float dx = (pi - a.cx) / a.fx, dy = -(pj - a.cy) / a.fy, dz = -1.f;
+        float ro[3], rd[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            rd[m] = __fadd_rn(__fadd_rn(__fmul_rn(dx, c2w[4 * m + 0]), __fmul_rn(dy, c2w[4 * m + 1])), __fmul_rn(dz, c2w[4 * m + 2]));
+            ro[m] = c2w[4 * m + 3];
+            a.rays_d[3 * t + m] = rd[m]; a.rays_o[3 * t + m] = ro[m];
+        }
+        // k_prefilter_mask
+        double tt = INFINITY; bool nan = false;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const double o = (double)ro[m], d = (double)rd[m];
+            const double t0 = (b[2 * m] - o) / d, t1 = (b[2 * m + 1] - o) / d;
+            nan |= (t0 != t0) | (t1 != t1);
+            const double tm = t0 > t1 ? t0 : t1;
+            tt = tm < tt ? tm : tt;
+        }
+        const bool k_ = !nan && (tt >= (double)dep);
+        a.keep[t] = k_ ? 1 : 0;
+        if (k_) mx = dep > mx ? dep : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float v = __shfl_xor(mx, o); mx = v > mx ? v : mx; }
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = s_m[0];
+        for (int w = 1; w < 16; ++w) m = s_m[w] > m ? s_m[w] : m;
+        *a.depth_max = m;
+    }
+}
+__global__ __launch_bounds__(256) void k_tracker_tail(adfp_tracker_tail_args a) {
+    __shared__ float s[4][12];
+    __shared__ float s_g[16];
+    // k_rays_from_uv_bwd
+    float acc[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) acc[t] = 0.f;
+    for (int i = threadIdx.x; i < a.n; i += 256) {
+        const float dir[3] = {(a.pix_i[i] - a.cx) / a.fx, -(a.pix_j[i] - a.cy) / a.fy, -1.f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float gd = a.g_rays_d ? a.g_rays_d[3 * i + k] : 0.f;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc[4 * k + m] = fmaf(gd, dir[m], acc[4 * k + m]);
+            acc[4 * k + 3] += a.g_rays_o ? a.g_rays_o[3 * i + k] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 12; ++t) acc[t] = wave_sum(acc[t]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int t = 0; t < 12; ++t) s[threadIdx.x >> 6][t] = acc[t];
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const float v = threadIdx.x < 12 ? (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]) : 0.f;
+        s_g[threadIdx.x] = v; a.g_c2w[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    // one thread from here on: 7 parameters
+    float g_cam[7];
+    camera_from_tensor_bwd_dev(a.cam, s_g, g_cam);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) a.g_cam[k] = g_cam[k];
+    if (!a.step) return;
+    const bool better_before = *a.loss < *a.best_loss;
+    if (a.n_groups == 2 && better_before) {                 // k_keep_best before the step
+#pragma unroll
+        for (int k = 0; k < 7; ++k) a.best_cam[k] = a.cam[k];
+        *a.best_loss = *a.loss;
+    }
+    AdamPrepArgs pa;
+    pa.steps = a.steps; pa.derived = a.derived; pa.n = a.n_groups; pa.beta1 = a.beta1; pa.beta2 = a.beta2; pa.skip = a.skip_flag;
+    for (int g = 0; g < ADFP_ADAM_MAX_GROUPS; ++g) pa.lr[g] = g < a.n_groups ? a.lr[g] : -1.f;
+    for (int g = 0; g < a.n_groups; ++g) adam_prep_group(pa, g);
+    for (int g = 0; g < a.n_groups; ++g) {
+        const int off = a.n_groups == 2 ? (g == 0 ? 4 : 0) : 0, cnt = a.n_groups == 2 ? (g == 0 ? 3 : 4) : 7;
+        const float step_size = a.derived[2 * g], sqrt_bc2 = a.derived[2 * g + 1];
+        if (sqrt_bc2 == 0.f) continue;                      // adam_prep_group's "skip this iteration"
+        AdamArgs ad;
+        ad.param = a.cam + off; ad.grad = a.g_cam + off; ad.exp_avg = a.exp_avg + off; ad.exp_avg_sq = a.exp_avg_sq + off; ad.mask = nullptr;
+        ad.nvox = cnt; ad.C = 1; ad.beta1 = a.beta1; ad.beta2 = a.beta2; ad.eps = a.eps; ad.step_size = 0.f; ad.sqrt_bc2 = 1.f; ad.derived = nullptr;
+        for (int k = 0; k < cnt; ++k) adam_one(ad, k, step_size, sqrt_bc2);
+    }
+    if (a.n_groups == 1 && better_before) {                 // k_keep_best after the step: the stepped pose, this iteration's loss
+#pragma unroll
+        for (int k = 0; k < 7; ++k) a.best_cam[k] = a.cam[k];
+        *a.best_loss = *a.loss;
+    }
+}
+extern "C" {
+int adfp_tracker_head(const adfp_tracker_head_args* a, void* stream) {
+    if (!a || a->n < 0 || a->H0 < 0 || a->W0 < 0 || a->H1 > a->H || a->W1 > a->W || a->H1 <= a->H0 || a->W1 <= a->W0) return ADFP_E_ARG;
+    if (!a->cam || !a->c2w || !a->bound || !a->keep || !a->depth_max) return ADFP_E_ARG;
+    if (a->n > 0 && (!a->idx || !a->depth_img || !a->color_img || !a->pix_i || !a->pix_j || !a->gt_depth || !a->gt_color || !a->rays_o || !a->rays_d)) return ADFP_E_ARG;
+    hipLaunchKernelGGL(k_tracker_head, dim3(1), dim3(1024), 0, (hipStream_t)stream, *a);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+int adfp_tracker_tail(const adfp_tracker_tail_args* a, void* stream) {
+    if (!a || a->n < 0 || !a->cam || !a->g_c2w || !a->g_cam) return ADFP_E_ARG;
+    if (a->n > 0 && (!a->pix_i || !a->pix_j)) return ADFP_E_ARG;
+    if (a->step && (!a->exp_avg || !a->exp_avg_sq || !a->steps || !a->derived || a->n_groups < 1 || a->n_groups > 2 || !a->loss || !a->best_loss || !a->best_cam))
+        return ADFP_E_ARG;
+    hipLaunchKernelGGL(k_tracker_tail, dim3(1), dim3(256), 0, (hipStream_t)stream, *a);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
 int adfp_camera_from_tensor(const float* cam, float* c2w, void* stream) {
     if (!cam || !c2w) return ADFP_E_ARG;
     hipLaunchKernelGGL(k_camera_from_tensor, dim3(1), dim3(64), 0, (hipStream_t)stream, cam, c2w);

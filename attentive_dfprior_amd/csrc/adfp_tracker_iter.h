@@ -20,8 +20,7 @@ ADFP_DEV void quat_terms(const float* q, float& two_s, float M[9]) {
     M[3] = qi * qj + qk * qr;    M[4] = -(qi * qi + qk * qk); M[5] = qj * qk - qi * qr;
     M[6] = qi * qk - qj * qr;    M[7] = qj * qk + qi * qr;   M[8] = -(qi * qi + qj * qj);
 }
-__global__ void k_camera_from_tensor(const float* __restrict__ cam, float* __restrict__ c2w) {
-    if (blockIdx.x || threadIdx.x) return;
+ADFP_DEV void camera_from_tensor_dev(const float* __restrict__ cam, float* c2w /*[16]*/) {
     float two_s, M[9];
     quat_terms(cam, two_s, M);
     for (int a = 0; a < 3; ++a) {
@@ -30,10 +29,18 @@ __global__ void k_camera_from_tensor(const float* __restrict__ cam, float* __res
     }
     c2w[12] = 0.f; c2w[13] = 0.f; c2w[14] = 0.f; c2w[15] = 1.f;
 }
+__global__ void k_camera_from_tensor(const float* __restrict__ cam, float* __restrict__ c2w) {
+    if (blockIdx.x || threadIdx.x) return;
+    camera_from_tensor_dev(cam, c2w);
+}
 // g_cam[0..3] = dL/dq, g_cam[4..6] = dL/dT from dL/d c2w (rows 0-2):
 //   dL/dq_m = two_s sum_ab G_ab dM_ab/dq_m - two_s^2 q_m sum_ab G_ab M_ab       (d two_s / d q_m = -two_s^2 q_m)
+ADFP_DEV void camera_from_tensor_bwd_dev(const float* __restrict__ cam, const float* g_c2w, float* g_cam);
 __global__ void k_camera_from_tensor_bwd(const float* __restrict__ cam, const float* __restrict__ g_c2w, float* __restrict__ g_cam) {
     if (blockIdx.x || threadIdx.x) return;
+    camera_from_tensor_bwd_dev(cam, g_c2w, g_cam);
+}
+ADFP_DEV void camera_from_tensor_bwd_dev(const float* __restrict__ cam, const float* g_c2w, float* g_cam) {
     float two_s, M[9], G[9];
     quat_terms(cam, two_s, M);
     float gm = 0.f;

@@ -113,16 +113,21 @@ class TrackerIteration(object):
         fx, fy, cx, cy = self.intr
         H0, H1, W0, W1 = self.window
         f32 = dict(dtype=torch.float32, device=dev)
-        check(L.adfp_camera_from_tensor(ptr(self.cam), ptr(self.c2w), st), 'adfp_camera_from_tensor')
+        # camera tensor -> c2w, the drawn pixels, their rays, the bounding-box keep flags and the kept rays' largest depth: ONE launch
+        # (adfp_tracker_head = adfp_camera_from_tensor + adfp_select_pixels + adfp_rays_from_uv + adfp_prefilter_mask)
         pi, pj, gd = torch.empty(n, **f32), torch.empty(n, **f32), torch.empty(n, **f32)
         gc = torch.empty((n, 3), **f32)
-        check(L.adfp_select_pixels(ptr(pick), n, H0, H1, W0, W1, self.H, self.W, ptr(self.depth_img), ptr(self.color_img),
-                                   ptr(pi), ptr(pj), ptr(gd), ptr(gc), st), 'adfp_select_pixels')
         ro, rd = torch.empty((n, 3), **f32), torch.empty((n, 3), **f32)
-        check(L.adfp_rays_from_uv(ptr(pi), ptr(pj), n, fx, fy, cx, cy, ptr(self.c2w), ptr(ro), ptr(rd), st), 'adfp_rays_from_uv')
         keep = torch.empty((n,), dtype=torch.uint8, device=dev)
         dmax = torch.empty((1,), **f32)
-        check(L.adfp_prefilter_mask(ptr(ro), ptr(rd), ptr(gd), n, ptr(self.bound_dev), ptr(keep), ptr(dmax), st), 'adfp_prefilter_mask')
+        ha = _lib.AdfpTrackerHeadArgs()
+        ha.cam, ha.c2w, ha.idx, ha.n = self.cam.data_ptr(), self.c2w.data_ptr(), pick.data_ptr(), n
+        ha.H0, ha.H1, ha.W0, ha.W1, ha.H, ha.W = H0, H1, W0, W1, self.H, self.W
+        ha.depth_img, ha.color_img = self.depth_img.data_ptr(), self.color_img.data_ptr()
+        ha.fx, ha.fy, ha.cx, ha.cy, ha.bound = fx, fy, cx, cy, self.bound_dev.data_ptr()
+        ha.pix_i, ha.pix_j, ha.gt_depth, ha.gt_color = pi.data_ptr(), pj.data_ptr(), gd.data_ptr(), gc.data_ptr()
+        ha.rays_o, ha.rays_d, ha.keep, ha.depth_max = ro.data_ptr(), rd.data_ptr(), keep.data_ptr(), dmax.data_ptr()
+        check(L.adfp_tracker_head(C.byref(ha), st), 'adfp_tracker_head')
         no_flat = {k: False for k in ('low', 'high', 'color', 'att')}
         depth, unc, color, weight, aux = eng.render_forward(dec, self.c, ro, rd, gd, self.tsdf, self.tsdf_bnds, rend.bound, 'color',
                                                             rend.N_samples, rend.N_surface, rend.lindisp, rend.perturb, None, dmax,
@@ -138,32 +143,25 @@ class TrackerIteration(object):
         none = {k: False for k in ('low', 'high', 'color')}
         _, _, (g_ro, g_rd) = eng.render_backward(dec, self.c, self.tsdf, self.tsdf_bnds, rend.bound, 'color', aux, g_depth, None,
                                                  g_color, None, none, no_flat, need_rays=True, ray_keep=keep)
-        check(L.adfp_rays_from_uv_backward(ptr(pi), ptr(pj), n, fx, fy, cx, cy, ptr(g_ro), ptr(g_rd), ptr(self.g_c2w), st),
-              'adfp_rays_from_uv_backward')
-        check(L.adfp_camera_from_tensor_backward(ptr(self.cam), ptr(self.g_c2w), ptr(self.g_cam), st), 'adfp_camera_from_tensor_backward')
-        if not adam:
-            return
-        if self.separate:
-            # camera_tensor = cat([quad, T]) is rebuilt BEFORE the step in the reference loop (:237-238), so the candidate it
-            # clones after the step is the pose this loss was measured at
-            check(L.adfp_track_keep_best(ptr(self.loss), ptr(self.cam), ptr(self.best_loss), ptr(self.best_cam), st), 'adfp_track_keep_best')
-        b1, b2 = self.betas
-        lrs = (C.c_float * self.n_groups)(*([self.cam_lr, self.cam_lr * 0.2] if self.separate else [self.cam_lr]))
-        # a forward repaired for an f16-range event has zero gradients by construction: nobody steps then (adfp_train_state.counter[8])
-        skip = C.c_void_p(aux['counter_ptr'] + 32)
-        check(L.adfp_adam_prep(ptr(self.step_count), ptr(self.derived), self.n_groups, lrs, b1, b2, skip, st), 'adfp_adam_prep')
-        parts = [(4, 3), (0, 4)] if self.separate else [(0, 7)]              # (offset, length) of each group inside the 7-vector
-        arr = (_lib.AdfpAdamGroup * len(parts))()
-        for k, (off, cnt) in enumerate(parts):
-            a = arr[k]
-            a.param, a.grad = self.cam.data_ptr() + 4 * off, self.g_cam.data_ptr() + 4 * off
-            a.exp_avg, a.exp_avg_sq = self.exp_avg.data_ptr() + 4 * off, self.exp_avg_sq.data_ptr() + 4 * off
-            a.mask, a.nvox, a.channels = None, cnt, 1
-            a.derived = self.derived[k].data_ptr()
-        check(L.adfp_masked_adam_multi(len(parts), C.byref(arr), b1, b2, self.eps, st), 'adfp_masked_adam_multi')
-        if not self.separate:
-            # the one-tensor optimiser updates camera_tensor in place: the reference's candidate is the pose AFTER the step
-            check(L.adfp_track_keep_best(ptr(self.loss), ptr(self.cam), ptr(self.best_loss), ptr(self.best_cam), st), 'adfp_track_keep_best')
+        # ray cotangents -> d/d c2w -> d/d camera tensor, and (adam) the Adam step on the pose's parameter groups and the running best
+        # pose: ONE launch (adfp_tracker_tail = adfp_rays_from_uv_backward + adfp_camera_from_tensor_backward + adfp_adam_prep +
+        # adfp_masked_adam_multi + adfp_track_keep_best).  The candidate is kept BEFORE the step with separate learning rates
+        # (camera_tensor = cat([quad, T]) is rebuilt before the step in the reference loop, :237-238, so the pose it clones after the step
+        # is the one this loss was measured at) and after it with the one-tensor optimiser (updated in place).
+        ta = _lib.AdfpTrackerTailArgs()
+        ta.pix_i, ta.pix_j, ta.n, ta.fx, ta.fy, ta.cx, ta.cy = pi.data_ptr(), pj.data_ptr(), n, fx, fy, cx, cy
+        ta.g_rays_o, ta.g_rays_d = g_ro.data_ptr(), g_rd.data_ptr()
+        ta.cam, ta.g_c2w, ta.g_cam = self.cam.data_ptr(), self.g_c2w.data_ptr(), self.g_cam.data_ptr()
+        ta.step = 1 if adam else 0
+        if adam:
+            ta.exp_avg, ta.exp_avg_sq = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+            ta.steps, ta.derived, ta.n_groups = self.step_count.data_ptr(), self.derived.data_ptr(), self.n_groups
+            ta.lr[0], ta.lr[1] = (self.cam_lr, self.cam_lr * 0.2) if self.separate else (self.cam_lr, 0.0)
+            ta.beta1, ta.beta2, ta.eps = self.betas[0], self.betas[1], self.eps
+            # a forward repaired for an f16-range event has zero gradients by construction: nobody steps then (adfp_train_state.counter[8])
+            ta.skip_flag = aux['counter_ptr'] + 32
+            ta.loss, ta.best_loss, ta.best_cam = self.loss.data_ptr(), self.best_loss.data_ptr(), self.best_cam.data_ptr()
+        check(L.adfp_tracker_tail(C.byref(ta), st), 'adfp_tracker_tail')
 
     @torch.no_grad()
     def gradient(self, batch_size, pick=None):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 129
+#define ADFP_VERSION 130
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -549,6 +549,37 @@ typedef struct adfp_keyframe {
 int adfp_sample_keyframes(int n_frames, const adfp_keyframe* frames /*host*/, int n, int H0, int H1, int W0, int W1, int H, int W,
                           float fx, float fy, float cx, float cy, float* rays_o /*[n_frames n,3]*/, float* rays_d, float* gt_depth /*[n_frames n]*/,
                           float* gt_color /*[n_frames n,3]*/, void* stream);
+/* The head and the tail of a Tracker iteration as ONE launch each (a launch costs ~5 us inside a graph replay whatever it does, and
+ * the chain below is seven of them).
+ * adfp_tracker_head = adfp_camera_from_tensor + adfp_select_pixels + adfp_rays_from_uv + adfp_prefilter_mask, same arithmetic:
+ *   cam [7] -> c2w [16]; the n drawn pixels -> pix_i / pix_j / gt_depth / gt_color, their rays, the bounding-box keep flags and
+ *   the largest sensor depth of the kept rays.
+ * adfp_tracker_tail = adfp_rays_from_uv_backward + adfp_camera_from_tensor_backward [+ adfp_adam_prep + adfp_masked_adam_multi on
+ *   the pose's parameter groups + adfp_track_keep_best]: ray cotangents -> g_c2w [16] -> g_cam [7]; with step != 0 the Adam step of
+ *   torch.optim.Adam on cam (groups: n_groups = 1 -> the 7 parameters with lr[0]; 2 -> translation cam[4..7) with lr[0], quaternion
+ *   cam[0..4) with lr[1], src/Tracker.py:219-229) and the running best pose -- kept BEFORE the step when n_groups = 2, after it
+ *   when n_groups = 1 (the reference rebuilds / clones its camera tensor at those points, src/Tracker.py:236-263).  steps [n_groups]
+ *   int / derived [n_groups][2] float as adfp_adam_prep; skip_flag as there. */
+typedef struct adfp_tracker_head_args {
+    const float* cam; float* c2w;
+    const long long* idx; int n; int H0, H1, W0, W1, H, W;
+    const float* depth_img; const float* color_img;
+    float fx, fy, cx, cy;
+    const double* bound;                     /* device [6] */
+    float* pix_i; float* pix_j; float* gt_depth; float* gt_color; float* rays_o; float* rays_d;
+    unsigned char* keep; float* depth_max;
+} adfp_tracker_head_args;
+int adfp_tracker_head(const adfp_tracker_head_args* args /*host*/, void* stream);
+typedef struct adfp_tracker_tail_args {
+    const float* pix_i; const float* pix_j; int n; float fx, fy, cx, cy;
+    const float* g_rays_o; const float* g_rays_d;
+    float* cam; float* g_c2w; float* g_cam;
+    int step;                                /* 0: gradients only */
+    float* exp_avg; float* exp_avg_sq;       /* [7] each */
+    int* steps; float* derived; int n_groups; float lr[2]; float beta1, beta2, eps; const int* skip_flag;
+    const double* loss; double* best_loss; float* best_cam;
+} adfp_tracker_tail_args;
+int adfp_tracker_tail(const adfp_tracker_tail_args* args /*host*/, void* stream);
 /* The tracking loss (src/Tracker.py:115-129) and its cotangents:
  *   tmp = |gt_depth - depth| / sqrt(uncertainty + 1e-10)        (float64, uncertainty detached)
  *   mask = keep & (gt_depth > 0) [& tmp < 10 median(tmp over the kept rays) when handle_dynamic]

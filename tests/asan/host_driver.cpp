@@ -275,6 +275,31 @@ int main() {
     EXPECT_NEG(adfp_select_pixels(dev<long long>(1), 100, 5, 4, 0, 64, 48, 64, dev<float>(2), dev<float>(3), dev<float>(4), dev<float>(5), dev<float>(6), dev<float>(7), st));      // H1 <= H0
     EXPECT_NEG(adfp_select_pixels(dev<long long>(1), 100, 0, 49, 0, 64, 48, 64, dev<float>(2), dev<float>(3), dev<float>(4), dev<float>(5), dev<float>(6), dev<float>(7), st));     // window beyond the image
     EXPECT_REACHES_LAUNCH(adfp_select_pixels(dev<long long>(1), 100, 4, 44, 4, 60, 48, 64, dev<float>(2), dev<float>(3), dev<float>(4), dev<float>(5), dev<float>(6), dev<float>(7), st));
+    {   // the Tracker iteration's head and tail
+        adfp_tracker_head_args h; memset(&h, 0, sizeof(h));
+        h.cam = dev<float>(1); h.c2w = dev<float>(2); h.idx = dev<long long>(3); h.n = 100; h.H0 = 4; h.H1 = 44; h.W0 = 4; h.W1 = 60; h.H = 48; h.W = 64;
+        h.depth_img = dev<float>(4); h.color_img = dev<float>(5); h.fx = h.fy = 50.f; h.cx = 32.f; h.cy = 24.f; h.bound = dev<double>(6);
+        h.pix_i = dev<float>(7); h.pix_j = dev<float>(8); h.gt_depth = dev<float>(9); h.gt_color = dev<float>(10); h.rays_o = dev<float>(11); h.rays_d = dev<float>(12);
+        h.keep = dev<unsigned char>(13); h.depth_max = dev<float>(14);
+        EXPECT_NEG(adfp_tracker_head(nullptr, st));
+        { adfp_tracker_head_args b = h; b.H1 = 49; EXPECT_NEG(adfp_tracker_head(&b, st)); }
+        { adfp_tracker_head_args b = h; b.cam = nullptr; EXPECT_NEG(adfp_tracker_head(&b, st)); }
+        { adfp_tracker_head_args b = h; b.rays_d = nullptr; EXPECT_NEG(adfp_tracker_head(&b, st)); }
+        { adfp_tracker_head_args b = h; b.n = -1; EXPECT_NEG(adfp_tracker_head(&b, st)); }
+        EXPECT_REACHES_LAUNCH(adfp_tracker_head(&h, st));
+        adfp_tracker_tail_args t; memset(&t, 0, sizeof(t));
+        t.pix_i = dev<float>(7); t.pix_j = dev<float>(8); t.n = 100; t.fx = t.fy = 50.f; t.cx = 32.f; t.cy = 24.f; t.g_rays_o = dev<float>(15); t.g_rays_d = dev<float>(16);
+        t.cam = dev<float>(1); t.g_c2w = dev<float>(17); t.g_cam = dev<float>(18);
+        EXPECT_NEG(adfp_tracker_tail(nullptr, st));
+        { adfp_tracker_tail_args b = t; b.g_cam = nullptr; EXPECT_NEG(adfp_tracker_tail(&b, st)); }
+        EXPECT_REACHES_LAUNCH(adfp_tracker_tail(&t, st));                     // gradients only
+        t.step = 1;
+        EXPECT_NEG(adfp_tracker_tail(&t, st));                                // a step without optimiser state
+        t.exp_avg = dev<float>(19); t.exp_avg_sq = dev<float>(20); t.steps = dev<int>(21); t.derived = dev<float>(22); t.n_groups = 2; t.lr[0] = 1e-3f; t.lr[1] = 2e-4f;
+        t.beta1 = 0.9f; t.beta2 = 0.999f; t.eps = 1e-8f; t.loss = dev<double>(23); t.best_loss = dev<double>(24); t.best_cam = dev<float>(25);
+        { adfp_tracker_tail_args b = t; b.n_groups = 3; EXPECT_NEG(adfp_tracker_tail(&b, st)); }
+        EXPECT_REACHES_LAUNCH(adfp_tracker_tail(&t, st));
+    }
     {
         adfp_keyframe kf[2];
         memset(kf, 0, sizeof(kf));
