@@ -418,9 +418,10 @@ struct DecodeLCTrainArgs {
     float* act_low; float* act_color;              // or NULL
     // SMALL batches (fewer tiles than half the launch's waves: a Tracker iteration, a 1 000-ray Mapper batch): a wave takes ONE network
     // of a tile instead of both in turn -- the launch is then the latency of one network's five dependent layers, not of two
+    // (k_decode_lc16_train<NT, true>; the host sets the flag and picks the instantiation)
     int split_networks;
 };
-template <int NT>
+template <int NT, bool SPLIT = false>
 __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16_train(DecodeLCTrainArgs t) {
     const DecodeLCArgs& a = t.f;
     using LL = DecLayoutG<32, 1>;
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16_train(DecodeLCTrai
     const int ntiles = (count + 31) >> 5;
     float amax_low = image_out_of_range<LL::P_FLAG, LL::NFLAG>(lds_low) ? INFINITY : 0.f;
     float amax_col = image_out_of_range<LC::P_FLAG, LC::NFLAG>(lds_col) ? INFINITY : 0.f;
-    const bool split = t.split_networks != 0;      // uniform over the launch
+    constexpr bool split = SPLIT;                   // a template parameter: the whole-batch kernel carries none of the branches below
     const int njobs = split ? 2 * ntiles : ntiles;
     for (int j = threadIdx.x >> 6, job; (job = claim_tile<NT / 64>(j, &s_next, njobs)) >= 0;) {
         const int tile = split ? job >> 1 : job;
@@ -471,9 +472,11 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16_train(DecodeLCTrai
         unsigned mw[3];
         int off_low = 0, off_col = LL::P_TOTAL;
         asm volatile("" : "+v"(off_low), "+v"(off_col));
-        occ[0][0] = 0.f; occ[1][0] = 0.f;
+        if constexpr (split) {
+            occ[0][0] = 0.f; occ[1][0] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { rgb[0][k] = 0.f; rgb[1][k] = 0.f; }
+            for (int k = 0; k < 4; ++k) { rgb[0][k] = 0.f; rgb[1][k] = 0.f; }
+        }
         if (do_low) {
             decode_net_g<32, 1, 1>(lds_all + off_low, a.g_low, a.g_low, pn, pf, lane, amax_low, occ, mw, t.act_low + (long long)i0 * ST::NXM, t.act_low ? rowbits : 0u ADFP_PHG_ARGS(8));
             if (valid) { unsigned* mrow = t.masks_low + ((long long)q * 2 + (g & 1)) * 3; mrow[0] = mw[0]; mrow[1] = mw[1]; mrow[2] = mw[2]; }

@@ -1596,7 +1596,8 @@ static int eval_points_impl(const adfp_scene* sc, const PtsDev& P, int stage, in
         t.masks_low = state->masks_low; t.masks_color = state->masks_color; t.act_low = state->act_low; t.act_color = state->act_color;
         // few tiles (every (tile, network) pair can have a wave of its own): one network per wave
         t.split_networks = 2 * ntiles <= num_cu() * (ADFP_LCT_NT / 64) ? 1 : 0;
-        hipLaunchKernelGGL((k_decode_lc16_train<ADFP_LCT_NT>), dim3(decode_grid(t.split_networks ? 2 * ntiles : ntiles, ADFP_LCT_NT / 64, 1)), dim3(ADFP_LCT_NT), 0, st, t);
+        if (t.split_networks) hipLaunchKernelGGL((k_decode_lc16_train<ADFP_LCT_NT, true>), dim3(decode_grid(2 * ntiles, ADFP_LCT_NT / 64, 1)), dim3(ADFP_LCT_NT), 0, st, t);
+        else hipLaunchKernelGGL((k_decode_lc16_train<ADFP_LCT_NT, false>), dim3(decode_grid(ntiles, ADFP_LCT_NT / 64, 1)), dim3(ADFP_LCT_NT), 0, st, t);
         ADFP_CHECK_LAUNCH();
     }
 #endif

@@ -67,6 +67,8 @@ def main(template, d):
     v['cpu_value'] = '%.0f' % b['cpu_baseline']['value']; v['cpu_cores'] = str(b['cpu_baseline']['cores'])
     rn = b.get('replica_native_frame') or b['config'].get('replica_native_frame')
     v['replica_ms'] = '%.2f' % rn['ms_per_frame']; v['replica_value'] = '%.1f' % (rn['rays_per_s'] / 1e6)
+    tb = b['tracker_iteration']['by_batch']
+    v['tracker_200'] = '%.3f' % tb['200']['ms_per_iteration']; v['tracker_1000'] = '%.3f' % tb['1000']['ms_per_iteration']
     c1 = b['config1']
     v['config1'] = '%.3f ms forward (%.1f M rays/s), %.2f ms forward + loss + backward through autograd' % (c1['forward']['ms'], c1['forward']['value'] / 1e6, c1['forward_backward']['ms'])
     v['config3_ms'] = '%.3f' % b['config3']['ms_per_iteration']
