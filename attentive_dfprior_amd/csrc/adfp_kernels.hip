@@ -2337,12 +2337,13 @@ struct BwdWorkspace { float* g_raw; float* att_g; float* g_pts; float* stage; in
                       int gmax_pending;              // > 0: gmax_parts[0 .. gmax_pending) still wait to be folded into gmax (backward_points)
                       // adfp_render_backward's first two launches (zero fill of the gradient outputs, k_composite_bwd), held back so that
                       // backward_points can send them off in ONE launch with k_bin_keys (k_backward_head)
+                      bool head_zeroes_g_pts;        // ... and g_pts with them
                       bool head_pending; ZeroJobs head_zero; unsigned head_zero_blocks; CompositeBwdArgs head_comp;
                       float* gc; size_t gc_stride; int* bin_key; int* bin_val; int* bin_key_sorted; int* bin_perm; int* sort_table;
                       size_t bytes; };
 static BwdWorkspace carve_bwd(void* base, long long P) {
     BwdWorkspace w; size_t o = 0;
-    w.gmax_pending = 0; w.head_pending = false;
+    w.gmax_pending = 0; w.head_pending = false; w.head_zeroes_g_pts = false;
     w.g_raw = at<float>(base, o); o += align256((size_t)P * 16);
     w.att_g = at<float>(base, o); o += align256((size_t)P * 4);
     w.g_pts = at<float>(base, o); o += align256((size_t)P * 12);
@@ -2733,7 +2734,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
     a.P = Pd; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
     a.list = nullptr; a.count_ptr = nullptr; a.g_raw = bw.g_raw; a.att_g = nullptr; a.stage = nullptr; a.dbg_masks = nullptr;
     a.g_pts = pgrad ? bw.g_pts : nullptr;
-    if (pgrad) { e = zero_async(bw.g_pts, (size_t)P * 12, st); if (e != hipSuccess) return (int)e; }
+    if (pgrad && !(bw.head_pending && bw.head_zeroes_g_pts)) { e = zero_async(bw.g_pts, (size_t)P * 12, st); if (e != hipSuccess) return (int)e; }
     // a decoder takes the f16-split backward when its T image and the forward's masks are there and -- if its weight gradients
     // are wanted -- the forward also left the layer inputs.  A position gradient comes from the f16-split kernels only on its own
     // (the Tracker: networks and grids frozen); together with weight or grid gradients (bundle adjustment) the exact kernels run.
@@ -2924,6 +2925,11 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
     {
         ZeroBatch zb;
         rc = zero_grad_jobs(sc, go, r->options, zb, st); if (rc) return rc;
+        bw.head_zeroes_g_pts = false;
+        if ((r->g_rays_o || r->g_rays_d) && zb.z.n < ZERO_MULTI) {      // the position gradients' accumulator rides along (the Tracker)
+            hipError_t ze = zb.add(bw.g_pts, (size_t)P * 12, st); if (ze != hipSuccess) return (int)ze;
+            bw.head_zeroes_g_pts = true;
+        }
         bw.head_zero = zb.z; bw.head_zero_blocks = zb.blocks;
         bw.head_zero.n = zb.z.n;
         CompositeBwdArgs& c = bw.head_comp;
