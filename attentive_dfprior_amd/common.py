@@ -9,7 +9,6 @@ The pose utilities of the Tracker (quad2rotation, get_camera_from_tensor, get_te
 plain torch / numpy here -- host API; inside the fused tracking iteration (tracking.TrackerIteration) the same conversion and its
 backward are device kernels (adfp_camera_from_tensor).
 """
-import ctypes as C
 
 import numpy as np
 import torch

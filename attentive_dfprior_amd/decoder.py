@@ -9,7 +9,6 @@ and src/utils/Logger.py:26 expect -- but ``DF.forward`` runs on the MI355X throu
 The modules only OWN parameters; all arithmetic happens in the HIP kernels.  There is no
 PyTorch fallback: calling ``DF`` on CPU tensors raises.
 """
-import math
 
 import torch
 import torch.nn as nn
