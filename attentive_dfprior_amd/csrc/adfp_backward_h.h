@@ -141,33 +141,24 @@ ADFP_DEV void stage_block_scaled(float* __restrict__ row, int col, int h, const 
 // PGRAD (the Tracker: pose gradients, networks and grids frozen -- only with WGRAD = SCAT = false): d/d position through the
 // Fourier features (the d/d e blocks of layers 3 and 0 stay in 48 accumulators; cos(p @ B) and the 3-vector product on the VALU
 // in f32) and through the trilinear lookup of the own grid (d/d c against the eight corner rows, as the exact kernel does).
-template <int CDIM, int NOUT, int ROLE, bool WGRAD, bool SCAT, int NT, bool PGRAD = false>
-__global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
+// The body of a workgroup: `blk` of `nblk` workgroups of ITS launch share (k_decode_bwd_h: the launch; k_decode_bwd_h_pgrad3: one
+// decoder's part of it), the T image loaded into `ldsu` (at least DecLayoutHT<CDIM, NOUT>::P_TOTAL words), `sm` = the wave's scatter
+// scratch (SCAT only).  ATOMIC_PTS: d/d position is added with atomics (several decoders' launches run side by side).
+template <int CDIM, int NOUT, int ROLE, bool WGRAD, bool SCAT, int NT, bool PGRAD, bool ATOMIC_PTS>
+ADFP_DEV void decode_bwd_h_body(const DecodeBwdHArgs& a, unsigned* __restrict__ ldsu, const ScatterSmem& sm, int blk, int nblk) {
     static_assert(!PGRAD || (!WGRAD && !SCAT), "the position gradient comes without weight / grid gradients");
     using LT = DecLayoutHT<CDIM, NOUT>;
     using ST = DecStage<CDIM>;
     constexpr int NW = NT / 64;
-    constexpr int NS = SCAT ? NW : 1;
     constexpr bool CACHE = true;
-    __shared__ __attribute__((aligned(16))) unsigned ldsu[LT::P_TOTAL];
-    __shared__ float s_tr[NS][SCAT ? 32 * 33 : 1];
-    __shared__ int s_vox[NS][SCAT ? 32 * 8 : 1];
-    __shared__ float s_cw[NS][SCAT ? 32 * 8 : 1];
-    __shared__ float s_cacc[NS][2][SCAT ? 32 * 32 : 1];
-    __shared__ int s_ctag[NS][2][SCAT ? 32 : 1];
     for (int i = threadIdx.x; i < LT::P_TOTAL / 4; i += NT) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed_t)[i];
-    if constexpr (SCAT) {
-        for (int i = threadIdx.x; i < NW * 2 * 32 * 32; i += NT) (&s_cacc[0][0][0])[i] = 0.f;
-        for (int i = threadIdx.x; i < NW * 2 * 32; i += NT) (&s_ctag[0][0][0])[i] = -1;
-    }
     __syncthreads();
     const float* lds = (const float*)ldsu;
 
     const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-    const ScatterSmem sm = {s_tr[SCAT ? wv : 0], s_vox[SCAT ? wv : 0], s_cw[SCAT ? wv : 0], &s_cacc[SCAT ? wv : 0][0][0], &s_ctag[SCAT ? wv : 0][0][0]};
     const int lane_off = h * 128 + p * 4;
-    const int wave = blockIdx.x * NW + wv;
-    const int nwaves = gridDim.x * NW;
+    const int wave = blk * NW + wv;
+    const int nwaves = nblk * NW;
     int hi = a.chunk_hi;
     if (ROLE == ROLE_HIGH) { const int cnt = *a.count_ptr; hi = hi < cnt ? hi : cnt; }
     const int count = hi - a.chunk_lo;
@@ -350,7 +341,11 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) gpos[k] += __shfl_xor(gpos[k], 32);
             if (valid && h == 0) {
-                a.g_pts[3ll * q + 0] += gpos[0] * isc; a.g_pts[3ll * q + 1] += gpos[1] * isc; a.g_pts[3ll * q + 2] += gpos[2] * isc;
+                if constexpr (ATOMIC_PTS) {
+                    atomicAdd(a.g_pts + 3ll * q + 0, gpos[0] * isc); atomicAdd(a.g_pts + 3ll * q + 1, gpos[1] * isc); atomicAdd(a.g_pts + 3ll * q + 2, gpos[2] * isc);
+                } else {
+                    a.g_pts[3ll * q + 0] += gpos[0] * isc; a.g_pts[3ll * q + 1] += gpos[1] * isc; a.g_pts[3ll * q + 2] += gpos[2] * isc;
+                }
             }
         } else if constexpr (SCAT) {
             if (a.g_grid) {
@@ -364,6 +359,42 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
     }
     if constexpr (SCAT) { if (a.g_grid) scatter_flush<CACHE>(a.g_grid, lane, sm); }
     if (!(a.skip && *a.skip)) report_range(a.status, amax, ADFP_STATUS_F16_RANGE_BWD);
+}
+template <int CDIM, int NOUT, int ROLE, bool WGRAD, bool SCAT, int NT, bool PGRAD = false>
+__global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
+    using LT = DecLayoutHT<CDIM, NOUT>;
+    constexpr int NW = NT / 64;
+    constexpr int NS = SCAT ? NW : 1;
+    __shared__ __attribute__((aligned(16))) unsigned ldsu[LT::P_TOTAL];
+    __shared__ float s_tr[NS][SCAT ? 32 * 33 : 1];
+    __shared__ int s_vox[NS][SCAT ? 32 * 8 : 1];
+    __shared__ float s_cw[NS][SCAT ? 32 * 8 : 1];
+    __shared__ float s_cacc[NS][2][SCAT ? 32 * 32 : 1];
+    __shared__ int s_ctag[NS][2][SCAT ? 32 : 1];
+    if constexpr (SCAT) {                                    // (the body's barrier after its image load covers these)
+        for (int i = threadIdx.x; i < NW * 2 * 32 * 32; i += NT) (&s_cacc[0][0][0])[i] = 0.f;
+        for (int i = threadIdx.x; i < NW * 2 * 32; i += NT) (&s_ctag[0][0][0])[i] = -1;
+    }
+    const int wv = threadIdx.x >> 6;
+    const ScatterSmem sm = {s_tr[SCAT ? wv : 0], s_vox[SCAT ? wv : 0], s_cw[SCAT ? wv : 0], &s_cacc[SCAT ? wv : 0][0][0], &s_ctag[SCAT ? wv : 0][0][0]};
+    decode_bwd_h_body<CDIM, NOUT, ROLE, WGRAD, SCAT, NT, PGRAD, false>(a, ldsu, sm, (int)blockIdx.x, (int)gridDim.x);
+}
+// The position-gradient backward of SEVERAL frozen decoders in ONE launch (the Tracker: high, low and colour decoder): with a few
+// hundred tiles each the three launches were three tile latencies in a row (~13 us each at 200 rays); side by side they are one.
+// Workgroups [first[k], first[k + 1]) run job k; d/d position is accumulated with atomics.
+#define ADFP_PGRAD_MAX_JOBS 3
+struct DecodeBwdH3Args { DecodeBwdHArgs j[ADFP_PGRAD_MAX_JOBS]; int role[ADFP_PGRAD_MAX_JOBS]; int first[ADFP_PGRAD_MAX_JOBS + 1]; int n; };
+__host__ __device__ constexpr int max3i(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+__global__ __launch_bounds__(512) void k_decode_bwd_h_pgrad3(DecodeBwdH3Args m) {
+    __shared__ __attribute__((aligned(16))) unsigned ldsu[max3i(DecLayoutHT<64, 1>::P_TOTAL, DecLayoutHT<32, 1>::P_TOTAL, DecLayoutHT<32, 4>::P_TOTAL)];
+    int k = 0;
+    while (k + 1 < m.n && (int)blockIdx.x >= m.first[k + 1]) ++k;            // block-uniform
+    const int blk = (int)blockIdx.x - m.first[k], nblk = m.first[k + 1] - m.first[k];
+    const ScatterSmem sm = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const DecodeBwdHArgs& a = m.j[k];
+    if (m.role[k] == ROLE_HIGH) decode_bwd_h_body<64, 1, ROLE_HIGH, false, false, 512, true, true>(a, ldsu, sm, blk, nblk);
+    else if (m.role[k] == ROLE_LOW) decode_bwd_h_body<32, 1, ROLE_LOW, false, false, 512, true, true>(a, ldsu, sm, blk, nblk);
+    else decode_bwd_h_body<32, 4, ROLE_COLOR, false, false, 512, true, true>(a, ldsu, sm, blk, nblk);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -2573,12 +2573,29 @@ static int launch_backward_head(BwdWorkspace& bw, const BinArgs* bins, int P, hi
 }
 
 // the grids whose d/d c rows wait for the call's ONE k_scatter_sorted launch (flush_scatter): job k has rows in bw.gc + k * gc_stride
-struct BinPlan { bool ok; BinArgs args; const int* perm; ScatterMultiArgs pend; };
+struct BinPlan { bool ok; BinArgs args; const int* perm; ScatterMultiArgs pend;
+                 DecodeBwdH3Args pgrad; };            // the position-gradient backwards of the call's decoders, launched together (flush_pgrad)
 static int scatter_bins(BinPlan& bp, const DecodeBwdArgs& o, float* gc, const unsigned char* flags) {
     if (o.g0.X > 1023 || o.g0.Y > 1023 || o.g0.Z > 1023) return ADFP_E_UNSUPPORTED;          // packed cell coordinates
     if (bp.pend.n_jobs >= ADFP_SCATTER_MAX_JOBS) return ADFP_E_UNSUPPORTED;
     ScatterSortedArgs& s = bp.pend.j[bp.pend.n_jobs++];
     s.P = o.P; s.nb = o.nb; s.g = o.g0; s.gc = gc; s.g_grid = o.g_grid; s.perm = bp.perm; s.n = o.P.n; s.flags = flags; s.flag_mask = ADFP_F_BAND;
+    return 0;
+}
+static int flush_pgrad(BinPlan& bp, hipStream_t st) {
+    DecodeBwdH3Args& m = bp.pgrad;
+    if (m.n == 0) return 0;
+    if (m.n == 1) {                                    // one decoder alone: its own launch (no atomics, the same sums run to run)
+        const DecodeBwdHArgs& a = m.j[0];
+        const int blocks = m.first[1];
+        if (m.role[0] == ROLE_HIGH) hipLaunchKernelGGL((k_decode_bwd_h<64, 1, ROLE_HIGH, false, false, 512, true>), dim3(blocks), dim3(512), 0, st, a);
+        else if (m.role[0] == ROLE_LOW) hipLaunchKernelGGL((k_decode_bwd_h<32, 1, ROLE_LOW, false, false, 512, true>), dim3(blocks), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_decode_bwd_h<32, 4, ROLE_COLOR, false, false, 512, true>), dim3(blocks), dim3(512), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(k_decode_bwd_h_pgrad3, dim3(m.first[m.n]), dim3(512), 0, st, m);
+    }
+    ADFP_CHECK_LAUNCH();
+    m.n = 0;
     return 0;
 }
 static int flush_scatter(BinPlan& bp, hipStream_t st) {
@@ -2611,8 +2628,13 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
     if (o.g_pts) {                                      // position gradient only (backward_points' use_h): frozen network and grid
         if (flat || o.g_grid) return ADFP_E_ARG;
         a.chunk_lo = 0; a.chunk_hi = total;
-        hipLaunchKernelGGL((k_decode_bwd_h<CDIM, NOUT, ROLE, false, false, 512, true>), dim3(decode_grid((total + 31) / 32, 8, 1)), dim3(512), 0, st, a);
-        ADFP_CHECK_LAUNCH();
+        // deferred: the call's decoders run side by side in ONE launch (flush_pgrad at the end of backward_points)
+        DecodeBwdH3Args& m = bp.pgrad;
+        if (m.n >= ADFP_PGRAD_MAX_JOBS) return ADFP_E_UNSUPPORTED;
+        if (m.n == 0) m.first[0] = 0;
+        m.j[m.n] = a; m.role[m.n] = ROLE;
+        m.first[m.n + 1] = m.first[m.n] + decode_grid((total + 31) / 32, 8, 1);
+        ++m.n;
         return 0;
     }
     if constexpr (CDIM == 32) {
@@ -2743,7 +2765,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
     };
     // The grid gradients of the decoders that take the f16-split backward are scattered in spatial order (k_scatter_sorted): one
     // radix sort of the points by (coarsest such grid's cell, finest grid's cell inside it), shared by all of them.
-    BinPlan bp; bp.ok = false; bp.pend.n_jobs = 0;
+    BinPlan bp; bp.ok = false; bp.pend.n_jobs = 0; bp.pgrad.n = 0;
     {
         const bool h_low = go.grid_low && use_h(sc->ht_low, state.masks_low, state.act_low, go.flat_low, go.grid_low);
         const bool h_high = fuse && go.grid_high && use_h(sc->ht_high, state.masks_high, state.act_high, go.flat_high, go.grid_high);
@@ -2892,6 +2914,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         else rc = sc->w_color ? run_decode_bwd<32, 4, ROLE_COLOR>(cl, P, nullptr, go.flat_color, bw, st) : ADFP_E_ARG;
         if (rc) return rc;
     }
+    rc = flush_pgrad(bp, st); if (rc) return rc;
     return flush_scatter(bp, st);
 }
 

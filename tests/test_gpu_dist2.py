@@ -85,6 +85,6 @@ def test_two_ranks_follow_the_single_process_iteration(masked):
     for k in one['grids']:
         assert_adam_trajectory(two['grids'][k], one['grids'][k], 0.01, 4, k, max_outliers=1e-2)
     for n in one['params']:
-        assert_adam_trajectory(two['params'][n], one['params'][n], 0.005, 4, n, max_outliers=1e-2)
+        assert_adam_trajectory(two['params'][n], one['params'][n], 0.005, 4, n, max_outliers=8e-2)      # (see tests/test_gpu_nccl.py)
     if masked:
         assert two['bucket_bytes'] < two['dense_bytes']            # only the selected voxels (and the parameters) travelled
