@@ -854,8 +854,11 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict
 }
 
 // d/d rays_o = sum_s d/dp_s,  d/d rays_d = sum_s z_s d/dp_s   (p = o + d z, Renderer.py:223)
+// extra / n_extra: further [P,3] buffers (the decoders' own, k_decode_bwd_h_pgrad3) added to g_pts in order, in float like the
+// accumulation in place they replace
+struct RaysGradExtra { const float* p[3]; int n; };
 __global__ __launch_bounds__(256) void k_rays_grad(const float* __restrict__ g_pts, const double* __restrict__ z, int n_rays, int S,
-                                                   float* __restrict__ g_o, float* __restrict__ g_d) {
+                                                   float* __restrict__ g_o, float* __restrict__ g_d, RaysGradExtra extra) {
     const int lane = threadIdx.x & 63;
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
@@ -864,7 +867,11 @@ __global__ __launch_bounds__(256) void k_rays_grad(const float* __restrict__ g_p
         const long long q = (long long)ray * S + s;
         const double zz = z[q];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { const double g = (double)g_pts[3 * q + k]; so[k] += g; sd[k] += g * zz; }
+        for (int k = 0; k < 3; ++k) {
+            float gf = g_pts[3 * q + k];
+            for (int e = 0; e < extra.n; ++e) gf += extra.p[e][3 * q + k];
+            const double g = (double)gf; so[k] += g; sd[k] += g * zz;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)

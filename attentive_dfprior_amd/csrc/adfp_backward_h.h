@@ -143,8 +143,9 @@ ADFP_DEV void stage_block_scaled(float* __restrict__ row, int col, int h, const 
 // in f32) and through the trilinear lookup of the own grid (d/d c against the eight corner rows, as the exact kernel does).
 // The body of a workgroup: `blk` of `nblk` workgroups of ITS launch share (k_decode_bwd_h: the launch; k_decode_bwd_h_pgrad3: one
 // decoder's part of it), the T image loaded into `ldsu` (at least DecLayoutHT<CDIM, NOUT>::P_TOTAL words), `sm` = the wave's scatter
-// scratch (SCAT only).  ATOMIC_PTS: d/d position is added with atomics (several decoders' launches run side by side).
-template <int CDIM, int NOUT, int ROLE, bool WGRAD, bool SCAT, int NT, bool PGRAD, bool ATOMIC_PTS>
+// scratch (SCAT only).  STORE_PTS: d/d position is WRITTEN to a.g_pts (a buffer of this decoder's own: several decoders run side by
+// side and k_rays_grad adds the buffers up in a fixed order) instead of added to it.
+template <int CDIM, int NOUT, int ROLE, bool WGRAD, bool SCAT, int NT, bool PGRAD, bool STORE_PTS>
 ADFP_DEV void decode_bwd_h_body(const DecodeBwdHArgs& a, unsigned* __restrict__ ldsu, const ScatterSmem& sm, int blk, int nblk) {
     static_assert(!PGRAD || (!WGRAD && !SCAT), "the position gradient comes without weight / grid gradients");
     using LT = DecLayoutHT<CDIM, NOUT>;
@@ -341,8 +342,8 @@ ADFP_DEV void decode_bwd_h_body(const DecodeBwdHArgs& a, unsigned* __restrict__ 
 #pragma unroll
             for (int k = 0; k < 3; ++k) gpos[k] += __shfl_xor(gpos[k], 32);
             if (valid && h == 0) {
-                if constexpr (ATOMIC_PTS) {
-                    atomicAdd(a.g_pts + 3ll * q + 0, gpos[0] * isc); atomicAdd(a.g_pts + 3ll * q + 1, gpos[1] * isc); atomicAdd(a.g_pts + 3ll * q + 2, gpos[2] * isc);
+                if constexpr (STORE_PTS) {
+                    a.g_pts[3ll * q + 0] = gpos[0] * isc; a.g_pts[3ll * q + 1] = gpos[1] * isc; a.g_pts[3ll * q + 2] = gpos[2] * isc;
                 } else {
                     a.g_pts[3ll * q + 0] += gpos[0] * isc; a.g_pts[3ll * q + 1] += gpos[1] * isc; a.g_pts[3ll * q + 2] += gpos[2] * isc;
                 }
@@ -381,7 +382,9 @@ __global__ __launch_bounds__(NT) void k_decode_bwd_h(DecodeBwdHArgs a) {
 }
 // The position-gradient backward of SEVERAL frozen decoders in ONE launch (the Tracker: high, low and colour decoder): with a few
 // hundred tiles each the three launches were three tile latencies in a row (~13 us each at 200 rays); side by side they are one.
-// Workgroups [first[k], first[k + 1]) run job k; d/d position is accumulated with atomics.
+// Workgroups [first[k], first[k + 1]) run job k; every job writes d/d position into a buffer of its own (zeroed by the caller: the
+// high decoder covers the in-band points only) and k_rays_grad adds the buffers in job order -- the sums of the launches in a row,
+// bit for bit (atomics on one buffer made a graph replay differ from the eager sequence in the last bits).
 #define ADFP_PGRAD_MAX_JOBS 3
 struct DecodeBwdH3Args { DecodeBwdHArgs j[ADFP_PGRAD_MAX_JOBS]; int role[ADFP_PGRAD_MAX_JOBS]; int first[ADFP_PGRAD_MAX_JOBS + 1]; int n; };
 __host__ __device__ constexpr int max3i(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }

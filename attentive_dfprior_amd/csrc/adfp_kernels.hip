@@ -2338,15 +2338,20 @@ struct BwdWorkspace { float* g_raw; float* att_g; float* g_pts; float* stage; in
                       // adfp_render_backward's first two launches (zero fill of the gradient outputs, k_composite_bwd), held back so that
                       // backward_points can send them off in ONE launch with k_bin_keys (k_backward_head)
                       bool head_zeroes_g_pts;        // ... and g_pts with them
+                      float* g_pts_dec; size_t g_pts_stride;   // [ADFP_PGRAD_MAX_JOBS][P,3]: the decoders' own d/d position buffers (k_decode_bwd_h_pgrad3)
+                      bool pgrad_separate;           // adfp_render_backward: the decoders write those and k_rays_grad adds them up
+                      int pgrad_used;                // how many of them the call's launch wrote
                       bool head_pending; ZeroJobs head_zero; unsigned head_zero_blocks; CompositeBwdArgs head_comp;
                       float* gc; size_t gc_stride; int* bin_key; int* bin_val; int* bin_key_sorted; int* bin_perm; int* sort_table;
                       size_t bytes; };
 static BwdWorkspace carve_bwd(void* base, long long P) {
     BwdWorkspace w; size_t o = 0;
-    w.gmax_pending = 0; w.head_pending = false; w.head_zeroes_g_pts = false;
+    w.gmax_pending = 0; w.head_pending = false; w.head_zeroes_g_pts = false; w.pgrad_separate = false; w.pgrad_used = 0;
     w.g_raw = at<float>(base, o); o += align256((size_t)P * 16);
     w.att_g = at<float>(base, o); o += align256((size_t)P * 4);
     w.g_pts = at<float>(base, o); o += align256((size_t)P * 12);
+    w.g_pts_stride = align256((size_t)P * 12) / 4;
+    w.g_pts_dec = at<float>(base, o); o += ADFP_PGRAD_MAX_JOBS * w.g_pts_stride * 4;
     w.stage_rows = (int)(P < STG_ROWS_MAX ? P : STG_ROWS_MAX);
     if (w.stage_rows < 32) w.stage_rows = 32;
     w.stage = at<float>(base, o); o += align256((size_t)w.stage_rows * AttStage::NCOLS * 4);
@@ -2582,19 +2587,22 @@ static int scatter_bins(BinPlan& bp, const DecodeBwdArgs& o, float* gc, const un
     s.P = o.P; s.nb = o.nb; s.g = o.g0; s.gc = gc; s.g_grid = o.g_grid; s.perm = bp.perm; s.n = o.P.n; s.flags = flags; s.flag_mask = ADFP_F_BAND;
     return 0;
 }
-static int flush_pgrad(BinPlan& bp, hipStream_t st) {
+static void launch_pgrad_single(const DecodeBwdHArgs& a, int role, int blocks, hipStream_t st) {
+    if (role == ROLE_HIGH) hipLaunchKernelGGL((k_decode_bwd_h<64, 1, ROLE_HIGH, false, false, 512, true>), dim3(blocks), dim3(512), 0, st, a);
+    else if (role == ROLE_LOW) hipLaunchKernelGGL((k_decode_bwd_h<32, 1, ROLE_LOW, false, false, 512, true>), dim3(blocks), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_decode_bwd_h<32, 4, ROLE_COLOR, false, false, 512, true>), dim3(blocks), dim3(512), 0, st, a);
+}
+static int flush_pgrad(BinPlan& bp, BwdWorkspace& bw, hipStream_t st) {
     DecodeBwdH3Args& m = bp.pgrad;
     if (m.n == 0) return 0;
-    if (m.n == 1) {                                    // one decoder alone: its own launch (no atomics, the same sums run to run)
-        const DecodeBwdHArgs& a = m.j[0];
-        const int blocks = m.first[1];
-        if (m.role[0] == ROLE_HIGH) hipLaunchKernelGGL((k_decode_bwd_h<64, 1, ROLE_HIGH, false, false, 512, true>), dim3(blocks), dim3(512), 0, st, a);
-        else if (m.role[0] == ROLE_LOW) hipLaunchKernelGGL((k_decode_bwd_h<32, 1, ROLE_LOW, false, false, 512, true>), dim3(blocks), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((k_decode_bwd_h<32, 4, ROLE_COLOR, false, false, 512, true>), dim3(blocks), dim3(512), 0, st, a);
-    } else {
+    if (m.n >= 2 && bw.pgrad_separate) {               // side by side, each into its own buffer (k_rays_grad adds them up)
+        for (int k = 0; k < m.n; ++k) m.j[k].g_pts = bw.g_pts_dec + (size_t)k * bw.g_pts_stride;
         hipLaunchKernelGGL(k_decode_bwd_h_pgrad3, dim3(m.first[m.n]), dim3(512), 0, st, m);
+        ADFP_CHECK_LAUNCH();
+        bw.pgrad_used = m.n;
+    } else {                                           // one after the other, accumulating into g_pts
+        for (int k = 0; k < m.n; ++k) { launch_pgrad_single(m.j[k], m.role[k], m.first[k + 1] - m.first[k], st); ADFP_CHECK_LAUNCH(); }
     }
-    ADFP_CHECK_LAUNCH();
     m.n = 0;
     return 0;
 }
@@ -2914,7 +2922,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         else rc = sc->w_color ? run_decode_bwd<32, 4, ROLE_COLOR>(cl, P, nullptr, go.flat_color, bw, st) : ADFP_E_ARG;
         if (rc) return rc;
     }
-    rc = flush_pgrad(bp, st); if (rc) return rc;
+    rc = flush_pgrad(bp, bw, st); if (rc) return rc;
     return flush_scatter(bp, st);
 }
 
@@ -2949,9 +2957,11 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
         ZeroBatch zb;
         rc = zero_grad_jobs(sc, go, r->options, zb, st); if (rc) return rc;
         bw.head_zeroes_g_pts = false;
-        if ((r->g_rays_o || r->g_rays_d) && zb.z.n < ZERO_MULTI) {      // the position gradients' accumulator rides along (the Tracker)
-            hipError_t ze = zb.add(bw.g_pts, (size_t)P * 12, st); if (ze != hipSuccess) return (int)ze;
-            bw.head_zeroes_g_pts = true;
+        if ((r->g_rays_o || r->g_rays_d) && zb.z.n + 1 < ZERO_MULTI) {  // the position gradients' accumulator and the decoders' own buffers
+            hipError_t ze = zb.add(bw.g_pts, (size_t)P * 12, st);       // ride along (the Tracker); contiguous: g_pts, then g_pts_dec
+            if (ze == hipSuccess) ze = zb.add(bw.g_pts_dec, ADFP_PGRAD_MAX_JOBS * bw.g_pts_stride * 4, st);
+            if (ze != hipSuccess) return (int)ze;
+            bw.head_zeroes_g_pts = true; bw.pgrad_separate = true;
         }
         bw.head_zero = zb.z; bw.head_zero_blocks = zb.blocks;
         bw.head_zero.n = zb.z.n;
@@ -2968,8 +2978,10 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
     rc = backward_points(sc, r->stage, Pd, P, r->state, r->g_weight, go, pgrad, r->options, bw, st);
     if (rc) return rc;
     if (pgrad) {
+        RaysGradExtra ex; ex.n = bw.pgrad_used;
+        for (int k = 0; k < 3; ++k) ex.p[k] = k < bw.pgrad_used ? bw.g_pts_dec + (size_t)k * bw.g_pts_stride : nullptr;
         hipLaunchKernelGGL(k_rays_grad, dim3((r->n_rays + 3) / 4), dim3(256), 0, st, bw.g_pts, r->z_vals, r->n_rays, r->S,
-                           r->g_rays_o, r->g_rays_d);
+                           r->g_rays_o, r->g_rays_d, ex);
         ADFP_CHECK_LAUNCH();
     }
     return 0;

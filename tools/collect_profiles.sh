@@ -4,7 +4,7 @@
 #   bash tools/collect_profiles.sh [section ...]        sections: tests pmc bench train diag config5 loops ab    (default: all)
 #
 # Every command's stderr is kept (gpurun_out/r05_logs/<step>.err) and a step that exits non-zero is reported, its target file is
-# removed (no empty or half-written summary is left to be copied), and the script itself exits 1 at the end.
+# moved to the logs (<step>.failed_output: no empty or half-written summary is left to be copied), and the script itself exits 1 at the end.
 # rocprofv3: program directly after `--`; PMC passes separate from --stats passes, FETCH_SIZE and WRITE_SIZE in separate passes.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
@@ -29,7 +29,7 @@ into() {
   local file=$1 step=$2; shift 2
   "$@" > $file 2> $L/$step.err
   local rc=$?
-  if [ $rc -ne 0 ]; then FAILED="$FAILED $step"; echo "FAILED rc=$rc: $step: $*"; tail -n 8 $L/$step.err; rm -f $file; fi
+  if [ $rc -ne 0 ]; then FAILED="$FAILED $step"; echo "FAILED rc=$rc: $step: $*"; tail -n 8 $L/$step.err; mv -f $file $L/$step.failed_output 2> /dev/null; tail -n 15 $L/$step.failed_output; fi
   return $rc
 }
 prof_stats() {   # <dir> <step> <program ...>: rocprofv3 --kernel-trace --stats
