@@ -246,6 +246,89 @@ def test_keep_best_follows_the_reference_comparison():
     assert best_l.item() == 3.0 and torch.equal(best_c.cpu(), torch.full((7,), 3.0))
 
 
+@pytest.mark.parametrize('n_groups', [1, 2])
+def test_tracker_head_and_tail_equal_the_entries_they_merge(n_groups):
+    """adfp_tracker_head = adfp_camera_from_tensor + adfp_select_pixels + adfp_rays_from_uv + adfp_prefilter_mask and
+    adfp_tracker_tail = adfp_rays_from_uv_backward + adfp_camera_from_tensor_backward + adfp_adam_prep + adfp_masked_adam_multi +
+    adfp_track_keep_best (before the step with two parameter groups, after it with one): every output bit for bit, over three steps."""
+    L = lib()
+    st = stream()
+    g = torch.Generator().manual_seed(21)
+    H, W, n = 60, 80, 777
+    H0, H1, W0, W1 = 5, 55, 7, 73
+    fx, fy, cx, cy = 70.0, 71.0, 39.5, 29.5
+    depth = (torch.rand(H, W, generator=g) * 4).to(DEV)
+    color = torch.rand(H, W, 3, generator=g).to(DEV)
+    bound = torch.tensor([-1.5, 2.0, -2.0, 1.0, -0.5, 2.5], dtype=torch.float64, device=DEV)
+    cam = torch.tensor([0.9, 0.1, -0.2, 0.3, 0.2, -0.1, 0.4]).to(DEV)
+    f32 = dict(dtype=torch.float32, device=DEV)
+
+    def state():
+        return dict(cam=cam.clone(), m=torch.zeros(7, **f32), v=torch.zeros(7, **f32), steps=torch.zeros(n_groups, dtype=torch.int32, device=DEV),
+                    derived=torch.zeros((n_groups, 2), **f32), best_l=torch.full((1,), float('inf'), dtype=torch.float64, device=DEV),
+                    best_c=torch.zeros(7, **f32))
+    A_, B_ = state(), state()
+    lrs = [1e-2, 2e-3][:n_groups] if n_groups == 2 else [1e-2]
+    for it in range(3):
+        pick = torch.randint((H1 - H0) * (W1 - W0), (n,), generator=g).to(DEV)
+        g_ro, g_rd = torch.randn(n, 3, generator=g).to(DEV), torch.randn(n, 3, generator=g).to(DEV)
+        loss = torch.tensor([5.0 - it if it != 1 else 9.0], dtype=torch.float64, device=DEV)       # better, worse, better
+        outs = []
+        for merged, S in ((False, A_), (True, B_)):
+            c2w = torch.empty(16, **f32)
+            pi, pj, gd = torch.empty(n, **f32), torch.empty(n, **f32), torch.empty(n, **f32)
+            gc, ro, rd = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 3, **f32)
+            keep, dmax = torch.empty(n, dtype=torch.uint8, device=DEV), torch.empty(1, **f32)
+            g_c2w, g_cam = torch.empty(16, **f32), torch.empty(7, **f32)
+            if not merged:
+                check(L.adfp_camera_from_tensor(ptr(S['cam']), ptr(c2w), st), 'cam')
+                check(L.adfp_select_pixels(ptr(pick), n, H0, H1, W0, W1, H, W, ptr(depth), ptr(color), ptr(pi), ptr(pj), ptr(gd), ptr(gc), st), 'sel')
+                check(L.adfp_rays_from_uv(ptr(pi), ptr(pj), n, fx, fy, cx, cy, ptr(c2w), ptr(ro), ptr(rd), st), 'rays')
+                check(L.adfp_prefilter_mask(ptr(ro), ptr(rd), ptr(gd), n, ptr(bound), ptr(keep), ptr(dmax), st), 'pre')
+                check(L.adfp_rays_from_uv_backward(ptr(pi), ptr(pj), n, fx, fy, cx, cy, ptr(g_ro), ptr(g_rd), ptr(g_c2w), st), 'rays bwd')
+                check(L.adfp_camera_from_tensor_backward(ptr(S['cam']), ptr(g_c2w), ptr(g_cam), st), 'cam bwd')
+                if n_groups == 2:
+                    check(L.adfp_track_keep_best(ptr(loss), ptr(S['cam']), ptr(S['best_l']), ptr(S['best_c']), st), 'keep')
+                check(L.adfp_adam_prep(ptr(S['steps']), ptr(S['derived']), n_groups, (C.c_float * n_groups)(*lrs), 0.9, 0.999, None, st), 'prep')
+                parts = [(4, 3), (0, 4)] if n_groups == 2 else [(0, 7)]
+                arr = (_lib.AdfpAdamGroup * len(parts))()
+                for k, (off, cnt) in enumerate(parts):
+                    a = arr[k]
+                    a.param, a.grad = S['cam'].data_ptr() + 4 * off, g_cam.data_ptr() + 4 * off
+                    a.exp_avg, a.exp_avg_sq = S['m'].data_ptr() + 4 * off, S['v'].data_ptr() + 4 * off
+                    a.mask, a.nvox, a.channels, a.derived = None, cnt, 1, S['derived'][k].data_ptr()
+                check(L.adfp_masked_adam_multi(len(parts), C.byref(arr), 0.9, 0.999, 1e-8, st), 'adam')
+                if n_groups == 1:
+                    check(L.adfp_track_keep_best(ptr(loss), ptr(S['cam']), ptr(S['best_l']), ptr(S['best_c']), st), 'keep')
+            else:
+                ha = _lib.AdfpTrackerHeadArgs()
+                ha.cam, ha.c2w, ha.idx, ha.n = S['cam'].data_ptr(), c2w.data_ptr(), pick.data_ptr(), n
+                ha.H0, ha.H1, ha.W0, ha.W1, ha.H, ha.W = H0, H1, W0, W1, H, W
+                ha.depth_img, ha.color_img = depth.data_ptr(), color.data_ptr()
+                ha.fx, ha.fy, ha.cx, ha.cy, ha.bound = fx, fy, cx, cy, bound.data_ptr()
+                ha.pix_i, ha.pix_j, ha.gt_depth, ha.gt_color = pi.data_ptr(), pj.data_ptr(), gd.data_ptr(), gc.data_ptr()
+                ha.rays_o, ha.rays_d, ha.keep, ha.depth_max = ro.data_ptr(), rd.data_ptr(), keep.data_ptr(), dmax.data_ptr()
+                check(L.adfp_tracker_head(C.byref(ha), st), 'head')
+                ta = _lib.AdfpTrackerTailArgs()
+                ta.pix_i, ta.pix_j, ta.n, ta.fx, ta.fy, ta.cx, ta.cy = pi.data_ptr(), pj.data_ptr(), n, fx, fy, cx, cy
+                ta.g_rays_o, ta.g_rays_d = g_ro.data_ptr(), g_rd.data_ptr()
+                ta.cam, ta.g_c2w, ta.g_cam, ta.step = S['cam'].data_ptr(), g_c2w.data_ptr(), g_cam.data_ptr(), 1
+                ta.exp_avg, ta.exp_avg_sq = S['m'].data_ptr(), S['v'].data_ptr()
+                ta.steps, ta.derived, ta.n_groups = S['steps'].data_ptr(), S['derived'].data_ptr(), n_groups
+                ta.lr[0], ta.lr[1] = lrs[0], lrs[1] if n_groups == 2 else 0.0
+                ta.beta1, ta.beta2, ta.eps = 0.9, 0.999, 1e-8
+                ta.loss, ta.best_loss, ta.best_cam = loss.data_ptr(), S['best_l'].data_ptr(), S['best_c'].data_ptr()
+                check(L.adfp_tracker_tail(C.byref(ta), st), 'tail')
+            torch.cuda.synchronize()
+            outs.append([t.clone() for t in (c2w, pi, pj, gd, gc, ro, rd, keep, dmax, g_c2w[:12], g_cam, S['cam'], S['m'], S['v'], S['steps'], S['derived'],
+                                             S['best_l'], S['best_c'])])
+        names = 'c2w pix_i pix_j gt_depth gt_color rays_o rays_d keep depth_max g_c2w g_cam cam exp_avg exp_avg_sq steps derived best_loss best_cam'.split()
+        for a, b, name in zip(outs[0], outs[1], names):
+            assert torch.equal(a, b), f'iteration {it}: {name}'
+        assert 0 < int(outs[0][7].sum()) < n                             # the pre-filter drops some and keeps some
+    assert B_['best_l'].item() == 3.0
+
+
 class Bench:
     def __init__(self, n_samples=16, n_surface=8):
         self.sc = sc = synthetic.mini_scene(device=DEV)
