@@ -158,3 +158,69 @@ def test_frustum_mask_vs_reference_lines():
             assert (again == ref).all()                                       # the oracle IS the reference-executed mask
             got = mapping.frustum_mask(c2w, ref.shape, depth.to(DEV), bound, int(H), int(W), fx, fy, cx, cy)
             assert_only_boundary_points_differ(got.cpu().numpy(), ref, boundary, f'pose {k} {key}')
+
+
+def test_adam_step_equals_the_two_entries_it_merges():
+    """adfp_adam_step (channels-last grids and flat network buffers in ONE launch) against adfp_adam_grids_cl + adfp_masked_adam_multi:
+    every tensor bit for bit over three steps -- parameters (shadow and reference-layout master), both moments, the consumed
+    gradients zeroed; with masks, a group without a mask, and a group that does not step (derived = 0, the skipped iteration)."""
+    import ctypes as C
+    from attentive_dfprior_amd import _lib
+    from attentive_dfprior_amd._lib import lib, ptr, check
+    L = lib()
+    st = _lib.current_stream(torch.device(DEV))
+    g = torch.Generator().manual_seed(8)
+    shapes = [(5, 6, 7), (9, 4, 11), (3, 3, 3)]
+    flats = [1000, 37, 4097]
+
+    def make():
+        G = torch.Generator().manual_seed(9)
+        cl = []
+        for k, (Z, Y, X) in enumerate(shapes):
+            nv = Z * Y * X
+            cl.append(dict(p_cl=torch.randn(nv, 32, generator=G).to(DEV), p_cm=torch.zeros(32, nv, device=DEV), g=None,
+                           m=torch.zeros(nv, 32, device=DEV), v=torch.zeros(nv, 32, device=DEV),
+                           mask=None if k == 1 else (torch.rand(nv, generator=G) < 0.4).to(DEV, torch.uint8), nv=nv))
+            cl[-1]['p_cm'].copy_(cl[-1]['p_cl'].t())
+        fl = [dict(p=torch.randn(n, generator=G).to(DEV), m=torch.zeros(n, device=DEV), v=torch.zeros(n, device=DEV), n=n) for n in flats]
+        derived = torch.zeros(len(shapes) + len(flats), 2, device=DEV)
+        return cl, fl, derived
+    A_, B_ = make(), make()
+    for it in range(3):
+        grads_cl = [torch.randn(s[0] * s[1] * s[2], 32, generator=g) for s in shapes]
+        grads_fl = [torch.randn(n, generator=g) for n in flats]
+        t = it + 1
+        der = torch.tensor([[1e-2 / (1 - 0.9 ** t), (1 - 0.999 ** t) ** 0.5]] * (len(shapes) + len(flats)))
+        der[2] = 0.0                                                       # the third grid does not step
+        for merged, (cl, fl, derived) in ((False, A_), (True, B_)):
+            derived.copy_(der.to(DEV))
+            carr = (_lib.AdfpAdamClGroup * len(cl))()
+            gcl = [x.clone().to(DEV) for x in grads_cl]
+            gfl = [x.clone().to(DEV) for x in grads_fl]
+            for k, c in enumerate(cl):
+                a = carr[k]
+                a.param_cl, a.param_cm, a.grad_cl = c['p_cl'].data_ptr(), c['p_cm'].data_ptr(), gcl[k].data_ptr()
+                a.exp_avg_cl, a.exp_avg_sq_cl = c['m'].data_ptr(), c['v'].data_ptr()
+                a.mask = c['mask'].data_ptr() if c['mask'] is not None else None
+                a.nvox, a.derived = c['nv'], derived[k].data_ptr()
+            farr = (_lib.AdfpAdamGroup * len(fl))()
+            for k, f in enumerate(fl):
+                a = farr[k]
+                a.param, a.grad, a.exp_avg, a.exp_avg_sq = f['p'].data_ptr(), gfl[k].data_ptr(), f['m'].data_ptr(), f['v'].data_ptr()
+                a.mask, a.nvox, a.channels, a.derived = None, f['n'], 1, derived[len(cl) + k].data_ptr()
+            if merged:
+                check(L.adfp_adam_step(len(cl), C.byref(carr), len(fl), C.byref(farr), 0.9, 0.999, 1e-8, st), 'adfp_adam_step')
+            else:
+                check(L.adfp_adam_grids_cl(len(cl), C.byref(carr), 0.9, 0.999, 1e-8, st), 'adfp_adam_grids_cl')
+                check(L.adfp_masked_adam_multi(len(fl), C.byref(farr), 0.9, 0.999, 1e-8, st), 'adfp_masked_adam_multi')
+            torch.cuda.synchronize()
+            for x in gcl:
+                assert not x.any()                                         # consumed and zeroed
+        for ca, cb in zip(A_[0], B_[0]):
+            for key in ('p_cl', 'p_cm', 'm', 'v'):
+                assert torch.equal(ca[key], cb[key]), (it, key)
+        for fa, fb in zip(A_[1], B_[1]):
+            for key in ('p', 'm', 'v'):
+                assert torch.equal(fa[key], fb[key]), (it, key)
+    assert A_[0][0]['m'].any() and not A_[0][2]['m'].any()                 # the stepping grid moved, the skipped one did not
+
