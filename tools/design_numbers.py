@@ -1,5 +1,5 @@
 """Fills the @@name@@ fields of a DESIGN.md template with the numbers of a profile collection (tools/collect_profiles.sh):
-    python tools/design_numbers.py <template> <dir with r05_* files> > DESIGN.md
+    python tools/design_numbers.py tools/DESIGN.template.md profiles > DESIGN.md
 Every field is read from the file DESIGN.md names next to it; a field the files do not yield stays visible as @@name@@."""
 import csv
 import json
