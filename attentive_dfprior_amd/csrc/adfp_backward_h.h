@@ -626,6 +626,10 @@ struct OuterHArgs {
     int nxm4, ngm4;            // f32x4 pieces per stored X / G piece (at most 128 each)
     int g_dst4;                // f32x4 index in the tile row where the stored G piece starts
     int x_gap_at4, x_gap4;     // the stored X piece skips x_gap4 f32x4 of the tile row after its first x_gap_at4 (decoders: the Fourier block)
+    int x_skip4;               // decoders: the first x_skip4 f32x4 of a stored X piece (the head [x, y, z, 1, 0 ...]) are NOT stored -- the training
+                               // forward does not write what the backward can rebuild (128 B of the 896-B row) -- and the tile's head
+                               // comes from the points themselves, by the forward's arithmetic; 0 = the piece is whole
+    PtsDev P; const int* list; // decoders: the points (row -> point: list[row], or row itself without a list)
     const unsigned* masks;     // decoders: the forward's ReLU mask words (absolute row index), NULL = no virtual columns
     const float* bm;           // decoders: [96][4] Fourier matrix rows (the packed image's P_BM block)
     int col_se, col_sgp;       // decoders: first column of the recomputed Fourier block / of the masked d/d pre block
@@ -675,6 +679,7 @@ __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
     }
     f32x4 ld[2][4];                                        // this wave's two rows: X pieces lane, lane + 64; G pieces likewise (a piece <= 2 KB)
     unsigned mreg = 0u;                                    // threads 0..95: one mask word of the tile
+    f32x4 hreg = {0.f, 0.f, 0.f, 0.f};                     // threads 0..15 (decoders): the head of one row of the tile
     auto fetch = [&](int row0) {
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
@@ -697,6 +702,18 @@ __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
             const int m = row0 + (int)threadIdx.x / 6;
             mreg = m < m1 ? b.masks[(long long)(a.chunk_lo + m) * 6 + threadIdx.x % 6] : 0u;
         }
+        if (dec && threadIdx.x < OUTER_RT) {               // p.float() of the row's point, NaN -> 0: what the training forward fed its Fourier features (k_decode_h)
+            const int m = row0 + (int)threadIdx.x;
+            hreg = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m < m1) {
+                int q = a.chunk_lo + m;
+                if (b.list) q = b.list[q];
+                double pt[3];
+                load_point(b.P, q, pt);
+                const bool pnan = (pt[0] != pt[0]) | (pt[1] != pt[1]) | (pt[2] != pt[2]);
+                hreg = pnan ? f32x4{0.f, 0.f, 0.f, 1.f} : f32x4{(float)pt[0], (float)pt[1], (float)pt[2], 1.f};
+            }
+        }
     };
     float amax = 0.f;
     fetch(m);
@@ -705,11 +722,16 @@ __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
         for (int rr = 0; rr < 2; ++rr) {                   // registers -> f32 tile (the stored X piece lacks the 96 Fourier columns)
             f32x4* dst = (f32x4*)(sf + (2 * wv + rr) * nc);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) { const int e = lane + 64 * k; if (e < b.nxm4) dst[e < b.x_gap_at4 ? e : e + b.x_gap4] = ld[rr][k]; }
+            for (int k = 0; k < 2; ++k) { const int e = lane + 64 * k; if (e >= b.x_skip4 && e < b.nxm4) dst[e < b.x_gap_at4 ? e : e + b.x_gap4] = ld[rr][k]; }
 #pragma unroll
             for (int k = 0; k < 2; ++k) { const int e = lane + 64 * k; if (e < b.ngm4) dst[b.g_dst4 + e] = ld[rr][2 + k]; }
         }
         if (dec && threadIdx.x < OUTER_RT * 6) s_mask[threadIdx.x / 6][threadIdx.x % 6] = mreg;
+        if (dec && threadIdx.x < OUTER_RT) {
+            f32x4* dst = (f32x4*)(sf + threadIdx.x * nc);
+            dst[0] = hreg;
+            for (int e = 1; e < b.x_skip4; ++e) dst[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         __syncthreads();                                   // tile complete; everyone is done with the previous operands
         int nm = m + OUTER_RT, nblk = blk, nm1 = m1;       // the tile after this one: same block, or the first of my next block
         if (nm >= m1) { nblk = blk + gridDim.x; nm = nblk * BR; nm1 = nm + BR < rows ? nm + BR : rows; }

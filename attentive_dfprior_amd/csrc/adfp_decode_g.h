@@ -170,9 +170,10 @@ ADFP_DEV void mfma_chain_g(f32x4g acc[2][2], const unsigned* __restrict__ w, con
 //        its two points = bits 15 - 8 ob - 4 (g >> 1) - r of the field of half g & 1: half of a field; the other half sits in lane
 //        l ^ 32, and ONE v_permlane32_swap per word brings the two halves of point-block 0 together on the lower lanes and those
 //        of point-block 1 on the upper lanes -- each lane ends up with the complete words of its front point.
-//   srow0 / rowbits: the X piece of point 16 pb + n's staging row (DecStage: [x, y, z, 1, 0 ...] | c | h_0..h_4, natural unit
-//        order).  The lane's units 16 ob + 4 g .. + 3 are one 16-byte piece: head pieces g and g + 4, 2 pieces of c and of every h_i
-//        per point -- the same 28 stores per lane and tile as the 32 x 32 kernel.
+//   srow0 / rowbits: the X piece of point 16 pb + n's staging row (DecStage: [head: not written] | c | h_0..h_4, natural unit
+//        order).  The lane's units 16 ob + 4 g .. + 3 are one 16-byte piece: 2 pieces of c and of every h_i per point, 24 stores
+//        per lane and tile.  The head [x, y, z, 1, 0 ...] (128 B of the 896) is NOT stored: k_decode_bwd_roles / _fused recompute
+//        the Fourier features from the points, and k_outer_h builds the head from the points (OuterHArgs.x_skip4).
 template <int CDIM, int NOUT, int TRAIN = 0>
 ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& grid, const GridDev& grid1, const float pn[3], const float (*pf)[3],
                            int lane, float& amax, float (*out)[NOUT], unsigned* __restrict__ mw, float* srow0, unsigned rowbits ADFP_PHG_PARAMS) {
@@ -186,14 +187,6 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
         srow[1] = (rowbits & 2u) ? srow0 + 16 * ST::NXM : nullptr;
 #if defined(ADFP_EXP_TRAIN_NOX)            // timing experiment: no layer-input rows at all (masks only)
         srow[0] = nullptr; srow[1] = nullptr;
-#endif
-#if !defined(ADFP_EXP_TRAIN_NOHEADC)      // timing experiment (tools/ab_train_fwd.sh): the training forward without the head and c pieces of the rows
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb) if (srow[pb]) {
-            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-            *(f32x4*)(srow[pb] + ST::xm(ST::SX) + 4 * g) = g == 0 ? f32x4{pf[pb][0], pf[pb][1], pf[pb][2], 1.f} : z4;
-            *(f32x4*)(srow[pb] + ST::xm(ST::SX) + 16 + 4 * g) = z4;
-        }
 #endif
     }
     // every LDS access below is one of three lane-dependent bases plus an immediate: the weight rows (4 l), the unit-order rows
@@ -218,7 +211,7 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
         float y[8] = {c[4], c[5], c[6], c[7], c[12], c[13], c[14], c[15]};
 #pragma unroll
         for (int s = 0; s < 8; ++s) swap_halves(x[s], y[s]);
-#if !defined(ADFP_EXP_TRAIN_NOHEADC)
+#if !defined(ADFP_EXP_TRAIN_NOC)          // timing experiment (tools/build_ab_libs.sh): the training forward without the c piece of the rows
         if constexpr (TRAIN) {
             static_assert(!TRAIN || CDIM == 32, "training rows: 32-channel decoders");
             if (srow[0]) { *(f32x4*)(srow[0] + ST::xm(ST::SC) + 4 * g) = f32x4{x[0], x[1], x[2], x[3]}; *(f32x4*)(srow[0] + ST::xm(ST::SC) + 16 + 4 * g) = f32x4{x[4], x[5], x[6], x[7]}; }

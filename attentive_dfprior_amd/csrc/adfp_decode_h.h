@@ -288,10 +288,8 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : (ROLE == ROLE_HIGH ? 1 
         if constexpr (TRAIN) {
             const bool pnan = (pt[0] != pt[0]) | (pt[1] != pt[1]) | (pt[2] != pt[2]);
             if (pnan) { pf[0] = 0.f; pf[1] = 0.f; pf[2] = 0.f; }
-            if (TRAIN == 2 && a.act && valid) {
-                srow = a.act + (long long)(ROLE == ROLE_HIGH ? idx : q) * ST::NXM;
-                stage_head(srow, ST::xm(ST::SX), h, f32x4{pf[0], pf[1], pf[2], 1.f});
-            }
+            // (the row's head [x, y, z, 1, 0 ...] is not stored: the backward rebuilds it from the point, OuterHArgs.x_skip4)
+            if (TRAIN == 2 && a.act && valid) srow = a.act + (long long)(ROLE == ROLE_HIGH ? idx : q) * ST::NXM;
         }
 
         // grid features -> split halves (k-steps of fc_c)

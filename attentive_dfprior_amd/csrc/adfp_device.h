@@ -465,7 +465,7 @@ struct DecStage {
     // What is actually stored of the two pieces (k_outer_h keeps the full column numbering in its LDS tile and fills in the
     // rest): the Fourier features are recomputed there from x, y, z (96 of the X piece's floats), and d/d pre_i = ReLU mask .
     // d/d h_i from the forward's mask words (160 of the G piece's).  Staging traffic is what bounds the weight-gradient path.
-    static constexpr int NXM = 32 + CDIM + 160;       // [x, y, z, 1, 0 ...] | c | h_0..h_4
+    static constexpr int NXM = 32 + CDIM + 160;       // [head: room for x, y, z, 1, 0 ..., NOT written by the training forward] | c | h_0..h_4
     static constexpr int NGM = 160 + 96 + 32;         // d/d h_0..h_4 | d/d (p @ B) | d/d out
     __host__ __device__ static constexpr int xm(int col) { return col < 32 ? col : col - 96; }     // X column -> offset in the stored piece
     __host__ __device__ static constexpr int gm(int col) { return col - SGH(0); }                  // G column (SGH.. on) -> offset

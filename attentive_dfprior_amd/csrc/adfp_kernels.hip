@@ -2696,7 +2696,7 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
     }
     using ST = DecStage<CDIM>;
     OuterHArgs oa; decoder_jobs<CDIM, NOUT>(oa.o);
-    oa.act = act; oa.nxm4 = ST::NXM / 4; oa.ngm4 = ST::NGM / 4; oa.g_dst4 = ST::SGH(0) / 4; oa.x_gap_at4 = 8; oa.x_gap4 = 24; oa.masks = masks; oa.bm = (const float*)t;   // P_BM = word 0 of the T image
+    oa.act = act; oa.nxm4 = ST::NXM / 4; oa.ngm4 = ST::NGM / 4; oa.g_dst4 = ST::SGH(0) / 4; oa.x_gap_at4 = 8; oa.x_gap4 = 24; oa.x_skip4 = 8; oa.P = o.P; oa.list = o.list; oa.masks = masks; oa.bm = (const float*)t;   // P_BM = word 0 of the T image
     oa.col_se = ST::SE; oa.col_sgp = ST::SGP(0); oa.status = status; oa.skip = skip; oa.overwrite = 0;
     a.stage = bw.stage;
     const int rows_cap = (int)((size_t)bw.stage_rows * AttStage::NCOLS / ST::NGM);
@@ -2835,7 +2835,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
             t.status = sc->status; t.gmax = bw.gmax; t.skip = state.counter ? state.counter + 8 : nullptr;
             t.P = Pd; t.nt = make_norm(sc->tsdf_bnds); t.t = make_tsdf(sc->tsdf); t.g_pts = a.g_pts;
             OuterHArgs oh; attention_jobs(oh.o);
-            oh.act = state.act_att; oh.nxm4 = 416 / 4; oh.ngm4 = 416 / 4; oh.g_dst4 = 416 / 4; oh.x_gap_at4 = 1 << 20; oh.x_gap4 = 0;
+            oh.act = state.act_att; oh.nxm4 = 416 / 4; oh.ngm4 = 416 / 4; oh.g_dst4 = 416 / 4; oh.x_gap_at4 = 1 << 20; oh.x_gap4 = 0; oh.x_skip4 = 0; oh.P = PtsDev{}; oh.list = nullptr;
             oh.masks = nullptr; oh.bm = nullptr; oh.col_se = 0; oh.col_sgp = 0; oh.status = sc->status; oh.skip = t.skip;
             OuterArgs& oa = oh.o;
             const int rows_cap = bw.stage_rows * 2;               // the G piece is half a row

@@ -13,5 +13,5 @@ one roles_span -DADFP_STAMPS_ROLES &
 wait
 one tune_shares -DADFP_TUNE_ROLE_SHARES &
 one train_NOX -DADFP_EXP_TRAIN_NOX &
-one train_NOHEADC -DADFP_EXP_TRAIN_NOHEADC &
+one train_NOC -DADFP_EXP_TRAIN_NOC &
 wait

@@ -114,7 +114,7 @@ if want ab; then
   into $O/${R}_ab_backward_roles.txt ab_roles bash tools/ab_roles.sh
   ADFP_LIB_PATH=$PWD/tools/ab_libs/libadfp_roles_span.so python tools/roles_span.py 2> $L/roles_span.err | tail -4 >> $O/${R}_ab_backward_roles.txt || FAILED="$FAILED roles_span"
   {
-    for lib in "" train_NOX train_NOHEADC; do
+    for lib in "" train_NOX train_NOC; do
       for rep in 1 2; do
         if [ -n "$lib" ]; then ADFP_LIB_PATH=$PWD/tools/ab_libs/libadfp_$lib.so python tools/ab_train_fwd.py 5000 48 300; else python tools/ab_train_fwd.py 5000 48 300; fi
       done

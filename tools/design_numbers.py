@@ -95,7 +95,7 @@ def main(template, d):
     t = open(P('r05_ab_train_forward.txt')).read()
     f = lambda pat: '%.3f' % avg([float(x) for x in re.findall(pat, t)])
     v['fwd_intree'] = f(r': (\S+) ms per call \(in-tree\)'); v['fwd_nox'] = f(r': (\S+) ms per call \(\S*NOX\.so\)')
-    v['fwd_noheadc'] = f(r': (\S+) ms per call \(\S*NOHEADC\.so\)')
+    v['fwd_noc'] = f(r': (\S+) ms per call \(\S*NOC\.so\)')
     s = open(template).read()
     out = re.sub(r'@@(\w+)@@', lambda m: v.get(m.group(1), m.group(0)), s)
     sys.stdout.write(out)
