@@ -96,6 +96,9 @@ def main(template, d):
     f = lambda pat: '%.3f' % avg([float(x) for x in re.findall(pat, t)])
     v['fwd_intree'] = f(r': (\S+) ms per call \(in-tree\)'); v['fwd_nox'] = f(r': (\S+) ms per call \(\S*NOX\.so\)')
     v['fwd_noc'] = f(r': (\S+) ms per call \(\S*NOC\.so\)')
+    for row in csv.reader(l for l in open(P('r05_pmc_hbm_train.csv')) if not l.startswith('#')):
+        if row and 'k_decode_lc16_train' in row[0]:
+            v['lc16_train_write_B'] = '%.0f' % float(row[4]); v['lc16_train_write_MB'] = '%.0f' % (float(row[2]) / 1000.0)
     s = open(template).read()
     out = re.sub(r'@@(\w+)@@', lambda m: v.get(m.group(1), m.group(0)), s)
     sys.stdout.write(out)
