@@ -639,8 +639,16 @@ struct OuterHArgs {
                                // 256 slots (34 MB for the attention network) before the launch; k_reduce_partials_scaled then reads only the
                                // slots of workgroups that had rows (slots_in_use)
 };
-// how many of the nslot partial-sum slots a k_outer_h launch over `rows` rows in blocks of `br` wrote
+// br = 0 in OuterArgs.rows_per_wave / k_reduce_partials_scaled: the EVEN split -- every one of the G workgroups takes one contiguous
+// block of ceil(rows / G) rows rounded up to whole tiles (the row count is only on the device: with fixed 64-row blocks dealt
+// round-robin the busiest workgroup of the 5 000 x 64 iteration ran 16 tiles where the average is 13)
+__host__ __device__ inline int even_block(int rows, int G) {
+    int br = ((rows + G - 1) / G + OUTER_RT - 1) / OUTER_RT * OUTER_RT;
+    return br < OUTER_RT ? OUTER_RT : br;
+}
+// how many of the nslot partial-sum slots a k_outer_h launch of nslot workgroups over `rows` rows in blocks of `br` wrote
 __host__ __device__ inline int slots_in_use(int rows, int br, int nslot) {
+    if (br == 0) br = even_block(rows, nslot);
     const int nb = rows > 0 ? (rows + br - 1) / br : 0;
     return nb < nslot ? nb : nslot;
 }
@@ -654,11 +662,11 @@ __global__ __launch_bounds__(512) void k_outer_h(OuterHArgs b) {
     int hi = a.chunk_hi;
     if (a.count_ptr) { const int cnt = *a.count_ptr; hi = hi < cnt ? hi : cnt; }
     const int rows = hi - a.chunk_lo;
-    // Blocks of a.rows_per_wave rows (a multiple of 16) are dealt round-robin: workgroup b takes blocks b, b + G, ...  The host
-    // makes the block the workgroup's whole share when it knows the row count (contiguous ranges: measured 25 % faster per
-    // tile than interleaved tiles) and 64 rows when it does not (the in-band list: the count is only on the device, and a
-    // share computed from its upper bound left half the workgroups idle).
-    const int BR = a.rows_per_wave;
+    // Blocks of BR rows (a multiple of 16) are dealt round-robin: workgroup b takes blocks b, b + G, ...  A block is the workgroup's
+    // whole share -- one contiguous range (measured 25 % faster per tile than interleaved tiles): computed by the host when it knows
+    // the row count, here (rows_per_wave = 0: even_block) when the count is only on the device (the in-band list; a share computed
+    // from the count's upper bound left half the workgroups idle, fixed 64-row blocks gave the busiest workgroup 16 tiles of 13).
+    const int BR = a.rows_per_wave ? a.rows_per_wave : even_block(rows, (int)gridDim.x);
     int blk = blockIdx.x, m = blk * BR;
     if (m >= rows) return;
     int m1 = m + BR < rows ? m + BR : rows;               // end of the current block = row limit of fetch()
@@ -815,13 +823,20 @@ __global__ __launch_bounds__(256) void k_reduce_partials_scaled(const float* __r
     __shared__ float s_p[8][32];
     const int ex = threadIdx.x & 31, sg = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + ex;
-    float s0 = 0.f, s1 = 0.f;
+    // (eight loads in flight per thread: with two, the 34 MB of the attention network's 256 slots came in at 2.7 TB/s, the rate of
+    // 2 x 4 B x the resident threads per memory latency)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (e < n) {
+        const float* p = partial + e;
         int k = sg;
-        for (; k + 8 < nslots; k += 16) { s0 += partial[(long long)k * stride + e]; s1 += partial[(long long)(k + 8) * stride + e]; }
-        if (k < nslots) s0 += partial[(long long)k * stride + e];
+        for (; k + 56 < nslots; k += 64) {
+            const float v0 = p[(long long)k * stride], v1 = p[(long long)(k + 8) * stride], v2 = p[(long long)(k + 16) * stride], v3 = p[(long long)(k + 24) * stride];
+            const float v4 = p[(long long)(k + 32) * stride], v5 = p[(long long)(k + 40) * stride], v6 = p[(long long)(k + 48) * stride], v7 = p[(long long)(k + 56) * stride];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3; s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+        }
+        for (; k < nslots; k += 8) s0 += p[(long long)k * stride];
     }
-    s_p[sg][ex] = s0 + s1;
+    s_p[sg][ex] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (sg == 0 && e < n) {
         float t = 0.f;

@@ -2710,11 +2710,11 @@ static int run_decode_bwd_h(const DecodeBwdArgs& o, const void* t, const unsigne
         ADFP_CHECK_LAUNCH();
         oa.o.stage = bw.stage; oa.o.count_ptr = count_ptr; oa.o.chunk_lo = lo; oa.o.chunk_hi = hi; oa.o.flat = flat;
         oa.o.partial = bw.partial; oa.o.part_stride = bw.part_stride;
-        {   // block = a workgroup's whole share when the row count is known here, 64 rows for a list (count on the device)
+        {   // block = a workgroup's whole share: computed here when the row count is known, by the kernel for a list (count on the device: br = 0)
             const int rows = hi - lo;
-            int br = 64;
+            int br = 0;
             if (!count_ptr) { br = (rows + OUTER_NSLOT - 1) / OUTER_NSLOT; br = ((br < 64 ? 64 : br) + OUTER_RT - 1) / OUTER_RT * OUTER_RT; }
-            const int nblk = (rows + br - 1) / br;
+            const int nblk = br ? (rows + br - 1) / br : (rows + OUTER_RT - 1) / OUTER_RT;
             oa.o.rows_per_wave = br;
             hipLaunchKernelGGL(k_outer_h, dim3(nblk < OUTER_NSLOT ? nblk : OUTER_NSLOT), dim3(512), 0, st, oa);
         }
@@ -2855,17 +2855,17 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
                 if (go.flat_att) {
                     oa.stage = bw.stage; oa.count_ptr = state.counter; oa.chunk_lo = lo; oa.chunk_hi = hi; oa.flat = go.flat_att;
                     oa.partial = bw.partial; oa.part_stride = bw.part_stride;
-                    const int nblk = (hi - lo + 63) / 64;          // list-based: blocks of 64 rows, round-robin
-                    oa.rows_per_wave = 64;
+                    const int nblk = (hi - lo + OUTER_RT - 1) / OUTER_RT;     // list-based: the count is on the device, the kernel splits its rows evenly (even_block)
+                    oa.rows_per_wave = 0;
                     hipLaunchKernelGGL(k_outer_h, dim3(nblk < OUTER_NSLOT ? nblk : OUTER_NSLOT), dim3(512), 0, st, oh);
                     ADFP_CHECK_LAUNCH();
                 }
             }
             if (go.flat_att) {
                 if (one_chunk) {
-                    const int nblk = (P + 63) / 64;
+                    const int nblk = (P + OUTER_RT - 1) / OUTER_RT;
                     hipLaunchKernelGGL(k_reduce_partials_scaled, dim3((AttLayout::F_TOTAL + 31) / 32), dim3(256), 0, st, bw.partial, nblk < OUTER_NSLOT ? nblk : OUTER_NSLOT,
-                                       bw.part_stride, AttLayout::F_TOTAL, go.flat_att, bw.gmax, state.counter, P, 64);
+                                       bw.part_stride, AttLayout::F_TOTAL, go.flat_att, bw.gmax, state.counter, P, 0);
                     ADFP_CHECK_LAUNCH();
                 } else { rc = outer_end_scaled(bw, AttLayout::F_TOTAL, go.flat_att, st); if (rc) return rc; }
             }
