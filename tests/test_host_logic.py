@@ -167,3 +167,19 @@ def test_get_tensor_from_camera_against_scipy_rotation():
         back = common.get_camera_from_tensor(torch.from_numpy(got).float()).double().numpy()
         assert np.abs(back[:3, :3] - R).max() < 5e-6
 
+
+
+def test_design_md_is_the_template_filled_from_profiles():
+    """DESIGN.md quotes profiles/ and nothing else: it is tools/DESIGN.template.md with its @@fields@@ read out of the committed
+    profile files by tools/design_numbers.py.  To change the text edit the TEMPLATE; after a new collection regenerate:
+        python tools/design_numbers.py tools/DESIGN.template.md profiles > DESIGN.md"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'design_numbers.py'), os.path.join(root, 'tools', 'DESIGN.template.md'),
+                        os.path.join(root, 'profiles')], capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stderr[-400:]
+    assert 'unfilled' not in r.stderr, r.stderr[-400:]
+    assert r.stdout == open(os.path.join(root, 'DESIGN.md')).read(), \
+        'DESIGN.md differs from the filled template: edit tools/DESIGN.template.md and regenerate (see this test\'s docstring)'
