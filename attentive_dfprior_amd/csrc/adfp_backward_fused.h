@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_decode_bwd_fused(DecodeBwdFArgs a) {
     constexpr int SLOT = 1024, XW = 6 * SLOT + 128;               // words per wave (with the colour decoder's image: 160 KB to the byte)
     static_assert(F::F_TOTAL <= 4 * XW, "the reduction copy must fit the per-wave region");
     __shared__ __attribute__((aligned(16))) unsigned ldsu[LT::P_TOTAL + 4 * XW];
-    for (int i = threadIdx.x; i < LT::P_TOTAL / 4; i += 256) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed_t)[i];
+    image_to_lds<256, LT::P_TOTAL / 4>(ldsu, a.packed_t);
     __syncthreads();
     const float* lds = (const float*)ldsu;
     float* s_red = (float*)(ldsu + LT::P_TOTAL);

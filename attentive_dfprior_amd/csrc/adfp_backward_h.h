@@ -152,7 +152,7 @@ ADFP_DEV void decode_bwd_h_body(const DecodeBwdHArgs& a, unsigned* __restrict__ 
     using ST = DecStage<CDIM>;
     constexpr int NW = NT / 64;
     constexpr bool CACHE = true;
-    for (int i = threadIdx.x; i < LT::P_TOTAL / 4; i += NT) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed_t)[i];
+    image_to_lds<NT, LT::P_TOTAL / 4>(ldsu, a.packed_t);
     __syncthreads();
     const float* lds = (const float*)ldsu;
 
@@ -923,7 +923,7 @@ __global__ __launch_bounds__(512) void k_attention_bwd_h(AttBwdHArgs a) {
     using T = AttLayoutHT;
     using ST = AttStage;
     __shared__ __attribute__((aligned(16))) unsigned ldsu[T::P_TOTAL];
-    for (int i = threadIdx.x; i < T::P_TOTAL / 4; i += 512) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed_t)[i];
+    image_to_lds<512, T::P_TOTAL / 4>(ldsu, a.packed_t);
     __syncthreads();
     const float* lds = (const float*)ldsu;
     const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void k_decode_bwd_roles(DecodeBwdFArgs a, int 
     if (role != ADFP_EXP_ONLY_ROLE) return;
 #endif
     auto copy_words = [&](int dst, int src, int n) {                         // n words of the packed image -> LDS (multiples of 4)
-        for (int i = threadIdx.x; i < n / 4; i += 512) ((u32x4*)(ldsu + dst))[i] = ((const u32x4*)(a.packed_t + src))[i];
+        image_to_lds<512>(ldsu + dst, a.packed_t + src, n / 4);
     };
     if (role == 0) {                                                         // block (i, ib) of pts_linears^T moves down by i + 1 blocks (PW below)
         copy_words(0, 0, LT::T_WC(0));

@@ -330,8 +330,8 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16(DecodeLCArgs a) {
     __shared__ unsigned long long s_ring[ADFP_POOL_RING];
     unsigned* lds_low = lds_all;
     unsigned* lds_col = lds_all + LL::P_TOTAL;
-    for (int i = threadIdx.x; i < LL::P_TOTAL / 4; i += NT) ((u32x4*)lds_low)[i] = ((const u32x4*)a.packed_low)[i];
-    for (int i = threadIdx.x; i < LC::P_TOTAL / 4; i += NT) ((u32x4*)lds_col)[i] = ((const u32x4*)a.packed_color)[i];
+    image_to_lds<NT, LL::P_TOTAL / 4>(lds_low, a.packed_low);
+    image_to_lds<NT, LC::P_TOTAL / 4>(lds_col, a.packed_color);
     if (threadIdx.x == 0) s_next = NT / 64;
     if (threadIdx.x < ADFP_POOL_RING) s_ring[threadIdx.x] = 0ull;
     __syncthreads();
@@ -424,8 +424,8 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_lc16_train(DecodeLCTrai
     __shared__ int s_next;
     unsigned* lds_low = lds_all;
     unsigned* lds_col = lds_all + LL::P_TOTAL;
-    for (int i = threadIdx.x; i < LL::P_TOTAL / 4; i += NT) ((u32x4*)lds_low)[i] = ((const u32x4*)a.packed_low)[i];
-    for (int i = threadIdx.x; i < LC::P_TOTAL / 4; i += NT) ((u32x4*)lds_col)[i] = ((const u32x4*)a.packed_color)[i];
+    image_to_lds<NT, LL::P_TOTAL / 4>(lds_low, a.packed_low);
+    image_to_lds<NT, LC::P_TOTAL / 4>(lds_col, a.packed_color);
     if (threadIdx.x == 0) s_next = NT / 64;
     __syncthreads();
     const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_decode_high_g(DecodeArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned ldsu[L::P_TOTAL];
     __shared__ int s_next;
     __shared__ unsigned long long s_ring[ADFP_POOL_RING];
-    for (int i = threadIdx.x; i < L::P_TOTAL / 4; i += NT) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed)[i];
+    image_to_lds<NT, L::P_TOTAL / 4>(ldsu, a.packed);
     if (threadIdx.x == 0) s_next = NT / 64;
     if (threadIdx.x < ADFP_POOL_RING) s_ring[threadIdx.x] = 0ull;
     __syncthreads();
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(NT) void k_attention_g(AttArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned ldsu[A::P_TOTAL];
     __shared__ int s_next;
     __shared__ unsigned long long s_ring[ADFP_POOL_RING];
-    for (int i = threadIdx.x; i < A::P_TOTAL / 4; i += NT) ((u32x4*)ldsu)[i] = ((const u32x4*)a.packed)[i];
+    image_to_lds<NT, A::P_TOTAL / 4>(ldsu, a.packed);
     if (threadIdx.x == 0) s_next = NT / 64;
     if (threadIdx.x < ADFP_POOL_RING) s_ring[threadIdx.x] = 0ull;
     __syncthreads();

@@ -639,6 +639,32 @@ ADFP_DEV int claim_tile(int& j, int* s_next, int ntiles) {
     return tile;
 }
 
+// A packed weight image (n4 pieces of 16 bytes) into LDS by the NT threads of the workgroup, B loads per thread in flight.  The plain
+// copy loop -- lds[i] = src[i], i += NT -- compiles to one load, s_waitcnt vmcnt(0), one ds_write per trip: a memory latency per
+// 16 bytes and thread.  The attention network's training forward (132 KB image, 256 threads: 33 trips) spent 14.3 us of its 44
+// there, before its first tile (tools/experiments/att_span.py); every kernel that keeps an image in LDS paid ~0.4 us per trip.
+// Call before the __syncthreads() that publishes the image.
+template <int NT, int B = 16>
+ADFP_DEV void image_to_lds(void* __restrict__ lds, const void* __restrict__ src, int n4) {
+    typedef unsigned piece __attribute__((ext_vector_type(4)));
+    const piece* __restrict__ s4 = (const piece*)src;
+    piece* __restrict__ d4 = (piece*)lds;
+    for (int base = (int)threadIdx.x; base < n4; base += B * NT) {
+        piece t[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) { const int i = base + b * NT; t[b] = s4[i < n4 ? i : n4 - 1]; }      // unconditional: no branch between the loads
+#pragma unroll
+        for (int b = 0; b < B; ++b) { const int i = base + b * NT; if (i < n4) d4[i] = t[b]; }
+    }
+}
+// the same for an image whose size is known at compile time: as few equal batches as the registers at the head of a kernel allow
+// (up to 34 pieces = 136 registers per thread in a 256-thread workgroup, which runs one wave per SIMD; 17 otherwise)
+template <int NT, int N4>
+ADFP_DEV void image_to_lds(void* __restrict__ lds, const void* __restrict__ src) {
+    constexpr int TRIPS = (N4 + NT - 1) / NT, MAXB = NT <= 256 ? 34 : 17, NBATCH = (TRIPS + MAXB - 1) / MAXB, B = (TRIPS + NBATCH - 1) / NBATCH;
+    image_to_lds<NT, B>(lds, src, N4);
+}
+
 // out[0] = max(parts[0 .. n)) by ONE workgroup of NT threads (all of them call)
 template <int NT>
 ADFP_DEV void max_fold_block(const float* __restrict__ parts, int n, float* __restrict__ out) {
