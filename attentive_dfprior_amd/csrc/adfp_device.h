@@ -643,7 +643,8 @@ ADFP_DEV int claim_tile(int& j, int* s_next, int ntiles) {
 // copy loop -- lds[i] = src[i], i += NT -- compiles to one load, s_waitcnt vmcnt(0), one ds_write per trip: a memory latency per
 // 16 bytes and thread.  The attention network's training forward (132 KB image, 256 threads: 33 trips) spent 14.3 us of its 44
 // there, before its first tile (tools/experiments/att_span.py); every kernel that keeps an image in LDS paid ~0.4 us per trip.
-// Call before the __syncthreads() that publishes the image.
+// Call before the __syncthreads() that publishes the image.  (The exact-f32 kernels of adfp_kernels.hip / adfp_backward.h keep the plain
+// loop: their workgroups are persistent over thousands of tiles in the one place they are timed, value_exact_f32_mode.)
 template <int NT, int B = 16>
 ADFP_DEV void image_to_lds(void* __restrict__ lds, const void* __restrict__ src, int n4) {
     typedef unsigned piece __attribute__((ext_vector_type(4)));
