@@ -163,7 +163,7 @@ class _SingleNet(object):
 
     def __setstate__(self, state):
         # unpickled = received from another process (torch.multiprocessing spawn, src/DF_Prior.py:302-311): see DF.__setstate__
-        self.__dict__.update(state)
+        super().__setstate__(state)              # nn.Module's own: the dict update + its default-attribute fix-ups for older pickles
         self.__dict__['_foreign'] = True
 
     @staticmethod
@@ -495,9 +495,22 @@ class DF(nn.Module):
         -- trains them in place (src/Mapper.py:364-375), and a write from another process does not move THIS process's tensor
         version counters, which is what every cached conversion of the parameters (packed weight images) is keyed on.  So a
         received module re-packs its images on every call (four pack kernels, ~20 us): what it renders with is what the trainer
-        last wrote.  Its deep copies (src/Tracker.py:144 takes one per frame) are private again and cache normally."""
-        self.__dict__.update(state)
+        last wrote.  Its deep copies (src/Tracker.py:144 takes one per frame) are private again and cache normally.  The process that
+        WRITES the parameters -- the spawned Mapper also receives a pickled copy -- says so with mark_owner()."""
+        super().__setstate__(state)              # nn.Module's own: the dict update + its default-attribute fix-ups for older pickles
         self._foreign, self._foreign_serial = True, 0
+
+    def mark_owner(self):
+        """This process is the only writer of the parameters (the Mapper process of src/DF_Prior.py:302-311, which trains the shared
+        decoders in place through its own optimiser): its version counters see every update, so the packed images and the flat
+        views cache on them again instead of being rebuilt per call.  mapping.MapperIteration calls it for the decoders it is
+        bound to; a caller that drives `torch.optim` itself on a received module calls it once.  Returns self."""
+        self._foreign, self._foreign_serial = False, 0
+        for m in self.modules():
+            m.__dict__.pop('_foreign', None)
+            m.__dict__.pop('_single', None)
+        self._packed = {}
+        return self
 
     def forward(self, p, c_grid, tsdf_volume, tsdf_bnds, stage='low', **kwargs):
         from .engine import Engine

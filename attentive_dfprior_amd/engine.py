@@ -101,12 +101,31 @@ class Engine(object):
         self._grid_cache = {}    # key name -> (key, channels-last tensor)
         self._tsdf_cb = None     # (key, corner-block copy, pinned source storage) of the last TSDF volume asked for (tsdf_blocks)
         self._bound_cache = {}   # id -> (key, host list)
+        self._owed_packs = None  # (job table, count, keep-alive) scene(hand_over_packs=True) leaves for the render call's first launch
 
     # ---- caches --------------------------------------------------------------------------
+    def _alloc_scratch(self, nbytes, device):
+        """A scratch allocation that may give the corner-block TSDF copy back: that copy (8 x the volume, tsdf_blocks) is an
+        optimisation, the workspaces are not -- on an out-of-memory error the copy is dropped, the allocator's cache released and the
+        allocation tried once more (the affected batches read the plain volume from then on if the copy no longer fits)."""
+        try:
+            return torch.empty(nbytes, dtype=torch.uint8, device=device)
+        except torch.cuda.OutOfMemoryError:
+            if self._tsdf_cb is None:
+                raise
+            import logging
+            logging.getLogger('attentive_dfprior_amd').warning(
+                'out of device memory allocating %d bytes of scratch: dropping the corner-block TSDF copy (%d bytes)', nbytes,
+                self._tsdf_cb[1].numel() * 4)
+            self._tsdf_cb = None
+            torch.cuda.empty_cache()
+            return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
     def workspace(self, n_points, device):
         need = lib().adfp_workspace_bytes(int(n_points))
         if self._ws is None or self._ws.numel() < need or self._ws.device != device:
-            self._ws = torch.empty(int(need * 1.25) + 1024, dtype=torch.uint8, device=device)
+            self._ws = None
+            self._ws = self._alloc_scratch(int(need * 1.25) + 1024, device)
         return self._ws
 
     def bwd_workspace(self, n_points, device):
@@ -114,7 +133,8 @@ class Engine(object):
         a training iteration used to allocate it afresh in every backward."""
         need = lib().adfp_backward_workspace_bytes(int(n_points))
         if self._bws is None or self._bws.numel() < need or self._bws.device != device:
-            self._bws = torch.empty(int(need * 1.25) + 1024, dtype=torch.uint8, device=device)
+            self._bws = None
+            self._bws = self._alloc_scratch(int(need * 1.25) + 1024, device)
         return self._bws
 
     @staticmethod
@@ -209,6 +229,10 @@ class Engine(object):
         free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
         if need > free // 2:
             return None
+        import logging
+        logging.getLogger('attentive_dfprior_amd').info(
+            'corner-block TSDF copy: allocating %.2f GB (8 x the %dx%dx%d volume) on %s; Renderer.tsdf_blocks = False / ADFP_TSDF_BLOCKS=0 '
+            'switches it off', need / 1e9, X, Y, Z, dev)
         with _lib.device_guard(dev):
             cb = torch.empty((X, Y, Z, 8), dtype=torch.float32, device=dev)
             td = _lib.AdfpTsdf()
@@ -216,6 +240,12 @@ class Engine(object):
             check(lib().adfp_relayout_tsdf(C.byref(td), ptr(cb), _lib.current_stream(dev)), 'adfp_relayout_tsdf')
         self._tsdf_cb = (key, cb, t.untyped_storage())
         return cb
+
+    def invalidate_tsdf_blocks(self):
+        """Drops the cached corner-block copy: for a TSDF volume somebody wrote WITHOUT PyTorch seeing it (a raw-pointer kernel of the
+        caller's own, another process through CUDA IPC -- version counters are process-local).  fusion.TSDFVolume.integrate bumps the
+        volume's version itself and needs no call.  The next incoherent batch rebuilds the copy (8 x the volume, one kernel)."""
+        self._tsdf_cb = None
 
     def refresh_tsdf_blocks(self, tsdf_volume, cb):
         """Re-lay `tsdf_volume` into an existing corner-block copy `cb` IN PLACE (a holder whose captured graphs carry cb's address:
@@ -286,20 +316,28 @@ class Engine(object):
                 del jobs[:]
             else:
                 flush_pack_jobs(jobs, decoders.status_word(), next(iter(c.values())).device)
+            if any_split:
+                for n in nets:
+                    setattr(sc, 'flat_' + n, decoders.flat_weights(n, keys[n]).data_ptr())
+            if stage != 'low':
+                _lib.fill_bound(sc.tsdf_bnds, self.host_bound(tsdf_bnds, 'tsdf_bnds'))
+                self.fill_tsdf(sc.tsdf, tsdf_volume, keep)
+                if tsdf_blocks is not None and tsdf_blocks is not False and not backward:
+                    # True: this engine's cached copy (None: not float32 / no room -- the plain volume serves); a tensor: the caller's own copy
+                    cb = tsdf_blocks if isinstance(tsdf_blocks, torch.Tensor) else self.tsdf_blocks(tsdf_volume)
+                    if cb is not None:
+                        sc.tsdf.corner_blocks = cb.data_ptr()
+                        keep.append(cb)
+        except BaseException:
+            # packed_weights(defer=...) has already recorded the deferred images as current in decoders._packed; if this call dies
+            # before they are packed (still in `jobs`) or handed to a render call (self._owed_packs), the cache would vouch for images
+            # nobody wrote: forget all of them, the next call re-packs
+            if jobs or self._owed_packs is not None:
+                decoders._packed = {}
+            self._owed_packs = None
+            raise
         finally:
             decoders._pack_jobs = None
-        if any_split:
-            for n in nets:
-                setattr(sc, 'flat_' + n, decoders.flat_weights(n, keys[n]).data_ptr())
-        if stage != 'low':
-            _lib.fill_bound(sc.tsdf_bnds, self.host_bound(tsdf_bnds, 'tsdf_bnds'))
-            self.fill_tsdf(sc.tsdf, tsdf_volume, keep)
-            if tsdf_blocks is not None and tsdf_blocks is not False and not backward:
-                # True: this engine's cached copy (None: not float32 / no room -- the plain volume serves); a tensor: the caller's own copy
-                cb = tsdf_blocks if isinstance(tsdf_blocks, torch.Tensor) else self.tsdf_blocks(tsdf_volume)
-                if cb is not None:
-                    sc.tsdf.corner_blocks = cb.data_ptr()
-                    keep.append(cb)
         return sc, keep
 
     # ---- training state --------------------------------------------------------------------

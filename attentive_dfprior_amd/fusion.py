@@ -56,6 +56,10 @@ class TSDFVolume(object):
                                             C.byref(org), np.float32(self._voxel_size).item(), C.byref(intr), C.byref(pose),
                                             ptr(packed), ptr(depth), im_h, im_w, np.float32(self._trunc_margin).item(),
                                             float(obs_weight), _lib.current_stream(self.device)), 'adfp_tsdf_integrate')
+        # The kernel wrote the volume through a raw pointer: tell PyTorch.  Every cached conversion of the render volume (the
+        # corner-block copy of Engine.tsdf_blocks / MapperIteration) is keyed on (data_ptr, _version), and the view handed out by
+        # get_render_volume() shares this counter.
+        torch.autograd.graph.increment_version(self._tsdf)
 
     def get_volume(self):
         """(tsdf [X,Y,Z], color [X,Y,Z], bounds [3,2]) as numpy, like src/fusion.py:297-301."""

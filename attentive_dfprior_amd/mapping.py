@@ -175,6 +175,8 @@ class MapperIteration(object):
         attr = {'low': 'low_decoder', 'high': 'high_decoder', 'color': 'color_decoder', 'att': 'mlp'}
         self.flat = {n: flatten_parameters(getattr(decoders, attr[n])) for n in self.nets}
         decoders._plists = {}                                        # the cached parameter tuples are still the same objects
+        if getattr(decoders, '_foreign', False):                     # a pickled copy received by the (spawned) Mapper process: this
+            decoders.mark_owner()                                    # iteration is the writer of its parameters, so their versions are valid here
         self.fstate = {n: (torch.zeros_like(f), torch.zeros_like(f)) for n, f in self.flat.items()}
         # torch.optim.Adam keeps one step counter PER PARAMETER and advances it only when the parameter has a gradient (the high
         # and colour grids join in later stages): one device counter + derived scalars per group
@@ -272,6 +274,12 @@ class MapperIteration(object):
         return buf.numel() * 4
 
     # ---- the kernel sequence ------------------------------------------------------------------------------------------
+    def invalidate_tsdf(self):
+        """The TSDF volume was written by something PyTorch's version counter does not see (another process through CUDA IPC, a
+        raw-pointer kernel): the next step() re-lays the corner-block copy out of it.  fusion.TSDFVolume.integrate and in-place torch
+        ops bump the version and need no call."""
+        self._cb_version = None
+
     def _sync_tsdf_blocks(self):
         if self._cb is not None and self.tsdf._version != self._cb_version:
             self.rend._engine.refresh_tsdf_blocks(self.tsdf, self._cb)

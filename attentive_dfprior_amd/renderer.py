@@ -48,7 +48,10 @@ class Renderer(object):
         # TSDF layout for INCOHERENT batches (the order probe's verdict): 'auto' = the corner-block copy of the volume (Engine.tsdf_blocks:
         # one aligned 32-byte piece per lookup instead of four 8-byte column pieces in four sectors; 8 x the volume's memory, built once),
         # False = never.  Coherent batches (frames in pixel order) always read the volume as it stands.
-        self.tsdf_blocks = 'auto'
+        # ADFP_TSDF_BLOCKS=0 in the HOST process's environment is the deployment switch (e.g. a Tracker and a Mapper process sharing
+        # one smaller-memory GPU: each process would hold its own copy): the library itself reads no environment.
+        import os
+        self.tsdf_blocks = False if os.environ.get('ADFP_TSDF_BLOCKS', 'auto').lower() in ('0', 'off', 'false', 'no') else 'auto'
         # Sorting an incoherent batch by (origin cell, surface cell) on top of that: round 4's answer to such batches (TSDF stage
         # 0.66 -> 1.22 TB/s on the plain volume).  With the corner blocks the stage runs at 1.8 TB/s as given and 2.05 TB/s sorted, and
         # keys + radix sort + four gathers + the outputs' way back cost more than the 0.04 ms that saves (whole 131 072-ray batch:
@@ -68,6 +71,13 @@ class Renderer(object):
             return set()
         decoders.absorb_status()
         return set(decoders._exact_latch)
+
+    def invalidate_tsdf(self):
+        """Not in the reference (its TSDF is static for a run).  Call after the TSDF volume was written by something PyTorch's version
+        counter does not see (another process through CUDA IPC, a raw-pointer kernel): the corner-block copy incoherent batches read
+        (`tsdf_blocks`) is rebuilt from the volume on its next use.  `fusion.TSDFVolume.integrate` needs no call (it bumps the
+        version), nor does any in-place torch op on the volume."""
+        self._engine.invalidate_tsdf_blocks()
 
     # ---- point queries --------------------------------------------------------------------
     def eval_points(self, p, decoders, tsdf_volume, tsdf_bnds, c=None, stage='color', device='cuda:0'):

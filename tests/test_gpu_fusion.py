@@ -194,3 +194,57 @@ def test_fused_volume_feeds_the_renderer():
                                         sc.bound, 'color', gd, 32, 16)
     assert ((d.cpu() - od).abs().max() / od.abs().max()).item() < 1e-4
     assert (w != 1).any()
+
+
+def test_corner_block_copy_follows_integrate():
+    """TSDFVolume.integrate writes the volume through a raw pointer.  It bumps the tensor's version, so the cached
+    corner-block copy (Engine.tsdf_blocks, what incoherent batches and MapperIteration read) is rebuilt: integrate, render through
+    the copy, integrate ANOTHER frame, render again -- both renders equal the plain-volume path bit for bit, the copy was replaced,
+    and a writer the version counter does not see is covered by Renderer.invalidate_tsdf()."""
+    sc = synthetic.mini_scene(device=DEV)
+    vol = TSDFVolume(sc.bound.numpy(), 0.04, device=DEV)
+    fr = list(frames(sc, 4))
+    for color, depth, K, pose in fr[:2]:
+        vol.integrate(color, depth, K, pose)
+    tsdf, bnds = vol.get_render_volume()
+    import attentive_dfprior_amd as A
+    from conftest import make_cfg
+    dec = A.DF(); dec.load_state_dict(O.random_state_dict(3)); dec.bound = sc.bound; dec = dec.to(DEV)
+    rend = A.Renderer(make_cfg(), None, sc)
+    eng = rend._engine
+    ro, rd, gd, gc = [t.to(DEV) for t in synthetic.make_ray_batch(sc, 900, seed=2)]
+    tb = bnds.to(DEV)
+
+    def render(blocks):
+        with torch.no_grad():
+            return eng.render_forward(dec, sc.c, ro, rd, gd, tsdf, tb, sc.bound, 'color', 32, 16, tsdf_blocks=blocks)[:4]
+    v0 = tsdf._version
+    a_plain, a_block = render(False), render(True)
+    cb0 = eng._tsdf_cb[1]
+    for x, y in zip(a_plain, a_block):
+        assert torch.equal(x, y)
+    color, depth, K, pose = fr[2]
+    vol.integrate(color, depth, K, pose)
+    assert tsdf._version > v0, 'integrate must move the version counter the caches are keyed on'
+    b_plain, b_block = render(False), render(True)
+    assert eng._tsdf_cb[1] is not cb0
+    for x, y in zip(b_plain, b_block):
+        assert torch.equal(x, y), 'the render through the corner-block copy must see the newly fused frame'
+    assert not torch.equal(a_plain[0], b_plain[0]), 'the third frame changed the volume inside the band (the test would be vacuous otherwise)'
+    # a writer PyTorch does not see (raw pointer / another process): the hook
+    cb1 = eng._tsdf_cb[1]
+    w = vol._tsdf.data_ptr()
+    half = (vol._tsdf * 0.5).contiguous()
+    import ctypes as C
+    hip = C.CDLL('libamdhip64.so')
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(w, half.data_ptr(), half.numel() * 4, 3) == 0            # device-to-device, behind PyTorch's back
+    torch.cuda.synchronize()
+    stale = render(True)
+    assert eng._tsdf_cb[1] is cb1                                                  # nobody told the cache: it is stale, by construction
+    rend.invalidate_tsdf()
+    c_plain, c_block = render(False), render(True)
+    assert eng._tsdf_cb[1] is not cb1
+    for x, y in zip(c_plain, c_block):
+        assert torch.equal(x, y)
+    assert not torch.equal(stale[0], c_block[0])

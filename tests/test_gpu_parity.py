@@ -408,6 +408,7 @@ def test_get_rays_from_uv_vs_golden_and_pose_gradient(mini):
     ((ro * wo.to(DEV)).sum() + (rd * wd.to(DEV)).sum()).backward()
     from conftest import assert_close_scale
     assert_close_scale(c2w_g.grad, c2w.grad, 1e-5, 'd/d c2w')          # a sum over the rays
+    assert_close(c2w_g.grad[:3], c2w.grad[:3], 1e-4, 'd/d c2w, per element')      # (the bottom row of c2w takes no part in a ray: 0 on both sides)
     assert 'libadfp.so' in open('/proc/self/maps').read()
 
 
