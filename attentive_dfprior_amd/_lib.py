@@ -7,9 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('ADFP_LIB_PATH', os.path.join(_HERE, 'libadfp.so'))   # override: kernel A/B builds
+LIB_PATH = os.environ.get('ADFP_LIB_PATH') or os.path.join(_HERE, 'libadfp.so')   # override: kernel A/B builds
 
-ABI_VERSION = 130                 # ADFP_VERSION of include/adfp.h this binding was written against
+ABI_VERSION = 131                 # ADFP_VERSION of include/adfp.h this binding was written against
 STATUS_F16_RANGE = 31              # ADFP_STATUS_F16_RANGE: any of the bits below
 STATUS_RANGE_BITS = {'low': 1, 'high': 2, 'color': 4, 'att': 8, 'bwd': 16}      # ADFP_STATUS_F16_RANGE_<net>
 BWD_SCATTER_IN_KERNEL = 1        # ADFP_BWD_SCATTER_IN_KERNEL
@@ -105,6 +105,11 @@ class AdfpAdamClGroup(C.Structure):
                 ('exp_avg_sq_cl', C.c_void_p), ('mask', C.c_void_p), ('nvox', C.c_longlong), ('derived', C.c_void_p)]
 
 
+class AdfpFrameJob(C.Structure):
+    _fields_ = [('c2w', C.c_void_p), ('H', C.c_int), ('W', C.c_int), ('fx', C.c_float), ('fy', C.c_float), ('cx', C.c_float), ('cy', C.c_float),
+                ('depth', C.c_void_p), ('rays_o', C.c_void_p), ('rays_d', C.c_void_p)]
+
+
 class AdfpRenderArgs(C.Structure):
     _fields_ = [('stage', C.c_int), ('n_rays', C.c_int), ('n_samples', C.c_int), ('n_surface', C.c_int),
                 ('lindisp', C.c_int), ('perturb', C.c_float),
@@ -114,7 +119,7 @@ class AdfpRenderArgs(C.Structure):
                 ('weight', C.c_void_p), ('z_vals', C.c_void_p), ('raw', C.c_void_p),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('state', C.POINTER(AdfpTrainState)),
                 ('depth_max_segment', C.c_int), ('depth_max_first_ray', C.c_int),
-                ('pack_jobs', C.c_void_p), ('n_pack_jobs', C.c_int)]
+                ('pack_jobs', C.c_void_p), ('n_pack_jobs', C.c_int), ('frame', C.POINTER(AdfpFrameJob))]
 
 
 class AdfpBackwardArgs(C.Structure):

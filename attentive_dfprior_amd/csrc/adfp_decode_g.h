@@ -223,6 +223,42 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
     }
     ADFP_PHG(1);
     f16x8 eh[L::KG_E][2], el[L::KG_E][2];
+#if defined(ADFP_PB_MFMA)
+    // p @ B on the f32 matrix pipe (round 6; role P of k_decode_bwd_roles does the same, bit-identical to the fma chain below:
+    // tools/micro/mfma_f32_fma_order.hip).  One v_mfma_f32_32x32x2_f32 pair per K-group: D[slot][point], K = 3 as (x, y) then (z, 0)
+    // -- each k step an f32 fma, so an element is fmaf(z, bz, fmaf(y, by, x * bx)).  Operands: A = the Fourier rows, lane
+    // (i = l & 31, k = l >> 5) reads ONE row -- the row of slot sigma(i) -- instead of eight; B = the positions, lane (c = l & 31)
+    // = point 16 (g & 1) + n.  D: lane (n, g) holds, for ITS point pb = g & 1, the 16 rows (r & 3) + 8 (r >> 2) + 4 (g >> 1); sigma
+    // places K-group 2 (g >> 1)'s eight slots in registers 0-7 and K-group 2 (g >> 1) + 1's in registers 8-15, so the lane pair
+    // (l, l ^ 16) -- same rows, the two point blocks -- trade what the other needs with eight v_permlane16_swap: afterwards
+    // a[s] = slot 8 g + s of point n, b[s] = the same slot of point 16 + n, on every lane.
+    {
+        const int i31 = lane & 31;
+        const int slot = 16 * ((i31 >> 2) & 1) + 8 * (i31 >> 4) + (i31 & 3) + 4 * ((i31 >> 3) & 1);
+        const float* bsl = (const float*)ldsu + L::P_BM + 4 * slot;
+        const bool k1 = lane >= 32, odd = (g & 1) != 0;
+        const float px = odd ? pf[1][0] : pf[0][0], py = odd ? pf[1][1] : pf[0][1], pz = odd ? pf[1][2] : pf[0][2];
+        const float pxy = k1 ? py : px, pz0 = k1 ? 0.f : pz;
+#pragma unroll
+        for (int kg = 0; kg < L::KG_E; ++kg) {
+            const f32x4 bm = *(const f32x4*)(bsl + 128 * kg);
+            f32x16 av;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) av[r] = 0.f;
+            av = __builtin_amdgcn_mfma_f32_32x32x2f32(k1 ? bm.y : bm.x, pxy, av, 0, 0, 0);
+            av = __builtin_amdgcn_mfma_f32_32x32x2f32(k1 ? 0.f : bm.z, pz0, av, 0, 0, 0);
+            float e0[8], e1[8];
+#pragma unroll
+            for (int s_ = 0; s_ < 8; ++s_) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(av[s_]), __float_as_uint(av[8 + s_]), false, false);
+                e0[s_] = adfp_sinf(__uint_as_float(sw[0]));
+                e1[s_] = adfp_sinf(__uint_as_float(sw[1]));
+            }
+            split8<false>(e0, eh[kg][0], el[kg][0], amax);
+            split8<false>(e1, eh[kg][1], el[kg][1], amax);
+        }
+    }
+#else
 #pragma unroll
     for (int kg = 0; kg < L::KG_E; ++kg) {
         float e0[8], e1[8];
@@ -235,6 +271,7 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
         split8<false>(e0, eh[kg][0], el[kg][0], amax);
         split8<false>(e1, eh[kg][1], el[kg][1], amax);
     }
+#endif
     ADFP_PHG(2);
     __builtin_amdgcn_sched_barrier(0);
     f32x4g acc[2][2];

@@ -342,6 +342,8 @@ __global__ __launch_bounds__(1024) void k_prefilter(const float* __restrict__ ro
 // =====================================================================================
 // a4: sampler
 // =====================================================================================
+#define SEGMAX_PARTS 16          // partial maxima per segment of rays: one block of the call's first launch each, folded by k_sample's lanes
+#define SEGMAX_SEGS 48           // segments per call (render_img's ray batches)
 __device__ __forceinline__ unsigned f2ord(float f) {
     const unsigned u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -387,6 +389,7 @@ struct SampleArgs {
     int dmax_seg;               // > 0: dmax_f[(dmax_first + ray) / dmax_seg] (one maximum per segment of rays), 0: dmax_f[0]
     int dmax_first;             // the call's first ray in the segmented batch (a ray shard of a frame), else 0
     const unsigned* dmax_ord;   // ordered-uint reduction result or NULL
+    const unsigned* dmax_parts; // or: SEGMAX_PARTS ordered-uint PARTIAL maxima per segment (k_forward_head's segment-maximum blocks), folded here
     double b[6];                // bound lo/hi per axis
     int n_rays, n_samples, n_surface, lindisp;
     float perturb;
@@ -466,7 +469,12 @@ __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
         if (has_depth) {
             dep_l = a.depth[lray];
             const int sg = a.dmax_seg > 0 ? (a.dmax_first + lray) / a.dmax_seg : 0;
-            dmax_l = a.dmax_f ? a.dmax_f[sg] : ord2f(a.dmax_ord[sg]);
+            if (a.dmax_parts) {                         // the 16 lanes of a ray fold the segment's 16 partial maxima (max is exact: any order)
+                unsigned pm = a.dmax_parts[sg * SEGMAX_PARTS + (lane & 15)];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { const unsigned q = __shfl_xor(pm, o); pm = q > pm ? q : pm; }
+                dmax_l = ord2f(pm);
+            } else dmax_l = a.dmax_f ? a.dmax_f[sg] : ord2f(a.dmax_ord[sg]);
         }
         // far_bb = min_axis max_side (bound - o)/d + 0.01   (Renderer.py:151-156), f64: ONE division per lane -- lane (ray, axis, side)
         // (an f64 division is ~40 instructions; six of them in every lane were most of this kernel's VALU work).
@@ -1130,6 +1138,7 @@ static int make_pts(const adfp_points* p, PtsDev* d) {
 // workspace carve-up (all offsets 256-B aligned)
 struct Workspace {
     double* z; float* raw; unsigned char* flags; int* list; float* att_occ; float* att_u; int* counter;
+    unsigned* segparts;          // [SEGMAX_SEGS][SEGMAX_PARTS] ordered-uint partial maxima of gt_depth (k_forward_head -> k_sample)
     size_t bytes;
 };
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1138,6 +1147,7 @@ template <typename T> static T* at(void* base, size_t o) { return (T*)((uintptr_
 static Workspace carve(void* base, long long P) {
     Workspace w; size_t o = 0;
     w.counter = at<int>(base, o); o += 256;
+    w.segparts = at<unsigned>(base, o); o += align256((size_t)SEGMAX_SEGS * SEGMAX_PARTS * 4);
     w.z = at<double>(base, o); o += align256((size_t)P * 8);
     w.raw = at<float>(base, o); o += align256((size_t)P * 16);
     w.list = at<int>(base, o); o += align256((size_t)P * 4);
@@ -1187,10 +1197,58 @@ __device__ inline void pack_multi_block(const PackJobs& j, int block) {
 __global__ __launch_bounds__(256) void k_pack_multi(PackJobs j) { pack_multi_block(j, (int)blockIdx.x); }
 // the first launch of a render call: the weight images it was handed to pack (adfp_render_args.pack_jobs) and the zero fill of its
 // device words
-struct ForwardHeadArgs { PackJobs p; ZeroJobs z; int nb_pack; };
+// ... and, since round 6, two more kinds of blocks, so that a frame (or a rank's share of one) needs no launch of its own for either:
+//   rays:   the rays of pixels [first, first + n) of an H x W frame (k_get_rays' arithmetic, src/common.py:254-272)
+//   segmax: SEGMAX_PARTS partial maxima of gt_depth per segment of `seg` rays, as ordered uints, plain stores (no atomics: nothing
+//           has to be zeroed before this launch); k_sample's lanes fold them.  Block (s, p) takes the p-th sixteenth of segment s.
+struct RayJob { const float* c2w; int W; float fx, fy, cx, cy; int first, n; float* ro; float* rd; };
+struct SegJob { const float* d; int n, seg, nseg; unsigned* parts; };
+struct ForwardHeadArgs { PackJobs p; ZeroJobs z; int nb_pack, nb_zero, nb_rays; RayJob rj; SegJob sj; };
+__device__ inline void rays_block(const RayJob& j, unsigned blk) {
+    const int k = (int)blk * 256 + threadIdx.x;
+    if (k >= j.n) return;
+    const int idx = j.first + k;
+    const int row = idx / j.W, col = idx - row * j.W;
+    const float dx = ((float)col - j.cx) / j.fx, dy = -((float)row - j.cy) / j.fy, dz = -1.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float s = __fadd_rn(__fadd_rn(__fmul_rn(dx, j.c2w[4 * a + 0]), __fmul_rn(dy, j.c2w[4 * a + 1])), __fmul_rn(dz, j.c2w[4 * a + 2]));
+        j.rd[3 * k + a] = s;
+        j.ro[3 * k + a] = j.c2w[4 * a + 3];
+    }
+}
+__device__ inline void segmax_block(const SegJob& j, unsigned blk) {
+    __shared__ unsigned s_m[4];
+    const int sg = (int)blk / SEGMAX_PARTS, part = (int)blk % SEGMAX_PARTS;
+    const long long s_lo = (long long)sg * j.seg, s_hi = s_lo + j.seg < j.n ? s_lo + j.seg : j.n;
+    const long long len = s_hi - s_lo, per = (len + SEGMAX_PARTS - 1) / SEGMAX_PARTS;
+    const long long lo = s_lo + part * per, hi = lo + per < s_hi ? lo + per : s_hi;
+    unsigned m = 0;
+    // eight independent loads per thread and trip: the slice is a few thousand floats, the cost is the latency of the trips
+    for (long long i = lo + threadIdx.x; i < hi; i += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = i + 256 * u < hi ? j.d[i + 256 * u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const unsigned q = i + 256 * u < hi ? f2ord(v[u]) : 0u; m = q > m ? q : m; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned q = __shfl_xor(m, o); m = q > m ? q : m; }
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) m = s_m[w] > m ? s_m[w] : m;
+        j.parts[blk] = m;                                   // 0 = "below every float": an empty slice
+    }
+}
 __global__ __launch_bounds__(256) void k_forward_head(ForwardHeadArgs h) {
-    if ((int)blockIdx.x < h.nb_pack) pack_multi_block(h.p, (int)blockIdx.x);
-    else zero_multi_block(h.z, blockIdx.x - (unsigned)h.nb_pack);
+    unsigned b = blockIdx.x;
+    if ((int)b < h.nb_pack) { pack_multi_block(h.p, (int)b); return; }
+    b -= (unsigned)h.nb_pack;
+    if ((int)b < h.nb_zero) { zero_multi_block(h.z, b); return; }
+    b -= (unsigned)h.nb_zero;
+    if ((int)b < h.nb_rays) { rays_block(h.rj, b); return; }
+    segmax_block(h.sj, b - (unsigned)h.nb_rays);
 }
 static int pack_jobs_table(int n_jobs, const adfp_pack_job* jobs, int* status, PackJobs& j) {
     if (n_jobs < 0 || n_jobs > ADFP_PACK_MAX_JOBS || (n_jobs && !jobs)) return ADFP_E_ARG;
@@ -1402,7 +1460,8 @@ int adfp_prefilter_rays(const float* rays_o, const float* rays_d, const float* g
 
 static int sample_rays_impl(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double bound[3][2],
                             int n_samples, int n_surface, int lindisp, float perturb, const float* t_rand, const float* depth_max,
-                            double* z_vals, void* scratch, void* stream, bool scratch_is_zero, int segment = 0, int first_ray = 0);
+                            double* z_vals, void* scratch, void* stream, bool scratch_is_zero, int segment = 0, int first_ray = 0,
+                            const unsigned* seg_parts = nullptr);
 int adfp_sample_rays(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double bound[3][2],
                      int n_samples, int n_surface, int lindisp, float perturb, const float* t_rand, const float* depth_max,
                      double* z_vals, void* scratch, void* stream) {
@@ -1411,19 +1470,22 @@ int adfp_sample_rays(const float* rays_o, const float* rays_d, const float* gt_d
 }
 static int sample_rays_impl(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double bound[3][2],
                             int n_samples, int n_surface, int lindisp, float perturb, const float* t_rand, const float* depth_max,
-                            double* z_vals, void* scratch, void* stream, bool scratch_is_zero, int segment, int first_ray) {
+                            double* z_vals, void* scratch, void* stream, bool scratch_is_zero, int segment, int first_ray,
+                            const unsigned* seg_parts) {
     if (!rays_o || !rays_d || !z_vals || !bound || n_rays < 0 || n_samples <= 0 || n_surface < 0) return ADFP_E_ARG;
-    if (first_ray < 0 || (first_ray > 0 && (!depth_max || segment <= 0))) return ADFP_E_ARG;
+    if (first_ray < 0 || (first_ray > 0 && ((!depth_max && !seg_parts) || segment <= 0))) return ADFP_E_ARG;
     if (perturb > 0.f && !t_rand) return ADFP_E_ARG;
     if (n_samples + n_surface > ADFP_MAX_SAMPLES) return ADFP_E_UNSUPPORTED;
     if (n_rays == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     SampleArgs a;
     a.ro = rays_o; a.rd = rays_d; a.depth = gt_depth; a.t_rand = perturb > 0.f ? t_rand : nullptr;
-    a.dmax_f = depth_max; a.dmax_ord = nullptr; a.dmax_seg = segment > 0 ? segment : 0; a.dmax_first = first_ray;
+    a.dmax_f = depth_max; a.dmax_ord = nullptr; a.dmax_parts = nullptr; a.dmax_seg = segment > 0 ? segment : 0; a.dmax_first = first_ray;
     fill_bound(a.b, bound);
     a.n_rays = n_rays; a.n_samples = n_samples; a.n_surface = n_surface; a.lindisp = lindisp; a.perturb = perturb; a.z = z_vals;
-    if (gt_depth && !depth_max && segment > 0) {        // one maximum per segment, into the scratch (48 floats of room)
+    if (gt_depth && !depth_max && seg_parts) {          // the caller's first launch left SEGMAX_PARTS partial maxima per segment: k_sample folds them
+        a.dmax_parts = seg_parts;
+    } else if (gt_depth && !depth_max && segment > 0) {        // one maximum per segment, into the scratch (48 floats of room)
         if (!scratch) return ADFP_E_ARG;
         const int nseg = (n_rays + segment - 1) / segment;
         if (nseg > 48) return ADFP_E_UNSUPPORTED;
@@ -2272,18 +2334,29 @@ int adfp_composite(const float* raw, const double* z_vals, int n_rays, int S, do
 int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void* stream) {
     if (!r) return ADFP_E_ARG;
     int rc = check_scene(scene, r->stage); if (rc) return rc;
-    if (!r->rays_o || !r->rays_d || !r->depth || !r->uncertainty || !r->color || !r->weight || !r->workspace) return ADFP_E_ARG;
+    const adfp_frame_job* fr = r->frame;
+    if (fr) {          // the call's rays are pixels [first, first + n_rays) of a frame: rays and far clamps come from the frame
+        if (!fr->c2w || !fr->depth || !fr->rays_o || !fr->rays_d || fr->H <= 0 || fr->W <= 0 || (long long)fr->H * fr->W > 0x7fffffffll) return ADFP_E_ARG;
+        if (r->depth_max || r->depth_max_segment <= 0 || r->depth_max_first_ray < 0) return ADFP_E_ARG;
+        if ((long long)r->depth_max_first_ray + r->n_rays > (long long)fr->H * fr->W) return ADFP_E_ARG;
+        if (r->perturb > 0.f) return ADFP_E_UNSUPPORTED;
+    }
+    const float* rays_o = fr ? fr->rays_o : r->rays_o;
+    const float* rays_d = fr ? fr->rays_d : r->rays_d;
+    const float* gt_depth = fr ? fr->depth + r->depth_max_first_ray : r->gt_depth;
+    if (!rays_o || !rays_d || !r->depth || !r->uncertainty || !r->color || !r->weight || !r->workspace) return ADFP_E_ARG;
     if (r->n_rays < 0 || r->n_samples <= 0 || r->n_surface < 0 || r->depth_max_segment < 0) return ADFP_E_ARG;
-    if (r->depth_max_first_ray < 0 || (r->depth_max_first_ray > 0 && (!r->depth_max || r->depth_max_segment <= 0 || !r->gt_depth))) return ADFP_E_ARG;
+    if (r->depth_max_first_ray < 0 || (r->depth_max_first_ray > 0 && !fr && (!r->depth_max || r->depth_max_segment <= 0 || !gt_depth))) return ADFP_E_ARG;
     if (r->n_pack_jobs < 0 || r->n_pack_jobs > ADFP_PACK_MAX_JOBS || (r->n_pack_jobs && !r->pack_jobs)) return ADFP_E_ARG;
     if (r->state && r->stage != ADFP_STAGE_LOW &&
         (!r->state->flags || !r->state->list || !r->state->counter || !r->state->att_occ || !r->state->att_u)) return ADFP_E_ARG;
-    const int S = r->n_samples + (r->gt_depth ? r->n_surface : 0);
+    const int S = r->n_samples + (gt_depth ? r->n_surface : 0);
     if (S > ADFP_MAX_SAMPLES) return ADFP_E_UNSUPPORTED;
     const long long Pn = (long long)r->n_rays * S;
     if (Pn > 0x7fffffffll) return ADFP_E_UNSUPPORTED;
-    // per-segment far clamp: the maxima live in 48 words of the workspace head (refused here, before anything is launched)
-    if (r->gt_depth && !r->depth_max && r->depth_max_segment > 0 && ((long long)r->n_rays + r->depth_max_segment - 1) / r->depth_max_segment > 48)
+    // per-segment far clamp: the partial maxima live in SEGMAX_SEGS x SEGMAX_PARTS words of the workspace head (refused here, before anything is launched)
+    if (gt_depth && !r->depth_max && r->depth_max_segment > 0 &&
+        ((fr ? (long long)fr->H * fr->W : (long long)r->n_rays) + r->depth_max_segment - 1) / r->depth_max_segment > SEGMAX_SEGS)
         return ADFP_E_UNSUPPORTED;
     Workspace ws = carve(r->workspace, Pn);
     if (r->workspace_bytes < ws.bytes) return ADFP_E_WORKSPACE;
@@ -2291,30 +2364,54 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
     hipStream_t st = (hipStream_t)stream;
     double* z = r->z_vals ? r->z_vals : ws.z;
     float* raw = r->raw ? r->raw : ws.raw;
-    // ONE zero fill for the call's small device words: the in-band counter and range flag (bytes 0-63) and the depth-max
-    // reduction's scratch (bytes 64-255: up to 48 per-segment maxima) share the first 256 bytes of the workspace
-    {   // ... and, in a training call, the caller's counter block that eval_points_impl uses instead: one launch for both -- and for
-        // the weight images the caller handed over to pack (k_forward_head)
+    // The call's FIRST launch (k_forward_head) does everything that has to precede the sampler:
+    //  * ONE zero fill for the call's small device words: the in-band counter and range flag (bytes 0-63) and the tile counters
+    //    share the first 256 bytes of the workspace -- and, in a training call, the caller's counter block that eval_points_impl
+    //    uses instead;
+    //  * the weight images the caller handed over to pack;
+    //  * a frame job's rays;
+    //  * the partial maxima of gt_depth (per segment of rays, or one "segment" = the whole call) when no depth_max was given.
+    ForwardHeadArgs h;
+    memset(&h, 0, sizeof(h));
+    {
         ZeroBatch zb;
         hipError_t e = zb.add(ws.counter, 256, st);
         if (e == hipSuccess && r->state && r->state->counter && r->state->counter != ws.counter) e = zb.add(r->state->counter, 64, st);
         if (e != hipSuccess) return (int)e;
-        if (r->n_pack_jobs > 0) {
-            ForwardHeadArgs h;
-            rc = pack_jobs_table(r->n_pack_jobs, r->pack_jobs, scene->status, h.p); if (rc) return rc;
-            h.z = zb.z; h.nb_pack = h.p.first[h.p.n];
-            hipLaunchKernelGGL(k_forward_head, dim3((unsigned)h.nb_pack + zb.blocks), dim3(256), 0, st, h);
-            ADFP_CHECK_LAUNCH();
-        } else {
-            e = zb.flush(st);
-            if (e != hipSuccess) return (int)e;
-        }
+        h.z = zb.z; h.nb_zero = (int)zb.blocks;
     }
-    rc = sample_rays_impl(r->rays_o, r->rays_d, r->gt_depth, r->n_rays, scene->bound, r->n_samples, r->n_surface, r->lindisp,
-                          r->perturb, r->t_rand, r->depth_max, z, (char*)ws.counter + 64, stream, true, r->depth_max_segment, r->depth_max_first_ray);
+    h.p.n = 0; h.nb_pack = 0;
+    if (r->n_pack_jobs > 0) {
+        rc = pack_jobs_table(r->n_pack_jobs, r->pack_jobs, scene->status, h.p); if (rc) return rc;
+        h.nb_pack = h.p.first[h.p.n];
+    }
+    h.nb_rays = 0;
+    if (fr) {
+        h.rj.c2w = fr->c2w; h.rj.W = fr->W; h.rj.fx = fr->fx; h.rj.fy = fr->fy; h.rj.cx = fr->cx; h.rj.cy = fr->cy;
+        h.rj.first = r->depth_max_first_ray; h.rj.n = r->n_rays; h.rj.ro = fr->rays_o; h.rj.rd = fr->rays_d;
+        h.nb_rays = (r->n_rays + 255) / 256;
+    }
+    const unsigned* seg_parts = nullptr;
+    int segment = r->depth_max_segment;
+    unsigned nb_seg = 0;
+    if (gt_depth && !r->depth_max) {
+        // whole frame's depth (frame job) or the call's own rays; no segments = one segment that is the whole call
+        h.sj.d = fr ? fr->depth : gt_depth;
+        h.sj.n = fr ? fr->H * fr->W : r->n_rays;
+        h.sj.seg = segment > 0 ? segment : h.sj.n;
+        h.sj.nseg = (h.sj.n + h.sj.seg - 1) / h.sj.seg;
+        h.sj.parts = ws.segparts;
+        if (segment <= 0) segment = h.sj.n;                // k_sample indexes segment (first + ray) / segment = 0
+        nb_seg = (unsigned)h.sj.nseg * SEGMAX_PARTS;
+        seg_parts = ws.segparts;
+    }
+    hipLaunchKernelGGL(k_forward_head, dim3((unsigned)(h.nb_pack + h.nb_zero + h.nb_rays) + nb_seg), dim3(256), 0, st, h);
+    ADFP_CHECK_LAUNCH();
+    rc = sample_rays_impl(rays_o, rays_d, gt_depth, r->n_rays, scene->bound, r->n_samples, r->n_surface, r->lindisp,
+                          r->perturb, r->t_rand, r->depth_max, z, (char*)ws.counter + 64, stream, true, segment, r->depth_max_first_ray, seg_parts);
     if (rc) return rc;
     PtsDev P;
-    P.mode = ADFP_PTS_RAYS; P.S = S; P.n = (int)Pn; P.pts = nullptr; P.ro = r->rays_o; P.rd = r->rays_d; P.z = z;
+    P.mode = ADFP_PTS_RAYS; P.S = S; P.n = (int)Pn; P.pts = nullptr; P.ro = rays_o; P.rd = rays_d; P.z = z;
     rc = eval_points_impl(scene, P, r->stage, 1, raw, r->weight, ws, st, r->state, true);
     if (rc) return rc;
     return adfp_composite(raw, z, r->n_rays, S, r->depth, r->uncertainty, r->color, nullptr, stream);

@@ -678,23 +678,43 @@ class Engine(object):
     # ---- a4..a13 ---------------------------------------------------------------------------
     def render_forward(self, decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage,
                        n_samples, n_surface, lindisp=False, perturb=0.0, t_rand=None, depth_max=None,
-                       want_aux=False, train=False, need_flat=None, depth_max_segment=0, depth_max_first_ray=0, tsdf_blocks=False):
-        _lib.require_cuda(rays_o, 'rays_o')
-        dev = rays_o.device
+                       want_aux=False, train=False, need_flat=None, depth_max_segment=0, depth_max_first_ray=0, tsdf_blocks=False,
+                       frame=None):
+        """frame (not with train): dict(c2w=, H=, W=, fx=, fy=, cx=, cy=, depth=<the WHOLE frame's sensor depth>, n_rays=) -- the call
+        renders pixels [depth_max_first_ray, + n_rays) of that frame (adfp_frame_job): rays_o / rays_d / gt_depth are ignored (pass
+        None), the rays and the per-segment far clamps of the whole frame come out of the call's first launch."""
         f32 = torch.float32
+        if frame is not None:
+            fdepth = frame['depth'].detach().reshape(-1)
+            _lib.require_cuda(fdepth, 'gt_depth')
+            dev = fdepth.device
+        else:
+            _lib.require_cuda(rays_o, 'rays_o')
+            dev = rays_o.device
         with _lib.device_guard(dev):
-            ro = rays_o.detach()
-            if ro.dtype != f32 or not ro.is_contiguous():
-                ro = ro.float().contiguous()
-            rd = rays_d.detach()
-            if rd.dtype != f32 or not rd.is_contiguous():
-                rd = rd.float().contiguous()
-            N = ro.shape[0]
-            gd = None
-            if gt_depth is not None:
-                gd = gt_depth.detach().reshape(-1)
-                if gd.dtype != f32 or not gd.is_contiguous():
-                    gd = gd.float().contiguous()
+            if frame is not None:
+                if fdepth.dtype != f32 or not fdepth.is_contiguous():
+                    fdepth = fdepth.float().contiguous()
+                N = int(frame['n_rays'])
+                fc2w = frame['c2w'].detach().to(dev, f32).contiguous()
+                if fc2w.numel() < 12:
+                    raise RuntimeError(f'c2w: expected [3,4] or [4,4], got {tuple(fc2w.shape)}')
+                ro = torch.empty((N, 3), dtype=f32, device=dev)
+                rd = torch.empty((N, 3), dtype=f32, device=dev)
+                gd = fdepth[depth_max_first_ray:depth_max_first_ray + N]
+            else:
+                ro = rays_o.detach()
+                if ro.dtype != f32 or not ro.is_contiguous():
+                    ro = ro.float().contiguous()
+                rd = rays_d.detach()
+                if rd.dtype != f32 or not rd.is_contiguous():
+                    rd = rd.float().contiguous()
+                N = ro.shape[0]
+                gd = None
+                if gt_depth is not None:
+                    gd = gt_depth.detach().reshape(-1)
+                    if gd.dtype != f32 or not gd.is_contiguous():
+                        gd = gd.float().contiguous()
             S = n_samples + (n_surface if gd is not None else 0)
             depth = torch.empty((N,), dtype=torch.float64, device=dev)
             unc = torch.empty((N,), dtype=torch.float64, device=dev)
@@ -735,6 +755,12 @@ class Engine(object):
                     a.t_rand = t_rand.data_ptr()
                 a.depth_max_segment = int(depth_max_segment)
                 a.depth_max_first_ray = int(depth_max_first_ray)
+                if frame is not None:
+                    fj = _lib.AdfpFrameJob()
+                    fj.c2w, fj.H, fj.W = fc2w.data_ptr(), int(frame['H']), int(frame['W'])
+                    fj.fx, fj.fy, fj.cx, fj.cy = float(frame['fx']), float(frame['fy']), float(frame['cx']), float(frame['cy'])
+                    fj.depth, fj.rays_o, fj.rays_d = fdepth.data_ptr(), ro.data_ptr(), rd.data_ptr()
+                    a.frame = C.pointer(fj)
                 if depth_max is not None:
                     depth_max = depth_max.to(dev, f32).reshape(-1).contiguous()
                     a.depth_max = depth_max.data_ptr()

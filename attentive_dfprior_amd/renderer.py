@@ -254,16 +254,20 @@ class Renderer(object):
             lo, hi = int(lo), int(hi)
             if not (0 <= lo <= hi <= H * W):
                 raise ValueError(f'render_img_shard: [{lo}, {hi}) is not a pixel range of a {H}x{W} frame')
-            rays_o, rays_d = get_rays(H, W, self.fx, self.fy, self.cx, self.cy, c2w, device)
-            gd = gt_depth.reshape(-1)
-            seg_max = self.segment_depth_max(gd)
-            if seg_max.shape[0] > 48:
+            if (H * W + self.ray_batch_size - 1) // self.ray_batch_size > 48:
                 raise NotImplementedError('render_img_shard: more than 48 ray batches per frame')
+            # ONE call, whose first launch also writes the rays of the rank's OWN pixels and reduces the whole frame's segment
+            # maxima (adfp_frame_job): a rank spends nothing on the rays of the other ranks' pixels, and no launch on the maxima
             depth, unc, color, _, _ = self._engine.render_forward(
-                decoders, c, rays_o.reshape(-1, 3)[lo:hi], rays_d.reshape(-1, 3)[lo:hi], gd[lo:hi], tsdf_volume, tsdf_bnds, self.bound,
-                stage, self.N_samples, self.N_surface, self.lindisp, self.perturb, None, seg_max,
-                depth_max_segment=self.ray_batch_size, depth_max_first_ray=lo)
+                decoders, c, None, None, None, tsdf_volume, tsdf_bnds, self.bound, stage, self.N_samples, self.N_surface, self.lindisp,
+                self.perturb, None, None, depth_max_segment=self.ray_batch_size, depth_max_first_ray=lo, frame=self._frame_job(c2w, gt_depth, hi - lo))
             return depth, unc, color
+
+    def _frame_job(self, c2w, gt_depth, n_rays):
+        import numpy as np
+        if isinstance(c2w, np.ndarray):
+            c2w = torch.from_numpy(c2w)
+        return dict(c2w=c2w, H=self.H, W=self.W, fx=self.fx, fy=self.fy, cx=self.cx, cy=self.cy, depth=gt_depth, n_rays=n_rays)
 
     def render_img(self, c, decoders, c2w, device, tsdf_volume, tsdf_bnds, stage, gt_depth=None):
         """Full-frame render under no_grad in ``ray_batch_size`` batches -> depth [H,W] f64,
@@ -271,22 +275,23 @@ class Renderer(object):
         depth, exactly like the reference's loop (Renderer.py:294-313)."""
         with torch.no_grad():
             H, W = self.H, self.W
-            rays_o, rays_d = get_rays(H, W, self.fx, self.fy, self.cx, self.cy, c2w, device)
-            rays_o = rays_o.reshape(-1, 3)
-            rays_d = rays_d.reshape(-1, 3)
             if gt_depth is not None:
                 gt_depth = gt_depth.reshape(-1)
-            n, S = rays_d.shape[0], self.N_samples + (self.N_surface if gt_depth is not None else 0)
+            n, S = H * W, self.N_samples + (self.N_surface if gt_depth is not None else 0)
             nseg = (n + self.ray_batch_size - 1) // self.ray_batch_size
-            if gt_depth is not None and self.perturb == 0 and 1 < nseg <= 48 and n * S < 2 ** 31 and self._fits_in_one_call(n, S, rays_d.device):
+            on_gpu = torch.device(device).type == 'cuda' and gt_depth is not None and gt_depth.is_cuda
+            if on_gpu and self.perturb == 0 and 1 < nseg <= 48 and n * S < 2 ** 31 and self._fits_in_one_call(n, S, gt_depth.device):
                 # The reference walks the frame in ray batches (memory), and the only thing a batch shares is max(gt_depth) for
                 # the far clamp -- carried per SEGMENT of ray_batch_size rays here (adfp_render_args.depth_max_segment), the whole
                 # frame is one kernel sequence with the batched loop's values bit for bit (tests: the golden image was rendered
-                # by the reference in 1 000-ray batches).
+                # by the reference in 1 000-ray batches).  The rays come out of the call's first launch (adfp_frame_job).
                 depth, unc, color, _, _ = self._engine.render_forward(
-                    decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, self.bound, stage, self.N_samples,
-                    self.N_surface, self.lindisp, self.perturb, None, None, depth_max_segment=self.ray_batch_size)
+                    decoders, c, None, None, None, tsdf_volume, tsdf_bnds, self.bound, stage, self.N_samples, self.N_surface, self.lindisp,
+                    self.perturb, None, None, depth_max_segment=self.ray_batch_size, frame=self._frame_job(c2w, gt_depth, n))
                 return depth.reshape(H, W), unc.reshape(H, W), color.reshape(H, W, 3)
+            rays_o, rays_d = get_rays(H, W, self.fx, self.fy, self.cx, self.cy, c2w, device)
+            rays_o = rays_o.reshape(-1, 3)
+            rays_d = rays_d.reshape(-1, 3)
             ds, us, cs = [], [], []
             for i in range(0, rays_d.shape[0], self.ray_batch_size):
                 sl = slice(i, i + self.ray_batch_size)

@@ -176,7 +176,7 @@ def pmc_traffic(kernel_prefix, samples_per_launch, fname='r05_pmc_hbm_traffic.cs
     header carries the source hash of the build it was taken from and `stale` says whether that is this build."""
     import csv
     stem = fname.split('_', 1)[1]                       # the newest round's file of that name, unless `exact`
-    names = (fname,) if exact else tuple(f'r{r:02d}_{stem}' for r in range(5, 0, -1))
+    names = (fname,) if exact else tuple(f'r{r:02d}_{stem}' for r in range(6, 0, -1))
     for name in names:
         path = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(path):
@@ -195,24 +195,45 @@ def pmc_traffic(kernel_prefix, samples_per_launch, fname='r05_pmc_hbm_traffic.cs
     return None, prov
 
 
-# Feature-grid scale of the bench scene.  SURVEY.md section 8d initialises the grids like src/DF_Prior.py:247-263 -- N(0, 0.01) low /
-# colour, N(0, 1e-4) high -- at which the seeded random decoders output an almost constant occupancy.  The bench multiplies them
-# (x 20, and the high grid x 100 on top: std 0.2 everywhere) so that occupancy, attention weights and colour vary along a ray like
-# with a trained map; kernel time does not depend on the values (tests/test_gpu_scale.py covers the init scale and a trained
-# scale for parity).  Named in config.workload and config.grid_init.
-GRID_STD_SCALE, GRID_HIGH_EXTRA = 20.0, 100.0
-# instruction counts of one 32-point tile of k_decode_lc16 (both networks), from the compiled kernel (tools/isa_mix.py)
-LC16_MFMA_PER_TILE, LC16_VALU_PER_TILE, LC16_LDS_PER_TILE = 360, 2415, 250      # static counts; ~35 of the VALU are the other branch of the tile hand-out
+# Feature-grid scale of the bench scene.  The HEADLINE runs at SURVEY.md section 8d's prescription: the grids initialised like
+# src/DF_Prior.py:247-263 -- N(0, 0.01) low / colour, N(0, 1e-4) high (GRID_STD_SCALE = 1).  At that scale the seeded random
+# decoders output an almost constant occupancy, so the same frame is ALSO timed and checked against the oracle with the grids
+# multiplied (x 20, the high grid x 100 on top: std 0.2 everywhere; rounds 1-5 ran the headline there), where occupancy, attention
+# weights and colour vary along a ray like with a trained map: `config.value_at_x20_grids`, `config.parity_max_rel_*_at_x20`.  Kernel
+# time does not depend on the values (tests/test_gpu_scale.py covers the init scale and a trained scale for parity).
+GRID_STD_SCALE, GRID_HIGH_EXTRA = 1.0, 1.0
+X20_STD_SCALE, X20_HIGH_EXTRA = 20.0, 100.0
+
+
+def isa_mix_lc16(fname='r06_isa_mix_lc16.txt'):
+    """Instruction counts of ONE 32-point tile of k_decode_lc16 (both networks): the TILE LOOP of the compiled kernel
+    (tools/gen_isa_mix.py -> tools/isa_mix.py --loop), read from the committed file whose header carries the source hash of the
+    build it was taken from; `stale` = that is not this build."""
+    import re
+    path = os.path.join(ROOT, 'profiles', fname)
+    out = {'file': 'profiles/' + fname, 'this_source_hash': source_hash()}
+    if not os.path.exists(path):
+        return dict(out, file=None)
+    text = open(path).read()
+    m = re.search(r'source_hash=(\w+)', text)
+    out['profiled_source_hash'] = m.group(1) if m else None
+    out['stale'] = out['profiled_source_hash'] != out['this_source_hash']
+    m = re.search(r'\[tile loop only\]: (\d+) instr, VALU (\d+) \(packed \d+\), MFMA (\d+), LDS (\d+), VMEM (\d+), SALU (\d+)', text)
+    if m:
+        out.update(instructions=int(m.group(1)), valu=int(m.group(2)), mfma=int(m.group(3)), lds=int(m.group(4)), vmem=int(m.group(5)), salu=int(m.group(6)))
+    return out
 
 
 def pmc_sq(kernel_prefix, fname='r05_pmc_sq_forward.txt'):
     """MFMA-busy fraction and delivered clock of one kernel from the committed SQ counter summary (tools/pmc_summary.py output)."""
-    path = os.path.join(ROOT, 'profiles', fname)
     out = {'file': None}
-    if not os.path.exists(path):
-        fname = fname.replace('r05_', 'r04_')
+    stem = fname.split('_', 1)[1]
+    for r in range(6, 3, -1):                            # the newest round's summary
+        fname = f'r{r:02d}_{stem}'
         path = os.path.join(ROOT, 'profiles', fname)
-    if not os.path.exists(path):
+        if os.path.exists(path):
+            break
+    else:
         return out
     out['file'] = 'profiles/' + fname
     take = False
@@ -230,9 +251,11 @@ def pmc_sq(kernel_prefix, fname='r05_pmc_sq_forward.txt'):
     return out
 
 
-def build_scene(A, synthetic, name, dev, H=480, W=640):
-    scene = synthetic.Scene(name, H=H, W=W, device=dev, grid_std_scale=GRID_STD_SCALE)
-    scene.c['grid_high'] = scene.c['grid_high'] * GRID_HIGH_EXTRA
+def build_scene(A, synthetic, name, dev, H=480, W=640, std_scale=X20_STD_SCALE, high_extra=X20_HIGH_EXTRA):
+    """(scene, state dict, decoders).  Default grids: the x20 variant (what the tools profile); the headline passes the reference's init."""
+    scene = synthetic.Scene(name, H=H, W=W, device=dev, grid_std_scale=std_scale)
+    if high_extra != 1.0:
+        scene.c['grid_high'] = scene.c['grid_high'] * high_extra
     sd = synthetic.seeded_state_dict(0)
     dec = A.DF()
     dec.load_state_dict(sd)
@@ -277,7 +300,7 @@ def main():
 
     H, W, NS, NF = 480, 640, 48, 16
     S = NS + NF
-    scene, sd, dec = build_scene(A, synthetic, args.scene, dev)
+    scene, sd, dec = build_scene(A, synthetic, args.scene, dev, std_scale=GRID_STD_SCALE, high_extra=GRID_HIGH_EXTRA)
     rend = A.Renderer(CFG64, None, scene)
     tsdf_bnds = scene.tsdf_bnds.to(dev)
     # one pose per rank (weak scaling: every rank renders a full frame)
@@ -341,12 +364,11 @@ def main():
         'dtype': ('f32 via f16x3 split (3 f16 MFMA products per f32 product: 22-bit products, f32 accumulate)'
                   if os.environ.get('ADFP_MATH', 'f16x3') == 'f16x3' else 'f32'),
         'data': 'synthetic', 'math': os.environ.get('ADFP_MATH', 'f16x3'),
-        'config': {'workload': f'{args.scene} synthetic box room, 640x480 full-frame render_img, stage color, '
-                               '64 samples/ray (N_samples 48 + N_surface 16), ray_batch_size 100000 (per-batch far clamp, '
-                               'rendered as one call with a depth maximum per 100 000-ray segment), ONE frame per step' + ('' if n_gpus == 1 else f', ray-sharded over the {n_gpus} GPUs (contiguous pixel ranges, one packed all-gather inside the step)') + '; seed-0 decoders, feature grids N(0, 0.2) '
-                               f'(the reference\'s init std x {GRID_STD_SCALE:g}, high grid x {GRID_HIGH_EXTRA:g} more)',
-                   'grid_init': {'std_scale_vs_reference_init': GRID_STD_SCALE, 'grid_high_extra_factor': GRID_HIGH_EXTRA,
-                                 'reference_init': 'N(0,0.01) low/colour, N(0,1e-4) high (src/DF_Prior.py:247-263)'},
+        # the first ~120 characters carry what qualifies the number (the driver's record cuts the string there)
+        'config': {'workload': f'{args.scene} 640x480 render_img, 64 spp (48+16), synthetic box room, seed-0 random decoders, grids at the REFERENCE init '
+                               '(N(0,.01), high N(0,1e-4)); stage color, ray_batch_size 100000 (per-batch far clamp, '
+                               'rendered as one call with a depth maximum per 100 000-ray segment), ONE frame per step' + ('' if n_gpus == 1 else f', ray-sharded over the {n_gpus} GPUs (contiguous pixel ranges, one packed all-gather inside the step)'),
+                   'grid_std_scale': GRID_STD_SCALE,     # 1 = src/DF_Prior.py:247-263; the x20 variant is value_at_x20_grids
                    'rays_per_step': n_rays, 'rays_per_step_per_gpu': (n_rays + n_gpus - 1) // n_gpus, 'samples_per_ray': S,
                    'tsdf_voxels': list(scene.tsdf_volume.shape[2:]),
                    'grid_high': list(scene.c['grid_high'].shape[2:])},
@@ -361,7 +383,8 @@ def main():
                           'workload': 'one whole 640x480 frame per rank per step (one pose per rank), no data-path collective'}
     elif rank == 0 and not args.no_shard_model:
         try:
-            result['config']['shard_model'] = shard_model(rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, n_rays)
+            result['config']['shard_model'] = shard_model(rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, n_rays, ms_per_step)
+            result['config']['k8_speedup_bound_incl_gather'] = result['config']['shard_model']['k8']['speedup_bound_incl_gather']
         except Exception as e:
             result['config']['shard_model'] = {'error': repr(e)[:300]}
 
@@ -427,25 +450,13 @@ def main():
                 'value': n_rays / dt, 'unit': 'rays/s', 'ms_per_step': dt * 1e3, 'n_gpus': 1,
                 'max_abs_diff_color_vs_default_mode': float((out32[2] - color_img).abs().max()),
                 'max_rel_diff_depth_vs_default_mode': float(((out32[0] - depth_img).abs() / depth_img.abs().clamp_min(1e-3)).max())}
-        # the same frame with the grids at the REFERENCE's init scale (src/DF_Prior.py:247-263: N(0, 0.01) low / colour, N(0, 1e-4)
-        # high): backs the statement that kernel time does not depend on the feature values
+        # the same frame with the grids multiplied (x 20, high x 100 more: the scene rounds 1-5 ran the headline on, where occupancy /
+        # attention weights / colour vary along a ray): backs the statement that kernel time does not depend on the feature values,
+        # and holds the timed path to the oracle where the values are not almost constant
         try:
-            scene_ref = synthetic.Scene(args.scene, H=H, W=W, device=dev, grid_std_scale=1.0)
-            for _ in range(2):
-                rend.render_img(scene_ref.c, dec, c2w, dev, scene.tsdf_volume, tsdf_bnds, 'color', gt_depth=gt_depth)
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                rend._engine._grid_cache.clear()
-                dec._packed.clear()
-                rend.render_img(scene_ref.c, dec, c2w, dev, scene.tsdf_volume, tsdf_bnds, 'color', gt_depth=gt_depth)
-            torch.cuda.synchronize(dev)
-            dt = (time.perf_counter() - t1) / args.steps
-            result['config']['value_at_reference_init'] = {'value': n_rays / dt, 'ms_per_step': dt * 1e3, 'steps': args.steps,
-                                                           'grids': 'N(0, 0.01) low / colour, N(0, 1e-4) high (src/DF_Prior.py:247-263)'}
-            del scene_ref
+            result['x20_grids'] = x20_leg(A, synthetic, rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF, args, min(4000, args.cpu_rays))
         except Exception as e:
-            result['config']['value_at_reference_init'] = {'error': repr(e)[:200]}
+            result['x20_grids'] = {'error': repr(e)[:200]}
         # sustained: the same loop for >= 2 s (the contract's 10-20 steps are ~0.1 s of GPU time)
         n_sus = max(50, int(2.2 / (ms_per_step * 1e-3)))
         el, _ = timed_loop(step, n_sus, 0)
@@ -470,11 +481,20 @@ def main():
         result.update(cpu_leg(rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, depth_img, color_img, dev, NS, NF, args.cpu_rays))
     if rank == 0:
         # the evidence a reader of the line needs, inside the objects the driver's record keeps whole (`config`, `roofline`)
+        # -- as SCALARS directly under `config`: the driver's record drops dict-valued keys
         cfgd = result['config']
         if 'value_f32' in result:
-            cfgd['value_exact_f32_mode'] = result['value_f32']
+            cfgd['exact_f32_value'] = result['value_f32']
         if 'parity_vs_oracle' in result:
-            cfgd['parity_vs_oracle'] = {k: result['parity_vs_oracle'][k] for k in ('max_rel_depth', 'max_rel_color', 'psnr_color_db', 'psnr_depth_db', 'rays')}
+            pv = result['parity_vs_oracle']
+            cfgd['parity_max_rel_depth'], cfgd['parity_max_rel_color'], cfgd['parity_rays'] = pv['max_rel_depth'], pv['max_rel_color'], pv['rays']
+            cfgd['parity_psnr_color_db'], cfgd['parity_psnr_depth_db'] = pv['psnr_color_db'], pv['psnr_depth_db']
+        xg = result.get('x20_grids')
+        if isinstance(xg, dict) and 'value' in xg:
+            cfgd['value_at_x20_grids'] = xg['value']
+            for k in ('parity_max_rel_depth', 'parity_max_rel_color'):
+                if k in xg:
+                    cfgd[k + '_at_x20'] = xg[k]
         tg = result.get('torch_gpu_baseline')
         if isinstance(tg, dict) and 'speedup' in tg:
             cfgd['speedup_vs_torch_gpu'] = tg['speedup']
@@ -482,7 +502,10 @@ def main():
             cfgd['in_band_fraction'] = result['in_band_fraction']
         rn = result.get('replica_native_frame')
         if isinstance(rn, dict) and 'rays_per_s' in rn:
-            cfgd['replica_native_frame'] = {k: rn[k] for k in ('ms_per_frame', 'rays_per_s', 'rays', 'samples_per_ray', 'far_clamp_segments')}
+            cfgd['replica_native_rays_per_s'], cfgd['replica_native_ms_per_frame'] = rn['rays_per_s'], rn['ms_per_frame']
+        c3 = result.get('config3')
+        if isinstance(c3, dict) and 'ms_per_iteration' in c3:
+            cfgd['config3_ms_per_iteration'] = c3['ms_per_iteration']
         print(json.dumps(result))
         sys.stdout.flush()
     if dist is not None:
@@ -491,44 +514,114 @@ def main():
 
 
 # ----------------------------------------------------------------------------------------------------------
-def shard_model(rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, n_rays, reps=5):
-    """What ONE GPU says about the ray-sharded frame at N = 2 / 4 / 8 (no multi-GPU node needed): the time of every 1/k shard of the
-    headline frame through Renderer.render_img_shard -- the call a rank of dist.render_img_sharded makes -- with the same caches
-    cleared as the headline step, i.e. with the per-step fixed costs every rank repeats (the three grid re-layouts, the weight-image
-    packs, the camera rays of the whole frame, the segment maxima, the launch tails of ~10 kernels).  For k ranks the step takes at
-    least max over the k shards of t(shard) (+ the all-gather of 28 B per ray, not measurable here), so
-        efficiency(N = k) <= t(full) / (k max_r t(shard r of k))."""
+def x20_leg(A, synthetic, rend, dec, sd, scene, tsdf_bnds, c2w, gt_depth, dev, NS, NF, args, n_cpu):
+    """The headline frame on the x20 grids (X20_STD_SCALE / X20_HIGH_EXTRA): rays/s over args.steps steps with the headline's cache
+    clearing, and the parity of THAT timed output against the oracle on n_cpu evenly strided rays (0 = timing only)."""
+    import torch
+    H, W = scene.H, scene.W
+    n_rays = H * W
+    sx = synthetic.Scene(args.scene, H=H, W=W, device=dev, grid_std_scale=X20_STD_SCALE)
+    sx.c['grid_high'] = sx.c['grid_high'] * X20_HIGH_EXTRA
+
+    def step():
+        rend._engine._grid_cache.clear()
+        dec._packed.clear()
+        return rend.render_img(sx.c, dec, c2w, dev, scene.tsdf_volume, tsdf_bnds, 'color', gt_depth=gt_depth)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t1) / args.steps
+    res = {'value': n_rays / dt, 'unit': 'rays/s', 'ms_per_step': dt * 1e3, 'steps': args.steps,
+           'grids': f'the reference init x {X20_STD_SCALE:g}, high grid x {X20_HIGH_EXTRA:g} more (N(0, 0.2) everywhere)'}
+    if n_cpu > 0:
+        from oracle import adfp_oracle as O
+        from attentive_dfprior_amd.common import get_rays
+        ro, rd = get_rays(H, W, scene.fx, scene.fy, scene.cx, scene.cy, c2w, dev)
+        pick = torch.arange(0, n_rays, max(1, n_rays // n_cpu), device=dev)[:n_cpu]
+        bsz = rend.ray_batch_size
+        gflat = gt_depth.reshape(-1)
+        c_cpu = {k: v.cpu() for k, v in sx.c.items()}
+        tsdf_cpu = scene.tsdf_volume.cpu()
+        od = torch.empty(len(pick), dtype=torch.float64)
+        oc = torch.empty(len(pick), 3)
+        batch_of = (pick // bsz).cpu()
+        with torch.no_grad():
+            for b in range((n_rays + bsz - 1) // bsz):
+                idx = torch.nonzero(batch_of == b).reshape(-1)
+                if idx.numel():
+                    sel = pick[idx.to(dev)]
+                    a, _, cc, _ = O.render_batch_ray(sd, c_cpu, rd.reshape(-1, 3)[sel].cpu(), ro.reshape(-1, 3)[sel].cpu(), tsdf_cpu, scene.tsdf_bnds,
+                                                     scene.bound, 'color', gflat[sel].cpu(), NS, NF, depth_max=gflat[b * bsz:(b + 1) * bsz].max().cpu())
+                    od[idx], oc[idx] = a, cc
+        d, c = out[0].reshape(-1)[pick].cpu(), out[2].reshape(-1, 3)[pick].cpu()
+        res['parity_max_rel_depth'] = float((d - od).abs().max() / od.abs().max())
+        res['parity_max_rel_color'] = float((c - oc).abs().max() / oc.abs().max())
+        res['parity_rays'] = len(pick)
+    return res
+
+
+# ----------------------------------------------------------------------------------------------------------
+XGMI_LINK_GBPS, RING_HOP_US = 153.0, 5.0       # MI355X_MICROARCH.md: one xGMI link, per direction; a hop's launch / link latency (bench_extra.allreduce_model)
+
+
+def allgather_model_ms(nbytes, k):
+    """Ring all-gather of `nbytes` in total over k GPUs: (k-1) steps, each moving nbytes / k over ONE xGMI link, + a hop latency per step
+    (the form of bench_extra.allreduce_model, without the reduce-scatter half)."""
+    return ((k - 1) / k * nbytes / (XGMI_LINK_GBPS * 1e9) + (k - 1) * RING_HOP_US * 1e-6) * 1e3
+
+
+def shard_model(rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, n_rays, headline_ms, steps=10, reps=3):
+    """What ONE GPU says about the ray-sharded frame at N = 2 / 4 / 8 (no multi-GPU node needed), measured THE WAY THE HEADLINE IS: every
+    1/k shard of the headline frame through Renderer.render_img_shard -- the call a rank of dist.render_img_sharded makes -- `steps`
+    steps back to back with the headline step's cache clearing (the grid re-layouts and weight-image packs every rank repeats) and ONE
+    synchronisation at the end; median of `reps` such runs.  A k-GPU step takes at least the slowest shard + the all-gather of 28 B
+    per ray, which is MODELLED (ring over xGMI, allgather_model_ms) because it cannot be measured here:
+        speedup_bound_incl_gather(N = k) = headline ms_per_step / (max_r t(shard r of k) + t_gather(k))
+    The numerator is the headline's own ms_per_step (what a SCALE run divides by), not a separately synchronised k = 1 call."""
     import torch
     from attentive_dfprior_amd import dist as adist
 
     def t_shard(lo, hi):
-        ts = []
-        for it in range(reps + 1):
+        def step():
             rend._engine._grid_cache.clear()
             dec._packed.clear()
+            rend.render_img_shard(scene.c, dec, c2w, dev, scene.tsdf_volume, tsdf_bnds, 'color', gt_depth, lo, hi)
+        ts = []
+        for it in range(reps):
+            step()
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
-            rend.render_img_shard(scene.c, dec, c2w, dev, scene.tsdf_volume, tsdf_bnds, 'color', gt_depth, lo, hi)
+            for _ in range(steps):
+                step()
             torch.cuda.synchronize(dev)
-            if it:
-                ts.append(time.perf_counter() - t0)
+            ts.append((time.perf_counter() - t0) / steps)
         return sorted(ts)[len(ts) // 2]
 
-    out = {'unit': 'ms', 'reps': reps, 'what': 'median wall time of Renderer.render_img_shard per shard of the headline frame, caches cleared as in the headline step'}
-    t_full = t_shard(0, n_rays)
-    out['k1'] = {'ms': t_full * 1e3}
+    nbytes = n_rays * 28
+    out = {'unit': 'ms', 'steps': steps, 'reps': reps, 'headline_ms_per_step': headline_ms,
+           'what': 'pipelined time per step of Renderer.render_img_shard for every shard of the headline frame: `steps` steps back to back, caches '
+                   'cleared as in the headline step, one synchronisation; median of `reps` runs',
+           'allgather_bytes': nbytes,
+           'allgather_model': f't = (k-1)/k x bytes / {XGMI_LINK_GBPS:g} GB/s (ring, one xGMI link per neighbour) + (k-1) x {RING_HOP_US:g} us; MODELLED, not measured'}
+    out['k1'] = {'ms': t_shard(0, n_rays) * 1e3}
     for k in (2, 4, 8):
         ts = [t_shard(*adist.shard_range(n_rays, r, k)) for r in range(k)]
-        out[f'k{k}'] = {'ms_slowest_shard': max(ts) * 1e3, 'ms_fastest_shard': min(ts) * 1e3,
-                        'efficiency_bound': t_full / (k * max(ts)), 'speedup_bound': t_full / max(ts)}
-    t_empty = t_shard(0, 0)
-    out['fixed_cost_ms'] = t_empty * 1e3
-    out['fixed_cost_what'] = 'an EMPTY shard: rays of the frame + segment maxima + nothing else (re-layouts and packs are skipped without rays)'
-    out['allgather_bytes'] = n_rays * 28
+        g = allgather_model_ms(nbytes, k)
+        out[f'k{k}'] = {'ms_slowest_shard': max(ts) * 1e3, 'ms_fastest_shard': min(ts) * 1e3, 'ms_allgather_model': g,
+                        'speedup_bound': headline_ms / (max(ts) * 1e3), 'speedup_bound_incl_gather': headline_ms / (max(ts) * 1e3 + g),
+                        'efficiency_bound_incl_gather': headline_ms / (max(ts) * 1e3 + g) / k}
+    out['fixed_cost_ms'] = t_shard(0, 0) * 1e3
+    out['fixed_cost_what'] = 'an EMPTY shard (host-side cost of a call that launches nothing)'
     out['north_star_target'] = '>= 6x at 8 GPUs'
-    out['verdict'] = ('reachable on this frame' if out['k8']['speedup_bound'] >= 6.0 else
-                      'NOT reachable on a 640x480 x 64 frame (5 ms of work): the per-rank fixed costs cap the speed-up below 6x; config 5 '
-                      '(1 M rays x 128 samples, ~35 ms per GPU at 8 GPUs) is the configuration where it is')
+    b8 = out['k8']['speedup_bound_incl_gather']
+    out['verdict'] = (f'reachable on this frame: {b8:.2f}x at 8 GPUs incl. the modelled all-gather' if b8 >= 6.0 else
+                      f'NOT reachable on a 640x480 x 64 frame (5 ms of work): {b8:.2f}x at 8 GPUs incl. the modelled all-gather -- the per-rank fixed '
+                      'costs and the gather cap the speed-up below 6x; config 5 (1 M rays x 128 samples, ~35 ms per GPU at 8 GPUs) is the '
+                      'configuration where it is')
     return out
 
 
@@ -773,18 +866,27 @@ def stage_timing(L, _lib, rend, dec, scene, tsdf_bnds, c2w, gt_depth, dev, NS, N
         sq = pmc_sq('k_decode_lc16')
         clock = sq.get('clock_ghz') or 2.0
         cyc_per_tile = t_color * clock * 1e9 * simds / tiles
-        roof['limiter'] = {
-            'what': 'VALU issue + MFMA pipe, additive (not HBM, not the MFMA peak)',
-            'per_tile_budget': {'mfma_instructions': LC16_MFMA_PER_TILE, 'mfma_pipe_cycles': LC16_MFMA_PER_TILE * 16, 'valu_instructions': LC16_VALU_PER_TILE,
-                                'lds_instructions': LC16_LDS_PER_TILE, 'source': 'tools/isa_mix.py on the compiled k_decode_lc16 (profiles/r04_isa_mix_lc16.txt)'},
-            'simd_cycles_per_tile': cyc_per_tile, 'clock_ghz_used': clock,
-            'mfma_pipe_frac': LC16_MFMA_PER_TILE * 16 / cyc_per_tile,
-            'valu_issue_frac': 1.0 - LC16_MFMA_PER_TILE * 16 / cyc_per_tile,
-            'valu_issue_cycles_per_instruction': (cyc_per_tile - LC16_MFMA_PER_TILE * 16) / LC16_VALU_PER_TILE,
-            'ceiling': 'with the 2 380 VALU instructions at the 2.2-cycle full-rate floor and the MFMAs on top the tile would take '
-                       f'{LC16_MFMA_PER_TILE * 16 + 2.2 * LC16_VALU_PER_TILE:.0f} cycles: frac_of_that_ceiling',
-            'frac_of_that_ceiling': (LC16_MFMA_PER_TILE * 16 + 2.2 * LC16_VALU_PER_TILE) / cyc_per_tile,
-            'pmc': sq}
+        mix = isa_mix_lc16()
+        if 'valu' in mix:
+            n_mfma, n_valu, n_lds = mix['mfma'], mix['valu'], mix['lds']
+            ceil_cycles = n_mfma * 16 + 2.2 * n_valu
+            roof['limiter'] = {
+                'what': 'VALU issue + MFMA pipe, additive (not HBM, not the MFMA peak)',
+                'per_tile_budget': {'mfma_instructions': n_mfma, 'mfma_pipe_cycles': n_mfma * 16, 'valu_instructions': n_valu,
+                                    'lds_instructions': n_lds, 'source': 'the TILE LOOP of the compiled k_decode_lc16 (tools/gen_isa_mix.py: tools/isa_mix.py --loop)',
+                                    'file': mix['file'], 'profiled_source_hash': mix['profiled_source_hash'], 'this_source_hash': mix['this_source_hash'],
+                                    'stale': mix['stale']},
+                'simd_cycles_per_tile': cyc_per_tile, 'clock_ghz_used': clock,
+                'mfma_pipe_frac': n_mfma * 16 / cyc_per_tile,
+                'valu_issue_frac': 1.0 - n_mfma * 16 / cyc_per_tile,
+                'valu_issue_cycles_per_instruction': (cyc_per_tile - n_mfma * 16) / n_valu,
+                'ceiling': f'with the {n_valu} VALU instructions of the tile loop at the 2.2-cycle full-rate floor and the {n_mfma} MFMAs (16 pipe cycles each) on '
+                           f'top the tile would take {ceil_cycles:.0f} cycles: frac_of_that_ceiling',
+                'frac_of_that_ceiling': ceil_cycles / cyc_per_tile,
+                'pmc': sq}
+        else:
+            roof['limiter'] = {'error': 'profiles/r06_isa_mix_lc16.txt missing or unreadable (python tools/gen_isa_mix.py)', 'pmc': sq,
+                               'valu_issue_frac': None}
         roof['valu_issue_frac'] = roof['limiter']['valu_issue_frac']
         roof['in_band_fraction'] = band_frac
     tsdf_traffic, _ = pmc_traffic('k_tsdf', pts_per_launch)
@@ -926,7 +1028,7 @@ def config5_leg(A, synthetic, _lib, L, dev, n_rays=131072, NS=96, NF=32):
                                  'as_given': {'value': n_rays / ex['t_all_blocks'], 'ms_per_batch': ex['t_all_blocks'] * 1e3,
                                               'tsdf_algorithmic_gbps': gb(ex['given_blocks']), 'tsdf_avg_launch_ms': ex['given_blocks'] * 1e3,
                                               'tsdf_frac_of_hbm_peak': gb(ex['given_blocks']) / PEAK_HBM_GBPS,
-                                              'tsdf_counter_bytes_per_sample': pmc_traffic('k_tsdf', 1, 'r05_pmc_hbm_config5_random.csv', exact=True)[0]},
+                                              'tsdf_counter_bytes_per_sample': pmc_traffic('k_tsdf', 1, 'r05_pmc_hbm_config5_random.csv')[0]},
                                  'sorted': {'value': n_rays / ex['t_auto_sorted'], 'ms_per_batch': ex['t_auto_sorted'] * 1e3,
                                             'tsdf_algorithmic_gbps': gb(ex['sorted_blocks']), 'tsdf_avg_launch_ms': ex['sorted_blocks'] * 1e3,
                                             'tsdf_frac_of_hbm_peak': gb(ex['sorted_blocks']) / PEAK_HBM_GBPS,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADFP_VERSION 130
+#define ADFP_VERSION 131
 
 /* error codes (host-detected) */
 #define ADFP_E_ARG        (-1)   /* null pointer / negative size */
@@ -289,6 +289,21 @@ typedef struct adfp_train_state {
 #define ADFP_TRAIN_ATT_ACT_FLOATS 416
 long long adfp_train_act_floats(int kind);
 
+/* A call whose rays ARE consecutive pixels of one camera frame (Renderer.render_img, src/utils/Renderer.py:278-327, and a rank's
+ * contiguous share of it): the call's FIRST launch -- the one that zeroes its device words and packs the weight images it was
+ * handed -- also writes the rays of pixels [first, first + n_rays) (src/common.py:254-272, adfp_get_rays' arithmetic) and reduces
+ * max(gt_depth) of every ray_batch_size segment of the WHOLE frame (src/utils/Renderer.py:294-313 with :159, :195).  A ray shard
+ * then costs no launch for "the rays of the frame" and none for "the maxima of rays it does not hold".
+ * `first` = adfp_render_args.depth_max_first_ray; the segment length = depth_max_segment (> 0 required; depth_max must be NULL). */
+typedef struct adfp_frame_job {
+    const float* c2w;           /* device float[16] (row-major 4x4; rows 0-2 are read): camera-to-world */
+    int H, W;
+    float fx, fy, cx, cy;
+    const float* depth;         /* device float[H*W]: the whole frame's sensor depth; the call's gt_depth = depth + first */
+    float* rays_o;              /* [n_rays,3] OUT (caller-owned; the kernels after the first launch read them) */
+    float* rays_d;              /* [n_rays,3] OUT */
+} adfp_frame_job;
+
 /* ---- a4..a13 in one call: Renderer.render_batch_ray (Renderer.py:110-255) ------------- */
 typedef struct adfp_render_args {
     int stage;
@@ -319,7 +334,7 @@ typedef struct adfp_render_args {
     /* With depth_max_segment > 0 and depth_max given: the index, in the segmented batch, of this call's FIRST ray -- the call is a
      * ray shard [first, first + n_rays) of a frame (one GPU's share, attentive_dfprior_amd.dist.render_img_sharded), ray i belongs
      * to segment (first + i) / depth_max_segment, and depth_max holds the maxima of the WHOLE frame's segments.  0 otherwise
-     * (non-zero without depth_max is ADFP_E_ARG: the call cannot know the maxima of rays it does not hold). */
+     * (non-zero without depth_max or `frame` is ADFP_E_ARG: the call cannot know the maxima of rays it does not hold). */
     int depth_max_first_ray;
     /* Optional: weight images this call's kernels read and that are not packed yet (adfp_pack_images' jobs, host array, at most
      * ADFP_PACK_MAX_JOBS) -- packed by the call's FIRST launch, beside the zero fill of its device words (two launches of ~5 us
@@ -327,6 +342,9 @@ typedef struct adfp_render_args {
      * the f16 range is reported to scene->status as by adfp_pack_images.  NULL / 0: none. */
     const adfp_pack_job* pack_jobs;
     int n_pack_jobs;
+    /* Optional (host struct, NULL = none): the call renders pixels [depth_max_first_ray, + n_rays) of this frame; rays_o / rays_d /
+     * gt_depth above are then ignored (the rays are written to frame->rays_o / rays_d, gt_depth = frame->depth + first). */
+    const adfp_frame_job* frame;
 } adfp_render_args;
 
 int adfp_render_forward(const adfp_scene* scene /*host*/, const adfp_render_args* args /*host*/, void* stream);

@@ -180,6 +180,22 @@ int main() {
       r2.depth_max = dev<float>(21); EXPECT_REACHES_LAUNCH(adfp_render_forward(&sc, &r2, st));
       r2.depth_max_first_ray = -1; EXPECT_NEG(adfp_render_forward(&sc, &r2, st));
       r2.depth_max_first_ray = 250; r2.depth_max_segment = 0; EXPECT_NEG(adfp_render_forward(&sc, &r2, st)); }
+    {   // a frame job: the call's rays are pixels [first, first + n_rays) of an H x W frame, rays and far clamps from the first launch
+        adfp_frame_job fj; memset(&fj, 0, sizeof(fj));
+        fj.c2w = dev<float>(41); fj.H = 60; fj.W = 80; fj.fx = fj.fy = 50.f; fj.cx = 39.5f; fj.cy = 29.5f;
+        fj.depth = dev<float>(42); fj.rays_o = dev<float>(43); fj.rays_d = dev<float>(44);
+        adfp_render_args r2 = ra; r2.rays_o = r2.rays_d = r2.gt_depth = nullptr; r2.frame = &fj;
+        r2.n_rays = 1200; r2.depth_max_segment = 1000; r2.depth_max_first_ray = 2400; r2.workspace_bytes = adfp_workspace_bytes(1200 * 48);
+        EXPECT_REACHES_LAUNCH(adfp_render_forward(&sc, &r2, st));
+        { adfp_render_args r3 = r2; r3.depth_max_segment = 0; EXPECT_NEG(adfp_render_forward(&sc, &r3, st)); }            // a frame is segmented
+        { adfp_render_args r3 = r2; r3.depth_max = dev<float>(21); EXPECT_NEG(adfp_render_forward(&sc, &r3, st)); }       // the maxima come from the frame
+        { adfp_render_args r3 = r2; r3.depth_max_first_ray = 4000; EXPECT_NEG(adfp_render_forward(&sc, &r3, st)); }       // 4000 + 1200 > 60 x 80
+        { adfp_render_args r3 = r2; r3.depth_max_segment = 10; EXPECT_CODE(adfp_render_forward(&sc, &r3, st), ADFP_E_UNSUPPORTED); }   // 480 segments of the FRAME
+        { adfp_render_args r3 = r2; r3.perturb = 0.5f; r3.t_rand = dev<float>(45); EXPECT_CODE(adfp_render_forward(&sc, &r3, st), ADFP_E_UNSUPPORTED); }
+        { adfp_frame_job f2 = fj; f2.rays_d = nullptr; adfp_render_args r3 = r2; r3.frame = &f2; EXPECT_NEG(adfp_render_forward(&sc, &r3, st)); }
+        { adfp_frame_job f2 = fj; f2.depth = nullptr; adfp_render_args r3 = r2; r3.frame = &f2; EXPECT_NEG(adfp_render_forward(&sc, &r3, st)); }
+        { adfp_frame_job f2 = fj; f2.W = 0; adfp_render_args r3 = r2; r3.frame = &f2; EXPECT_NEG(adfp_render_forward(&sc, &r3, st)); }
+    }
     adfp_backward_args ba; memset(&ba, 0, sizeof(ba));
     ba.stage = ADFP_STAGE_COLOR; ba.n_rays = 500; ba.S = 48; ba.rays_o = dev<float>(1); ba.rays_d = dev<float>(2); ba.z_vals = dev<double>(3); ba.raw = dev<float>(4);
     ba.state = ts; ba.g_depth = dev<double>(5); ba.g_color = dev<float>(6);

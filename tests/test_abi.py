@@ -79,6 +79,8 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(adfp_adam_group), offsetof(adfp_adam_group, mask), offsetof(adfp_adam_group, channels),
          offsetof(adfp_adam_group, derived), offsetof(adfp_scene, ht_low), offsetof(adfp_train_state, masks_low),
          offsetof(adfp_train_state, act_color));
+  printf("%zu %zu %zu %zu %zu\\n", sizeof(adfp_frame_job), offsetof(adfp_frame_job, fx), offsetof(adfp_frame_job, depth),
+         offsetof(adfp_frame_job, rays_d), offsetof(adfp_render_args, frame));
   return 0;
 }''')
     exe = tmp_path / 'layout'
@@ -103,6 +105,8 @@ int main(void) {
     G, T = _lib.AdfpAdamGroup, _lib.AdfpTrainState
     assert list(map(int, out[6].split())) == [ctypes.sizeof(G), G.mask.offset, G.channels.offset, G.derived.offset, S.ht_low.offset,
                                               T.masks_low.offset, T.act_color.offset]
+    F = _lib.AdfpFrameJob
+    assert list(map(int, out[7].split())) == [ctypes.sizeof(F), F.fx.offset, F.depth.offset, F.rays_d.offset, R.frame.offset]
 
 
 def test_reference_fusion_kernel_builds_as_a_checker():

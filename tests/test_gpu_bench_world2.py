@@ -64,8 +64,20 @@ def test_bench_one_gpu_line_carries_the_shard_model():
     m = r['config']['shard_model']
     assert 'error' not in m, m
     assert m['k1']['ms'] > 0
+    # the numerator is the HEADLINE's ms_per_step (what a SCALE run divides by), the shards are timed pipelined like it, and the
+    # all-gather is in the bound as a ring model (5.49 / (0.937 + 0.084) = 5.4x was printed as 6.24x)
+    assert m['headline_ms_per_step'] == r['ms_per_step']
+    assert m['allgather_bytes'] == 640 * 480 * 28
     for k in (2, 4, 8):
         e = m[f'k{k}']
         assert 0 < e['ms_fastest_shard'] <= e['ms_slowest_shard'] < m['k1']['ms'] * 1.05
-        assert abs(e['efficiency_bound'] - m['k1']['ms'] / (k * e['ms_slowest_shard'])) < 1e-9 and 0 < e['efficiency_bound'] <= 1.2
-    assert m['k8']['ms_slowest_shard'] >= m['fixed_cost_ms'] > 0
+        g = ((k - 1) / k * m['allgather_bytes'] / 153e9 + (k - 1) * 5e-6) * 1e3
+        assert abs(e['ms_allgather_model'] - g) < 1e-9
+        assert abs(e['speedup_bound'] - r['ms_per_step'] / e['ms_slowest_shard']) < 1e-9
+        assert abs(e['speedup_bound_incl_gather'] - r['ms_per_step'] / (e['ms_slowest_shard'] + g)) < 1e-9
+        assert 0 < e['speedup_bound_incl_gather'] < e['speedup_bound'] <= 1.3 * k
+    assert m['fixed_cost_ms'] > 0
+    # a scalar directly under `config` (the driver's record drops dict-valued keys), and a verdict derived from THAT number
+    b8 = r['config']['k8_speedup_bound_incl_gather']
+    assert b8 == m['k8']['speedup_bound_incl_gather']
+    assert m['verdict'].startswith('reachable' if b8 >= 6.0 else 'NOT reachable') and f'{b8:.2f}x' in m['verdict']

@@ -475,3 +475,36 @@ def test_render_img_shards_concatenate_to_render_img_bit_for_bit(mini, gm):
     assert empty[0].shape == (0,) and empty[2].shape == (0, 3)
     whole = adist.render_img_sharded(rend, gm.c, gm.dec, c2w, DEV, gm.tsdf, gm.tsdf_bnds, 'color', dimg)      # no process group: one rank
     assert torch.equal(whole[0], d1) and torch.equal(whole[2], c1)
+
+
+def test_frame_job_equals_explicit_rays_and_explicit_maxima_bit_for_bit(mini, gm):
+    """adfp_frame_job (round 6): the call's first launch writes the rays of its own pixels and reduces the WHOLE frame's per-segment
+    max(gt_depth) as 16 partial maxima per segment that the sampler's lanes fold.  Against the explicit form of the same call --
+    common.get_rays' rays of the pixel range, the maxima computed by torch (Renderer.segment_depth_max) and handed in as depth_max --
+    bit for bit, for pixel ranges that start and end inside segments, a ragged last segment, and a segment of invalid (zero) depth."""
+    from attentive_dfprior_amd.common import get_rays
+    dimg = mini.depth_img.to(DEV).clone()
+    dimg[: mini.H // 3] *= 0.35
+    dimg[mini.H // 3: mini.H // 3 + 12] = 0.0                     # a whole 700-ray segment without a valid depth: maximum 0
+    c2w = mini.c2w.to(DEV)
+    n = mini.H * mini.W
+    ro, rd = get_rays(mini.H, mini.W, mini.fx, mini.fy, mini.cx, mini.cy, c2w, DEV)
+    ro, rd, gd = ro.reshape(-1, 3), rd.reshape(-1, 3), dimg.reshape(-1)
+    for bs in (700, 1000, 64):
+        rend = A.Renderer(make_cfg(mini.n_samples, mini.n_surface), None, mini, ray_batch_size=bs)
+        seg_max = rend.segment_depth_max(dimg)
+        for lo, hi in ((0, n), (333, 2111), (n - 5, n), (1400, 1401)):
+            with torch.no_grad():
+                a = rend.render_img_shard(gm.c, gm.dec, c2w, DEV, gm.tsdf, gm.tsdf_bnds, 'color', dimg, lo, hi)
+                b = rend._engine.render_forward(gm.dec, gm.c, ro[lo:hi], rd[lo:hi], gd[lo:hi], gm.tsdf, gm.tsdf_bnds, mini.bound, 'color',
+                                                mini.n_samples, mini.n_surface, depth_max=seg_max, depth_max_segment=bs, depth_max_first_ray=lo)
+            for x, y, what in zip(a, b, ('depth', 'uncertainty', 'colour')):
+                assert torch.equal(x, y), (bs, lo, hi, what)
+    # the unsegmented call (render_batch_ray without depth_max): one "segment" = the whole call, the same partial maxima
+    with torch.no_grad():
+        a = rend._engine.render_forward(gm.dec, gm.c, ro[100:1777], rd[100:1777], gd[100:1777], gm.tsdf, gm.tsdf_bnds, mini.bound, 'color',
+                                        mini.n_samples, mini.n_surface)
+        b = rend._engine.render_forward(gm.dec, gm.c, ro[100:1777], rd[100:1777], gd[100:1777], gm.tsdf, gm.tsdf_bnds, mini.bound, 'color',
+                                        mini.n_samples, mini.n_surface, depth_max=gd[100:1777].max().reshape(1))
+    for x, y in zip(a[:4], b[:4]):
+        assert torch.equal(x, y)

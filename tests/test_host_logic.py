@@ -183,3 +183,22 @@ def test_design_md_is_the_template_filled_from_profiles():
     assert 'unfilled' not in r.stderr, r.stderr[-400:]
     assert r.stdout == open(os.path.join(root, 'DESIGN.md')).read(), \
         'DESIGN.md differs from the filled template: edit tools/DESIGN.template.md and regenerate (see this test\'s docstring)'
+
+
+def test_limiter_model_input_is_this_build():
+    """bench.py's `roofline.limiter` prices one tile of k_decode_lc16 with the instruction counts of its TILE LOOP, read from
+    profiles/r06_isa_mix_lc16.txt.  The file is generated from the sources (python tools/gen_isa_mix.py: hipcc -S + tools/isa_mix.py
+    --loop) and stamped with their hash: a kernel change without a regeneration fails here instead of citing a stale count
+    (the model quoted a round-4 whole-kernel count, 2 415 VALU, for a loop that has 2 175)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    mix = bench.isa_mix_lc16()
+    assert mix['file'] == 'profiles/r06_isa_mix_lc16.txt'
+    assert mix['profiled_source_hash'] == bench.source_hash() and mix['stale'] is False, \
+        'the kernel sources changed since profiles/r06_isa_mix_lc16.txt was generated: python tools/gen_isa_mix.py'
+    assert mix['mfma'] == 360 and 1500 < mix['valu'] < 2600 and mix['lds'] > 100      # one 32-point tile, both networks: 2 x 180 MFMAs
+    text = open(os.path.join(root, 'profiles', 'r06_isa_mix_lc16.txt')).read()
+    assert text.index('[tile loop only]') < text.index('12DecodeLCArgs:')               # the loop first, the whole kernel after it

@@ -59,7 +59,12 @@ def main(reps=int(os.environ.get("AB_REPS", "8"))):
             ts.append(e0.elapsed_time(e1))
         ts.sort()
         return ts[len(ts) // 2], ts[0]
-    res = {'lib': os.path.basename(_lib.LIB_PATH), 'checksum': [d.double().sum().item(), u.double().sum().item(), c.double().sum().item()]}
+    import hashlib
+    sha = hashlib.sha256()
+    for t_ in (d, u, c, w, aux['raw'], aux['z_vals']):
+        sha.update(t_.contiguous().cpu().numpy().tobytes())
+    res = {'lib': os.path.basename(_lib.LIB_PATH), 'checksum': [d.double().sum().item(), u.double().sum().item(), c.double().sum().item()],
+           'sha256_of_outputs_raw_z': sha.hexdigest()[:16]}
     res['color_ms'] = timed(lambda: L.adfp_decode_stage(C.byref(sc), C.byref(ap), 2, _lib.ptr(raw), _lib.ptr(wb), _lib.ptr(cnt[1:]), st))
     res['low_ms'] = timed(lambda: L.adfp_decode_stage(C.byref(sc), C.byref(ap), 0, _lib.ptr(raw), _lib.ptr(wb), _lib.ptr(cnt[1:]), st))
     if L.adfp_decode_stage(C.byref(sc), C.byref(ap), 3, _lib.ptr(raw), _lib.ptr(wb), _lib.ptr(cnt[1:]), st) == 0:      # the fused low + colour launch
