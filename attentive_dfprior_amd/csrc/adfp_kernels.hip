@@ -2439,11 +2439,16 @@ struct BwdWorkspace { float* g_raw; float* att_g; float* g_pts; float* stage; in
                       bool pgrad_separate;           // adfp_render_backward: the decoders write those and k_rays_grad adds them up
                       int pgrad_used;                // how many of them the call's launch wrote
                       bool head_pending; ZeroJobs head_zero; unsigned head_zero_blocks; CompositeBwdArgs head_comp;
+                      // adfp_backward_args.side_stream / side_events (host objects of the caller): the sort's own lane; join_pending =
+                      // the main stream has not waited for the sort's end yet (flush_scatter does)
+                      hipStream_t side; hipEvent_t side_ev[4]; bool side_join_pending;
+                      float* partial_side;           // the side lane's own per-workgroup gradient copies (k_outer_h there, k_decode_bwd_roles here)
                       float* gc; size_t gc_stride; int* bin_key; int* bin_val; int* bin_key_sorted; int* bin_perm; int* sort_table;
                       size_t bytes; };
 static BwdWorkspace carve_bwd(void* base, long long P) {
     BwdWorkspace w; size_t o = 0;
     w.gmax_pending = 0; w.head_pending = false; w.head_zeroes_g_pts = false; w.pgrad_separate = false; w.pgrad_used = 0;
+    w.side = nullptr; w.side_ev[0] = w.side_ev[1] = w.side_ev[2] = w.side_ev[3] = nullptr; w.side_join_pending = false;
     w.g_raw = at<float>(base, o); o += align256((size_t)P * 16);
     w.att_g = at<float>(base, o); o += align256((size_t)P * 4);
     w.g_pts = at<float>(base, o); o += align256((size_t)P * 12);
@@ -2458,6 +2463,7 @@ static BwdWorkspace carve_bwd(void* base, long long P) {
     if (AttLayout::F_TOTAL > fmax) fmax = AttLayout::F_TOTAL;
     w.part_stride = (fmax + 63) / 64 * 64;
     w.partial = at<float>(base, o); o += align256((size_t)OUTER_NSLOT * w.part_stride * 4);
+    w.partial_side = at<float>(base, o); o += align256((size_t)OUTER_NSLOT * w.part_stride * 4);
     w.gmax = at<float>(base, o); o += 256;            // largest |cotangent of raw| of the call (grad_scale)
     w.gmax_parts = at<float>(base, o); o += align256((size_t)P * 4);     // ... per ray / per workgroup, before k_max_reduce
     // spatially ordered grid-gradient scatter of the f16-split backward (k_scatter_sorted): d/d c rows, sort keys, sorted order
@@ -2609,7 +2615,8 @@ static constexpr int role_share_env(int, int dflt) { return dflt; }
 // Sorts n (key, value) pairs by the low key_bits bits of the key, stable.  The two buffer pairs are used in turn; *key_fin / *val_fin
 // = the pair the last pass wrote (a / b).  table: ADFP_RS_DIGITS * (ceil(n / ADFP_RS_TILE) + 1) ints.
 static int radix_sort_pairs(int* key_a, int* val_a, int* key_b, int* val_b, int n, int key_bits, int* table, const int** key_fin,
-                            const int** val_fin, hipStream_t st, const float* max_parts = nullptr, int max_n = 0, float* max_out = nullptr) {
+                            const int** val_fin, hipStream_t st, const float* max_parts = nullptr, int max_n = 0, float* max_out = nullptr,
+                            hipEvent_t after_first_launch = nullptr) {
     RadixArgs rs; rs.table = table; rs.n = n; rs.ntiles = (n + ADFP_RS_TILE - 1) / ADFP_RS_TILE;
     rs.max_parts = nullptr; rs.max_n = 0; rs.max_out = nullptr;
     constexpr int db = ADFP_RS_DIGIT_BITS, nd = ADFP_RS_DIGITS;
@@ -2621,6 +2628,7 @@ static int radix_sort_pairs(int* key_a, int* val_a, int* key_b, int* val_b, int 
         if (ps == 0 && max_parts) { rs.max_parts = max_parts; rs.max_n = max_n; rs.max_out = max_out; }      // one more workgroup: the fold
         hipLaunchKernelGGL(k_rs_hist<db>, dim3(rs.ntiles + (rs.max_parts ? 1 : 0)), dim3(256), 0, st, rs);
         ADFP_CHECK_LAUNCH();
+        if (ps == 0 && after_first_launch) { hipError_t e = hipEventRecord(after_first_launch, st); if (e != hipSuccess) return (int)e; }
         rs.max_parts = nullptr;
         hipLaunchKernelGGL(k_rs_scan, dim3(nd / 4), dim3(256), 0, st, rs.table, rs.ntiles, rs.totals);
         ADFP_CHECK_LAUNCH();
@@ -2856,6 +2864,15 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
                            const GradOut& go, bool pgrad, int options, BwdWorkspace& bw, hipStream_t st) {
     int rc;
     hipError_t e;
+    // whatever path leaves this function: the main stream has waited for the side lane (a capture must see it joined)
+    struct SideJoin { BwdWorkspace& bw; hipStream_t st;
+                      hipError_t join() {
+                          if (!bw.side_join_pending) return hipSuccess;
+                          bw.side_join_pending = false;
+                          hipError_t e_ = hipEventRecord(bw.side_ev[2], bw.side);            // after the lane's last launch
+                          return e_ == hipSuccess ? hipStreamWaitEvent(st, bw.side_ev[2], 0) : e_;
+                      }
+                      ~SideJoin() { (void)join(); } } side_join{bw, st};
     const bool fuse = stage != ADFP_STAGE_LOW;
     DecodeBwdArgs a;
     a.P = Pd; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
@@ -2904,9 +2921,26 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
                     ADFP_CHECK_LAUNCH();
                 }
                 bw.gmax_pending = 0;
-                // stable LSD radix sort (adfp_sort.h), ping-pong between the two buffer pairs
+                // stable LSD radix sort (adfp_sort.h), ping-pong between the two buffer pairs -- on the caller's side lane when there is
+                // one: nine short launches nobody but k_scatter_sorted waits for, beside the backward kernels instead of in front of them
                 const int* vfin = nullptr;
-                rc = radix_sort_pairs(bw.bin_key, bw.bin_val, bw.bin_key_sorted, bw.bin_perm, P, bin_key_bits(coarse->X, coarse->Y, coarse->Z), bw.sort_table, nullptr, &vfin, st,
+                hipStream_t sort_st = st;
+                if (bw.side) {
+                    // The gradient scale is folded HERE, on the main stream (one small launch): riding on the sort's first launch it would
+                    // make the first backward kernel wait for the side lane -- two cross-stream hops of ~15 us each (measured: 36 us
+                    // between k_backward_head's end and k_attention_bwd_h's start).
+                    if (fold_parts) {
+                        hipLaunchKernelGGL(k_max_reduce, dim3(1), dim3(1024), 0, st, fold_parts, fold_n, bw.gmax);
+                        ADFP_CHECK_LAUNCH();
+                        fold_parts = nullptr; fold_n = 0;
+                    }
+                    e = hipEventRecord(bw.side_ev[0], st);                       // the keys exist
+                    if (e == hipSuccess) e = hipStreamWaitEvent(bw.side, bw.side_ev[0], 0);
+                    if (e != hipSuccess) return (int)e;
+                    sort_st = bw.side;
+                    bw.side_join_pending = true;
+                }
+                rc = radix_sort_pairs(bw.bin_key, bw.bin_val, bw.bin_key_sorted, bw.bin_perm, P, bin_key_bits(coarse->X, coarse->Y, coarse->Z), bw.sort_table, nullptr, &vfin, sort_st,
                                       fold_parts, fold_n, bw.gmax);
                 if (rc) return rc;
                 const int* vin = vfin;
@@ -2940,6 +2974,12 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
             // the slots in use -- no zero fill of the 256 x 134 KB partial sums (9.5 us + a launch per iteration)
             const bool one_chunk = P <= rows_cap;
             oh.overwrite = one_chunk ? 1 : 0;
+            // The weight gradients (k_outer_h + reduction) on the side lane, beside the decoder backwards: they read the rows this
+            // kernel stages and write only the lane's own partial sums and go.flat_att -- provided no LATER kernel of the call stages
+            // rows of its own (a decoder whose weight gradients take the staged path) while they are being read.
+            const bool staged_later = go.flat_high || go.flat_low ||
+                (stage == ADFP_STAGE_COLOR && go.flat_color && (!use_h(sc->ht_color, state.masks_color, state.act_color, go.flat_color, go.grid_color) || (options & ADFP_BWD_STAGED_WGRAD)));
+            const bool outer_on_side = bw.side && go.flat_att && one_chunk && !staged_later && !pgrad;
             if (go.flat_att && !one_chunk) { rc = outer_begin(bw, AttLayout::F_TOTAL, st); if (rc) return rc; }
             for (int lo = 0; lo < P; lo += rows_cap) {
                 const int hi = lo + rows_cap < P ? lo + rows_cap : P;
@@ -2950,18 +2990,27 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
                 else hipLaunchKernelGGL(k_attention_bwd_h<false>, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
                 ADFP_CHECK_LAUNCH();
                 if (go.flat_att) {
+                    hipStream_t ost = st;
+                    if (outer_on_side) {
+                        e = hipEventRecord(bw.side_ev[3], st);                    // the rows are staged
+                        if (e == hipSuccess) e = hipStreamWaitEvent(bw.side, bw.side_ev[3], 0);
+                        if (e != hipSuccess) return (int)e;
+                        bw.side_join_pending = true;
+                        ost = bw.side;
+                    }
                     oa.stage = bw.stage; oa.count_ptr = state.counter; oa.chunk_lo = lo; oa.chunk_hi = hi; oa.flat = go.flat_att;
-                    oa.partial = bw.partial; oa.part_stride = bw.part_stride;
+                    oa.partial = outer_on_side ? bw.partial_side : bw.partial; oa.part_stride = bw.part_stride;
                     const int nblk = (hi - lo + OUTER_RT - 1) / OUTER_RT;     // list-based: the count is on the device, the kernel splits its rows evenly (even_block)
                     oa.rows_per_wave = 0;
-                    hipLaunchKernelGGL(k_outer_h, dim3(nblk < OUTER_NSLOT ? nblk : OUTER_NSLOT), dim3(512), 0, st, oh);
+                    hipLaunchKernelGGL(k_outer_h, dim3(nblk < OUTER_NSLOT ? nblk : OUTER_NSLOT), dim3(512), 0, ost, oh);
                     ADFP_CHECK_LAUNCH();
                 }
             }
             if (go.flat_att) {
                 if (one_chunk) {
                     const int nblk = (P + OUTER_RT - 1) / OUTER_RT;
-                    hipLaunchKernelGGL(k_reduce_partials_scaled, dim3((AttLayout::F_TOTAL + 31) / 32), dim3(256), 0, st, bw.partial, nblk < OUTER_NSLOT ? nblk : OUTER_NSLOT,
+                    hipLaunchKernelGGL(k_reduce_partials_scaled, dim3((AttLayout::F_TOTAL + 31) / 32), dim3(256), 0, outer_on_side ? bw.side : st,
+                                       outer_on_side ? bw.partial_side : bw.partial, nblk < OUTER_NSLOT ? nblk : OUTER_NSLOT,
                                        bw.part_stride, AttLayout::F_TOTAL, go.flat_att, bw.gmax, state.counter, P, 0);
                     ADFP_CHECK_LAUNCH();
                 } else { rc = outer_end_scaled(bw, AttLayout::F_TOTAL, go.flat_att, st); if (rc) return rc; }
@@ -3020,6 +3069,8 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         if (rc) return rc;
     }
     rc = flush_pgrad(bp, bw, st); if (rc) return rc;
+    e = side_join.join();                            // the sorted order is what k_scatter_sorted reads (and the caller's next kernel the attention gradients)
+    if (e != hipSuccess) return (int)e;
     return flush_scatter(bp, st);
 }
 
@@ -3068,6 +3119,11 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
         bw.head_pending = true;
     }
     bw.gmax_pending = r->n_rays;                     // folded into bw.gmax by the sort's first launch (or k_max_reduce)
+    if (r->side_stream) {                            // the sort's own lane (adfp_backward_args.side_stream)
+        if (!r->side_events[0] || !r->side_events[1] || !r->side_events[2] || !r->side_events[3] || r->side_stream == stream) return ADFP_E_ARG;
+        bw.side = (hipStream_t)r->side_stream;
+        for (int k = 0; k < 4; ++k) bw.side_ev[k] = (hipEvent_t)r->side_events[k];
+    }
 
     PtsDev Pd;
     Pd.mode = ADFP_PTS_RAYS; Pd.S = r->S; Pd.n = P; Pd.pts = nullptr; Pd.ro = r->rays_o; Pd.rd = r->rays_d; Pd.z = r->z_vals;

@@ -101,6 +101,10 @@ class Engine(object):
         self._grid_cache = {}    # key name -> (key, channels-last tensor)
         self._tsdf_cb = None     # (key, corner-block copy, pinned source storage) of the last TSDF volume asked for (tsdf_blocks)
         self._bound_cache = {}   # id -> (key, host list)
+        # The backward's second lane (adfp_backward_args.side_stream): the spatial sort of the sample points runs beside the backward
+        # kernels instead of in front of them.  ADFP_SIDE_LANE=0 in the host's environment keeps everything on one stream (A/B runs).
+        self.use_side_lane = os.environ.get('ADFP_SIDE_LANE', '1') not in ('0', 'off', 'false', 'no')
+        self._side = {}          # device -> (torch.cuda.Stream, [four torch.cuda.Event])
         self._owed_packs = None  # (job table, count, keep-alive) scene(hand_over_packs=True) leaves for the render call's first launch
 
     # ---- caches --------------------------------------------------------------------------
@@ -162,6 +166,25 @@ class Engine(object):
         if t is None or tuple(t.shape) != tuple(shape) or t.device != device:
             t = self._gcl[name] = torch.empty(shape, dtype=torch.float32, device=device)
         return t
+
+    def side_lane(self, device):
+        """(stream, four events) of the backward's second lane on `device`, created on first use -- never inside a stream capture
+        (the events are materialised by a first record, which a capture would swallow): a holder that captures graphs asks for the
+        lane BEFORE capturing (mapping.MapperIteration does); None when switched off or when first asked for during a capture."""
+        if not self.use_side_lane:
+            return None
+        key = torch.device(device)
+        hit = self._side.get(key)
+        if hit is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            with torch.cuda.device(key):
+                st = torch.cuda.Stream(device=key)
+                evs = [torch.cuda.Event() for _ in range(4)]
+                for ev in evs:
+                    ev.record(torch.cuda.current_stream(key))           # creates the hipEvent_t behind .cuda_event
+            hit = self._side[key] = (st, evs)
+        return hit
 
     def private_workspaces(self):
         """`with engine.private_workspaces():` -- a HIP-graph capture gets workspaces of its OWN (allocated from the graph's pool
@@ -873,6 +896,11 @@ class Engine(object):
             ws = self.bwd_workspace(N * S, dev)
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
             a.options = self.bwd_options | (_lib.BWD_GRIDS_PREZEROED if (grids_prezeroed and not grids_cl) else 0)
+            lane = self.side_lane(dev)
+            if lane is not None:
+                a.side_stream = lane[0].cuda_stream
+                for k in range(4):
+                    a.side_events[k] = lane[1][k].cuda_event
             stream = _lib.current_stream(dev)
             check(L.adfp_render_backward(C.byref(sc), C.byref(a), stream), 'adfp_render_backward')
             grids = dict(direct)

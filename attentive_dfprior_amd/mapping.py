@@ -175,6 +175,7 @@ class MapperIteration(object):
         attr = {'low': 'low_decoder', 'high': 'high_decoder', 'color': 'color_decoder', 'att': 'mlp'}
         self.flat = {n: flatten_parameters(getattr(decoders, attr[n])) for n in self.nets}
         decoders._plists = {}                                        # the cached parameter tuples are still the same objects
+        renderer._engine.side_lane(self.dev)                         # the backward's second lane exists before any graph is captured
         if getattr(decoders, '_foreign', False):                     # a pickled copy received by the (spawned) Mapper process: this
             decoders.mark_owner()                                    # iteration is the writer of its parameters, so their versions are valid here
         self.fstate = {n: (torch.zeros_like(f), torch.zeros_like(f)) for n, f in self.flat.items()}

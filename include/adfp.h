@@ -388,6 +388,19 @@ typedef struct adfp_backward_args {
     size_t workspace_bytes;
     const unsigned char* ray_keep;  /* [N] or NULL: rays flagged 0 (adfp_prefilter_mask) receive no gradient at all */
     int options;                 /* ADFP_BWD_* bits, 0 = defaults */
+    /* Optional second lane (NULL = none: everything runs on `stream`, in order).  Two pieces of the backward that nothing on the
+     * main path waits for then run on `side_stream` BESIDE the decoder backward kernels instead of in front of them: the spatial
+     * sort of the sample points (nine short, latency-bound launches that only k_scatter_sorted reads) and the attention
+     * network's weight gradients (k_outer_h + its reduction: bound by the staged rows' bytes, while the decoder kernels are
+     * bound by instruction issue).  Events: [0] recorded on `stream` when the sort keys exist (side waits), [1] on the side lane
+     * after the sort's first launch, which also folds the gradient scale (`stream` waits before the first kernel that reads
+     * it), [3] on `stream` after the attention backward has staged its rows (side waits), [2] on the side lane after its last
+     * launch (`stream` waits before the scatter -- the call's last launch).  On return `stream` has joined the lane: work
+     * queued on `stream` afterwards is ordered after everything, also inside a stream capture (forks and joins are captured as
+     * graph dependencies).  Caller-owned: a hipStream_t of the same device and four hipEvent_t (timing disabled is fine) that no
+     * other call in flight uses. */
+    void* side_stream;
+    void* side_events[4];
 } adfp_backward_args;
 /* grid gradients of the f16-split backward through the in-kernel write-combining scatter instead of the sorted scatter
  * (k_bin_keys + radix sort + k_scatter_sorted); same values up to the order of the float atomics */
