@@ -131,7 +131,7 @@ class AdfpBackwardArgs(C.Structure):
                 ('g_flat_low', C.c_void_p), ('g_flat_high', C.c_void_p), ('g_flat_color', C.c_void_p),
                 ('g_flat_att', C.c_void_p), ('g_rays_o', C.c_void_p), ('g_rays_d', C.c_void_p),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('ray_keep', C.c_void_p), ('options', C.c_int),
-                ('side_stream', C.c_void_p), ('side_events', C.c_void_p * 4)]
+                ('side_stream', C.c_void_p), ('side_events', C.c_void_p * 2)]
 
 
 class AdfpPointsBackwardArgs(C.Structure):

@@ -1100,10 +1100,19 @@ __global__ __launch_bounds__(256) void k_gather_rows(GatherJobs j, unsigned* __r
 // =====================================================================================
 // compute units of the CURRENT device (launch geometry of the persistent kernels).  Asked per call: the library keeps no global
 // mutable state, and a process may drive GPUs of different sizes.  hipDeviceGetAttribute is a table lookup (no device round trip).
+// t_cu_reserve: compute units the calling thread's CURRENT entry point leaves to its side lane (adfp_backward_args.side_stream): the
+// persistent kernels of the backward take a whole CU per workgroup (132-160 KB of LDS, the whole register file), so the sort's
+// short launches on the second stream would otherwise wait for a whole kernel to retire (measured: a 6-us histogram launch took
+// 130 us behind k_decode_bwd_roles).  Set and restored by backward_points (CuReserve); 0 everywhere else.
+static thread_local int t_cu_reserve = 0;
+#ifndef ADFP_SIDE_CU_RESERVE
+#define ADFP_SIDE_CU_RESERVE 8
+#endif
 static int num_cu() {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    return n;
+    n -= t_cu_reserve;
+    return n < 1 ? 1 : n;
 }
 
 static NormDev make_norm(const double b[3][2]) {
@@ -2429,7 +2438,7 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
 // 5 000-ray x 64-sample iteration (320 000 points) ONE chunk: four launches fewer per iteration than with 64 K rows; 545 MB.
 #define STG_ROWS_MAX 163840
 
-#define OUTER_NSLOT 256         // workgroups per weight-gradient launch = private gradient copies (one per CU)
+#define OUTER_NSLOT 256         // workgroups per weight-gradient launch = private gradient copies (one per CU); outer_slots() = the launch's cap
 struct BwdWorkspace { float* g_raw; float* att_g; float* g_pts; float* stage; int stage_rows; float* partial; int part_stride; float* gmax; float* gmax_parts;
                       int gmax_pending;              // > 0: gmax_parts[0 .. gmax_pending) still wait to be folded into gmax (backward_points)
                       // adfp_render_backward's first two launches (zero fill of the gradient outputs, k_composite_bwd), held back so that
@@ -2441,14 +2450,13 @@ struct BwdWorkspace { float* g_raw; float* att_g; float* g_pts; float* stage; in
                       bool head_pending; ZeroJobs head_zero; unsigned head_zero_blocks; CompositeBwdArgs head_comp;
                       // adfp_backward_args.side_stream / side_events (host objects of the caller): the sort's own lane; join_pending =
                       // the main stream has not waited for the sort's end yet (flush_scatter does)
-                      hipStream_t side; hipEvent_t side_ev[4]; bool side_join_pending;
-                      float* partial_side;           // the side lane's own per-workgroup gradient copies (k_outer_h there, k_decode_bwd_roles here)
+                      hipStream_t side; hipEvent_t side_ev[2]; bool side_join_pending;
                       float* gc; size_t gc_stride; int* bin_key; int* bin_val; int* bin_key_sorted; int* bin_perm; int* sort_table;
                       size_t bytes; };
 static BwdWorkspace carve_bwd(void* base, long long P) {
     BwdWorkspace w; size_t o = 0;
     w.gmax_pending = 0; w.head_pending = false; w.head_zeroes_g_pts = false; w.pgrad_separate = false; w.pgrad_used = 0;
-    w.side = nullptr; w.side_ev[0] = w.side_ev[1] = w.side_ev[2] = w.side_ev[3] = nullptr; w.side_join_pending = false;
+    w.side = nullptr; w.side_ev[0] = w.side_ev[1] = nullptr; w.side_join_pending = false;
     w.g_raw = at<float>(base, o); o += align256((size_t)P * 16);
     w.att_g = at<float>(base, o); o += align256((size_t)P * 4);
     w.g_pts = at<float>(base, o); o += align256((size_t)P * 12);
@@ -2463,7 +2471,6 @@ static BwdWorkspace carve_bwd(void* base, long long P) {
     if (AttLayout::F_TOTAL > fmax) fmax = AttLayout::F_TOTAL;
     w.part_stride = (fmax + 63) / 64 * 64;
     w.partial = at<float>(base, o); o += align256((size_t)OUTER_NSLOT * w.part_stride * 4);
-    w.partial_side = at<float>(base, o); o += align256((size_t)OUTER_NSLOT * w.part_stride * 4);
     w.gmax = at<float>(base, o); o += 256;            // largest |cotangent of raw| of the call (grad_scale)
     w.gmax_parts = at<float>(base, o); o += align256((size_t)P * 4);     // ... per ray / per workgroup, before k_max_reduce
     // spatially ordered grid-gradient scatter of the f16-split backward (k_scatter_sorted): d/d c rows, sort keys, sorted order
@@ -2869,10 +2876,11 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
                       hipError_t join() {
                           if (!bw.side_join_pending) return hipSuccess;
                           bw.side_join_pending = false;
-                          hipError_t e_ = hipEventRecord(bw.side_ev[2], bw.side);            // after the lane's last launch
-                          return e_ == hipSuccess ? hipStreamWaitEvent(st, bw.side_ev[2], 0) : e_;
+                          hipError_t e_ = hipEventRecord(bw.side_ev[1], bw.side);            // after the lane's last launch
+                          return e_ == hipSuccess ? hipStreamWaitEvent(st, bw.side_ev[1], 0) : e_;
                       }
                       ~SideJoin() { (void)join(); } } side_join{bw, st};
+    struct CuReserve { int saved; CuReserve() : saved(t_cu_reserve) {} ~CuReserve() { t_cu_reserve = saved; } } cu_reserve;     // see num_cu()
     const bool fuse = stage != ADFP_STAGE_LOW;
     DecodeBwdArgs a;
     a.P = Pd; a.nb = make_norm(sc->bound); fill_bound(a.b, sc->bound);
@@ -2939,6 +2947,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
                     if (e != hipSuccess) return (int)e;
                     sort_st = bw.side;
                     bw.side_join_pending = true;
+                    t_cu_reserve = ADFP_SIDE_CU_RESERVE;          // the whole-CU kernels below leave the lane room (restored on return)
                 }
                 rc = radix_sort_pairs(bw.bin_key, bw.bin_val, bw.bin_key_sorted, bw.bin_perm, P, bin_key_bits(coarse->X, coarse->Y, coarse->Z), bw.sort_table, nullptr, &vfin, sort_st,
                                       fold_parts, fold_n, bw.gmax);
@@ -2974,12 +2983,9 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
             // the slots in use -- no zero fill of the 256 x 134 KB partial sums (9.5 us + a launch per iteration)
             const bool one_chunk = P <= rows_cap;
             oh.overwrite = one_chunk ? 1 : 0;
-            // The weight gradients (k_outer_h + reduction) on the side lane, beside the decoder backwards: they read the rows this
-            // kernel stages and write only the lane's own partial sums and go.flat_att -- provided no LATER kernel of the call stages
-            // rows of its own (a decoder whose weight gradients take the staged path) while they are being read.
-            const bool staged_later = go.flat_high || go.flat_low ||
-                (stage == ADFP_STAGE_COLOR && go.flat_color && (!use_h(sc->ht_color, state.masks_color, state.act_color, go.flat_color, go.grid_color) || (options & ADFP_BWD_STAGED_WGRAD)));
-            const bool outer_on_side = bw.side && go.flat_att && one_chunk && !staged_later && !pgrad;
+            // one private gradient copy per workgroup; with one chunk the reduction reads the slots in use, so the launch may leave
+            // compute units to the side lane (num_cu()); several chunks accumulate into all OUTER_NSLOT zero-filled slots
+            const int att_slots = one_chunk ? (num_cu() < OUTER_NSLOT ? num_cu() : OUTER_NSLOT) : OUTER_NSLOT;
             if (go.flat_att && !one_chunk) { rc = outer_begin(bw, AttLayout::F_TOTAL, st); if (rc) return rc; }
             for (int lo = 0; lo < P; lo += rows_cap) {
                 const int hi = lo + rows_cap < P ? lo + rows_cap : P;
@@ -2990,27 +2996,18 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
                 else hipLaunchKernelGGL(k_attention_bwd_h<false>, dim3(decode_grid(ntiles, 8, 1)), dim3(512), 0, st, t);
                 ADFP_CHECK_LAUNCH();
                 if (go.flat_att) {
-                    hipStream_t ost = st;
-                    if (outer_on_side) {
-                        e = hipEventRecord(bw.side_ev[3], st);                    // the rows are staged
-                        if (e == hipSuccess) e = hipStreamWaitEvent(bw.side, bw.side_ev[3], 0);
-                        if (e != hipSuccess) return (int)e;
-                        bw.side_join_pending = true;
-                        ost = bw.side;
-                    }
                     oa.stage = bw.stage; oa.count_ptr = state.counter; oa.chunk_lo = lo; oa.chunk_hi = hi; oa.flat = go.flat_att;
-                    oa.partial = outer_on_side ? bw.partial_side : bw.partial; oa.part_stride = bw.part_stride;
+                    oa.partial = bw.partial; oa.part_stride = bw.part_stride;
                     const int nblk = (hi - lo + OUTER_RT - 1) / OUTER_RT;     // list-based: the count is on the device, the kernel splits its rows evenly (even_block)
                     oa.rows_per_wave = 0;
-                    hipLaunchKernelGGL(k_outer_h, dim3(nblk < OUTER_NSLOT ? nblk : OUTER_NSLOT), dim3(512), 0, ost, oh);
+                    hipLaunchKernelGGL(k_outer_h, dim3(nblk < att_slots ? nblk : att_slots), dim3(512), 0, st, oh);
                     ADFP_CHECK_LAUNCH();
                 }
             }
             if (go.flat_att) {
                 if (one_chunk) {
                     const int nblk = (P + OUTER_RT - 1) / OUTER_RT;
-                    hipLaunchKernelGGL(k_reduce_partials_scaled, dim3((AttLayout::F_TOTAL + 31) / 32), dim3(256), 0, outer_on_side ? bw.side : st,
-                                       outer_on_side ? bw.partial_side : bw.partial, nblk < OUTER_NSLOT ? nblk : OUTER_NSLOT,
+                    hipLaunchKernelGGL(k_reduce_partials_scaled, dim3((AttLayout::F_TOTAL + 31) / 32), dim3(256), 0, st, bw.partial, nblk < att_slots ? nblk : att_slots,
                                        bw.part_stride, AttLayout::F_TOTAL, go.flat_att, bw.gmax, state.counter, P, 0);
                     ADFP_CHECK_LAUNCH();
                 } else { rc = outer_end_scaled(bw, AttLayout::F_TOTAL, go.flat_att, st); if (rc) return rc; }
@@ -3069,7 +3066,7 @@ static int backward_points(const adfp_scene* sc, int stage, const PtsDev& Pd, in
         if (rc) return rc;
     }
     rc = flush_pgrad(bp, bw, st); if (rc) return rc;
-    e = side_join.join();                            // the sorted order is what k_scatter_sorted reads (and the caller's next kernel the attention gradients)
+    e = side_join.join();                            // the sorted order is what k_scatter_sorted reads
     if (e != hipSuccess) return (int)e;
     return flush_scatter(bp, st);
 }
@@ -3120,9 +3117,9 @@ extern "C" int adfp_render_backward(const adfp_scene* sc, const adfp_backward_ar
     }
     bw.gmax_pending = r->n_rays;                     // folded into bw.gmax by the sort's first launch (or k_max_reduce)
     if (r->side_stream) {                            // the sort's own lane (adfp_backward_args.side_stream)
-        if (!r->side_events[0] || !r->side_events[1] || !r->side_events[2] || !r->side_events[3] || r->side_stream == stream) return ADFP_E_ARG;
+        if (!r->side_events[0] || !r->side_events[1] || r->side_stream == stream) return ADFP_E_ARG;
         bw.side = (hipStream_t)r->side_stream;
-        for (int k = 0; k < 4; ++k) bw.side_ev[k] = (hipEvent_t)r->side_events[k];
+        for (int k = 0; k < 2; ++k) bw.side_ev[k] = (hipEvent_t)r->side_events[k];
     }
 
     PtsDev Pd;

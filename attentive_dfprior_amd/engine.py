@@ -104,7 +104,7 @@ class Engine(object):
         # The backward's second lane (adfp_backward_args.side_stream): the spatial sort of the sample points runs beside the backward
         # kernels instead of in front of them.  ADFP_SIDE_LANE=0 in the host's environment keeps everything on one stream (A/B runs).
         self.use_side_lane = os.environ.get('ADFP_SIDE_LANE', '1') not in ('0', 'off', 'false', 'no')
-        self._side = {}          # device -> (torch.cuda.Stream, [four torch.cuda.Event])
+        self._side = {}          # device -> (torch.cuda.Stream, [two torch.cuda.Event])
         self._owed_packs = None  # (job table, count, keep-alive) scene(hand_over_packs=True) leaves for the render call's first launch
 
     # ---- caches --------------------------------------------------------------------------
@@ -168,7 +168,7 @@ class Engine(object):
         return t
 
     def side_lane(self, device):
-        """(stream, four events) of the backward's second lane on `device`, created on first use -- never inside a stream capture
+        """(stream, two events) of the backward's second lane on `device`, created on first use -- never inside a stream capture
         (the events are materialised by a first record, which a capture would swallow): a holder that captures graphs asks for the
         lane BEFORE capturing (mapping.MapperIteration does); None when switched off or when first asked for during a capture."""
         if not self.use_side_lane:
@@ -180,7 +180,7 @@ class Engine(object):
                 return None
             with torch.cuda.device(key):
                 st = torch.cuda.Stream(device=key)
-                evs = [torch.cuda.Event() for _ in range(4)]
+                evs = [torch.cuda.Event() for _ in range(2)]
                 for ev in evs:
                     ev.record(torch.cuda.current_stream(key))           # creates the hipEvent_t behind .cuda_event
             hit = self._side[key] = (st, evs)
@@ -899,7 +899,7 @@ class Engine(object):
             lane = self.side_lane(dev)
             if lane is not None:
                 a.side_stream = lane[0].cuda_stream
-                for k in range(4):
+                for k in range(2):
                     a.side_events[k] = lane[1][k].cuda_event
             stream = _lib.current_stream(dev)
             check(L.adfp_render_backward(C.byref(sc), C.byref(a), stream), 'adfp_render_backward')

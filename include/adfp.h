@@ -388,19 +388,17 @@ typedef struct adfp_backward_args {
     size_t workspace_bytes;
     const unsigned char* ray_keep;  /* [N] or NULL: rays flagged 0 (adfp_prefilter_mask) receive no gradient at all */
     int options;                 /* ADFP_BWD_* bits, 0 = defaults */
-    /* Optional second lane (NULL = none: everything runs on `stream`, in order).  Two pieces of the backward that nothing on the
-     * main path waits for then run on `side_stream` BESIDE the decoder backward kernels instead of in front of them: the spatial
-     * sort of the sample points (nine short, latency-bound launches that only k_scatter_sorted reads) and the attention
-     * network's weight gradients (k_outer_h + its reduction: bound by the staged rows' bytes, while the decoder kernels are
-     * bound by instruction issue).  Events: [0] recorded on `stream` when the sort keys exist (side waits), [1] on the side lane
-     * after the sort's first launch, which also folds the gradient scale (`stream` waits before the first kernel that reads
-     * it), [3] on `stream` after the attention backward has staged its rows (side waits), [2] on the side lane after its last
-     * launch (`stream` waits before the scatter -- the call's last launch).  On return `stream` has joined the lane: work
-     * queued on `stream` afterwards is ordered after everything, also inside a stream capture (forks and joins are captured as
-     * graph dependencies).  Caller-owned: a hipStream_t of the same device and four hipEvent_t (timing disabled is fine) that no
-     * other call in flight uses. */
+    /* Optional second lane (NULL = none: everything runs on `stream`, in order).  The spatial sort of the sample points -- nine
+     * short, latency-bound launches whose result only k_scatter_sorted, the call's LAST launch, reads -- then runs on
+     * `side_stream` BESIDE the backward kernels instead of in front of them: the call records side_events[0] on `stream` when the
+     * sort keys exist, makes `side_stream` wait for it and sorts there; before the scatter it records side_events[1] on the lane
+     * and makes `stream` wait for it.  While the lane is busy the call's persistent kernels (a whole CU per workgroup) leave
+     * ADFP_SIDE_CU_RESERVE compute units free, or the lane's launches would each wait for a whole kernel to retire.  On return
+     * `stream` has joined the lane: work queued on `stream` afterwards is ordered after everything, also inside a stream capture
+     * (fork and join are captured as graph dependencies).  Caller-owned: a hipStream_t of the same device and two hipEvent_t
+     * (timing disabled is fine) that no other call in flight uses. */
     void* side_stream;
-    void* side_events[4];
+    void* side_events[2];
 } adfp_backward_args;
 /* grid gradients of the f16-split backward through the in-kernel write-combining scatter instead of the sorted scatter
  * (k_bin_keys + radix sort + k_scatter_sorted); same values up to the order of the float atomics */

@@ -209,6 +209,10 @@ int main() {
       b2 = ba; b2.S = 1 << 20; b2.workspace_bytes = (size_t)1 << 44; EXPECT_CODE(adfp_render_backward(&sc, &b2, st), ADFP_E_UNSUPPORTED);
       b2 = ba; memset(&b2.state, 0, sizeof(b2.state)); EXPECT_NEG(adfp_render_backward(&sc, &b2, st));
       b2 = ba; b2.g_rays_o = dev<float>(15); b2.g_rays_d = dev<float>(16); EXPECT_REACHES_LAUNCH(adfp_render_backward(&sc, &b2, st));
+      // the side lane: a second stream needs its two events, and must not be the call's own stream
+      b2 = ba; b2.side_stream = dev<void>(51); EXPECT_NEG(adfp_render_backward(&sc, &b2, st));
+      b2 = ba; b2.side_stream = dev<void>(51); b2.side_events[0] = dev<void>(52); EXPECT_NEG(adfp_render_backward(&sc, &b2, st));
+      b2 = ba; b2.side_stream = st; b2.side_events[0] = dev<void>(52); b2.side_events[1] = dev<void>(53); EXPECT_NEG(adfp_render_backward(&sc, &b2, st));
       b2 = ba; b2.options = ADFP_BWD_SCATTER_IN_KERNEL | ADFP_BWD_GRIDS_PREZEROED | ADFP_BWD_STAGED_WGRAD; EXPECT_REACHES_LAUNCH(adfp_render_backward(&sc, &b2, st));
       adfp_scene s2 = sc; s2.w_att = nullptr; EXPECT_NEG(adfp_render_backward(&s2, &ba, st)); }
     EXPECT_REACHES_LAUNCH(adfp_render_backward(&sc, &ba, st));

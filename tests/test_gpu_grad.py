@@ -40,7 +40,7 @@ def grad_close(got, ref, what, tol=GTOL, mode=None):
         assert_close_scale(got.detach(), ref, tol, what, flip_frac=2e-3 if last.startswith('grid') else 0.0)
 
 
-def run(mini, stage, warm, sd=None, n_samples=None, n_surface=None, rays=None, bwd_options=None, capture=None):
+def run(mini, stage, warm, sd=None, n_samples=None, n_surface=None, rays=None, bwd_options=None, capture=None, side_lane=None):
     """capture: a dict; the backward then exports its ReLU decisions and capture['relu_masks'] = Engine.relu_masks(...)."""
     sd = mini.sd if sd is None else sd
     dec = A.DF()
@@ -53,6 +53,8 @@ def run(mini, stage, warm, sd=None, n_samples=None, n_surface=None, rays=None, b
                       None, mini)
     if bwd_options is not None:
         rend._engine.bwd_options = bwd_options
+    if side_lane is not None:
+        rend._engine.use_side_lane = side_lane
     if capture is not None:
         cap = ReluCapture(rend)
     c = {k: v.to(DEV).clone().requires_grad_(True) for k, v in mini.c.items()}
@@ -452,6 +454,25 @@ def test_sorted_scatter_equals_cached_scatter(mini):
         got[name] = {k: v.grad.cpu() for k, v in c.items()}
     for k in got['sorted']:
         assert_close_scale(got['sorted'][k], got['cache'][k], 2e-6, f'{k}: sorted vs cached scatter')
+
+
+@pytest.mark.parametrize('n_rays', [3, 700])
+def test_side_lane_changes_nothing_but_the_schedule(mini, n_rays):
+    """adfp_backward_args.side_stream (round 6): the spatial sort on a second stream beside the backward kernels, the call's
+    persistent kernels on ADFP_SIDE_CU_RESERVE fewer compute units.  Against the one-stream backward: the same gradients up to the
+    summation order (fewer workgroups = fewer partial sums; float atomics in the scatter), every stage, and the calls are
+    ordered -- a gradient read right after backward() on the caller's stream is complete."""
+    rays = synthetic.make_ray_batch(synthetic.mini_scene(), n_rays, seed=8, poses=3)
+    for stage in ('low', 'high', 'color'):
+        got = {}
+        for name, lane in (('side', True), ('one_stream', False)):
+            loss, c, dec = run(mini, stage, stage != 'color', sd=O.random_state_dict(seed=17), n_samples=48, n_surface=16, rays=rays, side_lane=lane)
+            got[name] = {k: v.grad.clone() for k, v in c.items() if v.grad is not None}              # read on the caller's stream, no synchronize
+            got[name].update({n: p.grad.detach().clone() for n, p in dec.named_parameters() if p.grad is not None})
+        assert set(got['side']) == set(got['one_stream']) and len(got['side']) >= 1
+        for k in got['side']:
+            assert torch.isfinite(got['side'][k]).all(), k
+            assert_close_scale(got['side'][k], got['one_stream'][k], 3e-6, f'{stage}, {n_rays} rays: {k}: side lane vs one stream')
 
 
 @pytest.mark.parametrize('stage', ['low', 'color'])
