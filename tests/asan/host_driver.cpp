@@ -212,7 +212,7 @@ int main() {
       // the side lane: a second stream needs its two events, and must not be the call's own stream
       b2 = ba; b2.side_stream = dev<void>(51); EXPECT_NEG(adfp_render_backward(&sc, &b2, st));
       b2 = ba; b2.side_stream = dev<void>(51); b2.side_events[0] = dev<void>(52); EXPECT_NEG(adfp_render_backward(&sc, &b2, st));
-      b2 = ba; b2.side_stream = st; b2.side_events[0] = dev<void>(52); b2.side_events[1] = dev<void>(53); EXPECT_NEG(adfp_render_backward(&sc, &b2, st));
+      b2 = ba; b2.side_stream = dev<void>(54); b2.side_events[0] = dev<void>(52); b2.side_events[1] = dev<void>(53); EXPECT_NEG(adfp_render_backward(&sc, &b2, dev<void>(54)));
       b2 = ba; b2.options = ADFP_BWD_SCATTER_IN_KERNEL | ADFP_BWD_GRIDS_PREZEROED | ADFP_BWD_STAGED_WGRAD; EXPECT_REACHES_LAUNCH(adfp_render_backward(&sc, &b2, st));
       adfp_scene s2 = sc; s2.w_att = nullptr; EXPECT_NEG(adfp_render_backward(&s2, &ba, st)); }
     EXPECT_REACHES_LAUNCH(adfp_render_backward(&sc, &ba, st));
