@@ -40,6 +40,13 @@ class AdfpPackJob(C.Structure):
     _fields_ = [('net', C.c_int), ('format', C.c_int), ('flat', C.c_void_p), ('packed', C.c_void_p)]
 
 
+class AdfpRelayoutJob(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('voxels', C.c_longlong)]
+
+
+RELAYOUT_MAX_JOBS = 4
+
+
 class AdfpTrackerHeadArgs(C.Structure):
     _fields_ = [('cam', C.c_void_p), ('c2w', C.c_void_p), ('idx', C.c_void_p), ('n', C.c_int),
                 ('H0', C.c_int), ('H1', C.c_int), ('W0', C.c_int), ('W1', C.c_int), ('H', C.c_int), ('W', C.c_int),
@@ -119,7 +126,8 @@ class AdfpRenderArgs(C.Structure):
                 ('weight', C.c_void_p), ('z_vals', C.c_void_p), ('raw', C.c_void_p),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('state', C.POINTER(AdfpTrainState)),
                 ('depth_max_segment', C.c_int), ('depth_max_first_ray', C.c_int),
-                ('pack_jobs', C.c_void_p), ('n_pack_jobs', C.c_int), ('frame', C.POINTER(AdfpFrameJob))]
+                ('pack_jobs', C.c_void_p), ('n_pack_jobs', C.c_int), ('frame', C.POINTER(AdfpFrameJob)),
+                ('relayout_jobs', C.c_void_p), ('n_relayout_jobs', C.c_int)]
 
 
 class AdfpBackwardArgs(C.Structure):
@@ -166,6 +174,7 @@ SYMBOLS = [
     ('adfp_workspace_bytes', C.c_size_t, [C.c_longlong]),
     ('adfp_relayout_grid', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ('adfp_relayout_grid_back', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ('adfp_relayout_grids', C.c_int, [C.c_int, C.POINTER(AdfpRelayoutJob), C.c_int, C.c_void_p]),
     ('adfp_relayout_tsdf', C.c_int, [C.POINTER(AdfpTsdf), C.c_void_p, C.c_void_p]),
     ('adfp_pack_decoder', C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ('adfp_pack_attention', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -108,6 +108,37 @@ __global__ __launch_bounds__(256) void k_relayout_cm_to_cl(const float* __restri
         if (v < V) dst[v * 32 + cx] = tile[cx][j];
     }
 }
+// the same two conversions as block functions of a multi-job launch (k_relayout_multi, k_forward_head): `tile` = 32 x 65 floats of LDS
+struct RelayoutJobs { int n; unsigned first[ADFP_RELAYOUT_MAX_JOBS + 1]; const float* src[ADFP_RELAYOUT_MAX_JOBS]; float* dst[ADFP_RELAYOUT_MAX_JOBS];
+                      long long V[ADFP_RELAYOUT_MAX_JOBS]; };
+template <bool BACK>
+__device__ inline void relayout_multi_block(const RelayoutJobs& j, unsigned blk, float (*tile)[65]) {
+    int k = 0;
+    while (k + 1 < j.n && blk >= j.first[k + 1]) ++k;                     // block-uniform
+    const float* __restrict__ src = j.src[k];
+    float* __restrict__ dst = j.dst[k];
+    const long long V = j.V[k], v0 = (long long)(blk - j.first[k]) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+    const int cx = threadIdx.x & 31, vy = threadIdx.x >> 5;   // 32 x 8
+    if (!BACK) {
+#pragma unroll
+        for (int c = ty; c < 32; c += 4) { const long long v = v0 + tx; tile[c][tx] = v < V ? src[(long long)c * V + v] : 0.f; }
+        __syncthreads();
+#pragma unroll
+        for (int jv = vy; jv < 64; jv += 8) { const long long v = v0 + jv; if (v < V) dst[v * 32 + cx] = tile[cx][jv]; }
+    } else {
+#pragma unroll
+        for (int jv = vy; jv < 64; jv += 8) { const long long v = v0 + jv; tile[cx][jv] = v < V ? src[v * 32 + cx] : 0.f; }
+        __syncthreads();
+#pragma unroll
+        for (int c = ty; c < 32; c += 4) { const long long v = v0 + tx; if (v < V) dst[(long long)c * V + v] = tile[c][tx]; }
+    }
+}
+template <bool BACK>
+__global__ __launch_bounds__(256) void k_relayout_multi(RelayoutJobs j) {
+    __shared__ float tile[32][65];
+    relayout_multi_block<BACK>(j, blockIdx.x, tile);
+}
 __global__ __launch_bounds__(256) void k_relayout_cl_to_cm(const float* __restrict__ src, float* __restrict__ dst, long long V) {
     __shared__ float tile[32][65];
     const long long v0 = (long long)blockIdx.x * 64;
@@ -1106,7 +1137,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(GatherJobs j, unsigned* __r
 // 130 us behind k_decode_bwd_roles).  Set and restored by backward_points (CuReserve); 0 everywhere else.
 static thread_local int t_cu_reserve = 0;
 #ifndef ADFP_SIDE_CU_RESERVE
-#define ADFP_SIDE_CU_RESERVE 8
+#define ADFP_SIDE_CU_RESERVE 4
 #endif
 static int num_cu() {
     int dev = 0, n = 0;
@@ -1210,9 +1241,10 @@ __global__ __launch_bounds__(256) void k_pack_multi(PackJobs j) { pack_multi_blo
 //   rays:   the rays of pixels [first, first + n) of an H x W frame (k_get_rays' arithmetic, src/common.py:254-272)
 //   segmax: SEGMAX_PARTS partial maxima of gt_depth per segment of `seg` rays, as ordered uints, plain stores (no atomics: nothing
 //           has to be zeroed before this launch); k_sample's lanes fold them.  Block (s, p) takes the p-th sixteenth of segment s.
+//   relayout: the feature grids the caller handed over to convert to channels-last (adfp_render_args.relayout_jobs)
 struct RayJob { const float* c2w; int W; float fx, fy, cx, cy; int first, n; float* ro; float* rd; };
 struct SegJob { const float* d; int n, seg, nseg; unsigned* parts; };
-struct ForwardHeadArgs { PackJobs p; ZeroJobs z; int nb_pack, nb_zero, nb_rays; RayJob rj; SegJob sj; };
+struct ForwardHeadArgs { PackJobs p; ZeroJobs z; int nb_pack, nb_zero, nb_rays, nb_seg; RayJob rj; SegJob sj; RelayoutJobs rl; };
 __device__ inline void rays_block(const RayJob& j, unsigned blk) {
     const int k = (int)blk * 256 + threadIdx.x;
     if (k >= j.n) return;
@@ -1257,7 +1289,10 @@ __global__ __launch_bounds__(256) void k_forward_head(ForwardHeadArgs h) {
     if ((int)b < h.nb_zero) { zero_multi_block(h.z, b); return; }
     b -= (unsigned)h.nb_zero;
     if ((int)b < h.nb_rays) { rays_block(h.rj, b); return; }
-    segmax_block(h.sj, b - (unsigned)h.nb_rays);
+    b -= (unsigned)h.nb_rays;
+    if ((int)b < h.nb_seg) { segmax_block(h.sj, b); return; }
+    __shared__ float tile[32][65];                 // (the grid conversions: the last blocks of the launch)
+    relayout_multi_block<false>(h.rl, b - (unsigned)h.nb_seg, tile);
 }
 static int pack_jobs_table(int n_jobs, const adfp_pack_job* jobs, int* status, PackJobs& j) {
     if (n_jobs < 0 || n_jobs > ADFP_PACK_MAX_JOBS || (n_jobs && !jobs)) return ADFP_E_ARG;
@@ -1303,6 +1338,27 @@ int adfp_relayout_grid(const float* src, float* dst, int C, int Z, int Y, int X,
     if (C != 32) return ADFP_E_UNSUPPORTED;
     const long long V = (long long)Z * Y * X;
     hipLaunchKernelGGL(k_relayout_cm_to_cl, dim3((unsigned)((V + 63) / 64)), dim3(256), 0, (hipStream_t)stream, src, dst, V);
+    ADFP_CHECK_LAUNCH();
+    return 0;
+}
+static int relayout_jobs_table(int n_jobs, const adfp_relayout_job* jobs, RelayoutJobs& j) {
+    if (n_jobs < 0 || n_jobs > ADFP_RELAYOUT_MAX_JOBS || (n_jobs && !jobs)) return ADFP_E_ARG;
+    j.n = n_jobs; j.first[0] = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        if (!jobs[k].src || !jobs[k].dst || jobs[k].voxels <= 0) return ADFP_E_ARG;
+        const long long nb = (jobs[k].voxels + 63) / 64;
+        if (nb + j.first[k] > 0x7fffffffll) return ADFP_E_UNSUPPORTED;
+        j.src[k] = jobs[k].src; j.dst[k] = jobs[k].dst; j.V[k] = jobs[k].voxels;
+        j.first[k + 1] = j.first[k] + (unsigned)nb;
+    }
+    return 0;
+}
+int adfp_relayout_grids(int n_jobs, const adfp_relayout_job* jobs, int back, void* stream) {
+    RelayoutJobs j;
+    int rc = relayout_jobs_table(n_jobs, jobs, j); if (rc) return rc;
+    if (n_jobs == 0) return 0;
+    if (back) hipLaunchKernelGGL(k_relayout_multi<true>, dim3(j.first[j.n]), dim3(256), 0, (hipStream_t)stream, j);
+    else hipLaunchKernelGGL(k_relayout_multi<false>, dim3(j.first[j.n]), dim3(256), 0, (hipStream_t)stream, j);
     ADFP_CHECK_LAUNCH();
     return 0;
 }
@@ -2357,6 +2413,7 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
     if (r->n_rays < 0 || r->n_samples <= 0 || r->n_surface < 0 || r->depth_max_segment < 0) return ADFP_E_ARG;
     if (r->depth_max_first_ray < 0 || (r->depth_max_first_ray > 0 && !fr && (!r->depth_max || r->depth_max_segment <= 0 || !gt_depth))) return ADFP_E_ARG;
     if (r->n_pack_jobs < 0 || r->n_pack_jobs > ADFP_PACK_MAX_JOBS || (r->n_pack_jobs && !r->pack_jobs)) return ADFP_E_ARG;
+    if (r->n_relayout_jobs < 0 || r->n_relayout_jobs > ADFP_RELAYOUT_MAX_JOBS || (r->n_relayout_jobs && !r->relayout_jobs)) return ADFP_E_ARG;
     if (r->state && r->stage != ADFP_STAGE_LOW &&
         (!r->state->flags || !r->state->list || !r->state->counter || !r->state->att_occ || !r->state->att_u)) return ADFP_E_ARG;
     const int S = r->n_samples + (gt_depth ? r->n_surface : 0);
@@ -2369,7 +2426,10 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
         return ADFP_E_UNSUPPORTED;
     Workspace ws = carve(r->workspace, Pn);
     if (r->workspace_bytes < ws.bytes) return ADFP_E_WORKSPACE;
-    if (r->n_rays == 0) return r->n_pack_jobs ? adfp_pack_images(r->n_pack_jobs, r->pack_jobs, scene->status, stream) : 0;   // the images are still owed
+    if (r->n_rays == 0) {                                // the images and the grid conversions are still owed
+        rc = r->n_pack_jobs ? adfp_pack_images(r->n_pack_jobs, r->pack_jobs, scene->status, stream) : 0;
+        return rc ? rc : adfp_relayout_grids(r->n_relayout_jobs, r->relayout_jobs, 0, stream);
+    }
     hipStream_t st = (hipStream_t)stream;
     double* z = r->z_vals ? r->z_vals : ws.z;
     float* raw = r->raw ? r->raw : ws.raw;
@@ -2414,7 +2474,13 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
         nb_seg = (unsigned)h.sj.nseg * SEGMAX_PARTS;
         seg_parts = ws.segparts;
     }
-    hipLaunchKernelGGL(k_forward_head, dim3((unsigned)(h.nb_pack + h.nb_zero + h.nb_rays) + nb_seg), dim3(256), 0, st, h);
+    h.nb_seg = (int)nb_seg;
+    unsigned nb_rl = 0;
+    if (r->n_relayout_jobs > 0) {
+        rc = relayout_jobs_table(r->n_relayout_jobs, r->relayout_jobs, h.rl); if (rc) return rc;
+        nb_rl = h.rl.first[h.rl.n];
+    }
+    hipLaunchKernelGGL(k_forward_head, dim3((unsigned)(h.nb_pack + h.nb_zero + h.nb_rays) + nb_seg + nb_rl), dim3(256), 0, st, h);
     ADFP_CHECK_LAUNCH();
     rc = sample_rays_impl(rays_o, rays_d, gt_depth, r->n_rays, scene->bound, r->n_samples, r->n_surface, r->lindisp,
                           r->perturb, r->t_rand, r->depth_max, z, (char*)ws.counter + 64, stream, true, segment, r->depth_max_first_ray, seg_parts);

@@ -106,6 +106,7 @@ class Engine(object):
         self.use_side_lane = os.environ.get('ADFP_SIDE_LANE', '1') not in ('0', 'off', 'false', 'no')
         self._side = {}          # device -> (torch.cuda.Stream, [two torch.cuda.Event])
         self._owed_packs = None  # (job table, count, keep-alive) scene(hand_over_packs=True) leaves for the render call's first launch
+        self._owed_relayouts = None   # the same for grid conversions (adfp_render_args.relayout_jobs)
 
     # ---- caches --------------------------------------------------------------------------
     def _alloc_scratch(self, nbytes, device):
@@ -206,8 +207,10 @@ class Engine(object):
         key = (g.data_ptr(), g._version, g.shape, g.stride())
         self._grid_cache[name] = (key, shadow, g.untyped_storage(), 'adopted')      # never recycled as a re-layout destination
 
-    def grid_cl(self, name, g):
-        """channels-last copy of a [1,32,Z,Y,X] grid, converted by adfp_relayout_grid."""
+    def grid_cl(self, name, g, defer=None):
+        """channels-last copy of a [1,32,Z,Y,X] grid, converted by adfp_relayout_grid -- or, with `defer` (a list), recorded there as
+        a job (src, dst, voxels, keep-alive) for ONE launch of the caller's (flush_relayout_jobs / adfp_render_args.relayout_jobs); the
+        cache calls the copy current at once, so a caller that fails to run the jobs must drop the entry (scene() does)."""
         _lib.require_cuda(g, name)
         if g.dim() != 5 or g.shape[0] != 1 or g.shape[1] != 32:
             raise RuntimeError(f'{name}: expected [1,32,Z,Y,X], got {tuple(g.shape)}')
@@ -224,8 +227,11 @@ class Engine(object):
             dst = hit[1]
         else:
             dst = torch.empty((Z, Y, X, 32), dtype=torch.float32, device=src.device)
-        check(lib().adfp_relayout_grid(ptr(src), ptr(dst), 32, Z, Y, X, _lib.current_stream(src.device)),
-              'adfp_relayout_grid')
+        if defer is not None and len(defer) < _lib.RELAYOUT_MAX_JOBS:
+            defer.append((src, dst, Z * Y * X))
+        else:
+            check(lib().adfp_relayout_grid(ptr(src), ptr(dst), 32, Z, Y, X, _lib.current_stream(src.device)),
+                  'adfp_relayout_grid')
         # the cache entry keeps the source's storage alive: (data_ptr, _version) identifies the contents only as
         # long as the allocator cannot hand the same address to another tensor
         self._grid_cache[name] = (key, dst, g.untyped_storage())
@@ -278,6 +284,21 @@ class Engine(object):
             self.fill_tsdf(td, tsdf_volume, [])
             check(lib().adfp_relayout_tsdf(C.byref(td), ptr(cb), _lib.current_stream(tsdf_volume.device)), 'adfp_relayout_tsdf')
 
+    @staticmethod
+    def relayout_jobs_array(rjobs):
+        """(ctypes array, count, keep-alive) of deferred grid conversions (grid_cl(defer=...))."""
+        arr = (_lib.AdfpRelayoutJob * len(rjobs))()
+        for k, (src, dst, vox) in enumerate(rjobs):
+            arr[k].src, arr[k].dst, arr[k].voxels = src.data_ptr(), dst.data_ptr(), vox
+        return arr, len(rjobs), [t for j in rjobs for t in j[:2]]
+
+    def flush_relayout_jobs(self, rjobs, device):
+        if not rjobs:
+            return
+        arr, n, _ = self.relayout_jobs_array(rjobs)
+        with _lib.device_guard(device):
+            check(lib().adfp_relayout_grids(n, arr, 0, _lib.current_stream(device)), 'adfp_relayout_grids')
+
     # ---- descriptor ----------------------------------------------------------------------
     def scene(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, backward=False, ht_nets=(), keys=None, images=None, state=None,
               tsdf_blocks=False, hand_over_packs=False):
@@ -296,8 +317,9 @@ class Engine(object):
         sc.status = decoders.status_word().data_ptr()
         keep = []
         _lib.fill_bound(sc.bound, self.host_bound(bound, 'bound'))
+        rjobs = []                               # grids to convert: ONE launch (the render call's first, or flush_relayout_jobs below)
         for field, key in _STAGE_GRIDS[stage]:
-            g = self.grid_cl(key, c[key])
+            g = self.grid_cl(key, c[key], defer=rjobs)
             keep.append(g)
             gd = getattr(sc, field)
             gd.data = g.data_ptr()
@@ -331,6 +353,13 @@ class Engine(object):
                     setattr(sc, 'w_' + n, decoders.packed_weights(n, 'f32', k).data_ptr())
             # hand_over_packs: the caller's render call packs them in its first launch (adfp_render_args.pack_jobs); at most
             # ADFP_PACK_MAX_JOBS fit one table
+            self._owed_relayouts = None
+            if rjobs:
+                if hand_over_packs:
+                    self._owed_relayouts = self.relayout_jobs_array(rjobs)
+                else:
+                    self.flush_relayout_jobs(rjobs, next(iter(c.values())).device)
+                rjobs = []
             self._owed_packs = None
             if hand_over_packs and 0 < len(jobs) <= 8:
                 from .decoder import pack_jobs_array
@@ -357,7 +386,9 @@ class Engine(object):
             # nobody wrote: forget all of them, the next call re-packs
             if jobs or self._owed_packs is not None:
                 decoders._packed = {}
-            self._owed_packs = None
+            if rjobs or self._owed_relayouts is not None:      # the same for channels-last copies nobody wrote
+                self._grid_cache = {k: v for k, v in self._grid_cache.items() if len(v) == 4}
+            self._owed_packs = self._owed_relayouts = None
             raise
         finally:
             decoders._pack_jobs = None
@@ -601,11 +632,14 @@ class Engine(object):
             stream = _lib.current_stream(dev)
             check(L.adfp_eval_points_backward(C.byref(sc), C.byref(ap), C.byref(a), stream), 'adfp_eval_points_backward')
             grids = {}
-            for name, g in grids_cl.items():
-                Z, Y, X = g.shape[:3]
-                out = torch.empty((1, 32, Z, Y, X), dtype=torch.float32, device=dev)
-                check(L.adfp_relayout_grid_back(ptr(g), ptr(out), 32, Z, Y, X, stream), 'adfp_relayout_grid_back')
-                grids[name] = out
+            if grids_cl:
+                arr = (_lib.AdfpRelayoutJob * len(grids_cl))()
+                for k, (name, g) in enumerate(grids_cl.items()):
+                    Z, Y, X = g.shape[:3]
+                    out = torch.empty((1, 32, Z, Y, X), dtype=torch.float32, device=dev)
+                    arr[k].src, arr[k].dst, arr[k].voxels = g.data_ptr(), out.data_ptr(), Z * Y * X
+                    grids[name] = out
+                check(L.adfp_relayout_grids(len(grids_cl), arr, 1, stream), 'adfp_relayout_grids')
         return grids, flats, g_pts
 
     def sample_tsdf(self, pts, tsdf_volume, tsdf_bnds):
@@ -759,11 +793,14 @@ class Engine(object):
             sc, keep = self.scene(decoders, c, tsdf_volume, tsdf_bnds, bound, stage, keys=keys, state=aux, tsdf_blocks=tsdf_blocks,
                                   hand_over_packs=True)
             owed, self._owed_packs = self._owed_packs, None
+            owed_rl, self._owed_relayouts = self._owed_relayouts, None
             launched = False
             try:
                 a = _lib.AdfpRenderArgs()
                 if owed is not None:                     # this call's first launch packs them beside its zero fill
                     a.pack_jobs, a.n_pack_jobs = C.cast(owed[0], C.c_void_p), owed[1]
+                if owed_rl is not None:                  # ... and converts the grids
+                    a.relayout_jobs, a.n_relayout_jobs = C.cast(owed_rl[0], C.c_void_p), owed_rl[1]
                 a.stage = _lib.STAGE[stage]
                 a.n_rays = N
                 a.n_samples = n_samples
@@ -811,6 +848,8 @@ class Engine(object):
             finally:
                 if owed is not None and not launched:      # the images the cache already calls current were never packed
                     decoders._packed = {}
+                if owed_rl is not None and not launched:   # nor the channels-last copies written
+                    self._grid_cache = {k: v for k, v in self._grid_cache.items() if len(v) == 4}
         return depth, unc, color, weight, aux
 
     # ---- a15 -------------------------------------------------------------------------------
@@ -904,13 +943,16 @@ class Engine(object):
             stream = _lib.current_stream(dev)
             check(L.adfp_render_backward(C.byref(sc), C.byref(a), stream), 'adfp_render_backward')
             grids = dict(direct)
-            for name, g in grids_cl.items():
-                Z, Y, X = g.shape[:3]
-                if out_grids and name in out_grids:
-                    out = out_grids[name]
-                else:
-                    o = boff['g' + name]
-                    out = bucket[o:o + 32 * Z * Y * X].view(1, 32, Z, Y, X)
-                check(L.adfp_relayout_grid_back(ptr(g), ptr(out), 32, Z, Y, X, stream), 'adfp_relayout_grid_back')
-                grids[name] = out
+            if grids_cl:                                  # the kernels' channels-last gradients -> the reference's layout: ONE launch
+                arr = (_lib.AdfpRelayoutJob * len(grids_cl))()
+                for k, (name, g) in enumerate(grids_cl.items()):
+                    Z, Y, X = g.shape[:3]
+                    if out_grids and name in out_grids:
+                        out = out_grids[name]
+                    else:
+                        o = boff['g' + name]
+                        out = bucket[o:o + 32 * Z * Y * X].view(1, 32, Z, Y, X)
+                    arr[k].src, arr[k].dst, arr[k].voxels = g.data_ptr(), out.data_ptr(), Z * Y * X
+                    grids[name] = out
+                check(L.adfp_relayout_grids(len(grids_cl), arr, 1, stream), 'adfp_relayout_grids')
         return grids, flats, (g_ro, g_rd)

@@ -53,6 +53,17 @@ int main() {
     EXPECT_NEG(adfp_relayout_grid_back(dev<float>(1), nullptr, 32, 4, 4, 4, st));
     EXPECT_REACHES_LAUNCH(adfp_relayout_grid(dev<float>(1), dev<float>(2), 32, 5, 6, 7, st));
     EXPECT_REACHES_LAUNCH(adfp_relayout_grid_back(dev<float>(1), dev<float>(2), 32, 5, 6, 7, st));
+    {   // several grids in one launch
+        adfp_relayout_job rj[3] = {{dev<float>(1), dev<float>(2), 210}, {dev<float>(3), dev<float>(4), 1}, {dev<float>(5), dev<float>(6), 4096}};
+        EXPECT_CODE(adfp_relayout_grids(0, nullptr, 0, st), 0);
+        EXPECT_NEG(adfp_relayout_grids(-1, rj, 0, st));
+        EXPECT_NEG(adfp_relayout_grids(ADFP_RELAYOUT_MAX_JOBS + 1, rj, 0, st));
+        EXPECT_NEG(adfp_relayout_grids(2, nullptr, 0, st));
+        { adfp_relayout_job bad[2] = {rj[0], rj[1]}; bad[1].voxels = 0; EXPECT_NEG(adfp_relayout_grids(2, bad, 0, st)); }
+        { adfp_relayout_job bad[2] = {rj[0], rj[1]}; bad[0].dst = nullptr; EXPECT_NEG(adfp_relayout_grids(2, bad, 1, st)); }
+        EXPECT_REACHES_LAUNCH(adfp_relayout_grids(3, rj, 0, st));
+        EXPECT_REACHES_LAUNCH(adfp_relayout_grids(3, rj, 1, st));
+    }
     for (int k = -1; k < 4; ++k) {
         if (k < 0 || k > 2) {
             EXPECT_NEG(adfp_pack_decoder(k, dev<float>(1), dev<float>(2), st));
@@ -169,6 +180,14 @@ int main() {
           r2 = ra; r2.pack_jobs = pj; r2.n_pack_jobs = 2; pj[1].format = 99; EXPECT_NEG(adfp_render_forward(&sc, &r2, st)); pj[1].format = ADFP_IMAGE_HT;
           r2 = ra; r2.pack_jobs = pj; r2.n_pack_jobs = 2; EXPECT_REACHES_LAUNCH(adfp_render_forward(&sc, &r2, st));
           r2 = ra; r2.pack_jobs = pj; r2.n_pack_jobs = 2; r2.n_rays = 0; EXPECT_REACHES_LAUNCH(adfp_render_forward(&sc, &r2, st));     // no rays: the images are still packed
+      }
+      {   // grids handed over to the call's first launch
+          adfp_relayout_job rj[2] = {{dev<float>(35), dev<float>(36), 210}, {dev<float>(37), dev<float>(38), 4096}};
+          r2 = ra; r2.relayout_jobs = rj; r2.n_relayout_jobs = -1; EXPECT_NEG(adfp_render_forward(&sc, &r2, st));
+          r2 = ra; r2.relayout_jobs = nullptr; r2.n_relayout_jobs = 1; EXPECT_NEG(adfp_render_forward(&sc, &r2, st));
+          r2 = ra; r2.relayout_jobs = rj; r2.n_relayout_jobs = ADFP_RELAYOUT_MAX_JOBS + 1; EXPECT_NEG(adfp_render_forward(&sc, &r2, st));
+          r2 = ra; r2.relayout_jobs = rj; r2.n_relayout_jobs = 2; EXPECT_REACHES_LAUNCH(adfp_render_forward(&sc, &r2, st));
+          r2 = ra; r2.relayout_jobs = rj; r2.n_relayout_jobs = 2; r2.n_rays = 0; EXPECT_REACHES_LAUNCH(adfp_render_forward(&sc, &r2, st));      // no rays: still converted
       }
       adfp_train_state t0; memset(&t0, 0, sizeof(t0)); r2.state = &t0; EXPECT_NEG(adfp_render_forward(&sc, &r2, st));
       r2 = ra; r2.n_rays = 60000000; r2.workspace_bytes = (size_t)1 << 44; EXPECT_CODE(adfp_render_forward(&sc, &r2, st), ADFP_E_UNSUPPORTED); }     // 2.9e9 points

@@ -218,6 +218,42 @@ def test_relayout_round_trip(gm):
     assert torch.equal(back, g)
 
 
+def test_relayout_several_grids_in_one_launch(mini, gm):
+    """adfp_relayout_grids (round 6): up to four grids of different sizes in one launch, both directions, against plain permutes;
+    and the form the render path uses -- the conversions handed to the render call's FIRST launch (adfp_render_args.relayout_jobs)
+    give the outputs of a call that found the channels-last copies ready, bit for bit."""
+    from attentive_dfprior_amd import _lib
+    L = _lib.lib()
+    st = _lib.current_stream(torch.device(DEV))
+    shapes = [(7, 9, 11), (1, 1, 1), (13, 5, 64), (3, 70, 2)]
+    gs = [torch.randn(1, 32, *s, device=DEV) for s in shapes]
+    cls = [torch.empty(*s, 32, device=DEV) for s in shapes]
+    arr = (_lib.AdfpRelayoutJob * 4)()
+    for k in range(4):
+        arr[k].src, arr[k].dst, arr[k].voxels = gs[k].data_ptr(), cls[k].data_ptr(), shapes[k][0] * shapes[k][1] * shapes[k][2]
+    assert L.adfp_relayout_grids(4, arr, 0, st) == 0
+    for g, cl in zip(gs, cls):
+        assert torch.equal(cl, g[0].permute(1, 2, 3, 0).contiguous())
+    backs = [torch.empty_like(g) for g in gs]
+    for k in range(4):
+        arr[k].src, arr[k].dst = cls[k].data_ptr(), backs[k].data_ptr()
+    assert L.adfp_relayout_grids(3, arr, 1, st) == 0                      # three of the four
+    for k in range(3):
+        assert torch.equal(backs[k], gs[k])
+    assert L.adfp_relayout_grids(5, arr, 0, st) < 0 and L.adfp_relayout_grids(0, None, 0, st) == 0
+    # through the render call: cold caches (the first launch converts) against warm ones
+    eng = gm.rend._engine
+    with torch.no_grad():
+        eng._grid_cache.clear()
+        cold = gm.rend.render_batch_ray(gm.c, gm.dec, gm.rays_d, gm.rays_o, DEV, gm.tsdf, gm.tsdf_bnds, 'color', gt_depth=gm.gt_depth)
+        assert len(eng._grid_cache) == 3
+        warm = gm.rend.render_batch_ray(gm.c, gm.dec, gm.rays_d, gm.rays_o, DEV, gm.tsdf, gm.tsdf_bnds, 'color', gt_depth=gm.gt_depth)
+    for x, y in zip(cold, warm):
+        assert torch.equal(x, y)
+    for key in ('grid_low', 'grid_high', 'grid_color'):
+        assert torch.equal(eng._grid_cache[key][1], gm.c[key][0].permute(1, 2, 3, 0).contiguous())
+
+
 # --------------------------------------------------------------------------- edge cases
 def test_empty_and_single_ray(mini, gm):
     with torch.no_grad():
