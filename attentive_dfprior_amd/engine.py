@@ -855,14 +855,17 @@ class Engine(object):
     # ---- a15 -------------------------------------------------------------------------------
     def render_backward(self, decoders, c, tsdf_volume, tsdf_bnds, bound, stage, saved, g_depth, g_unc, g_color,
                         g_weight, need_grid, need_flat, need_rays=False, ray_keep=None, out_grids=None, out_flats=None,
-                        out_grids_cl=None, grids_prezeroed=False):
+                        out_grids_cl=None, grids_prezeroed=False, side_lane=False):
         """saved: the aux dict of render_forward(train=True).  need_grid / need_flat: dicts of bools.
         out_grids / out_flats: optional caller-owned result tensors (name -> [1,32,Z,Y,X] / flat), e.g. slices of one
         gradient bucket that is all-reduced as it stands.
         out_grids_cl: caller-owned CHANNELS-LAST gradient tensors (name -> [Z,Y,X,32]): the kernels' own layout, handed back as
         it is (no re-layout); grids_prezeroed = they are all zero on entry (mapping.MapperIteration keeps them so).
         Returns (grid grads dict in the reference's [1,32,Z,Y,X] layout -- or channels-last for out_grids_cl --, flat parameter
-        grads dict)."""
+        grads dict).
+        side_lane: run the spatial sort on the engine's second stream (side_lane()).  For callers whose iteration is bound by the
+        GPU (mapping.MapperIteration: one graph replay per iteration); the autograd path of the unchanged callers is bound by host
+        time, where the lane's four event calls cost more than the overlap returns (profiles/r06_host_breakdown.txt)."""
         ro = saved['rays_o']
         dev = ro.device
         L = lib()
@@ -935,7 +938,7 @@ class Engine(object):
             ws = self.bwd_workspace(N * S, dev)
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
             a.options = self.bwd_options | (_lib.BWD_GRIDS_PREZEROED if (grids_prezeroed and not grids_cl) else 0)
-            lane = self.side_lane(dev)
+            lane = self.side_lane(dev) if side_lane else None
             if lane is not None:
                 a.side_stream = lane[0].cuda_stream
                 for k in range(2):

@@ -53,8 +53,10 @@ def run(mini, stage, warm, sd=None, n_samples=None, n_surface=None, rays=None, b
                       None, mini)
     if bwd_options is not None:
         rend._engine.bwd_options = bwd_options
-    if side_lane is not None:
-        rend._engine.use_side_lane = side_lane
+    if side_lane is not None:                                # the autograd path takes the lane only when told to (default: MapperIteration alone)
+        eng = rend._engine
+        orig_bwd = eng.render_backward
+        eng.render_backward = lambda *a, **k: orig_bwd(*a, **dict(k, side_lane=side_lane))
     if capture is not None:
         cap = ReluCapture(rend)
     c = {k: v.to(DEV).clone().requires_grad_(True) for k, v in mini.c.items()}

@@ -14,4 +14,5 @@ wait
 one tune_shares -DADFP_TUNE_ROLE_SHARES &
 one train_NOX -DADFP_EXP_TRAIN_NOX &
 one train_NOC -DADFP_EXP_TRAIN_NOC &
+one pb_mfma -DADFP_PB_MFMA &
 wait

@@ -1,7 +1,7 @@
-# Round-5 measurement collection (one gpurun call; everything lands in gpurun_out/, the summaries are copied to profiles/ by hand
+# Round-6 measurement collection (one gpurun call; everything lands in gpurun_out/, the summaries are copied to profiles/ by hand
 # apart from the three PMC files bench.py reads, which are copied here so that the bench lines carry this build's traffic).
 #
-#   bash tools/collect_profiles.sh [section ...]        sections: tests pmc bench train diag config5 loops ab    (default: all)
+#   bash tools/collect_profiles.sh [section ...]        sections: tests pmc bench shard train diag config5 loops ab    (default: all)
 #
 # Every command's stderr is kept (gpurun_out/r05_logs/<step>.err) and a step that exits non-zero is reported, its target file is
 # moved to the logs (<step>.failed_output: no empty or half-written summary is left to be copied), and the script itself exits 1 at the end.
@@ -9,11 +9,11 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out
-R=r05
+R=r06
 L=$O/${R}_logs
 mkdir -p $L
 FAILED=""
-SECTIONS="${*:-tests pmc bench train diag config5 loops ab}"
+SECTIONS="${*:-tests pmc bench shard train diag config5 loops ab}"
 want() { case " $SECTIONS " in *" $1 "*) return 0;; esac; return 1; }
 
 # run <step> <command ...>: stdout -> logs/<step>.out
@@ -70,6 +70,16 @@ if want bench; then
   run sum_headline python profiles/summarize.py $O/prof_headline $O/${R}_kernel_stats_headline.csv
 fi
 
+if want shard; then
+  # one rank's 1/8 share of the ray-sharded headline frame, run the way bench.py --gpus 8 runs it
+  into $O/${R}_shard_pipelined.txt shard_pipelined python tools/shard_step.py
+  prof_stats $O/prof_shard8 prof_shard8 python3 tools/shard_step.py --trace 8 3
+  run sum_shard8 python profiles/summarize.py $O/prof_shard8 $O/${R}_kernel_stats_shard8.csv
+  f=$(find $O/prof_shard8 -name '*kernel_trace.csv' | head -1)
+  into $O/${R}_shard8_timeline.txt shard8_timeline python tools/trace_timeline.py $f k_forward_head
+  into $O/${R}_weight_histogram.txt weight_histogram python tools/weight_histogram.py
+fi
+
 if want train; then
   prof_stats $O/prof_train prof_train python3 tools/profile_iteration.py --rays 5000 --samples 48 --masked
   run sum_train python profiles/summarize.py $O/prof_train $O/${R}_kernel_stats_train.csv
@@ -79,6 +89,7 @@ if want train; then
     for rep in 1 2; do
       python tools/profile_iteration.py --rays 5000 --samples 48 --masked --iters 200 --graph | tail -1 | sed "s/^/fused iteration, graph replay, 5000 x 64: /"
       python tools/profile_iteration.py --rays 1000 --samples 32 --masked --iters 200 --graph | tail -1 | sed "s/^/fused iteration, graph replay, 1000 x 48: /"
+      ADFP_SIDE_LANE=0 python tools/profile_iteration.py --rays 5000 --samples 48 --masked --iters 200 --graph | tail -1 | sed "s/^/one stream (ADFP_SIDE_LANE=0), graph replay, 5000 x 64: /"
     done
   } > $O/${R}_fused_iteration.txt 2> $L/fused_iteration.err || FAILED="$FAILED fused_iteration"
 fi
@@ -111,6 +122,7 @@ if want loops; then
 fi
 
 if want ab; then
+  into $O/${R}_ab_fourier_mfma.txt ab_fourier_mfma bash tools/ab_fourier_mfma.sh
   into $O/${R}_ab_backward_roles.txt ab_roles bash tools/ab_roles.sh
   ADFP_LIB_PATH=$PWD/tools/ab_libs/libadfp_roles_span.so python tools/roles_span.py 2> $L/roles_span.err | tail -4 >> $O/${R}_ab_backward_roles.txt || FAILED="$FAILED roles_span"
   {
