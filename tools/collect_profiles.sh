@@ -119,6 +119,7 @@ if want loops; then
   into $O/${R}_mapping_loop.json loop_plain python tools/mapping_loop.py --frames 200 --every-frame 5
   python tools/mapping_loop.py --frames 200 --every-frame 5 --fused 2> $L/loop_fused.err | tail -1 >> $O/${R}_mapping_loop.json || FAILED="$FAILED loop_fused"
   ADFP_HOST_TIMING=1 into $O/${R}_host_breakdown.txt host_breakdown python tools/host_breakdown.py --rays 1000 5000
+  [ -d tools/ab_r05 ] && into $O/${R}_host_ab.txt host_ab bash tools/host_ab.sh
 fi
 
 if want ab; then
