@@ -425,6 +425,11 @@ struct SampleArgs {
     int n_rays, n_samples, n_surface, lindisp;
     float perturb;
     double* z;
+    // side job of the launch (adfp_render_forward): blocks [nb_sample, gridDim.x) convert the feature grids the caller handed over
+    // (adfp_render_args.relayout_jobs) to channels-last.  The sampler is a latency-bound launch that leaves most of the chip idle and
+    // the decoders, the first readers of the grids, are two launches later; inside the call's FIRST launch the conversions (96 MB
+    // moved per frame) stood in front of the sampler.
+    int nb_sample; RelayoutJobs rl;
 };
 
 // torch.linspace(0, 1, n) for float32 (ATen RangeFactories: symmetric fill).  The upper half is
@@ -483,6 +488,11 @@ struct RaySampler {
 __global__ __launch_bounds__(256) void k_sample(SampleArgs a) {
     constexpr int RPW = ADFP_SAMPLE_RPW;
     static_assert(RPW == 1 || RPW == 2 || RPW == 4, "16 lanes per ray");
+    if ((int)blockIdx.x >= a.nb_sample) {              // block-uniform: the launch's grid-conversion blocks
+        __shared__ float tile[32][65];
+        relayout_multi_block<false>(a.rl, blockIdx.x - (unsigned)a.nb_sample, tile);
+        return;
+    }
     __shared__ double sv[4][ADFP_MAX_SAMPLES];
     const int lane = threadIdx.x & 63;
     const int ray0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
@@ -1241,10 +1251,9 @@ __global__ __launch_bounds__(256) void k_pack_multi(PackJobs j) { pack_multi_blo
 //   rays:   the rays of pixels [first, first + n) of an H x W frame (k_get_rays' arithmetic, src/common.py:254-272)
 //   segmax: SEGMAX_PARTS partial maxima of gt_depth per segment of `seg` rays, as ordered uints, plain stores (no atomics: nothing
 //           has to be zeroed before this launch); k_sample's lanes fold them.  Block (s, p) takes the p-th sixteenth of segment s.
-//   relayout: the feature grids the caller handed over to convert to channels-last (adfp_render_args.relayout_jobs)
 struct RayJob { const float* c2w; int W; float fx, fy, cx, cy; int first, n; float* ro; float* rd; };
 struct SegJob { const float* d; int n, seg, nseg; unsigned* parts; };
-struct ForwardHeadArgs { PackJobs p; ZeroJobs z; int nb_pack, nb_zero, nb_rays, nb_seg; RayJob rj; SegJob sj; RelayoutJobs rl; };
+struct ForwardHeadArgs { PackJobs p; ZeroJobs z; int nb_pack, nb_zero, nb_rays; RayJob rj; SegJob sj; };
 __device__ inline void rays_block(const RayJob& j, unsigned blk) {
     const int k = (int)blk * 256 + threadIdx.x;
     if (k >= j.n) return;
@@ -1289,10 +1298,7 @@ __global__ __launch_bounds__(256) void k_forward_head(ForwardHeadArgs h) {
     if ((int)b < h.nb_zero) { zero_multi_block(h.z, b); return; }
     b -= (unsigned)h.nb_zero;
     if ((int)b < h.nb_rays) { rays_block(h.rj, b); return; }
-    b -= (unsigned)h.nb_rays;
-    if ((int)b < h.nb_seg) { segmax_block(h.sj, b); return; }
-    __shared__ float tile[32][65];                 // (the grid conversions: the last blocks of the launch)
-    relayout_multi_block<false>(h.rl, b - (unsigned)h.nb_seg, tile);
+    segmax_block(h.sj, b - (unsigned)h.nb_rays);
 }
 static int pack_jobs_table(int n_jobs, const adfp_pack_job* jobs, int* status, PackJobs& j) {
     if (n_jobs < 0 || n_jobs > ADFP_PACK_MAX_JOBS || (n_jobs && !jobs)) return ADFP_E_ARG;
@@ -1526,7 +1532,7 @@ int adfp_prefilter_rays(const float* rays_o, const float* rays_d, const float* g
 static int sample_rays_impl(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double bound[3][2],
                             int n_samples, int n_surface, int lindisp, float perturb, const float* t_rand, const float* depth_max,
                             double* z_vals, void* scratch, void* stream, bool scratch_is_zero, int segment = 0, int first_ray = 0,
-                            const unsigned* seg_parts = nullptr);
+                            const unsigned* seg_parts = nullptr, const RelayoutJobs* relayout = nullptr);
 int adfp_sample_rays(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double bound[3][2],
                      int n_samples, int n_surface, int lindisp, float perturb, const float* t_rand, const float* depth_max,
                      double* z_vals, void* scratch, void* stream) {
@@ -1536,7 +1542,7 @@ int adfp_sample_rays(const float* rays_o, const float* rays_d, const float* gt_d
 static int sample_rays_impl(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays, const double bound[3][2],
                             int n_samples, int n_surface, int lindisp, float perturb, const float* t_rand, const float* depth_max,
                             double* z_vals, void* scratch, void* stream, bool scratch_is_zero, int segment, int first_ray,
-                            const unsigned* seg_parts) {
+                            const unsigned* seg_parts, const RelayoutJobs* relayout) {
     if (!rays_o || !rays_d || !z_vals || !bound || n_rays < 0 || n_samples <= 0 || n_surface < 0) return ADFP_E_ARG;
     if (first_ray < 0 || (first_ray > 0 && ((!depth_max && !seg_parts) || segment <= 0))) return ADFP_E_ARG;
     if (perturb > 0.f && !t_rand) return ADFP_E_ARG;
@@ -1567,7 +1573,11 @@ static int sample_rays_impl(const float* rays_o, const float* rays_d, const floa
         ADFP_CHECK_LAUNCH();
         a.dmax_ord = (const unsigned*)scratch;
     }
-    hipLaunchKernelGGL(k_sample, dim3((n_rays + 4 * ADFP_SAMPLE_RPW - 1) / (4 * ADFP_SAMPLE_RPW)), dim3(256), 0, st, a);
+    a.nb_sample = (n_rays + 4 * ADFP_SAMPLE_RPW - 1) / (4 * ADFP_SAMPLE_RPW);
+    a.rl.n = 0;
+    unsigned nb_rl = 0;
+    if (relayout && relayout->n > 0) { a.rl = *relayout; nb_rl = relayout->first[relayout->n]; }
+    hipLaunchKernelGGL(k_sample, dim3((unsigned)a.nb_sample + nb_rl), dim3(256), 0, st, a);
     ADFP_CHECK_LAUNCH();
     return 0;
 }
@@ -2474,16 +2484,12 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
         nb_seg = (unsigned)h.sj.nseg * SEGMAX_PARTS;
         seg_parts = ws.segparts;
     }
-    h.nb_seg = (int)nb_seg;
-    unsigned nb_rl = 0;
-    if (r->n_relayout_jobs > 0) {
-        rc = relayout_jobs_table(r->n_relayout_jobs, r->relayout_jobs, h.rl); if (rc) return rc;
-        nb_rl = h.rl.first[h.rl.n];
-    }
-    hipLaunchKernelGGL(k_forward_head, dim3((unsigned)(h.nb_pack + h.nb_zero + h.nb_rays) + nb_seg + nb_rl), dim3(256), 0, st, h);
+    RelayoutJobs rl; rl.n = 0;                          // the grids the caller handed over: converted by blocks of the SAMPLER's launch
+    if (r->n_relayout_jobs > 0) { rc = relayout_jobs_table(r->n_relayout_jobs, r->relayout_jobs, rl); if (rc) return rc; }
+    hipLaunchKernelGGL(k_forward_head, dim3((unsigned)(h.nb_pack + h.nb_zero + h.nb_rays) + nb_seg), dim3(256), 0, st, h);
     ADFP_CHECK_LAUNCH();
     rc = sample_rays_impl(rays_o, rays_d, gt_depth, r->n_rays, scene->bound, r->n_samples, r->n_surface, r->lindisp,
-                          r->perturb, r->t_rand, r->depth_max, z, (char*)ws.counter + 64, stream, true, segment, r->depth_max_first_ray, seg_parts);
+                          r->perturb, r->t_rand, r->depth_max, z, (char*)ws.counter + 64, stream, true, segment, r->depth_max_first_ray, seg_parts, &rl);
     if (rc) return rc;
     PtsDev P;
     P.mode = ADFP_PTS_RAYS; P.S = S; P.n = (int)Pn; P.pts = nullptr; P.ro = rays_o; P.rd = rays_d; P.z = z;

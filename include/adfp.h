@@ -150,7 +150,7 @@ int adfp_relayout_grid(const float* src_cm, float* dst_cl, int C, int Z, int Y, 
 int adfp_relayout_grid_back(const float* src_cl, float* dst_cm, int C, int Z, int Y, int X, void* stream);
 /* Several grids in ONE launch (a launch costs ~5 us of host time and ~5 us on the device whatever it converts; the Mapper
  * re-materialises three grids per iteration, src/Mapper.py:382-388).  back = 0: [32][V] -> [V][32]; back = 1: the way back.
- * At most ADFP_RELAYOUT_MAX_JOBS jobs; adfp_render_args.relayout_jobs hands the forward conversions to the render call's first launch. */
+ * At most ADFP_RELAYOUT_MAX_JOBS jobs; adfp_render_args.relayout_jobs hands the forward conversions to the render call itself. */
 typedef struct adfp_relayout_job { const float* src; float* dst; long long voxels; } adfp_relayout_job;
 #define ADFP_RELAYOUT_MAX_JOBS 4
 int adfp_relayout_grids(int n_jobs, const adfp_relayout_job* jobs /*host*/, int back, void* stream);
@@ -352,8 +352,8 @@ typedef struct adfp_render_args {
      * gt_depth above are then ignored (the rays are written to frame->rays_o / rays_d, gt_depth = frame->depth + first). */
     const adfp_frame_job* frame;
     /* Optional: feature grids this call's kernels read in channels-last form and that are not converted yet (host array of
-     * [32][V] -> [V][32] jobs, at most ADFP_RELAYOUT_MAX_JOBS): converted by the call's FIRST launch, beside the zero fill and
-     * the weight images -- the decoders, the first readers, are three launches later.  NULL / 0: none. */
+     * [32][V] -> [V][32] jobs, at most ADFP_RELAYOUT_MAX_JOBS): converted by extra workgroups of the call's SECOND launch (the
+     * sampler: latency-bound, most of the chip idle) -- the decoders, the first readers, are two launches later.  NULL / 0: none. */
     const adfp_relayout_job* relayout_jobs;
     int n_relayout_jobs;
 } adfp_render_args;
