@@ -127,7 +127,7 @@ class AdfpRenderArgs(C.Structure):
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('state', C.POINTER(AdfpTrainState)),
                 ('depth_max_segment', C.c_int), ('depth_max_first_ray', C.c_int),
                 ('pack_jobs', C.c_void_p), ('n_pack_jobs', C.c_int), ('frame', C.POINTER(AdfpFrameJob)),
-                ('relayout_jobs', C.c_void_p), ('n_relayout_jobs', C.c_int)]
+                ('relayout_jobs', C.c_void_p), ('n_relayout_jobs', C.c_int), ('prefilter_bound', C.c_void_p), ('prefilter_keep', C.c_void_p)]
 
 
 class AdfpBackwardArgs(C.Structure):

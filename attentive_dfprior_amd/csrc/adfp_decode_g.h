@@ -174,6 +174,14 @@ ADFP_DEV void mfma_chain_g(f32x4g acc[2][2], const unsigned* __restrict__ w, con
 //        order).  The lane's units 16 ob + 4 g .. + 3 are one 16-byte piece: 2 pieces of c and of every h_i per point, 24 stores
 //        per lane and tile.  The head [x, y, z, 1, 0 ...] (128 B of the 896) is NOT stored: k_decode_bwd_roles / _fused recompute
 //        the Fourier features from the points, and k_outer_h builds the head from the points (OuterHArgs.x_skip4).
+// the training rows' stores: plain, or (timing experiment -DADFP_EXP_NT_ROWS) non-temporal -- written once, read once ~300 us later
+ADFP_DEV void row_store(float* p, const f32x4 v) {
+#if defined(ADFP_EXP_NT_ROWS)
+    __builtin_nontemporal_store(v, (f32x4*)p);
+#else
+    *(f32x4*)p = v;
+#endif
+}
 template <int CDIM, int NOUT, int TRAIN = 0>
 ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& grid, const GridDev& grid1, const float pn[3], const float (*pf)[3],
                            int lane, float& amax, float (*out)[NOUT], unsigned* __restrict__ mw, float* srow0, unsigned rowbits ADFP_PHG_PARAMS) {
@@ -214,8 +222,8 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
 #if !defined(ADFP_EXP_TRAIN_NOC)          // timing experiment (tools/build_ab_libs.sh): the training forward without the c piece of the rows
         if constexpr (TRAIN) {
             static_assert(!TRAIN || CDIM == 32, "training rows: 32-channel decoders");
-            if (srow[0]) { *(f32x4*)(srow[0] + ST::xm(ST::SC) + 4 * g) = f32x4{x[0], x[1], x[2], x[3]}; *(f32x4*)(srow[0] + ST::xm(ST::SC) + 16 + 4 * g) = f32x4{x[4], x[5], x[6], x[7]}; }
-            if (srow[1]) { *(f32x4*)(srow[1] + ST::xm(ST::SC) + 4 * g) = f32x4{y[0], y[1], y[2], y[3]}; *(f32x4*)(srow[1] + ST::xm(ST::SC) + 16 + 4 * g) = f32x4{y[4], y[5], y[6], y[7]}; }
+            if (srow[0]) { row_store(srow[0] + ST::xm(ST::SC) + 4 * g, f32x4{x[0], x[1], x[2], x[3]}); row_store(srow[0] + ST::xm(ST::SC) + 16 + 4 * g, f32x4{x[4], x[5], x[6], x[7]}); }
+            if (srow[1]) { row_store(srow[1] + ST::xm(ST::SC) + 4 * g, f32x4{y[0], y[1], y[2], y[3]}); row_store(srow[1] + ST::xm(ST::SC) + 16 + 4 * g, f32x4{y[4], y[5], y[6], y[7]}); }
         }
 #endif
         split8(x, ch[kc][0], cl[kc][0], amax);      // block 0: channels unit16(8 g + j)
@@ -302,8 +310,8 @@ ADFP_DEV void decode_net_g(const unsigned* __restrict__ ldsu, const GridDev& gri
         if constexpr (TRAIN) {
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb) if (srow[pb]) {
-                *(f32x4*)(srow[pb] + ST::xm(ST::SH(i)) + 4 * g) = f32x4{acc[0][pb][0], acc[0][pb][1], acc[0][pb][2], acc[0][pb][3]};
-                *(f32x4*)(srow[pb] + ST::xm(ST::SH(i)) + 16 + 4 * g) = f32x4{acc[1][pb][0], acc[1][pb][1], acc[1][pb][2], acc[1][pb][3]};
+                row_store(srow[pb] + ST::xm(ST::SH(i)) + 4 * g, f32x4{acc[0][pb][0], acc[0][pb][1], acc[0][pb][2], acc[0][pb][3]});
+                row_store(srow[pb] + ST::xm(ST::SH(i)) + 16 + 4 * g, f32x4{acc[1][pb][0], acc[1][pb][1], acc[1][pb][2], acc[1][pb][3]});
             }
         }
         if (i < 4) {

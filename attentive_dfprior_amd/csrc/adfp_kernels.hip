@@ -1252,7 +1252,10 @@ __global__ __launch_bounds__(256) void k_pack_multi(PackJobs j) { pack_multi_blo
 //   segmax: SEGMAX_PARTS partial maxima of gt_depth per segment of `seg` rays, as ordered uints, plain stores (no atomics: nothing
 //           has to be zeroed before this launch); k_sample's lanes fold them.  Block (s, p) takes the p-th sixteenth of segment s.
 struct RayJob { const float* c2w; int W; float fx, fy, cx, cy; int first, n; float* ro; float* rd; };
-struct SegJob { const float* d; int n, seg, nseg; unsigned* parts; };
+struct SegJob { const float* d; int n, seg, nseg; unsigned* parts;
+                // pre-filter mode (adfp_render_args.prefilter_bound): the maximum is taken over the rays the Mapper's bounding-box test keeps,
+                // and the test's verdict is written to keep[ray] -- k_prefilter_mask's arithmetic (adfp_mapper_iter.h)
+                const float* ro; const float* rd; const double* bnd; unsigned char* keep; };
 struct ForwardHeadArgs { PackJobs p; ZeroJobs z; int nb_pack, nb_zero, nb_rays; RayJob rj; SegJob sj; };
 __device__ inline void rays_block(const RayJob& j, unsigned blk) {
     const int k = (int)blk * 256 + threadIdx.x;
@@ -1274,6 +1277,28 @@ __device__ inline void segmax_block(const SegJob& j, unsigned blk) {
     const long long len = s_hi - s_lo, per = (len + SEGMAX_PARTS - 1) / SEGMAX_PARTS;
     const long long lo = s_lo + part * per, hi = lo + per < s_hi ? lo + per : s_hi;
     unsigned m = 0;
+    if (j.keep) {                                      // block-uniform
+        double b[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) b[k] = j.bnd[k];
+        float mx = -INFINITY;                           // k_prefilter_mask's start value: no kept ray -> -inf
+        for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+            double t = INFINITY; bool nan = false;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double o = (double)j.ro[3 * i + k], d = (double)j.rd[3 * i + k];
+                const double t0 = (b[2 * k] - o) / d, t1 = (b[2 * k + 1] - o) / d;
+                nan |= (t0 != t0) | (t1 != t1);        // torch.max / torch.min propagate NaN
+                const double tm = t0 > t1 ? t0 : t1;
+                t = tm < t ? tm : t;
+            }
+            const float dep = j.d[i];
+            const bool k_ = !nan && (t >= (double)dep);
+            j.keep[i] = k_ ? 1 : 0;
+            if (k_) mx = dep > mx ? dep : mx;
+        }
+        m = f2ord(mx);
+    } else
     // eight independent loads per thread and trip: the slice is a few thousand floats, the cost is the latency of the trips
     for (long long i = lo + threadIdx.x; i < hi; i += 256 * 8) {
         float v[8];
@@ -2424,6 +2449,8 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
     if (r->depth_max_first_ray < 0 || (r->depth_max_first_ray > 0 && !fr && (!r->depth_max || r->depth_max_segment <= 0 || !gt_depth))) return ADFP_E_ARG;
     if (r->n_pack_jobs < 0 || r->n_pack_jobs > ADFP_PACK_MAX_JOBS || (r->n_pack_jobs && !r->pack_jobs)) return ADFP_E_ARG;
     if (r->n_relayout_jobs < 0 || r->n_relayout_jobs > ADFP_RELAYOUT_MAX_JOBS || (r->n_relayout_jobs && !r->relayout_jobs)) return ADFP_E_ARG;
+    if ((r->prefilter_bound != nullptr) != (r->prefilter_keep != nullptr)) return ADFP_E_ARG;
+    if (r->prefilter_bound && (fr || !gt_depth || r->depth_max || r->depth_max_segment != 0 || r->depth_max_first_ray != 0)) return ADFP_E_ARG;
     if (r->state && r->stage != ADFP_STAGE_LOW &&
         (!r->state->flags || !r->state->list || !r->state->counter || !r->state->att_occ || !r->state->att_u)) return ADFP_E_ARG;
     const int S = r->n_samples + (gt_depth ? r->n_surface : 0);
@@ -2480,6 +2507,7 @@ int adfp_render_forward(const adfp_scene* scene, const adfp_render_args* r, void
         h.sj.seg = segment > 0 ? segment : h.sj.n;
         h.sj.nseg = (h.sj.n + h.sj.seg - 1) / h.sj.seg;
         h.sj.parts = ws.segparts;
+        h.sj.keep = r->prefilter_keep; h.sj.bnd = r->prefilter_bound; h.sj.ro = rays_o; h.sj.rd = rays_d;       // NULL: a plain maximum
         if (segment <= 0) segment = h.sj.n;                // k_sample indexes segment (first + ray) / segment = 0
         nb_seg = (unsigned)h.sj.nseg * SEGMAX_PARTS;
         seg_parts = ws.segparts;

@@ -736,10 +736,12 @@ class Engine(object):
     def render_forward(self, decoders, c, rays_o, rays_d, gt_depth, tsdf_volume, tsdf_bnds, bound, stage,
                        n_samples, n_surface, lindisp=False, perturb=0.0, t_rand=None, depth_max=None,
                        want_aux=False, train=False, need_flat=None, depth_max_segment=0, depth_max_first_ray=0, tsdf_blocks=False,
-                       frame=None):
+                       frame=None, prefilter=None):
         """frame (not with train): dict(c2w=, H=, W=, fx=, fy=, cx=, cy=, depth=<the WHOLE frame's sensor depth>, n_rays=) -- the call
         renders pixels [depth_max_first_ray, + n_rays) of that frame (adfp_frame_job): rays_o / rays_d / gt_depth are ignored (pass
-        None), the rays and the per-segment far clamps of the whole frame come out of the call's first launch."""
+        None), the rays and the per-segment far clamps of the whole frame come out of the call's first launch.
+        prefilter: (bound_dev [6] float64 device tensor, keep [N] uint8 device tensor) -- the Mapper's bounding-box pre-filter as a job of
+        the call's first launch (adfp_render_args.prefilter_bound): keep is written, the far clamp is the kept rays' max depth."""
         f32 = torch.float32
         if frame is not None:
             fdepth = frame['depth'].detach().reshape(-1)
@@ -815,6 +817,8 @@ class Engine(object):
                     a.t_rand = t_rand.data_ptr()
                 a.depth_max_segment = int(depth_max_segment)
                 a.depth_max_first_ray = int(depth_max_first_ray)
+                if prefilter is not None:
+                    a.prefilter_bound, a.prefilter_keep = prefilter[0].data_ptr(), prefilter[1].data_ptr()
                 if frame is not None:
                     fj = _lib.AdfpFrameJob()
                     fj.c2w, fj.H, fj.W = fc2w.data_ptr(), int(frame['H']), int(frame['W'])

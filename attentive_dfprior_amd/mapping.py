@@ -292,18 +292,22 @@ class MapperIteration(object):
         st = _lib.current_stream(dev)
         N = ro.shape[0]
         keep = torch.empty((N,), dtype=torch.uint8, device=dev)
-        dmax = torch.empty((1,), dtype=torch.float32, device=dev)
-        check(L.adfp_prefilter_mask(ptr(ro), ptr(rd), ptr(gd), N, ptr(self.bound_dev), ptr(keep), ptr(dmax), st), 'adfp_prefilter_mask')
+        dmax, prefilter = None, None
         if self.distributed:
+            # the far clamp sees the whole batch (Renderer.py:159): the pre-filter is a launch of its own, its maximum all-reduced
             import torch.distributed as tdist
-            tdist.all_reduce(dmax, op=tdist.ReduceOp.MAX, group=self.group)       # the far clamp sees the whole batch (Renderer.py:159)
+            dmax = torch.empty((1,), dtype=torch.float32, device=dev)
+            check(L.adfp_prefilter_mask(ptr(ro), ptr(rd), ptr(gd), N, ptr(self.bound_dev), ptr(keep), ptr(dmax), st), 'adfp_prefilter_mask')
+            tdist.all_reduce(dmax, op=tdist.ReduceOp.MAX, group=self.group)
+        else:
+            prefilter = (self.bound_dev, keep)           # a job of the render call's first launch (adfp_render_args.prefilter_bound)
         self._sync_shadows()
         used = {'low': ('low',), 'high': ('low', 'high', 'att'), 'color': ('low', 'high', 'color', 'att')}[stage]
         need_grid = {k: (k in used) for k in ('low', 'high', 'color')}
         need_flat = {n: (n in used and n in self.nets) for n in ('low', 'high', 'color', 'att')}
         depth, unc, color, weight, aux = eng.render_forward(dec, self.c, ro, rd, gd, self.tsdf, self.tsdf_bnds, rend.bound, stage,
                                                             rend.N_samples, rend.N_surface, rend.lindisp, rend.perturb, None, dmax,
-                                                            train=True, need_flat=need_flat, tsdf_blocks=self._cb)
+                                                            train=True, need_flat=need_flat, tsdf_blocks=self._cb, prefilter=prefilter)
         S = aux['S']
         la = _lib.AdfpLossArgs()
         la.n_rays, la.S, la.stage, la.warmup, la.w_color_loss = N, S, _lib.STAGE[stage], 1 if warmup else 0, self.w_color

@@ -356,6 +356,14 @@ typedef struct adfp_render_args {
      * sampler: latency-bound, most of the chip idle) -- the decoders, the first readers, are two launches later.  NULL / 0: none. */
     const adfp_relayout_job* relayout_jobs;
     int n_relayout_jobs;
+    /* Optional: the Mapper's bounding-box pre-filter (src/Mapper.py:438-449: keep a ray iff min_axis max_side((bound - o) / d) >=
+     * gt_depth, in float64) as a job of the call's first launch instead of a launch of its own (adfp_prefilter_mask): that launch
+     * writes prefilter_keep[ray] (1 / 0) for every ray of the call, and the call's far clamp is max(gt_depth) over the KEPT rays
+     * (adfp_prefilter_mask's depth_max).  All rays are rendered; the caller masks the dropped ones out of loss and gradients
+     * (adfp_loss_args.keep, adfp_backward_args.ray_keep).  prefilter_bound: device double[6] = (lo, hi) per axis.  Needs gt_depth,
+     * no depth_max, depth_max_segment = 0, no frame.  NULL: none. */
+    const double* prefilter_bound;
+    unsigned char* prefilter_keep;
 } adfp_render_args;
 
 int adfp_render_forward(const adfp_scene* scene /*host*/, const adfp_render_args* args /*host*/, void* stream);

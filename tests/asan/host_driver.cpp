@@ -189,6 +189,14 @@ int main() {
           r2 = ra; r2.relayout_jobs = rj; r2.n_relayout_jobs = 2; EXPECT_REACHES_LAUNCH(adfp_render_forward(&sc, &r2, st));
           r2 = ra; r2.relayout_jobs = rj; r2.n_relayout_jobs = 2; r2.n_rays = 0; EXPECT_REACHES_LAUNCH(adfp_render_forward(&sc, &r2, st));      // no rays: still converted
       }
+      {   // the pre-filter as a job of the first launch
+          r2 = ra; r2.prefilter_bound = dev<double>(39); EXPECT_NEG(adfp_render_forward(&sc, &r2, st));                       // bound without keep
+          r2 = ra; r2.prefilter_keep = dev<unsigned char>(40); EXPECT_NEG(adfp_render_forward(&sc, &r2, st));                 // keep without bound
+          r2 = ra; r2.prefilter_bound = dev<double>(39); r2.prefilter_keep = dev<unsigned char>(40); r2.depth_max = dev<float>(21); EXPECT_NEG(adfp_render_forward(&sc, &r2, st));
+          r2 = ra; r2.prefilter_bound = dev<double>(39); r2.prefilter_keep = dev<unsigned char>(40); r2.depth_max_segment = 100; EXPECT_NEG(adfp_render_forward(&sc, &r2, st));
+          r2 = ra; r2.prefilter_bound = dev<double>(39); r2.prefilter_keep = dev<unsigned char>(40); r2.gt_depth = nullptr; EXPECT_NEG(adfp_render_forward(&sc, &r2, st));
+          r2 = ra; r2.prefilter_bound = dev<double>(39); r2.prefilter_keep = dev<unsigned char>(40); EXPECT_REACHES_LAUNCH(adfp_render_forward(&sc, &r2, st));
+      }
       adfp_train_state t0; memset(&t0, 0, sizeof(t0)); r2.state = &t0; EXPECT_NEG(adfp_render_forward(&sc, &r2, st));
       r2 = ra; r2.n_rays = 60000000; r2.workspace_bytes = (size_t)1 << 44; EXPECT_CODE(adfp_render_forward(&sc, &r2, st), ADFP_E_UNSUPPORTED); }     // 2.9e9 points
     EXPECT_REACHES_LAUNCH(adfp_render_forward(&sc, &ra, st));

@@ -544,3 +544,40 @@ def test_frame_job_equals_explicit_rays_and_explicit_maxima_bit_for_bit(mini, gm
                                         mini.n_samples, mini.n_surface, depth_max=gd[100:1777].max().reshape(1))
     for x, y in zip(a[:4], b[:4]):
         assert torch.equal(x, y)
+
+
+def test_prefilter_job_equals_the_prefilter_launch_bit_for_bit(mini, gm):
+    """adfp_render_args.prefilter_bound (round 6): the Mapper's bounding-box pre-filter (src/Mapper.py:438-449) as a job of the render
+    call's first launch -- keep flags and the kept rays' maximum depth -- against adfp_prefilter_mask + depth_max: the same flags, the
+    same outputs bit for bit, for a batch with dropped rays (depth beyond the bound), zero depths and a NaN direction; and a batch
+    whose rays are ALL dropped (maximum = -inf on both sides)."""
+    from attentive_dfprior_amd import _lib
+    L = _lib.lib()
+    eng = gm.rend._engine
+    st = _lib.current_stream(torch.device(DEV))
+    bound_dev = torch.as_tensor(mini.bound).to(DEV, torch.float64).contiguous()
+    ro, rd, gd, _ = [t.to(DEV) for t in synthetic.make_ray_batch(synthetic.mini_scene(), 1500, seed=11, poses=3)]
+    gd = gd.clone()
+    gd[::7] *= 40.0                                               # beyond the bound: dropped
+    rd = rd.clone()
+    rd[5, 1] = float('nan')
+    for case in ('mixed', 'all dropped'):
+        if case == 'all dropped':
+            gd = gd * 0 + 1e6
+        keep_a = torch.empty((ro.shape[0],), dtype=torch.uint8, device=DEV)
+        dmax = torch.empty((1,), dtype=torch.float32, device=DEV)
+        _lib.check(L.adfp_prefilter_mask(_lib.ptr(ro), _lib.ptr(rd), _lib.ptr(gd), ro.shape[0], _lib.ptr(bound_dev), _lib.ptr(keep_a), _lib.ptr(dmax), st), 'prefilter')
+        keep_b = torch.zeros_like(keep_a) + 7
+        with torch.no_grad():
+            a = eng.render_forward(gm.dec, gm.c, ro, rd, gd, gm.tsdf, gm.tsdf_bnds, mini.bound, 'color', mini.n_samples, mini.n_surface, depth_max=dmax)
+            b = eng.render_forward(gm.dec, gm.c, ro, rd, gd, gm.tsdf, gm.tsdf_bnds, mini.bound, 'color', mini.n_samples, mini.n_surface,
+                                   prefilter=(bound_dev, keep_b))
+        assert torch.equal(keep_a, keep_b), case
+        if case == 'mixed':
+            assert 0 < int(keep_a.sum()) < keep_a.numel() and int(keep_a[5]) == 0
+        else:
+            assert int(keep_a.sum()) == 0 and float(dmax) == float('-inf')
+        k = keep_a.bool()
+        for x, y, what in zip(a[:4], b[:4], ('depth', 'uncertainty', 'colour', 'weight')):
+            assert torch.equal(x[k], y[k]), (case, what)                                      # the kept rays: bit for bit
+            assert torch.equal(torch.isnan(x), torch.isnan(y)), (case, what)
