@@ -104,6 +104,11 @@ class Engine(object):
         # The backward's second lane (adfp_backward_args.side_stream): the spatial sort of the sample points runs beside the backward
         # kernels instead of in front of them.  ADFP_SIDE_LANE=0 in the host's environment keeps everything on one stream (A/B runs).
         self.use_side_lane = os.environ.get('ADFP_SIDE_LANE', '1') not in ('0', 'off', 'false', 'no')
+        # ... and for which stages: the lane pays when the backward's main path is longer than the sort (nine launches, ~55 us + two
+        # cross-stream hops).  Fused iteration at office0, 5 000 x 64, one stream -> lane: stage low 0.204 -> 0.215 ms, high 0.408 ->
+        # 0.390, colour 0.695 -> 0.672 (profiles/r06_ab_side_lane.txt).  ADFP_SIDE_LANE=<stage>[+<stage>] overrides.
+        lane_env = os.environ.get('ADFP_SIDE_LANE', '')
+        self.side_lane_stages = frozenset(lane_env.split('+')) if lane_env and lane_env[0] in 'lhc' else frozenset(('high', 'color'))
         self._side = {}          # device -> (torch.cuda.Stream, [two torch.cuda.Event])
         self._owed_packs = None  # (job table, count, keep-alive) scene(hand_over_packs=True) leaves for the render call's first launch
         self._owed_relayouts = None   # the same for grid conversions (adfp_render_args.relayout_jobs)
@@ -167,6 +172,10 @@ class Engine(object):
         if t is None or tuple(t.shape) != tuple(shape) or t.device != device:
             t = self._gcl[name] = torch.empty(shape, dtype=torch.float32, device=device)
         return t
+
+    def lane_for(self, stage):
+        """Does a backward of `stage` take the side lane (when its caller asks for one at all)?"""
+        return self.use_side_lane and stage in self.side_lane_stages
 
     def side_lane(self, device):
         """(stream, two events) of the backward's second lane on `device`, created on first use -- never inside a stream capture

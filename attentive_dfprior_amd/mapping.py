@@ -350,7 +350,7 @@ class MapperIteration(object):
                 end = off + n
         grids, flats, _ = eng.render_backward(dec, self.c, self.tsdf, self.tsdf_bnds, rend.bound, stage, aux, g_depth, None,
                                               g_color if stage == 'color' else None, g_weight, need_grid, need_flat, ray_keep=keep,
-                                              out_grids_cl=out_grids, out_flats=out_flats, grids_prezeroed=True, side_lane=True)
+                                              out_grids_cl=out_grids, out_flats=out_flats, grids_prezeroed=True, side_lane=eng.lane_for(stage))
         self.bucket_bytes = end * 4
         if self.distributed:
             import torch.distributed as tdist

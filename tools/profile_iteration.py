@@ -16,10 +16,12 @@ ap.add_argument('--rays', type=int, default=1000)
 ap.add_argument('--samples', type=int, default=32)
 ap.add_argument('--iters', type=int, default=50)
 ap.add_argument('--graph', action='store_true')
+ap.add_argument('--scene', default='room0')
+ap.add_argument('--stage', default='color')
 ap.add_argument('--masked', action='store_true', help='frustum-masked grids (as the Mapper runs) instead of whole-grid Adam')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
-scene = synthetic.Scene('room0', device=dev, grid_std_scale=20.0)
+scene = synthetic.Scene(args.scene, device=dev, grid_std_scale=20.0)
 scene.c['grid_high'] = scene.c['grid_high'] * 100
 dec = A.DF()
 dec.load_state_dict(synthetic.seeded_state_dict(0))
@@ -38,15 +40,16 @@ masks = None
 if args.masked:
     masks = {k: mapping.frustum_mask(c2w, tuple(v.shape[2:]), gt, scene.bound, scene.H, scene.W, scene.fx, scene.fy, scene.cx, scene.cy)
              for k, v in scene.c.items()}
-lr = {'color': dict(low=0.005, high=0.005, color=0.005, decoders=0.005, mlp=0.005)}
+lr = {'color': dict(low=0.005, high=0.005, color=0.005, decoders=0.005, mlp=0.005), 'high': dict(low=0.005, high=0.005, color=0.0, decoders=0.0, mlp=0.005),
+      'low': dict(low=0.1, high=0.0, color=0.0, decoders=0.0, mlp=0.0)}
 it = mapping.MapperIteration(rend, dec, {k: v.clone() for k, v in scene.c.items()}, masks, scene.tsdf_volume, scene.tsdf_bnds.to(dev), lr,
                              use_graph=args.graph)
 import time
 for _ in range(3):
-    it.step(ro, rd, gd, gc, 'color')
+    it.step(ro, rd, gd, gc, args.stage)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(args.iters):
-    it.step(ro, rd, gd, gc, 'color')
+    it.step(ro, rd, gd, gc, args.stage)
 torch.cuda.synchronize()
 print('ms per iteration', (time.perf_counter() - t0) / args.iters * 1e3)
