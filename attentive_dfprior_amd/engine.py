@@ -764,6 +764,9 @@ class Engine(object):
                 if fdepth.dtype != f32 or not fdepth.is_contiguous():
                     fdepth = fdepth.float().contiguous()
                 N = int(frame['n_rays'])
+                if fdepth.numel() != int(frame['H']) * int(frame['W']) or not (0 <= depth_max_first_ray and depth_max_first_ray + N <= fdepth.numel()):
+                    raise RuntimeError(f"frame job: gt_depth has {fdepth.numel()} pixels for a {frame['H']}x{frame['W']} frame, pixels "
+                                       f'[{depth_max_first_ray}, {depth_max_first_ray + N}) asked for')
                 fc2w = frame['c2w'].detach().to(dev, f32).contiguous()
                 if fc2w.numel() < 12:
                     raise RuntimeError(f'c2w: expected [3,4] or [4,4], got {tuple(fc2w.shape)}')
