@@ -326,13 +326,7 @@ class Engine(object):
         sc.status = decoders.status_word().data_ptr()
         keep = []
         _lib.fill_bound(sc.bound, self.host_bound(bound, 'bound'))
-        rjobs = []                               # grids to convert: ONE launch (the render call's first, or flush_relayout_jobs below)
-        for field, key in _STAGE_GRIDS[stage]:
-            g = self.grid_cl(key, c[key], defer=rjobs)
-            keep.append(g)
-            gd = getattr(sc, field)
-            gd.data = g.data_ptr()
-            gd.Z, gd.Y, gd.X = g.shape[0], g.shape[1], g.shape[2]
+        rjobs = []                               # grids to convert: ONE launch (inside the render call, or flush_relayout_jobs below)
         nets = _STAGE_NETS[stage]
         if keys is None:
             keys = {}
@@ -342,6 +336,12 @@ class Engine(object):
         from .decoder import flush_pack_jobs
         jobs = decoders._pack_jobs = []          # the split / transposed images this call has to (re)build: packed in ONE launch below
         try:
+            for field, key in _STAGE_GRIDS[stage]:
+                g = self.grid_cl(key, c[key], defer=rjobs)
+                keep.append(g)
+                gd = getattr(sc, field)
+                gd.data = g.data_ptr()
+                gd.Z, gd.Y, gd.X = g.shape[0], g.shape[1], g.shape[2]
             for n in nets:
                 k = keys.get(n)
                 if k is None:

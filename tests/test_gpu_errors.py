@@ -80,3 +80,25 @@ def test_missing_weight_image_and_bad_stage():
     assert L.adfp_eval_points(C.byref(scene), C.byref(ap), _lib.STAGE['high'], 0, raw.data_ptr(), w.data_ptr(),
                               ws.data_ptr(), need, st) == 0
     torch.cuda.synchronize()
+
+
+def test_a_failed_call_leaves_no_conversion_the_caches_vouch_for():
+    """scene() defers the grid conversions and the weight-image packs of a call into ONE launch each and records them as current at
+    once.  A call that dies in between -- here: the third grid has the wrong shape, after the first two were deferred -- must not
+    leave cache entries for copies nobody wrote: the next, correct call renders what a fresh renderer renders, bit for bit."""
+    sc, dec, rend, ro, rd, gd = _setup()
+    tb = sc.tsdf_bnds.to(DEV)
+    with torch.no_grad():
+        want = A.Renderer(make_cfg(32, 16), None, sc).render_batch_ray(sc.c, dec, rd, ro, DEV, sc.tsdf_volume, tb, 'color', gt_depth=gd)
+    fresh = {k: v.clone() for k, v in sc.c.items()}              # new tensors: nothing cached for them
+    bad = dict(fresh)
+    bad['grid_color'] = fresh['grid_color'][:, :16]               # [1,16,Z,Y,X]: grid_cl raises for the THIRD grid
+    dec._packed.clear()
+    rend._engine._grid_cache.clear()
+    with torch.no_grad(), pytest.raises(RuntimeError, match='grid_color'):
+        rend.render_batch_ray(bad, dec, rd, ro, DEV, sc.tsdf_volume, tb, 'color', gt_depth=gd)
+    assert rend._engine._owed_relayouts is None and rend._engine._owed_packs is None
+    with torch.no_grad():
+        got = rend.render_batch_ray(fresh, dec, rd, ro, DEV, sc.tsdf_volume, tb, 'color', gt_depth=gd)
+    for x, y in zip(got, want):
+        assert torch.equal(x, y)

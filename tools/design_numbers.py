@@ -38,7 +38,7 @@ def main(template, d):
     iters = int(next(r for k, r in tr.items() if 'k_mapper_loss' in k)['calls'])
     per = lambda *names: sum(float(r['total_ms']) * 1e3 / iters for k, r in tr.items() if any(n in k for n in names))
     zero = per('k_zero_multi')
-    head = per('k_backward_head')
+    head = per('k_backward_head', 'k_max_reduce')
     v['train_head'] = '%.0f' % (per('k_prefilter_mask', 'k_pack_multi', 'k_forward_head', 'k_sample', 'k_tsdf(') + (zero if head else zero / 2))
     v['k_decode_lc16_train'] = '%.0f' % per('k_decode_lc16_train')
     v['train_inband_fwd'] = '%.0f' % per('k_decode_h<64', 'k_attention_h<1')
